@@ -1,0 +1,211 @@
+/*
+ * srlz.h — C ABI of libsrlz_hip.so: the MI355X (gfx950) kernels behind srl-zoo's image-representation
+ * training hot path.
+ *
+ * The reference (araffin/srl-zoo, /root/reference) has NO native code: every op below is reached there through
+ * PyTorch (torch.nn / autograd / torch.optim).  Each entry point therefore cites the reference call site whose
+ * arithmetic it replaces (file:line into /root/reference).  The Python binding a maintainer adds is a ctypes stub
+ * (see INTEGRATION.md); this build's own is srl-zoo_amd/srlz/_cabi.py.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - all floating point data is fp32; activations are NHWC ([N][H][W][C], C fastest) unless stated NCHW.
+ *     The reference's tensors are NCHW ([B,C,D1,D2]; D1/D2 are the image's W/H because the loader transposes,
+ *     preprocessing/data_loader.py:255); the NCHW<->NHWC change happens INSIDE conv1 (reads NCHW) and the last
+ *     ConvTranspose (writes NCHW), so callers only ever hand over / receive reference-layout images.
+ *   - parameters cross the ABI in the reference's state_dict layouts (Conv2d [Cout,Cin,kh,kw],
+ *     ConvTranspose2d [Cin,Cout,kh,kw], Linear [out,in]); *_pack_* entry points build the kernels' private copies.
+ *   - the caller owns all memory (weights, activations, workspaces); nothing is allocated, freed or retained.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no call synchronises.
+ *   - return 0 on success, a negative srlz_status otherwise; srlz_last_error() gives the text (thread-local).
+ */
+#ifndef SRLZ_H
+#define SRLZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* srlz_stream_t; /* hipStream_t */
+
+enum srlz_status {
+  SRLZ_OK = 0,
+  SRLZ_ERR_BAD_DESC = -1,   /* unsupported shape / inconsistent descriptor */
+  SRLZ_ERR_WORKSPACE = -2,  /* workspace too small */
+  SRLZ_ERR_HIP = -3,        /* a HIP runtime call failed (text in srlz_last_error) */
+  SRLZ_ERR_NULL = -4        /* required pointer is NULL */
+};
+
+int srlz_version(void);
+const char* srlz_last_error(void);
+/* Number of CUs of the current device (used by callers to size persistent grids / workspaces). */
+int srlz_device_cus(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 64 -> 64 channel convolutions (3x3, stride 1 or 2): fp32 MFMA implicit GEMM.
+ * Replaces nn.Conv2d / nn.ConvTranspose2d forward + autograd backward for
+ *   conv3x3 s1 p1      models/models.py:54,217-226      conv3x3 s2 p1   models/models.py:59
+ *   ConvTranspose2d(64,64,3,stride=2) x4               models/models.py:66,70,74,78
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int n;          /* images */
+  int hi, wi;     /* forward-input spatial size  (NHWC, 64 channels) */
+  int ho, wo;     /* forward-output spatial size (NHWC, 64 channels) */
+  int ksize;      /* 3 */
+  int stride;     /* 1 or 2 */
+  int pad;        /* conv: zero padding; convT: `padding` argument */
+  int transposed; /* 0 = nn.Conv2d, 1 = nn.ConvTranspose2d */
+} srlz_conv64_desc;
+
+/* floats needed for one packed weight copy (9 taps x 64 x 64) */
+size_t srlz_conv64_packed_floats(void);
+/* w_ref (reference layout) -> wpack_fwd (forward / weight-grad operand) and wpack_bwd (data-grad operand). */
+int srlz_conv64_pack_weights(const float* w_ref, float* wpack_fwd, float* wpack_bwd,
+                             const srlz_conv64_desc* d, srlz_stream_t stream);
+/* number of per-tile BatchNorm partial records forward() writes (each record = 128 floats: sum[64], sumsq[64]) */
+int srlz_conv64_fwd_tiles(const srlz_conv64_desc* d);
+/* y = conv(x) (+bias).  bias may be NULL.  stats_partial may be NULL; otherwise receives
+ * srlz_conv64_fwd_tiles(d) x 128 floats of per-tile sum / sum-of-squares per channel over y (BatchNorm input). */
+int srlz_conv64_fwd(const float* x, const float* wpack_fwd, const float* bias, float* y, float* stats_partial,
+                    const srlz_conv64_desc* d, srlz_stream_t stream);
+/* dx = d(loss)/d(x) from dy. */
+int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx,
+                         const srlz_conv64_desc* d, srlz_stream_t stream);
+/* workspace (bytes) for bwd_weight */
+size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d);
+/* dw_ref (reference layout) = d(loss)/d(w); dbias[64] = sum of dy over n,h,w (may be NULL).
+ * Deterministic: split-K partials in `ws`, fixed-order second-stage reduction (learner.py:62 asks cuDNN for the same). */
+int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float* dbias, void* ws, size_t ws_bytes,
+                           const srlz_conv64_desc* d, srlz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * "Skinny" convolutions: one side has C in {3,6,9} image channels stored NCHW, the other 64 channels NHWC.
+ *   kind 0: nn.Conv2d(C,64,k=7,s=2,p=3,bias=False)       models/models.py:49   (encoder conv1)
+ *   kind 1: nn.ConvTranspose2d(64,C,k=4,s=2)             models/models.py:82   (decoder's last layer)
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int n;       /* images */
+  int c;       /* image channels: 3, 6 or 9 */
+  int himg, wimg; /* image-side spatial size (224 x 224) */
+  int hf, wf;  /* 64-channel feature-map spatial size (112x112 for kind 0, 111x111 for kind 1) */
+  int kind;    /* 0 = conv1 7x7 s2 p3 ; 1 = convT 4x4 s2 p0 */
+} srlz_skinny_desc;
+
+int srlz_skinny_tiles(const srlz_skinny_desc* d); /* BN partial records written by conv1 forward */
+/* kind 0 forward: x_nchw [N,C,H,W] -> y_nhwc [N,hf,wf,64]; w_ref [64,C,7,7]. stats_partial as in srlz_conv64_fwd. */
+int srlz_conv1_fwd(const float* x_nchw, const float* w_ref, float* y_nhwc, float* stats_partial,
+                   const srlz_skinny_desc* d, srlz_stream_t stream);
+size_t srlz_skinny_bwd_weight_workspace(const srlz_skinny_desc* d);
+/* kind 0 weight gradient: dw_ref [64,C,7,7] from x_nchw and dy_nhwc. */
+int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, float* dw_ref, void* ws, size_t ws_bytes,
+                          const srlz_skinny_desc* d, srlz_stream_t stream);
+/* kind 1 forward: x_nhwc [N,hf,wf,64] -> y_nchw [N,C,H,W] = convT(x) + bias; w_ref [64,C,4,4]. */
+int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
+                       const srlz_skinny_desc* d, srlz_stream_t stream);
+/* kind 1 data gradient: dx_nhwc [N,hf,wf,64] from dy_nchw. */
+int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc,
+                            const srlz_skinny_desc* d, srlz_stream_t stream);
+/* kind 1 weight gradient: dw_ref [64,C,4,4], dbias [C]. */
+int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias,
+                              void* ws, size_t ws_bytes, const srlz_skinny_desc* d, srlz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BatchNorm2d(64) (+ ReLU (+ MaxPool 3x3 s2)) — nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d,
+ * models/models.py:50-52,55-57,60-62 (encoder) and 67-68,71-72,75-76,79-80 (decoder).
+ * bnp is a 4x64 float record {mean, invstd, scale = gamma*invstd, shift = beta - mean*scale}.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* Training-mode statistics from the convolution's per-tile partials: fills bnp and applies `repeat` momentum
+ * updates of running_mean / running_var (momentum, unbiased variance — torch defaults eps 1e-5, momentum 0.1).
+ * batch_stat[2][64] (may be NULL) receives {mean, unbiased var} so the update can be replayed (VAE getStates quirk,
+ * models/learner.py:402). */
+int srlz_bn_finalize(const float* stats_partial, int n_partials, long long count, const float* gamma,
+                     const float* beta, float eps, float momentum, int repeat, float* running_mean,
+                     float* running_var, float* bnp, float* batch_stat, srlz_stream_t stream);
+/* Eval-mode bnp from running statistics. */
+int srlz_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, float* bnp, srlz_stream_t stream);
+/* running = (1-m)*running + m*batch_stat, once (replay of a previous call's statistics). */
+int srlz_bn_replay(const float* batch_stat, float momentum, float* running_mean, float* running_var,
+                   srlz_stream_t stream);
+
+typedef struct {
+  int n, h, w;      /* input  [N,h,w,64] */
+  int hp, wp;       /* pooled [N,hp,wp,64] */
+  int pool_pad;     /* 0 or 1 (kernel 3, stride 2) */
+  int out_nchw;     /* 1: write the pooled map as [N,64,hp,wp] (feeds Linear(2304,S), autoencoders.py:107-108) */
+} srlz_pool_desc;
+
+/* pooled = maxpool3x3s2(relu(y*scale+shift)); argmax (uint8 per output, window index 0..8) may be NULL (eval). */
+int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* pooled, uint8_t* argmax,
+                          const srlz_pool_desc* d, srlz_stream_t stream);
+size_t srlz_bn_bwd_workspace(long long elems);
+/* dy (same shape as y) and dgamma[64], dbeta[64] from dpooled.  training != 0: batch-statistics backward;
+ * training == 0: running-statistics backward (validation minibatches, models/learner.py:362-364,489). */
+int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
+                          float* dy, float* dgamma, float* dbeta, int training, void* ws, size_t ws_bytes,
+                          const srlz_pool_desc* d, srlz_stream_t stream);
+/* a = relu(y*scale+shift) over `pixels` x 64 */
+int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long long pixels, srlz_stream_t stream);
+int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* da, float* dy, float* dgamma, float* dbeta,
+                     int training, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream);
+/* [N,C,H,W] <-> [N,H,W,C] for the two 6x6x64 seams around the FC layers (autoencoders.py:107-108,116-117). */
+int srlz_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, srlz_stream_t stream);
+int srlz_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, srlz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Linear layers — nn.Linear: autoencoders.py:94-100, vae.py:52-57, forward_inverse.py:16,48-55.
+ * y[M,N] = x[M,K] . w[N,K]^T + b[N]   (w in torch [out,in] layout), optional ReLU on y.
+ * ------------------------------------------------------------------------------------------------------------ */
+int srlz_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,
+                    srlz_stream_t stream);
+/* dx[M,K] = dy[M,N] . w[N,K] */
+int srlz_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, srlz_stream_t stream);
+/* dw[N,K] = dy^T . x ; db[N] = column sums of dy (may be NULL) */
+int srlz_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+                           srlz_stream_t stream);
+/* dy *= (y > 0)  — backward of the fused ReLU */
+int srlz_relu_bwd_inplace(const float* y, float* dy, long long n, srlz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Losses — losses/losses.py.  `out` scalars are device floats; partial sums are reduced in fp64 in a fixed order.
+ * ------------------------------------------------------------------------------------------------------------ */
+size_t srlz_reduce_workspace(long long n);
+/* out[0] = sum((a-b)^2)            reconstructionLoss 172-181 (caller divides by numel) / F.mse_loss(sum) 210-211 */
+int srlz_sqdiff_sum(const float* a, const float* b, long long n, float* out, void* ws, size_t ws_bytes,
+                    srlz_stream_t stream);
+/* da[i] = coef_dev[0] * coef * (a[i]-b[i])   (gradient of the above w.r.t. a; coef_dev may be NULL = 1) */
+int srlz_sqdiff_grad(const float* a, const float* b, const float* coef_dev, float coef, float* da, long long n,
+                     srlz_stream_t stream);
+/* out[0] = -0.5*sum(1 + logvar - mu^2 - exp(logvar))      kullbackLeiblerLoss 239-256 */
+int srlz_kl_sum(const float* mu, const float* logvar, long long n, float* out, void* ws, size_t ws_bytes,
+                srlz_stream_t stream);
+/* dmu += g*mu ; dlogvar += g*0.5*(exp(logvar)-1)   with g = coef_dev[0]*coef */
+int srlz_kl_grad(const float* mu, const float* logvar, const float* coef_dev, float coef, float* dmu,
+                 float* dlogvar, long long n, srlz_stream_t stream);
+/* z = eps*exp(0.5*logvar) + mu        BaseModelVAE.reparameterize models/models.py:147-165 (eps drawn by the host) */
+int srlz_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long long n,
+                     srlz_stream_t stream);
+/* dmu = dz ; dlogvar = dz*eps*0.5*exp(0.5*logvar) */
+int srlz_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar,
+                     long long n, srlz_stream_t stream);
+/* out[0] = mean_b( logsumexp(logits[b,:]) - logits[b,target[b]] )   nn.CrossEntropyLoss, inverseModelLoss 117-129
+ * dlogits (may be NULL) = (softmax - onehot)/B */
+int srlz_cross_entropy(const float* logits, const int64_t* target, int B, int A, float* out, float* dlogits,
+                       srlz_stream_t stream);
+/* cat[b,:] = [s[b,:S], onehot(a[b])]          forwardModel forward_inverse.py:21-31 + encodeOneHot models.py:229-237 */
+int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, int B, int S, int A, srlz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Adam over one flat parameter buffer — th.optim.Adam(params, lr) models/learner.py:199,495 (torch defaults).
+ * step is 1-based; grad_scale multiplies g first (1/world_size after the RCCL sum).
+ * ------------------------------------------------------------------------------------------------------------ */
+int srlz_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, srlz_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRLZ_H */

@@ -1,0 +1,457 @@
+// bn_pool.hip — BatchNorm2d(64) statistics, fused BN-apply + ReLU (+ MaxPool 3x3 s2) forward/backward, layout seams.
+// Replaces nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d of /root/reference/models/models.py:50-52,55-57,60-62,67-80.
+// All kernels are HBM-bound: NHWC rows are 256 B, one thread handles 4 channels (float4), 16 threads one pixel.
+// Reductions: per-block partials (fp32 inside a block, fp64 across blocks) in a fixed order -> deterministic.
+#include "common.h"
+
+namespace {
+
+// bnp record: [0,64) mean, [64,128) invstd, [128,192) scale, [192,256) shift
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int n_partials, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, int repeat, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ bnp,
+                                   float* __restrict__ batch_stat) {
+  // one block of 256 threads: thread (c = tid & 63, part = tid >> 6) sums a strided quarter of the partial records
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  double s = 0.0, q = 0.0;
+  for (int i = part; i < n_partials; i += 4) {
+    s += (double)partial[(size_t)i * 128 + c];
+    q += (double)partial[(size_t)i * 128 + 64 + c];
+  }
+  __shared__ double sm[2][4][64];
+  sm[0][part][c] = s; sm[1][part][c] = q;
+  __syncthreads();
+  if (part == 0) {
+    s = sm[0][0][c] + sm[0][1][c] + sm[0][2][c] + sm[0][3][c];
+    q = sm[1][0][c] + sm[1][1][c] + sm[1][2][c] + sm[1][3][c];
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma[c], b = beta[c];
+    const float scale = g * invstd;
+    bnp[c] = (float)mean; bnp[64 + c] = invstd; bnp[128 + c] = scale; bnp[192 + c] = b - (float)mean * scale;
+    const double unbiased = (count > 1.0) ? var * count / (count - 1.0) : var;
+    if (batch_stat) { batch_stat[c] = (float)mean; batch_stat[64 + c] = (float)unbiased; }
+    if (running_mean && running_var) {
+      float rm = running_mean[c], rv = running_var[c];
+      for (int r = 0; r < repeat; ++r) {
+        rm = (1.f - momentum) * rm + momentum * (float)mean;
+        rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+      }
+      running_mean[c] = rm; running_var[c] = rv;
+    }
+  }
+}
+
+__global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* bnp) {
+  const int c = threadIdx.x;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float scale = gamma[c] * invstd;
+  bnp[c] = rm[c]; bnp[64 + c] = invstd; bnp[128 + c] = scale; bnp[192 + c] = beta[c] - rm[c] * scale;
+}
+
+__global__ void bn_replay_kernel(const float* batch_stat, float momentum, float* rm, float* rv) {
+  const int c = threadIdx.x;
+  rm[c] = (1.f - momentum) * rm[c] + momentum * batch_stat[c];
+  rv[c] = (1.f - momentum) * rv[c] + momentum * batch_stat[64 + c];
+}
+
+// ---- fused BN-apply + ReLU + MaxPool(3, stride 2, pad p) forward ----
+// Element (pooled pixel, 4 channels) per thread.  argmax = window index ky*3+kx of the first maximum.
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                              float* __restrict__ pooled, uint8_t* __restrict__ argmax,
+                                                              int N, int H, int W, int HP, int WP, int pad, int out_nchw) {
+  const long long total = (long long)N * HP * WP * 16;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(id & 15);
+    const long long pix = id >> 4;
+    const int px = (int)(pix % WP);
+    const long long t = pix / WP;
+    const int py = (int)(t % HP);
+    const int n = (int)(t / HP);
+    const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
+    const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
+    f32x4 best = {-1.f, -1.f, -1.f, -1.f};  // relu output is >= 0, so -1 marks "nothing seen yet"
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = py * 2 - pad + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = px * 2 - pad + kx;
+        if (ix < 0 || ix >= W) continue;
+        const f32x4 v = *(const f32x4*)(y + ((size_t)(n * H + iy) * W + ix) * 64 + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float z = v[j] * sc[j] + sh[j];
+          z = z > 0.f ? z : 0.f;
+          if (z > best[j]) { best[j] = z; bi[j] = ky * 3 + kx; }
+        }
+      }
+    }
+    if (out_nchw) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px] = best[j];
+    } else {
+      *(f32x4*)(pooled + (size_t)pix * 64 + c4 * 4) = best;
+    }
+    if (argmax) {
+      const uint32_t packed = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+      *(uint32_t*)(argmax + (size_t)pix * 64 + c4 * 4) = packed;
+    }
+  }
+}
+
+// ---- backward, stage 1: per-channel sums of dz and dz*xhat over the pooled outputs (dz lives at the argmax) ----
+// partial[block][128]: [0,64) sum dz, [64,128) sum dz*xhat
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                              const uint8_t* __restrict__ argmax,
+                                                              const float* __restrict__ dpooled, float* __restrict__ partial,
+                                                              int N, int H, int W, int HP, int WP, int pad, int dp_nchw) {
+  const int c4 = threadIdx.x & 15;
+  const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
+  const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
+  const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
+  const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const long long npix = (long long)N * HP * WP;
+  for (long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long long)gridDim.x * 16) {
+    const int px = (int)(pix % WP);
+    const long long t = pix / WP;
+    const int py = (int)(t % HP);
+    const int n = (int)(t / HP);
+    const uint32_t packed = *(const uint32_t*)(argmax + (size_t)pix * 64 + c4 * 4);
+    f32x4 dp;
+    if (dp_nchw) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dp[j] = dpooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px];
+    } else {
+      dp = *(const f32x4*)(dpooled + (size_t)pix * 64 + c4 * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int a = (packed >> (8 * j)) & 0xff;
+      const int iy = py * 2 - pad + a / 3, ix = px * 2 - pad + a % 3;
+      const float v = y[((size_t)(n * H + iy) * W + ix) * 64 + c4 * 4 + j];
+      const float z = v * sc[j] + sh[j];
+      if (z > 0.f) {
+        s1[j] += dp[j];
+        s2[j] += dp[j] * (v - mean[j]) * invstd[j];
+      }
+    }
+  }
+  __shared__ float sm[16][128];
+  const int prow = threadIdx.x >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sm[prow][c4 * 4 + j] = s1[j]; sm[prow][64 + c4 * 4 + j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += sm[r][threadIdx.x];
+    partial[(size_t)blockIdx.x * 128 + threadIdx.x] = s;
+  }
+}
+
+// sums[0..64) = sum dz (= dbeta), sums[64..128) = sum dz*xhat (= dgamma); also written to dgamma/dbeta
+__global__ void bn_bwd_finalize(const float* __restrict__ partial, int nblocks, float* __restrict__ sums,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = threadIdx.x;  // 128 threads
+  double s = 0.0;
+  for (int i = 0; i < nblocks; ++i) s += (double)partial[(size_t)i * 128 + c];
+  sums[c] = (float)s;
+  if (c < 64) { if (dbeta) dbeta[c] = (float)s; } else { if (dgamma) dgamma[c - 64] = (float)s; }
+}
+
+// ---- backward, stage 2: dy = scale * (dz - m1 - xhat*m2) (training) or scale * dz (eval) for every y element ----
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                             const uint8_t* __restrict__ argmax,
+                                                             const float* __restrict__ dpooled, const float* __restrict__ sums,
+                                                             float* __restrict__ dy, int N, int H, int W, int HP, int WP,
+                                                             int pad, int dp_nchw, int training, float inv_count) {
+  const long long total = (long long)N * H * W * 16;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(id & 15);
+    const long long pix = id >> 4;
+    const int ix = (int)(pix % W);
+    const long long t = pix / W;
+    const int iy = (int)(t % H);
+    const int n = (int)(t / H);
+    const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
+    const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
+    const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
+    const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
+    const f32x4 v = *(const f32x4*)(y + (size_t)pix * 64 + c4 * 4);
+    f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+    // pooled outputs whose window contains (iy,ix): py with py*2 - pad + ky == iy, ky in 0..2
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = iy + pad - ky;
+      if (ty < 0 || (ty & 1)) continue;
+      const int py = ty >> 1;
+      if (py >= HP) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = ix + pad - kx;
+        if (tx < 0 || (tx & 1)) continue;
+        const int px = tx >> 1;
+        if (px >= WP) continue;
+        const size_t pp = ((size_t)(n * HP + py) * WP + px);
+        const uint32_t packed = *(const uint32_t*)(argmax + pp * 64 + c4 * 4);
+        const int me = ky * 3 + kx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((int)((packed >> (8 * j)) & 0xff) == me) {
+            dz[j] += dp_nchw ? dpooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px]
+                             : dpooled[pp * 64 + c4 * 4 + j];
+          }
+        }
+      }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = v[j] * sc[j] + sh[j];
+      const float d = z > 0.f ? dz[j] : 0.f;
+      if (training) {
+        const float xh = (v[j] - mean[j]) * invstd[j];
+        o[j] = sc[j] * (d - sums[c4 * 4 + j] * inv_count - xh * sums[64 + c4 * 4 + j] * inv_count);
+      } else {
+        o[j] = sc[j] * d;
+      }
+    }
+    *(f32x4*)(dy + (size_t)pix * 64 + c4 * 4) = o;
+  }
+}
+
+// ---- BN-apply + ReLU (decoder) ----
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                         float* __restrict__ a, long long pixels) {
+  const long long total = pixels * 16;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(id & 15);
+    const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
+    const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
+    const f32x4 v = *(const f32x4*)(y + id * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float z = v[j] * sc[j] + sh[j]; o[j] = z > 0.f ? z : 0.f; }
+    *(f32x4*)(a + id * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                         const float* __restrict__ da, float* __restrict__ partial,
+                                                         long long pixels) {
+  const int c4 = threadIdx.x & 15;
+  const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
+  const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
+  const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
+  const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < pixels; pix += (long long)gridDim.x * 16) {
+    const f32x4 v = *(const f32x4*)(y + pix * 64 + c4 * 4);
+    const f32x4 d = *(const f32x4*)(da + pix * 64 + c4 * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = v[j] * sc[j] + sh[j];
+      if (z > 0.f) { s1[j] += d[j]; s2[j] += d[j] * (v[j] - mean[j]) * invstd[j]; }
+    }
+  }
+  __shared__ float sm[16][128];
+  const int prow = threadIdx.x >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sm[prow][c4 * 4 + j] = s1[j]; sm[prow][64 + c4 * 4 + j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += sm[r][threadIdx.x];
+    partial[(size_t)blockIdx.x * 128 + threadIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                        const float* __restrict__ da, const float* __restrict__ sums,
+                                                        float* __restrict__ dy, long long pixels, int training,
+                                                        float inv_count) {
+  const long long total = pixels * 16;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(id & 15);
+    const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
+    const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
+    const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
+    const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
+    const f32x4 v = *(const f32x4*)(y + id * 4);
+    const f32x4 d = *(const f32x4*)(da + id * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = v[j] * sc[j] + sh[j];
+      const float g = z > 0.f ? d[j] : 0.f;
+      if (training) {
+        const float xh = (v[j] - mean[j]) * invstd[j];
+        o[j] = sc[j] * (g - sums[c4 * 4 + j] * inv_count - xh * sums[64 + c4 * 4 + j] * inv_count);
+      } else {
+        o[j] = sc[j] * g;
+      }
+    }
+    *(f32x4*)(dy + id * 4) = o;
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
+  const long long total = (long long)N * C * HW;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(id % C);
+    const long long t = id / C;
+    const int p = (int)(t % HW);
+    const long long n = t / HW;
+    dst[id] = src[((size_t)n * C + c) * HW + p];
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
+  const long long total = (long long)N * C * HW;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(id % HW);
+    const long long t = id / HW;
+    const int c = (int)(t % C);
+    const long long n = t / C;
+    dst[id] = src[((size_t)n * HW + p) * C + c];
+  }
+}
+
+static int grid_for(long long work_items, int per_block) {
+  long long b = (work_items + per_block - 1) / per_block;
+  const long long cap = 8LL * srlz_device_cus();
+  if (b > cap) b = cap;
+  return b < 1 ? 1 : (int)b;
+}
+
+constexpr int RED_BLOCKS = 1024;
+
+static int check_pool(const srlz_pool_desc* d) {
+  SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "pool: null descriptor");
+  SRLZ_REQUIRE(d->n > 0 && (d->pool_pad == 0 || d->pool_pad == 1), SRLZ_ERR_BAD_DESC, "pool: bad descriptor");
+  SRLZ_REQUIRE(d->hp == (d->h + 2 * d->pool_pad - 3) / 2 + 1 && d->wp == (d->w + 2 * d->pool_pad - 3) / 2 + 1,
+               SRLZ_ERR_BAD_DESC, "pool: pooled size %dx%d inconsistent with %dx%d pad %d", d->hp, d->wp, d->h, d->w, d->pool_pad);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, long long count, const float* gamma,
+                                const float* beta, float eps, float momentum, int repeat, float* running_mean,
+                                float* running_var, float* bnp, float* batch_stat, srlz_stream_t stream) {
+  SRLZ_REQUIRE(stats_partial && gamma && beta && bnp, SRLZ_ERR_NULL, "bn_finalize: null pointer");
+  SRLZ_REQUIRE(n_partials > 0 && count > 0, SRLZ_ERR_BAD_DESC, "bn_finalize: empty reduction");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), stats_partial, n_partials, (double)count,
+                     gamma, beta, eps, momentum, repeat, running_mean, running_var, bnp, batch_stat);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* bnp, srlz_stream_t stream) {
+  SRLZ_REQUIRE(gamma && beta && running_mean && running_var && bnp, SRLZ_ERR_NULL, "bn_eval_params: null pointer");
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3(1), dim3(64), 0, as_stream(stream), gamma, beta, running_mean, running_var,
+                     eps, bnp);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_bn_replay(const float* batch_stat, float momentum, float* running_mean, float* running_var,
+                              srlz_stream_t stream) {
+  SRLZ_REQUIRE(batch_stat && running_mean && running_var, SRLZ_ERR_NULL, "bn_replay: null pointer");
+  hipLaunchKernelGGL(bn_replay_kernel, dim3(1), dim3(64), 0, as_stream(stream), batch_stat, momentum, running_mean, running_var);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* pooled, uint8_t* argmax,
+                                     const srlz_pool_desc* d, srlz_stream_t stream) {
+  if (int rc = check_pool(d)) return rc;
+  SRLZ_REQUIRE(y && bnp && pooled, SRLZ_ERR_NULL, "bn_relu_pool_fwd: null pointer");
+  const long long items = (long long)d->n * d->hp * d->wp * 16;
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(grid_for(items, 256)), dim3(256), 0, as_stream(stream), y, bnp, pooled,
+                     argmax, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" size_t srlz_bn_bwd_workspace(long long elems) {
+  (void)elems;
+  return (size_t)(RED_BLOCKS * 128 + 128) * sizeof(float);
+}
+
+extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
+                                     float* dy, float* dgamma, float* dbeta, int training, void* ws, size_t ws_bytes,
+                                     const srlz_pool_desc* d, srlz_stream_t stream) {
+  if (int rc = check_pool(d)) return rc;
+  SRLZ_REQUIRE(y && bnp && argmax && dpooled && dy && ws, SRLZ_ERR_NULL, "bn_relu_pool_bwd: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  float* partial = (float*)ws;
+  float* sums = partial + RED_BLOCKS * 128;
+  const long long npix = (long long)d->n * d->hp * d->wp;
+  int nb = (int)((npix + 15) / 16);
+  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+  hipLaunchKernelGGL(bn_relu_pool_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, argmax, dpooled, partial, d->n, d->h, d->w,
+                     d->hp, d->wp, d->pool_pad, d->out_nchw);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, partial, nb, sums, dgamma, dbeta);
+  SRLZ_LAUNCHED();
+  const long long items = (long long)d->n * d->h * d->w * 16;
+  const float inv_count = 1.0f / (float)((double)d->n * d->h * d->w);
+  hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3(grid_for(items, 256)), dim3(256), 0, st, y, bnp, argmax, dpooled, sums, dy,
+                     d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long long pixels, srlz_stream_t stream) {
+  SRLZ_REQUIRE(y && bnp && a, SRLZ_ERR_NULL, "bn_relu_fwd: null pointer");
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(grid_for(pixels * 16, 256)), dim3(256), 0, as_stream(stream), y, bnp, a, pixels);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* da, float* dy, float* dgamma, float* dbeta,
+                                int training, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream) {
+  SRLZ_REQUIRE(y && bnp && da && dy && ws, SRLZ_ERR_NULL, "bn_relu_bwd: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  float* partial = (float*)ws;
+  float* sums = partial + RED_BLOCKS * 128;
+  int nb = (int)((pixels + 15) / 16);
+  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+  hipLaunchKernelGGL(bn_relu_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, da, partial, pixels);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, partial, nb, sums, dgamma, dbeta);
+  SRLZ_LAUNCHED();
+  const float inv_count = 1.0f / (float)(double)pixels;
+  hipLaunchKernelGGL(bn_relu_bwd_apply, dim3(grid_for(pixels * 16, 256)), dim3(256), 0, st, y, bnp, da, sums, dy, pixels,
+                     training, inv_count);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, srlz_stream_t stream) {
+  SRLZ_REQUIRE(src && dst, SRLZ_ERR_NULL, "nchw_to_nhwc: null pointer");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)n * c * h * w, 256)), dim3(256), 0, as_stream(stream), src,
+                     dst, n, c, h * w);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, srlz_stream_t stream) {
+  SRLZ_REQUIRE(src && dst, SRLZ_ERR_NULL, "nhwc_to_nchw: null pointer");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)n * c * h * w, 256)), dim3(256), 0, as_stream(stream), src,
+                     dst, n, c, h * w);
+  SRLZ_LAUNCHED();
+  return 0;
+}

@@ -1,0 +1,518 @@
+// conv64.hip — 3x3, 64->64 channel convolutions and transposed convolutions (stride 1 / 2) as fp32-MFMA implicit GEMM.
+//
+// Replaces (forward + autograd backward) nn.Conv2d / nn.ConvTranspose2d of /root/reference/models/models.py:54,59
+// (conv3x3 s1/s2) and :66,70,74,78 (ConvTranspose2d(64,64,3,stride=2) x4).
+//
+// One formulation covers every case ("virtual-grid program"):
+//   * a virtual grid of PH x PW positions per image, flattened to q = (n*PH + a)*PW + b;
+//   * source class c = (cy,cx):  S_c(q) = src[n, a*ss+cy, b*ss+cx, :]  (64 floats) if in bounds, else 0;
+//   * dest   class d = (dy,dx):  D_d(q) -> dst[n, a*ds+dy, b*ds+dx, :] if in bounds, else discarded;
+//   * D_d(q) = sum over taps t of  S_{c_t}(q + off_t) . W[w_t]   (W[w] is a 64x64 slab of the 3x3 kernel).
+// PH/PW carry one spare (zero) row/column so that a flat offset never wraps onto real data (see build_program).
+//   conv s1         : 1 src class, 1 dst class, 9 taps          (conv2 fwd, conv2 dgrad)
+//   conv s2 (gather): 4 src classes (input parity), 1 dst class  (conv3 fwd, ConvT dgrad)
+//   convT s2 (scatter): 1 src class, 4 dst classes (output parity, 4/2/2/1 taps) (ConvT fwd, conv3 dgrad)
+// GEMM view per tile: M = 128 grid positions, N = 64 output channels, K = 64 input channels per tap.
+//
+// Kernel structure (fwd): 256 threads = 4 waves, wave w owns rows [32w,32w+32) x 64 columns = two 32x32
+// v_mfma_f32_32x32x2_f32 accumulators.  The source rows the tile touches (128 + halo) are staged ONCE in LDS and
+// re-used by all taps; the weight slab of the current tap (16 KB) is staged per tap.  Both operands are read with
+// ds_read_b128: lanes 0-31 take k = 8c..8c+3 and lanes 32-63 k = 8c+4..8c+7 of a chunk (MFMA k-order is free as
+// long as A and B agree), so one 16-byte read feeds four MFMAs.  Rows are 256 B; the 16-byte slot index is XORed
+// with (row & 15) so a 16-lane ds_read_b128 group (consecutive rows, same k) covers all 64 banks.
+// LDS: (128+116)*256 + 16384 + 1536 = 80.4 KB for conv2 -> 2 workgroups per CU, which is what hides the staging.
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 128;       // grid positions per forward tile
+constexpr int TK = 64;        // grid positions per weight-gradient chunk
+constexpr int NTAPS = 9;
+
+struct ConvProg {
+  int N, PH, PW, PHW, total_q;
+  int ss, Hs, Ws;  // source: stride, image dims
+  int ds, Hd, Wd;  // dest
+  int tsrc[NTAPS], tdst[NTAPS], toff[NTAPS], tw[NTAPS];
+  int min_off, span;
+  int s2;          // 1 if taps are grouped {4,2,2,1} by class, 0 if a single group of 9
+};
+
+struct Axis {
+  int cls[3], d[3];  // per kernel index ky: class (parity) and grid offset
+};
+
+// GATHER: out[o] = sum_k in[o*s - p + k];  SCATTER: out[o] = sum_{k: (o+p-k)%s==0} in[(o+p-k)/s]
+static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// Build the program.  gather != 0: conv-like (dst is the low-res / same-res side); else convT-like.
+static int build_program(ConvProg* P, int gather, int stride, int pad, int N, int Hs, int Ws, int Hd, int Wd) {
+  if (stride != 1 && stride != 2) return -1;
+  P->N = N; P->Hs = Hs; P->Ws = Ws; P->Hd = Hd; P->Wd = Wd;
+  int kcls[3], kd[3];  // identical for both axes (square kernel, same stride/pad)
+  if (gather) {
+    P->ss = stride; P->ds = 1;
+    for (int k = 0; k < 3; ++k) {
+      int t = k - pad;
+      int c = ((t % stride) + stride) % stride;
+      kcls[k] = c; kd[k] = (t - c) / stride;
+    }
+  } else {
+    P->ss = 1; P->ds = stride;
+    // for dest class py: k valid iff (py + pad - k) % stride == 0; exactly one py per k
+    for (int k = 0; k < 3; ++k) {
+      int py = (((k - pad) % stride) + stride) % stride;
+      kcls[k] = py; kd[k] = floordiv(py + pad - k, stride);
+      if ((py + pad - k) != kd[k] * stride) return -1;
+    }
+  }
+  // grid extents per axis
+  auto extent = [&](int Hsrc, int Hdst) {
+    int mx = 0, mn = 0;
+    for (int k = 0; k < 3; ++k) { if (kd[k] > mx) mx = kd[k]; if (kd[k] < mn) mn = kd[k]; }
+    int n_out = (Hdst + P->ds - 1) / P->ds;
+    int n_src = (Hsrc + P->ss - 1) / P->ss;
+    int ph = n_out + mx; if (n_src > ph) ph = n_src;
+    if (mn < 0) {
+      // the last row must read as zero for every source class (it is what offset -1 wraps onto)
+      bool nonzero = false;
+      for (int c = 0; c < P->ss; ++c) if (P->ss * (ph - 1) + c < Hsrc) nonzero = true;
+      if (nonzero) ph += 1;
+      if (mn < -1) return -1;
+    }
+    return ph;
+  };
+  P->PH = extent(Hs, Hd);
+  P->PW = extent(Ws, Wd);
+  if (P->PH <= 0 || P->PW <= 0) return -1;
+  P->PHW = P->PH * P->PW;
+  long long tq = (long long)N * P->PHW;
+  if (tq > 0x7fffff00LL) return -1;
+  P->total_q = (int)tq;
+  // taps, grouped by class, groups in descending size (4,2,2,1 for stride 2)
+  int nclass = stride * stride;
+  int order[4] = {0, 1, 2, 3}, cnt[4] = {0, 0, 0, 0};
+  for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) cnt[kcls[ky] * stride + kcls[kx]]++;
+  for (int i = 0; i < nclass; ++i) for (int j = i + 1; j < nclass; ++j)
+    if (cnt[order[j]] > cnt[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+  int nt = 0;
+  P->min_off = 0; int max_off = 0;
+  for (int g = 0; g < nclass; ++g) {
+    int cy = order[g] / stride, cx = order[g] % stride;
+    for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+      if (kcls[ky] != cy || kcls[kx] != cx) continue;
+      int cls2 = cy * 2 + cx;  // class encoding used by the kernels: (cy<<1)|cx
+      P->tsrc[nt] = gather ? cls2 : 0;
+      P->tdst[nt] = gather ? 0 : cls2;
+      P->toff[nt] = kd[ky] * P->PW + kd[kx];
+      P->tw[nt] = ky * 3 + kx;
+      if (P->toff[nt] < P->min_off) P->min_off = P->toff[nt];
+      if (P->toff[nt] > max_off) max_off = P->toff[nt];
+      nt++;
+    }
+  }
+  if (nt != NTAPS) return -1;
+  P->span = max_off - P->min_off;
+  P->s2 = (stride == 2);
+  if (P->s2 && !(cnt[order[0]] == 4 && cnt[order[1]] == 2 && cnt[order[2]] == 2 && cnt[order[3]] == 1)) return -1;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tile staging: rows [qstart, qstart+nrows) of class `cls` of an NHWC/64 tensor -> LDS (256 B per row).
+// 16 lanes fetch one row (256 contiguous bytes); out-of-range rows are zero-filled.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool SWZ>
+__device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
+                                           int stride, int cls, int PW, int PHW, int total_q, int qstart,
+                                           int nrows) {
+  const int t = threadIdx.x;
+  const int slot = t & 15;
+  const int cy = cls >> 1, cx = cls & 1;
+  for (int R = t >> 4; R < nrows; R += 16) {
+    const int q = qstart + R;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q >= 0 && q < total_q) {
+      const int n = q / PHW;
+      const int rem = q - n * PHW;
+      const int a = rem / PW;
+      const int b = rem - a * PW;
+      const int y = a * stride + cy, x = b * stride + cx;
+      if (y < H && x < W) v = *(const f32x4*)(src + ((size_t)(n * H + y) * W + x) * 64 + slot * 4);
+    }
+    const int sl = SWZ ? (slot ^ (R & 15)) : slot;
+    *(f32x4*)(lds + R * 64 + sl * 4) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward / data-gradient kernel
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restrict__ src,
+                                                           const float* __restrict__ wpack,
+                                                           const float* __restrict__ bias, float* __restrict__ dst,
+                                                           float* __restrict__ stats_partial, const ConvProg P,
+                                                           int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* As = (float*)smem;                 // (TM + span) x 64, swizzled
+  float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap, pre-swizzled in global
+  int* rowinfo = (int*)(Bs + 4096);         // [3][TM]: image index (or -1), a*ds, b*ds
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int q0 = tile * TM;
+
+  if (tid < TM) {
+    const int q = q0 + tid;
+    int n = -1, ya = 0, xb = 0;
+    if (q < P.total_q) {
+      n = q / P.PHW;
+      const int rem = q - n * P.PHW;
+      const int a = rem / P.PW;
+      ya = a * P.ds;
+      xb = (rem - a * P.PW) * P.ds;
+    }
+    rowinfo[tid] = n; rowinfo[TM + tid] = ya; rowinfo[2 * TM + tid] = xb;
+  }
+
+  f32x16 acc0, acc1;
+  float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;  // BatchNorm partials (columns l31 and l31+32)
+  const float bias0 = bias ? bias[l31] : 0.f;
+  const float bias1 = bias ? bias[l31 + 32] : 0.f;
+
+  int cur_src = -1, cur_dst = -1;
+
+  auto flush = [&](int d) {
+    const int dy = d >> 1, dx = d & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int n = rowinfo[row];
+      const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
+      if (n >= 0 && y < P.Hd && x < P.Wd) {
+        const float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+        float* o = dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 + l31;
+        o[0] = v0; o[32] = v1;
+        s0 += v0; ss0 += v0 * v0; s1 += v1; ss1 += v1 * v1;
+      }
+    }
+  };
+
+#pragma unroll
+  for (int ti = 0; ti < NTAPS; ++ti) {
+    const int tsrc = P.tsrc[ti], tdst = P.tdst[ti];
+    __syncthreads();  // all waves are done with the previous tap's Bs (and with As if it is about to be replaced)
+    if (tdst != cur_dst) {
+      if (cur_dst >= 0) flush(cur_dst);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      cur_dst = tdst;
+    }
+    if (tsrc != cur_src) {
+      stage_rows<true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PHW, P.total_q, q0 + P.min_off, TM + P.span);
+      cur_src = tsrc;
+    }
+    {  // weight slab: 16 KB linear copy
+      const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[ti] * 4096);
+      f32x4* wdst = (f32x4*)Bs;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wdst[i * 256 + tid] = wsrc[i * 256 + tid];
+    }
+    __syncthreads();
+    const int R = wave * 32 + l31 + P.toff[ti] - P.min_off;
+    const float* arow = As + R * 64;
+    const int akey = R & 15;
+    const float* brow0 = Bs + l31 * 64;
+    const float* brow1 = Bs + (l31 + 32) * 64;
+    const int bkey = lane & 15;
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+      const int slot = kc * 2 + h;
+      const f32x4 a = *(const f32x4*)(arow + ((slot ^ akey) << 2));
+      const f32x4 b0 = *(const f32x4*)(brow0 + ((slot ^ bkey) << 2));
+      const f32x4 b1 = *(const f32x4*)(brow1 + ((slot ^ bkey) << 2));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0[r], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1[r], acc1, 0, 0, 0);
+      }
+    }
+  }
+  flush(cur_dst);
+
+  if (stats_partial) {
+    // lanes l and l+32 hold the same columns; then the 4 waves are combined through LDS
+    s0 += __shfl_xor(s0, 32, 64); ss0 += __shfl_xor(ss0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64); ss1 += __shfl_xor(ss1, 32, 64);
+    __syncthreads();
+    float* red = Bs;  // [4 waves][128]
+    if (h == 0) {
+      red[wave * 128 + l31] = s0; red[wave * 128 + 32 + l31] = s1;
+      red[wave * 128 + 64 + l31] = ss0; red[wave * 128 + 96 + l31] = ss1;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const float v = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+      stats_partial[(size_t)tile * 128 + tid] = v;  // [0,64): sum, [64,128): sum of squares
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-gradient kernel: dW[w][ci][co] = sum_q S_c(q+off)[ci] * G_d(q)[co]   (G = dy at dest class d).
+// GEMM view: M = ci (64), N = co (64), K = grid positions.  4 waves = 4 quadrants of 32x32, each holding all 9 taps
+// (144 accumulator registers); persistent over K-chunks of 64 positions; per-workgroup partials are reduced by
+// conv64_wgrad_reduce in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool S2>
+__global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ g,
+                                                             float* __restrict__ partial, const ConvProg P,
+                                                             int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Ss = (float*)smem;              // (TK + span) x 64
+  float* Gs = Ss + (TK + P.span) * 64;   // TK x 64
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mi = wave & 1, nj = wave >> 1;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;  // column sum of dy (bias gradient): thread (col = tid&63, part = tid>>6)
+
+  constexpr int NG = S2 ? 4 : 1;
+  constexpr int GSTART[5] = {0, S2 ? 4 : 9, 6, 8, 9};
+
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int q0 = chunk * TK;
+    int cur_s = -1, cur_g = -1;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int t0 = GSTART[gi], t1 = GSTART[gi + 1];
+      const int cs = P.tsrc[t0], cd = P.tdst[t0];
+      __syncthreads();
+      if (cs != cur_s) {
+        stage_rows<false>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PHW, P.total_q, q0 + P.min_off, TK + P.span);
+        cur_s = cs;
+      }
+      const bool newg = (cd != cur_g);
+      if (newg) {
+        stage_rows<false>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PHW, P.total_q, q0, TK);
+        cur_g = cd;
+      }
+      __syncthreads();
+      if (newg) {
+        const int col = tid & 63, part = tid >> 6;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bsum += Gs[(part * 16 + r) * 64 + col];
+      }
+      const float* gcol = Gs + nj * 32 + l31;
+      const float* scol = Ss + mi * 32 + l31;
+#pragma unroll 4
+      for (int ks = 0; ks < TK / 2; ++ks) {
+        const int row = 2 * ks + h;
+        const float bfrag = gcol[row * 64];
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {
+          const float afrag = scol[(row + P.toff[t] - P.min_off) * 64];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial[wg][9 (reference tap index)][64 ci][64 co] + [wg][64] bias sums after all workgroups' tap blocks
+  float* out = partial + (size_t)blockIdx.x * (NTAPS * 4096);
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t) {
+    float* o = out + (size_t)P.tw[t] * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      o[row * 64 + nj * 32 + l31] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  float* red = Ss;
+  red[tid] = bsum;
+  __syncthreads();
+  if (tid < 64) {
+    float* bout = partial + (size_t)gridDim.x * (NTAPS * 4096) + (size_t)blockIdx.x * 64;
+    bout[tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+  }
+}
+
+// dw_ref[...] = sum over workgroups (fixed order); layout: conv [co][ci][3][3], convT [ci][co][3][3].
+__global__ void conv64_wgrad_reduce(const float* __restrict__ partial, int nwg, float* __restrict__ dw_ref,
+                                    float* __restrict__ dbias, int transposed) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id < NTAPS * 4096) {
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * (NTAPS * 4096) + id];
+    const int tap = id >> 12, ci = (id >> 6) & 63, co = id & 63;
+    const int o = transposed ? ((ci * 64 + co) * 9 + tap) : ((co * 64 + ci) * 9 + tap);
+    dw_ref[o] = s;
+  } else if (id < NTAPS * 4096 + 64 && dbias) {
+    const int c = id - NTAPS * 4096;
+    const float* b = partial + (size_t)nwg * (NTAPS * 4096);
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += b[(size_t)w * 64 + c];
+    dbias[c] = s;
+  }
+}
+
+// w_ref -> packed [tap][n_out][slot ^ (n_out&15)][4]; fwd: (n=co,k=ci), bwd: (n=ci,k=co)
+__global__ void conv64_pack_kernel(const float* __restrict__ w_ref, float* __restrict__ pf, float* __restrict__ pb,
+                                   int transposed) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= NTAPS * 4096) return;
+  const int tap = id >> 12, n = (id >> 6) & 63, k = id & 63;
+  const int o = (tap * 64 + n) * 64 + ((((k >> 2) ^ (n & 15)) << 2) | (k & 3));
+  // reference element [A][B][tap]: conv A=co,B=ci ; convT A=ci,B=co
+  const int fwd_idx = transposed ? ((k * 64 + n) * 9 + tap) : ((n * 64 + k) * 9 + tap);
+  const int bwd_idx = transposed ? ((n * 64 + k) * 9 + tap) : ((k * 64 + n) * 9 + tap);
+  if (pf) pf[o] = w_ref[fwd_idx];
+  if (pb) pb[o] = w_ref[bwd_idx];
+}
+
+static int check_desc(const srlz_conv64_desc* d) {
+  SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "conv64: null descriptor");
+  SRLZ_REQUIRE(d->ksize == 3 && (d->stride == 1 || d->stride == 2) && d->n > 0, SRLZ_ERR_BAD_DESC,
+               "conv64: only 3x3 stride 1/2 supported (k=%d s=%d)", d->ksize, d->stride);
+  int eho, ewo;
+  if (!d->transposed) {
+    eho = (d->hi + 2 * d->pad - 3) / d->stride + 1;
+    ewo = (d->wi + 2 * d->pad - 3) / d->stride + 1;
+  } else {
+    eho = (d->hi - 1) * d->stride - 2 * d->pad + 3;
+    ewo = (d->wi - 1) * d->stride - 2 * d->pad + 3;
+  }
+  SRLZ_REQUIRE(eho == d->ho && ewo == d->wo, SRLZ_ERR_BAD_DESC, "conv64: output size %dx%d inconsistent (expected %dx%d)",
+               d->ho, d->wo, eho, ewo);
+  return 0;
+}
+
+static int program_for(ConvProg* P, const srlz_conv64_desc* d, int backward_data) {
+  int rc;
+  if (!backward_data)
+    rc = build_program(P, !d->transposed, d->stride, d->pad, d->n, d->hi, d->wi, d->ho, d->wo);
+  else
+    rc = build_program(P, d->transposed, d->stride, d->pad, d->n, d->ho, d->wo, d->hi, d->wi);
+  SRLZ_REQUIRE(rc == 0, SRLZ_ERR_BAD_DESC, "conv64: cannot build a grid program for this descriptor");
+  return 0;
+}
+
+static size_t fwd_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) * 256 + 16384 + 3 * TM * 4; }
+static size_t wgrad_lds_bytes(const ConvProg& P) { return (size_t)(TK + P.span + TK) * 256; }
+
+static int launch_fwd(const float* src, const float* wpack, const float* bias, float* dst, float* stats,
+                      const ConvProg& P, hipStream_t st) {
+  const int ntiles = (P.total_q + TM - 1) / TM;
+  const size_t lds = fwd_lds_bytes(P);
+  SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64: tile needs %zu bytes of LDS", lds);
+  SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(conv64_fwd_kernel, dim3(ntiles), dim3(256), lds, st, src, wpack, bias, dst, stats, P, ntiles);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+static int wgrad_grid(const ConvProg& P) {
+  const int nchunks = (P.total_q + TK - 1) / TK;
+  int g = 2 * srlz_device_cus();
+  if (g > nchunks) g = nchunks;
+  return g < 1 ? 1 : g;
+}
+
+}  // namespace
+
+extern "C" size_t srlz_conv64_packed_floats(void) { return (size_t)NTAPS * 4096; }
+
+extern "C" int srlz_conv64_pack_weights(const float* w_ref, float* wpack_fwd, float* wpack_bwd,
+                                        const srlz_conv64_desc* d, srlz_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRLZ_REQUIRE(w_ref, SRLZ_ERR_NULL, "conv64_pack: null weights");
+  hipLaunchKernelGGL(conv64_pack_kernel, dim3((NTAPS * 4096 + 255) / 256), dim3(256), 0, as_stream(stream), w_ref,
+                     wpack_fwd, wpack_bwd, d->transposed);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_conv64_fwd_tiles(const srlz_conv64_desc* d) {
+  if (check_desc(d)) return -1;
+  ConvProg P;
+  if (program_for(&P, d, 0)) return -1;
+  return (P.total_q + TM - 1) / TM;
+}
+
+extern "C" int srlz_conv64_fwd(const float* x, const float* wpack_fwd, const float* bias, float* y,
+                               float* stats_partial, const srlz_conv64_desc* d, srlz_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRLZ_REQUIRE(x && wpack_fwd && y, SRLZ_ERR_NULL, "conv64_fwd: null pointer");
+  ConvProg P;
+  if (int rc = program_for(&P, d, 0)) return rc;
+  return launch_fwd(x, wpack_fwd, bias, y, stats_partial, P, as_stream(stream));
+}
+
+extern "C" int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx, const srlz_conv64_desc* d,
+                                    srlz_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRLZ_REQUIRE(dy && wpack_bwd && dx, SRLZ_ERR_NULL, "conv64_bwd_data: null pointer");
+  ConvProg P;
+  if (int rc = program_for(&P, d, 1)) return rc;
+  return launch_fwd(dy, wpack_bwd, nullptr, dx, nullptr, P, as_stream(stream));
+}
+
+extern "C" size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d) {
+  if (check_desc(d)) return 0;
+  ConvProg P;
+  if (program_for(&P, d, 0)) return 0;
+  return (size_t)wgrad_grid(P) * (NTAPS * 4096 + 64) * sizeof(float);
+}
+
+extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float* dbias, void* ws,
+                                      size_t ws_bytes, const srlz_conv64_desc* d, srlz_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRLZ_REQUIRE(x && dy && dw_ref && ws, SRLZ_ERR_NULL, "conv64_bwd_weight: null pointer");
+  ConvProg P;
+  if (int rc = program_for(&P, d, 0)) return rc;
+  const int grid = wgrad_grid(P);
+  SRLZ_REQUIRE(ws_bytes >= (size_t)grid * (NTAPS * 4096 + 64) * sizeof(float), SRLZ_ERR_WORKSPACE,
+               "conv64_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
+  const int nchunks = (P.total_q + TK - 1) / TK;
+  const size_t lds = wgrad_lds_bytes(P);
+  SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64 wgrad: chunk needs %zu bytes of LDS", lds);
+  hipStream_t st = as_stream(stream);
+  float* partial = (float*)ws;
+  if (P.s2) {
+    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv64_wgrad_kernel<true>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks);
+  } else {
+    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv64_wgrad_kernel<false>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks);
+  }
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(256), 0, st, partial, grid,
+                     dw_ref, dbias, d->transposed);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+// Debug/test hook (host only, no GPU needed): dump the grid program so tests can interpret it on the CPU.
+// out[0..]: N,PH,PW,ss,Hs,Ws,ds,Hd,Wd,min_off,span,s2, then 9 x {src,dst,off,w}.  Returns number of ints or <0.
+extern "C" int srlz_conv64_debug_program(const srlz_conv64_desc* d, int backward_data, int* out, int cap) {
+  if (int rc = check_desc(d)) return rc;
+  ConvProg P;
+  if (int rc = program_for(&P, d, backward_data)) return rc;
+  if (cap < 12 + 4 * NTAPS) return SRLZ_ERR_WORKSPACE;
+  int i = 0;
+  out[i++] = P.N; out[i++] = P.PH; out[i++] = P.PW; out[i++] = P.ss; out[i++] = P.Hs; out[i++] = P.Ws;
+  out[i++] = P.ds; out[i++] = P.Hd; out[i++] = P.Wd; out[i++] = P.min_off; out[i++] = P.span; out[i++] = P.s2;
+  for (int t = 0; t < NTAPS; ++t) { out[i++] = P.tsrc[t]; out[i++] = P.tdst[t]; out[i++] = P.toff[t]; out[i++] = P.tw[t]; }
+  return i;
+}

@@ -1,0 +1,123 @@
+// linear.hip — nn.Linear forward / backward as one strided fp32-MFMA GEMM.
+// Replaces nn.Linear of /root/reference/models/autoencoders.py:94-100, models/vae.py:52-57,
+// models/forward_inverse.py:16,48-55 (and their autograd backward).
+//   C[i][j] = sum_r A(i,r) * B(r,j)  (+ bias[j]) (+ ReLU),  A(i,r) = A[i*sai + r*sar],  B(r,j) = B[r*sbr + j*sbj]
+//   forward   : i=m, j=n, r=k : A = x  (sai=K, sar=1), B = w (sbr=1, sbj=K)
+//   data grad : i=m, j=k, r=n : A = dy (sai=N, sar=1), B = w (sbr=K, sbj=1)
+//   weight grad: i=n, j=k, r=m : A = dy (sai=1, sar=N), B = x (sbr=K, sbj=1)
+// 64x64 tile per workgroup, 4 waves = 4 quadrants of v_mfma_f32_32x32x2_f32, r-step 16 through LDS ([r][i] layout,
+// padded).  These GEMMs are tiny (M = batch); the kernel is deliberately simple.
+#include "common.h"
+
+namespace {
+
+constexpr int BR = 16;
+constexpr int LD = 68;  // 64 + 4 padding floats
+
+__global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restrict__ A, long long sai, long long sar,
+                                                          const float* __restrict__ B, long long sbr, long long sbj,
+                                                          const float* __restrict__ bias, float* __restrict__ C, int I,
+                                                          int J, int R, int relu) {
+  __shared__ float As[BR][LD];
+  __shared__ float Bs[BR][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wi = wave & 1, wj = wave >> 1;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int r0 = 0; r0 < R; r0 += BR) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;  // 1024 elements of a 64 x 16 tile
+      int i, r;
+      if (sar == 1) { i = e >> 4; r = e & 15; } else { r = e >> 6; i = e & 63; }
+      float v = 0.f;
+      if (i0 + i < I && r0 + r < R) v = A[(long long)(i0 + i) * sai + (long long)(r0 + r) * sar];
+      As[r][i] = v;
+      int j, rb;
+      if (sbr == 1) { j = e >> 4; rb = e & 15; } else { rb = e >> 6; j = e & 63; }
+      float w = 0.f;
+      if (j0 + j < J && r0 + rb < R) w = B[(long long)(r0 + rb) * sbr + (long long)(j0 + j) * sbj];
+      Bs[rb][j] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < BR / 2; ++s) {
+      const float a = As[2 * s + h][wi * 32 + l31];
+      const float b = Bs[2 * s + h][wj * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  const int j = j0 + wj * 32 + l31;
+  const float bj = (bias && j < J) ? bias[j] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (i < I && j < J) {
+      float v = acc[r] + bj;
+      if (relu) v = v > 0.f ? v : 0.f;
+      C[(long long)i * J + j] = v;
+    }
+  }
+}
+
+// db[n] = sum_m dy[m][n]
+__global__ void colsum_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += dy[(long long)m * N + n];
+  db[n] = s;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ y, float* __restrict__ dy, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (!(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+static int launch(const float* A, long long sai, long long sar, const float* B, long long sbr, long long sbj,
+                  const float* bias, float* C, int I, int J, int R, int relu, hipStream_t st) {
+  SRLZ_REQUIRE(I > 0 && J > 0 && R > 0, SRLZ_ERR_BAD_DESC, "linear: empty GEMM %dx%dx%d", I, J, R);
+  hipLaunchKernelGGL(gemm_strided_kernel, dim3((J + 63) / 64, (I + 63) / 64), dim3(256), 0, st, A, sai, sar, B, sbr, sbj,
+                     bias, C, I, J, R, relu);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int srlz_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,
+                               srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && w && y, SRLZ_ERR_NULL, "linear_fwd: null pointer");
+  return launch(x, K, 1, w, 1, K, b, y, M, N, K, relu, as_stream(stream));
+}
+
+extern "C" int srlz_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, srlz_stream_t stream) {
+  SRLZ_REQUIRE(dy && w && dx, SRLZ_ERR_NULL, "linear_bwd_data: null pointer");
+  return launch(dy, N, 1, w, K, 1, nullptr, dx, M, K, N, 0, as_stream(stream));
+}
+
+extern "C" int srlz_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+                                      srlz_stream_t stream) {
+  SRLZ_REQUIRE(dy && x && dw, SRLZ_ERR_NULL, "linear_bwd_weight: null pointer");
+  if (int rc = launch(dy, 1, N, x, K, 1, nullptr, dw, N, K, M, 0, as_stream(stream))) return rc;
+  if (db) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), dy, db, M, N);
+    SRLZ_LAUNCHED();
+  }
+  return 0;
+}
+
+extern "C" int srlz_relu_bwd_inplace(const float* y, float* dy, long long n, srlz_stream_t stream) {
+  SRLZ_REQUIRE(y && dy, SRLZ_ERR_NULL, "relu_bwd: null pointer");
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), y, dy, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}

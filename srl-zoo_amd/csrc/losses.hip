@@ -1,0 +1,239 @@
+// losses.hip — loss reductions, their gradients, the small head glue and Adam.
+// Replaces the torch arithmetic behind /root/reference/losses/losses.py:102-129 (forward / inverse model losses),
+// :172-214 (reconstruction / generation), :239-256 (KL), models/models.py:147-165 (reparameterisation),
+// models/models.py:229-237 (one-hot) and th.optim.Adam (models/learner.py:199,495).
+// Reductions: fp32 per thread over a strided slice, fp64 from the wave level up, fixed order -> deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;
+
+template <int OP>  // 0: (a-b)^2 ; 1: -0.5*(1 + b - a^2 - exp(b))  (a = mu, b = logvar)
+__global__ __launch_bounds__(256) void reduce_partial(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                     double* __restrict__ partial) {
+  double acc = 0.0;
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  float local = 0.f;
+  int cnt = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 x = *(const f32x4*)(a + i * 4);
+    const f32x4 y = *(const f32x4*)(b + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (OP == 0) { const float d = x[j] - y[j]; local += d * d; }
+      else local += -0.5f * (1.f + y[j] - x[j] * x[j] - expf(y[j]));
+    }
+    if (++cnt == 8) { acc += (double)local; local = 0.f; cnt = 0; }
+  }
+  // tail
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (OP == 0) { const float d = a[i] - b[i]; local += d * d; }
+    else local += -0.5f * (1.f + b[i] - a[i] * a[i] - expf(b[i]));
+  }
+  acc += (double)local;
+  acc = wave_sum_d(acc);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void reduce_final(const double* __restrict__ partial, int nb, float* __restrict__ out) {
+  // one wave
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void sqdiff_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ coef_dev, float coef,
+                                                         float* __restrict__ da, long long n) {
+  const float g = (coef_dev ? coef_dev[0] : 1.f) * coef;
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 x = *(const f32x4*)(a + i * 4);
+    const f32x4 y = *(const f32x4*)(b + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g * (x[j] - y[j]);
+    *(f32x4*)(da + i * 4) = o;
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) da[i] = g * (a[i] - b[i]);
+}
+
+__global__ void kl_grad_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ coef_dev,
+                               float coef, float* __restrict__ dmu, float* __restrict__ dlv, long long n) {
+  const float g = (coef_dev ? coef_dev[0] : 1.f) * coef;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    dmu[i] += g * mu[i];
+    dlv[i] += g * 0.5f * (expf(lv[i]) - 1.f);
+  }
+}
+
+__global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                                   float* __restrict__ z, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    z[i] = eps[i] * expf(0.5f * lv[i]) + mu[i];
+}
+
+__global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ lv, const float* __restrict__ eps,
+                                   float* __restrict__ dmu, float* __restrict__ dlv, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    dmu[i] = dz[i];
+    dlv[i] = dz[i] * eps[i] * 0.5f * expf(0.5f * lv[i]);
+  }
+}
+
+// one block; thread per sample
+__global__ void cross_entropy_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int B, int A,
+                                     float* __restrict__ out, float* __restrict__ dlogits) {
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float* l = logits + (size_t)b * A;
+    float mx = l[0];
+    for (int j = 1; j < A; ++j) mx = l[j] > mx ? l[j] : mx;
+    float se = 0.f;
+    for (int j = 0; j < A; ++j) se += expf(l[j] - mx);
+    const float lse = mx + logf(se);
+    const int t = (int)target[b];
+    acc += (double)(lse - l[t]);
+    if (dlogits) {
+      const float invB = 1.f / (float)B;
+      for (int j = 0; j < A; ++j) dlogits[(size_t)b * A + j] = (expf(l[j] - lse) - (j == t ? 1.f : 0.f)) * invB;
+    }
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) / (double)B);
+}
+
+__global__ void concat_onehot_kernel(const float* __restrict__ s, const int64_t* __restrict__ a, float* __restrict__ cat,
+                                     int B, int S, int A) {
+  const int total = B * (S + A);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / (S + A), j = i - b * (S + A);
+    cat[i] = (j < S) ? s[(size_t)b * S + j] : ((int)a[b] == j - S ? 1.f : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                  float bc1, float bc2_sqrt, float grad_scale) {
+  // torch.optim.Adam (no amsgrad, no weight decay): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+  // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+
+static int blocks_for(long long n, int cap) {
+  long long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  return b < 1 ? 1 : (int)b;
+}
+
+template <int OP>
+static int reduce_launch(const float* a, const float* b, long long n, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+  SRLZ_REQUIRE(a && b && out && ws, SRLZ_ERR_NULL, "reduce: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= RED_BLOCKS * sizeof(double), SRLZ_ERR_WORKSPACE, "reduce: workspace too small");
+  SRLZ_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, SRLZ_ERR_BAD_DESC, "reduce: inputs must be 16-byte aligned");
+  const int nb = blocks_for((n + 3) / 4, RED_BLOCKS);
+  hipLaunchKernelGGL(reduce_partial<OP>, dim3(nb), dim3(256), 0, st, a, b, n, (double*)ws);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(reduce_final, dim3(1), dim3(64), 0, st, (const double*)ws, nb, out);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t srlz_reduce_workspace(long long n) {
+  (void)n;
+  return RED_BLOCKS * sizeof(double);
+}
+
+extern "C" int srlz_sqdiff_sum(const float* a, const float* b, long long n, float* out, void* ws, size_t ws_bytes,
+                               srlz_stream_t stream) {
+  return reduce_launch<0>(a, b, n, out, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int srlz_sqdiff_grad(const float* a, const float* b, const float* coef_dev, float coef, float* da, long long n,
+                                srlz_stream_t stream) {
+  SRLZ_REQUIRE(a && b && da, SRLZ_ERR_NULL, "sqdiff_grad: null pointer");
+  hipLaunchKernelGGL(sqdiff_grad_kernel, dim3(blocks_for((n + 3) / 4, 8192)), dim3(256), 0, as_stream(stream), a, b, coef_dev,
+                     coef, da, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_kl_sum(const float* mu, const float* logvar, long long n, float* out, void* ws, size_t ws_bytes,
+                           srlz_stream_t stream) {
+  return reduce_launch<1>(mu, logvar, n, out, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int srlz_kl_grad(const float* mu, const float* logvar, const float* coef_dev, float coef, float* dmu,
+                            float* dlogvar, long long n, srlz_stream_t stream) {
+  SRLZ_REQUIRE(mu && logvar && dmu && dlogvar, SRLZ_ERR_NULL, "kl_grad: null pointer");
+  hipLaunchKernelGGL(kl_grad_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), mu, logvar, coef_dev, coef,
+                     dmu, dlogvar, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long long n,
+                                srlz_stream_t stream) {
+  SRLZ_REQUIRE(mu && logvar && eps && z, SRLZ_ERR_NULL, "reparam_fwd: null pointer");
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), mu, logvar, eps, z, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar,
+                                long long n, srlz_stream_t stream) {
+  SRLZ_REQUIRE(dz && logvar && eps && dmu && dlogvar, SRLZ_ERR_NULL, "reparam_bwd: null pointer");
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), dz, logvar, eps, dmu,
+                     dlogvar, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_cross_entropy(const float* logits, const int64_t* target, int B, int A, float* out, float* dlogits,
+                                  srlz_stream_t stream) {
+  SRLZ_REQUIRE(logits && target && out, SRLZ_ERR_NULL, "cross_entropy: null pointer");
+  SRLZ_REQUIRE(B > 0 && A > 0, SRLZ_ERR_BAD_DESC, "cross_entropy: empty batch");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, target, B, A, out, dlogits);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, int B, int S, int A, srlz_stream_t stream) {
+  SRLZ_REQUIRE(s && a && cat, SRLZ_ERR_NULL, "concat_onehot: null pointer");
+  hipLaunchKernelGGL(concat_onehot_kernel, dim3(blocks_for((long long)B * (S + A), 1024)), dim3(256), 0, as_stream(stream), s, a,
+                     cat, B, S, A);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                              float eps, int step, float grad_scale, srlz_stream_t stream) {
+  SRLZ_REQUIRE(p && g && m && v, SRLZ_ERR_NULL, "adam_step: null pointer");
+  SRLZ_REQUIRE(step >= 1, SRLZ_ERR_BAD_DESC, "adam_step: step is 1-based");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2,
+                     eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  SRLZ_LAUNCHED();
+  return 0;
+}

@@ -1,0 +1,483 @@
+// skinny.hip — the two image-side layers: one operand has C in {3,6,9} channels stored NCHW (the reference's image
+// layout), the other 64 channels NHWC.  Both are stride-2 and share one formulation:
+//   kind 0: nn.Conv2d(C,64,k=7,s=2,p=3,bias=False)    /root/reference/models/models.py:49   (K=7, PAD=3)
+//   kind 1: nn.ConvTranspose2d(64,C,k=4,s=2)          /root/reference/models/models.py:82   (K=4, PAD=0)
+// Kernels
+//   skinny_conv_kernel<K,PAD>   feat[pix][64] = im2col(img)[pix][3*K*K] . W        kind0 forward, kind1 data-grad
+//   skinny_wgrad_kernel<K,PAD>  dW[64][3*K*K] = sum_pix feat[pix][64] (x) im2col(img)[pix][:]  kind0/kind1 weight-grad
+//   convT_out_kernel            img = col2im(feat[pix][64] . W[64][C*16]) + bias   kind1 forward
+// The image tile lives in LDS with even/odd columns de-interleaved (stride-2 taps become unit-stride, conflict-free
+// ds_read_b32) and is re-used by all taps; im2col is never materialised.  fp32 MFMA 32x32x2 (16x16x4 for the
+// 48-column convT GEMM).  Channels are processed in groups of 3 (C=6/9 multi-view loops over groups).
+#include "common.h"
+
+namespace {
+
+constexpr int XP = 24;  // LDS row pitch (floats) of one half-row; 2*XP % 32 == 16 -> two tile rows never collide
+
+template <int K>
+struct Geo {
+  static constexpr int ROWS = 30 + K;              // image rows/cols feeding a 16x16 output tile
+  static constexpr int COLS = 30 + K;
+  static constexpr int KT = 3 * K * K;             // taps per channel group
+  static constexpr int KS = (KT + 1) / 2;          // MFMA k-steps (2 taps per step)
+  static constexpr int TILE_FLOATS = 3 * 2 * ROWS * XP;
+};
+
+template <int K>
+__host__ __device__ constexpr int koff(int k) {
+  // LDS offset of tap k = (c,ky,kx) relative to the pixel base (2*ty*XP + tx)
+  const int kk = (k < Geo<K>::KT) ? k : 0;
+  const int c = kk / (K * K), ky = (kk / K) % K, kx = kk % K;
+  return ((c * 2 + (kx & 1)) * Geo<K>::ROWS + ky) * XP + (kx >> 1);
+}
+
+// Stage channels [3cg, 3cg+3) of the image window of output tile (oy0, ox0) into LDS.
+template <int K, int PAD>
+__device__ __forceinline__ void stage_image(float* __restrict__ T, const float* __restrict__ img, int n, int C,
+                                            int cg, int H, int W, int oy0, int ox0) {
+  constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS;
+  const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
+  for (int idx = threadIdx.x; idx < 3 * ROWS * COLS; idx += 256) {
+    const int c = idx / (ROWS * COLS);
+    const int rem = idx - c * (ROWS * COLS);
+    const int r = rem / COLS, xl = rem - r * COLS;
+    const int iy = iy0 + r, ix = ix0 + xl;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix];
+    T[((c * 2 + (xl & 1)) * ROWS + r) * XP + (xl >> 1)] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// feat[n,oy,ox,:] = sum_{c,ky,kx} img[n,c,2oy-PAD+ky,2ox-PAD+kx] * w_ref[:,c,ky,kx]      (w_ref: [64][C][K][K])
+// 256 threads, tile = 16x16 output pixels; wave w owns tile rows 4w..4w+3 (two 32-pixel M-tiles) x 64 channels.
+// Persistent over tiles; for C == 3 the 64 x KT weight matrix is staged in LDS once per workgroup.
+// ------------------------------------------------------------------------------------------------------------------
+template <int K, int PAD>
+__global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __restrict__ img,
+                                                            const float* __restrict__ w_ref,
+                                                            float* __restrict__ feat,
+                                                            float* __restrict__ stats_partial, int N, int C, int H,
+                                                            int W, int HF, int WF, int tiles_y, int tiles_x) {
+  constexpr int KT = Geo<K>::KT, KS = Geo<K>::KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* T = (float*)smem;                      // image window
+  float* Wl = T + Geo<K>::TILE_FLOATS;          // [KS][2][64]
+  float* red = Wl + KS * 128;                   // [4][128]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ncg = C / 3;
+  const int ntiles = N * tiles_y * tiles_x;
+
+  auto stage_weights = [&](int cg) {
+    for (int idx = tid; idx < KS * 128; idx += 256) {
+      const int co = idx & 63, sh = idx >> 6;
+      const int k = (sh & 1) * KS + (sh >> 1);
+      float v = 0.f;
+      if (k < KT) v = w_ref[((size_t)co * C + cg * 3) * (K * K) + k];  // [co][cg*3 + c][ky][kx], k = (c*K+ky)*K+kx
+      Wl[idx] = v;
+    }
+  };
+  if (ncg == 1) stage_weights(0);
+
+  const int tx = l31 & 15, tyl = l31 >> 4;
+  const int pb0 = 2 * (wave * 4 + tyl) * XP + tx;        // M-tile 0: tile rows 4w, 4w+1
+  const int pb1 = pb0 + 4 * XP;                          // M-tile 1: tile rows 4w+2, 4w+3
+  const float* wl0 = Wl + h * 64 + l31;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tiles_y * tiles_x);
+    const int trem = tile - n * (tiles_y * tiles_x);
+    const int oy0 = (trem / tiles_x) * 16, ox0 = (trem % tiles_x) * 16;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int cg = 0; cg < ncg; ++cg) {
+      __syncthreads();
+      stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
+      if (ncg > 1) stage_weights(cg);
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int ko = h ? koff<K>(KS + s) : koff<K>(s);
+        const float a0 = T[pb0 + ko], a1 = T[pb1 + ko];
+        const float b0 = wl0[s * 128], b1 = wl0[s * 128 + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int oy = oy0 + wave * 4 + mt * 2 + (i >> 4), ox = ox0 + (i & 15);
+        if (oy < HF && ox < WF) {
+          const float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
+          float* o = feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + l31;
+          o[0] = v0; o[32] = v1;
+          s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1;
+        }
+      }
+    if (stats_partial) {
+      s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+      if (h == 0) {
+        red[wave * 128 + l31] = s0; red[wave * 128 + 32 + l31] = s1;
+        red[wave * 128 + 64 + l31] = q0; red[wave * 128 + 96 + l31] = q1;
+      }
+      __syncthreads();
+      if (tid < 128) stats_partial[(size_t)tile * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dW[ch][k] = sum_{n,pix} feat[n,pix,ch] * im2col(img)[n,pix,k]     ch in [0,64), k = (c,ky,kx) of channel group cg.
+// GEMM view: M = 64 feature channels (2 M-tiles), N = KT taps (NT tiles of 32), K = pixels.
+// Wave w owns M-tile (w&1) and N-tiles (w>>1), (w>>1)+2, ...; every wave walks all 256 pixels of a tile.
+// Persistent over tiles; per-workgroup partial [64][NT*32] -> skinny_wgrad_reduce (fixed order).
+// ------------------------------------------------------------------------------------------------------------------
+template <int K, int PAD>
+__global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __restrict__ img,
+                                                             const float* __restrict__ feat,
+                                                             float* __restrict__ partial, int N, int C, int H, int W,
+                                                             int HF, int WF, int tiles_y, int tiles_x) {
+  constexpr int KT = Geo<K>::KT;
+  constexpr int NT = (KT + 31) / 32;
+  constexpr int MAXJ = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* T = (float*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mt = wave & 1, nt0 = wave >> 1;
+  const int cg = blockIdx.y;
+  const int ntiles = N * tiles_y * tiles_x;
+
+  int kb[MAXJ];  // per-lane LDS offset of this lane's tap in N-tile j (+h: the odd pixel of a k-step is one column on)
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int k = (nt0 + 2 * j) * 32 + l31;
+    const int kk = (k < KT) ? k : 0;
+    const int c = kk / (K * K), ky = (kk / K) % K, kx = kk % K;
+    kb[j] = ((c * 2 + (kx & 1)) * Geo<K>::ROWS + ky) * XP + (kx >> 1) + h;
+  }
+  f32x16 acc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tiles_y * tiles_x);
+    const int trem = tile - n * (tiles_y * tiles_x);
+    const int oy0 = (trem / tiles_x) * 16, ox0 = (trem % tiles_x) * 16;
+    __syncthreads();
+    stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
+    __syncthreads();
+    // 128 k-steps: step s covers pixels (ty = s>>3, tx = 2*(s&7) + h)
+#pragma unroll 1
+    for (int sb = 0; sb < 128; sb += 8) {
+      float a[8];
+      const int ty = sb >> 3;
+      const int oy = oy0 + ty;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ox = ox0 + 2 * u + h;
+        a[u] = (oy < HF && ox < WF) ? feat[((size_t)(n * HF + oy) * WF + ox) * 64 + mt * 32 + l31] : 0.f;
+      }
+      const int base = 2 * ty * XP;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+          if (nt0 + 2 * j < NT) {
+            const float b = T[base + 2 * u + kb[j]];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b, acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  float* out = partial + ((size_t)cg * gridDim.x + blockIdx.x) * (64 * NT * 32);
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    if (nt0 + 2 * j < NT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[row * (NT * 32) + (nt0 + 2 * j) * 32 + l31] = acc[j][r];
+      }
+    }
+  }
+}
+
+// dw_ref[ch][cg*3+c][ky][kx] = sum over workgroups of partial[cg][wg][ch][k]
+__global__ void skinny_wgrad_reduce(const float* __restrict__ partial, int nwg, int C, int KK, int KT, int NTW,
+                                    float* __restrict__ dw_ref) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncg = C / 3;
+  if (id >= ncg * 64 * KT) return;
+  const int cg = id / (64 * KT);
+  const int rem = id - cg * 64 * KT;
+  const int ch = rem / KT, k = rem - ch * KT;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += partial[((size_t)cg * nwg + w) * (64 * NTW) + ch * NTW + k];
+  dw_ref[((size_t)ch * C + cg * 3) * KK + k] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kind 1 forward: img[n,co,oy,ox] = bias[co] + sum_{ci,ky,kx: oy=2iy+ky, ox=2ix+kx} feat[n,iy,ix,ci]*w_ref[ci,co,ky,kx]
+// Tile: 16x16 positions of the (a,b) = (oy>>1, ox>>1) grid -> 32x32 output pixels x 3 channels; needs the 17x17 feature
+// pixels (a0-1.., b0-1..).  Step 1: Tt[p][co*16+tap] = feat[p][:] . W (M = 289 px in 19 M-tiles of 16, N = 48, K = 64)
+// with v_mfma_f32_16x16x4_f32, A fragments straight from global (each is used once), B held in 48 VGPRs.
+// Step 2: every output pixel sums its 2x2 contributing (pixel, tap) pairs from LDS and is stored NCHW.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int TP = 49;  // LDS pitch (floats) of one feature pixel's 48 products
+
+__global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restrict__ feat,
+                                                          const float* __restrict__ w_ref,
+                                                          const float* __restrict__ bias, float* __restrict__ img,
+                                                          int N, int C, int H, int W, int HF, int WF, int tiles_y,
+                                                          int tiles_x) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Tt = (float*)smem;  // [304][TP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int cg = blockIdx.y;
+  const int ntiles = N * tiles_y * tiles_x;
+
+  // B fragments: breg[co][c][r] = w_ref[ci = 16c + 4kq + r][cg*3 + co][tap = li]
+  f32x4 breg[3][4];
+#pragma unroll
+  for (int co = 0; co < 3; ++co)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        breg[co][c][r] = w_ref[((size_t)(16 * c + 4 * kq + r) * C + cg * 3 + co) * 16 + li];
+  float bs[3];
+#pragma unroll
+  for (int co = 0; co < 3; ++co) bs[co] = bias ? bias[cg * 3 + co] : 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tiles_y * tiles_x);
+    const int trem = tile - n * (tiles_y * tiles_x);
+    const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
+    __syncthreads();  // previous tile's gather is done with Tt
+    for (int mtile = wave; mtile < 19; mtile += 4) {
+      const int p = mtile * 16 + li;
+      const int ia = p / 17, ib = p - ia * 17;
+      const int fy = a0 - 1 + ia, fx = b0 - 1 + ib;
+      const bool ok = (p < 289) && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
+      const float* src = feat + ((size_t)(n * HF + (ok ? fy : 0)) * WF + (ok ? fx : 0)) * 64 + 4 * kq;
+      f32x4 a[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a[c] = *(const f32x4*)(src + 16 * c);
+        if (!ok) a[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      f32x4 acc[3];
+#pragma unroll
+      for (int co = 0; co < 3; ++co) {
+        acc[co] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][r], breg[co][c][r], acc[co], 0, 0, 0);
+      }
+      // D layout: column (tap) = lane & 15, row (pixel) = (lane >> 4) * 4 + reg
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tt[(mtile * 16 + kq * 4 + r) * TP + co * 16 + li] = acc[co][r];
+    }
+    __syncthreads();
+    const int oxl = tid & 31, rg = tid >> 5;
+    const int bl = oxl >> 1, px = oxl & 1;
+    const int ox = 2 * b0 + oxl;
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oyl = rg + 8 * i;
+        const int al = oyl >> 1, py = oyl & 1;
+        const int oy = 2 * a0 + oyl;
+        float v = bs[co];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx)
+            v += Tt[((al + 1 - dy) * 17 + (bl + 1 - dx)) * TP + co * 16 + (py + 2 * dy) * 4 + (px + 2 * dx)];
+        if (oy < H && ox < W) img[((size_t)(n * C + cg * 3 + co) * H + oy) * W + ox] = v;
+      }
+    }
+  }
+}
+
+// per-channel sum of an NCHW tensor (bias gradient of the last ConvTranspose): partial then final, fixed order.
+__global__ void nchw_chan_sum_partial(const float* __restrict__ x, int N, int C, int HW, double* __restrict__ partial) {
+  // grid (64, C): block (bx, c) sums elements of channel c with stride 64 blocks over (n, hw)
+  const int c = blockIdx.y;
+  const long long total = (long long)N * HW;
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW, r = i - n * HW;
+    s += (double)x[((size_t)n * C + c) * HW + r];
+  }
+  s = wave_sum_d(s);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[c * gridDim.x + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ void nchw_chan_sum_final(const double* __restrict__ partial, int nb, float* __restrict__ out) {
+  const int c = threadIdx.x;
+  double s = 0.0;
+  for (int i = 0; i < nb; ++i) s += partial[c * nb + i];
+  out[c] = (float)s;
+}
+
+static int check_skinny(const srlz_skinny_desc* d) {
+  SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "skinny: null descriptor");
+  SRLZ_REQUIRE(d->n > 0 && d->c > 0 && d->c % 3 == 0 && d->c <= 9, SRLZ_ERR_BAD_DESC, "skinny: C must be 3, 6 or 9 (got %d)", d->c);
+  if (d->kind == 0) {
+    SRLZ_REQUIRE(d->hf == (d->himg + 6 - 7) / 2 + 1 && d->wf == (d->wimg + 6 - 7) / 2 + 1, SRLZ_ERR_BAD_DESC,
+                 "conv1: feature map %dx%d inconsistent with image %dx%d", d->hf, d->wf, d->himg, d->wimg);
+  } else if (d->kind == 1) {
+    SRLZ_REQUIRE(d->himg == (d->hf - 1) * 2 + 4 && d->wimg == (d->wf - 1) * 2 + 4, SRLZ_ERR_BAD_DESC,
+                 "convT_out: image %dx%d inconsistent with feature map %dx%d", d->himg, d->wimg, d->hf, d->wf);
+  } else {
+    SRLZ_REQUIRE(false, SRLZ_ERR_BAD_DESC, "skinny: unknown kind %d", d->kind);
+  }
+  return 0;
+}
+
+template <int K>
+static size_t conv_lds() { return (size_t)(Geo<K>::TILE_FLOATS + Geo<K>::KS * 128 + 512) * 4; }
+
+static int persistent_grid(int ntiles) {
+  int g = 2 * srlz_device_cus();
+  return g > ntiles ? ntiles : g;
+}
+
+template <int K, int PAD>
+static int launch_conv(const float* img, const float* w, float* feat, float* stats, const srlz_skinny_desc* d, hipStream_t st) {
+  const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
+  const int ntiles = d->n * ty * tx;
+  const size_t lds = conv_lds<K>();
+  SRLZ_HIP(hipFuncSetAttribute((const void*)skinny_conv_kernel<K, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((skinny_conv_kernel<K, PAD>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
+                     d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+template <int K>
+static size_t wgrad_ws(const srlz_skinny_desc* d) {
+  constexpr int NT = (Geo<K>::KT + 31) / 32;
+  const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
+  const int g = persistent_grid(d->n * ty * tx);
+  return (size_t)(d->c / 3) * g * 64 * NT * 32 * sizeof(float) + 64 * 16 * sizeof(double);
+}
+
+template <int K, int PAD>
+static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
+                        hipStream_t st) {
+  constexpr int NT = (Geo<K>::KT + 31) / 32;
+  const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
+  const int ntiles = d->n * ty * tx;
+  const int g = persistent_grid(ntiles);
+  SRLZ_REQUIRE(ws_bytes >= wgrad_ws<K>(d), SRLZ_ERR_WORKSPACE, "skinny wgrad: workspace too small (%zu)", ws_bytes);
+  const size_t lds = (size_t)Geo<K>::TILE_FLOATS * 4;
+  float* partial = (float*)ws;
+  hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
+                     d->himg, d->wimg, d->hf, d->wf, ty, tx);
+  SRLZ_LAUNCHED();
+  const int total = (d->c / 3) * 64 * Geo<K>::KT;
+  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, st, partial, g, d->c, K * K, Geo<K>::KT,
+                     NT * 32, dw);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int srlz_skinny_tiles(const srlz_skinny_desc* d) {
+  if (check_skinny(d)) return -1;
+  return d->n * ((d->hf + 15) / 16) * ((d->wf + 15) / 16);
+}
+
+extern "C" int srlz_conv1_fwd(const float* x_nchw, const float* w_ref, float* y_nhwc, float* stats_partial,
+                              const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 0, SRLZ_ERR_BAD_DESC, "conv1_fwd: descriptor kind must be 0");
+  SRLZ_REQUIRE(x_nchw && w_ref && y_nhwc, SRLZ_ERR_NULL, "conv1_fwd: null pointer");
+  return launch_conv<7, 3>(x_nchw, w_ref, y_nhwc, stats_partial, d, as_stream(stream));
+}
+
+extern "C" size_t srlz_skinny_bwd_weight_workspace(const srlz_skinny_desc* d) {
+  if (check_skinny(d)) return 0;
+  return d->kind == 0 ? wgrad_ws<7>(d) : wgrad_ws<4>(d);
+}
+
+extern "C" int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, float* dw_ref, void* ws, size_t ws_bytes,
+                                     const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 0, SRLZ_ERR_BAD_DESC, "conv1_bwd_weight: descriptor kind must be 0");
+  SRLZ_REQUIRE(x_nchw && dy_nhwc && dw_ref && ws, SRLZ_ERR_NULL, "conv1_bwd_weight: null pointer");
+  return launch_wgrad<7, 3>(x_nchw, dy_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream));
+}
+
+extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
+                                  const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_fwd: descriptor kind must be 1");
+  SRLZ_REQUIRE(x_nhwc && w_ref && y_nchw, SRLZ_ERR_NULL, "convT_out_fwd: null pointer");
+  const int ty = (d->himg / 2 + 15) / 16, tx = (d->wimg / 2 + 15) / 16;
+  const int ntiles = d->n * ty * tx;
+  const size_t lds = (size_t)304 * TP * 4;
+  hipLaunchKernelGGL(convT_out_kernel, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
+                     w_ref, bias, y_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const srlz_skinny_desc* d,
+                                       srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_bwd_data: descriptor kind must be 1");
+  SRLZ_REQUIRE(dy_nchw && w_ref && dx_nhwc, SRLZ_ERR_NULL, "convT_out_bwd_data: null pointer");
+  // dx[n,iy,ix,ci] = sum_{co,ky,kx} dy[n,co,2iy+ky,2ix+kx] * w_ref[ci,co,ky,kx]  == a 4x4 s2 p0 "conv" of dy
+  return launch_conv<4, 0>(dy_nchw, w_ref, dx_nhwc, nullptr, d, as_stream(stream));
+}
+
+extern "C" int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias, void* ws,
+                                         size_t ws_bytes, const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_bwd_weight: descriptor kind must be 1");
+  SRLZ_REQUIRE(x_nhwc && dy_nchw && dw_ref && ws, SRLZ_ERR_NULL, "convT_out_bwd_weight: null pointer");
+  // dw_ref[ci,co,ky,kx] = sum_{n,iy,ix} x[n,iy,ix,ci] * dy[n,co,2iy+ky,2ix+kx]
+  if (int rc = launch_wgrad<4, 0>(dy_nchw, x_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream))) return rc;
+  if (dbias) {
+    double* part = (double*)((char*)ws + wgrad_ws<4>(d) - 64 * 16 * sizeof(double));
+    hipLaunchKernelGGL(nchw_chan_sum_partial, dim3(64, d->c), dim3(256), 0, as_stream(stream), dy_nchw, d->n, d->c,
+                       d->himg * d->wimg, part);
+    SRLZ_LAUNCHED();
+    hipLaunchKernelGGL(nchw_chan_sum_final, dim3(1), dim3(d->c), 0, as_stream(stream), part, 64, dbias);
+    SRLZ_LAUNCHED();
+  }
+  return 0;
+}

@@ -1,0 +1,94 @@
+"""LossManager and the hot-path losses (reference losses/losses.py:19-59, 102-129, 172-214, 239-256).
+
+Same function names, argument order and return values as the reference; the reductions and their gradients run as
+fused HIP kernels (srlz/ops.py).  Losses of other SRL methods (priors, reward, triplet, perceptual, l1/l2, ...) are
+outside the hot path and not provided.
+"""
+from __future__ import print_function, division, absolute_import
+
+import torch as th
+
+from srlz import ops
+
+
+class LossManager:
+    """Collects (name, weight, value) triples for one minibatch, forms the weighted total and keeps the history."""
+
+    def __init__(self, model, loss_history=None):
+        """
+        :param model: (PyTorch model)
+        :param loss_history: (dict)
+        """
+        # trainable, regularisable parameters (biases excluded), as in the reference
+        self.reg_params = [param for name, param in model.named_parameters() if
+                           ".bias" not in name and param.requires_grad]
+        self.loss_history = loss_history
+        self.names, self.weights, self.losses = [], [], []
+
+    def addToLosses(self, name, weight, loss_value):
+        self.names.append(name)
+        self.weights.append(weight)
+        self.losses.append(loss_value)
+
+    def lossValues(self):
+        """All loss scalars of this minibatch with ONE device->host copy (the reference pays one .item() each)."""
+        if not self.losses:
+            return []
+        return th.stack([l.detach().reshape(()) for l in self.losses]).tolist()
+
+    def updateLossHistory(self, values=None):
+        if self.loss_history is not None:
+            if values is None:
+                values = self.lossValues()
+            for name, w, value in zip(self.names, self.weights, values):
+                if w > 0:
+                    if len(self.loss_history[name]) > 0:
+                        self.loss_history[name][-1] += w * value
+                    else:
+                        self.loss_history[name].append(w * value)
+
+    def computeTotalLoss(self):
+        return sum([self.weights[i] * self.losses[i] for i in range(len(self.losses))])
+
+    def resetLosses(self):
+        self.names, self.weights, self.losses = [], [], []
+
+
+def reconstructionLoss(input_image, target_image):
+    """sum((a-b)^2) / numel  (reference losses.py:172-181)."""
+    return ops.SqDiffSumFn.apply(input_image, target_image) / input_image.numel()
+
+
+def forwardModelLoss(next_states_pred, next_states, weight, loss_manager):
+    """mean squared error between predicted and encoded next states (reference losses.py:102-114)."""
+    forward_loss = reconstructionLoss(next_states_pred, next_states)
+    loss_manager.addToLosses('forward_loss', weight, forward_loss)
+    return weight * forward_loss
+
+
+def inverseModelLoss(actions_pred, actions_st, weight, loss_manager):
+    """cross-entropy between action logits and the taken actions (reference losses.py:117-129)."""
+    inverse_loss = ops.CrossEntropyFn.apply(actions_pred, actions_st.view(-1))
+    loss_manager.addToLosses('inverse_loss', weight, inverse_loss)
+    return weight * inverse_loss
+
+
+def autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs, weight, loss_manager):
+    """reconstruction error of both frames (reference losses.py:184-196)."""
+    ae_loss = reconstructionLoss(obs, decoded_obs) + reconstructionLoss(next_obs, decoded_next_obs)
+    loss_manager.addToLosses('reconstruction_loss', weight, ae_loss)
+    return weight * ae_loss
+
+
+def generationLoss(decoded, next_decoded, obs, next_obs, weight, loss_manager):
+    """pixel-wise summed squared error of both frames (reference losses.py:199-214)."""
+    generation_loss = ops.SqDiffSumFn.apply(decoded, obs) + ops.SqDiffSumFn.apply(next_decoded, next_obs)
+    loss_manager.addToLosses('generation_loss', weight, generation_loss)
+    return weight * generation_loss
+
+
+def kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager, beta=1):
+    """KL(q(z|x) || N(0, I)) summed over elements and batch, both frames (reference losses.py:239-256)."""
+    kl_divergence = ops.KLSumFn.apply(mu, logvar) + ops.KLSumFn.apply(next_mu, next_logvar)
+    loss_manager.addToLosses('kl_loss', beta, kl_divergence)
+    return beta * kl_divergence

@@ -1,0 +1,353 @@
+"""BaseLearner / SRL4robotics — the trainer plugin surface of the reference (models/learner.py:40-579), MI355X-native.
+
+Constructor arguments, module-level knobs (N_EPOCHS, BATCH_SIZE, ... set by train.py), ``learn()``'s signature and
+return triple, the files written and the exit codes are the reference's.  What differs is underneath:
+  * the model's forward/backward, the losses and Adam run as HIP kernels (srlz/);
+  * all parameters live in one flat buffer; one fused Adam step; with torch.distributed initialised (one process per
+    GPU, backend "nccl" == RCCL) ONE all-reduce of the flat gradient bucket per step (srlz/optim.py);
+  * loss scalars are read back once per step (one D2H copy) instead of once per loss.
+There is no CPU path: ``cuda=False`` (or no GPU) raises.
+"""
+from __future__ import print_function, division, absolute_import
+
+import json
+import os
+import sys
+import time
+from collections import defaultdict, OrderedDict
+from pprint import pprint
+
+import numpy as np
+import torch as th
+
+from losses.losses import LossManager, autoEncoderLoss, forwardModelLoss, inverseModelLoss, kullbackLeiblerLoss, \
+    generationLoss
+from pipeline import NAN_ERROR
+from preprocessing.data_loader import DataLoader
+from utils import printRed, detachToNumpy, printYellow
+from srlz import optim
+from .modules import SRLModules
+
+MAX_BATCH_SIZE_GPU = 256  # minibatch size used when predicting states
+EPOCH_FLAG = 1            # print every epoch
+N_WORKERS = 4
+
+# set by train.py from the command line (reference train.py:72-77)
+DISPLAY_PLOTS = True
+BATCH_SIZE = 256
+N_EPOCHS = 1
+VALIDATION_SIZE = 0.2
+BALANCED_SAMPLING = False
+
+SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "random"}
+
+
+def _requireGpu(cuda):
+    if not cuda or not th.cuda.is_available():
+        raise RuntimeError("srl-zoo_amd runs the training hot path on MI355X only: cuda=%s, torch.cuda.is_available()=%s. "
+                           "There is deliberately no CPU fallback (use the reference implementation on CPU)."
+                           % (cuda, th.cuda.is_available()))
+
+
+class BaseLearner(object):
+    """Base class of a state-representation learner.
+
+    :param state_dim: (int)
+    :param batch_size: (int)
+    :param seed: (int)
+    :param cuda: (bool)
+    """
+
+    def __init__(self, state_dim, batch_size, seed=1, cuda=False):
+        super(BaseLearner, self).__init__()
+        self.state_dim = state_dim
+        self.batch_size = batch_size
+        self.model = None
+        self.seed = seed
+        self.use_dae = False
+        np.random.seed(seed)
+        th.manual_seed(seed)
+        if cuda and th.cuda.is_available():
+            th.cuda.manual_seed(seed)
+        self.device = th.device("cuda" if th.cuda.is_available() and cuda else "cpu")
+
+    def _predFn(self, observations):
+        """Observations -> states (np.ndarray), model in whatever mode the caller set."""
+        return detachToNumpy(self.model.getStates(observations))
+
+    def predStatesWithDataLoader(self, data_loader):
+        """States for every minibatch the loader yields, concatenated."""
+        predictions = []
+        for obs_var in data_loader:
+            if obs_var.shape[0] == 0:  # the test minibatch list may end with an empty range
+                continue
+            predictions.append(self._predFn(obs_var.to(self.device)))
+        return np.concatenate(predictions, axis=0)
+
+    def learn(self, *args, **kwargs):
+        raise NotImplementedError("Learn method not implemented")
+
+    @staticmethod
+    def saveStates(states, images_path, rewards, log_folder, name=""):
+        """image_to_state<name>.json and states_rewards<name>.npz (reference learner.py:97-118)."""
+        print("Saving image path to state representation (image_to_state{}.json)".format(name))
+        image_to_state = {path: list(map(str, state)) for path, state in zip(images_path, states)}
+        with open("{}/image_to_state{}.json".format(log_folder, name), 'w') as f:
+            json.dump(image_to_state, f, sort_keys=True)
+        print("Saving states and rewards (states_rewards{}.npz)".format(name))
+        np.savez('{}/states_rewards{}.npz'.format(log_folder, name), states=states, rewards=rewards)
+
+
+class SRL4robotics(BaseLearner):
+    """Trainer for the conv auto-encoder / VAE / forward-inverse family.
+
+    Arguments as in the reference (models/learner.py:121-148).  Accepted but unused because their code paths are
+    outside the hot path: l1_reg / l2_reg (must be 0), split_dimensions (must be -1), path_to_dae / state_dim_dae.
+    """
+
+    def __init__(self, state_dim, model_type="resnet", inverse_model_type="linear", log_folder="logs/default",
+                 seed=1, learning_rate=0.001, l1_reg=0.0, l2_reg=0.0, cuda=False,
+                 multi_view=False, losses=None, losses_weights_dict=None, n_actions=6, beta=1,
+                 split_dimensions=-1, path_to_dae=None, state_dim_dae=200, occlusion_percentage=None):
+        super(SRL4robotics, self).__init__(state_dim, BATCH_SIZE, seed, cuda)
+        losses = list(losses) if losses is not None else []
+        unsupported = set(losses) - SUPPORTED_LOSSES
+        if unsupported:
+            raise NotImplementedError("losses %s are outside the MI355X hot path of this build (supported: %s)"
+                                      % (sorted(unsupported), sorted(SUPPORTED_LOSSES)))
+        if isinstance(split_dimensions, dict) and sum(split_dimensions.values()) > 0:
+            raise NotImplementedError("split state representation (SRLModulesSplit) is not part of this build yet")
+        if l1_reg > 0 or l2_reg > 0:
+            raise NotImplementedError("l1/l2 regularisation losses are outside the MI355X hot path of this build")
+
+        self.multi_view = multi_view
+        self.losses = losses
+        self.dim_action = n_actions
+        self.beta = beta
+        self.use_forward_loss = "forward" in losses
+        self.use_inverse_loss = "inverse" in losses
+        self.use_autoencoder = "autoencoder" in losses
+        self.use_vae = "vae" in losses
+        self.use_dae = "dae" in losses
+        self.use_triplets = False
+
+        self.model = SRLModules(state_dim=self.state_dim, action_dim=self.dim_action, model_type=model_type,
+                                cuda=cuda, losses=losses, inverse_model_type=inverse_model_type)
+        print("Using {} model".format(model_type))
+
+        _requireGpu(cuda)
+        self.cuda = cuda
+        self.device = th.device("cuda", th.cuda.current_device())
+        self.model = self.model.to(self.device)
+        self.rank, self.world_size = optim.world()
+
+        # one flat parameter / gradient buffer + fused Adam (torch.optim.Adam defaults)
+        self.flat_params = optim.FlatParams(self.model)
+        self.optimizer = optim.FusedAdam(self.flat_params, lr=learning_rate)
+        self.log_folder = log_folder
+        self.model_type = model_type
+
+        self.losses_weights_dict = {"forward": 1.0, "inverse": 2.0, "reward": 1.0, "priors": 1.0,
+                                    "episode-prior": 1.0, "reward-prior": 10, "triplet": 1.0,
+                                    "autoencoder": 1.0, "vae": 0.5e-6, "perceptual": 1e-6, "dae": 1.0,
+                                    'l1_reg': l1_reg, "l2_reg": l2_reg, 'random': 1.0}
+        self.occlusion_percentage = occlusion_percentage
+        self.state_dim_dae = state_dim_dae
+        if losses_weights_dict is not None:
+            self.losses_weights_dict.update(losses_weights_dict)
+        if self.use_dae and self.occlusion_percentage is not None:
+            print("Using a maximum occlusion surface of {}".format(str(self.occlusion_percentage)))
+
+    @staticmethod
+    def loadSavedModel(log_folder, valid_models, cuda=True):
+        """Rebuild a learner from <log_folder>/exp_config.json + srl_model.pth.
+        :return: (SRL4robotics, OrderedDict)"""
+        assert os.path.exists(log_folder), "Error: folder '{}' does not exist".format(log_folder)
+        assert os.path.exists(log_folder + "exp_config.json"), \
+            "Error: could not find 'exp_config.json' in '{}'".format(log_folder)
+        assert os.path.exists(log_folder + "srl_model.pth"), \
+            "Error: could not find 'srl_model.pth' in '{}'".format(log_folder)
+        with open(log_folder + 'exp_config.json', 'r') as f:
+            exp_config = json.load(f, object_pairs_hook=OrderedDict)  # keep the order of the losses
+
+        losses = exp_config['losses']
+        difference = set(losses).symmetric_difference(valid_models)
+        assert set(losses).intersection(valid_models) != set(), "Error: Not supported losses " + ", ".join(difference)
+
+        if exp_config.get('multi-view', False):
+            import preprocessing.preprocess as pre
+            pre.N_CHANNELS = 6
+        srl_model = SRL4robotics(exp_config['state-dim'], model_type=exp_config['model-type'], cuda=cuda,
+                                 multi_view=exp_config.get('multi-view', False), losses=losses,
+                                 n_actions=exp_config['n_actions'],
+                                 split_dimensions=exp_config.get('split-dimensions', -1),
+                                 inverse_model_type=exp_config.get('inverse-model-type', 'linear'),
+                                 occlusion_percentage=exp_config.get('occlusion-percentage', 0))
+        srl_model.model.load_state_dict(th.load(log_folder + 'srl_model.pth', map_location=srl_model.device))
+        return srl_model, exp_config
+
+    # ---------------------------------------------------------------------------------------------------------
+    def saveModel(self, path):
+        """th.save(state_dict) with the reference's keys and NCHW shapes (CPU tensors, loadable anywhere)."""
+        th.save(OrderedDict((k, v.detach().cpu().clone()) for k, v in self.model.state_dict().items()), path)
+
+    def trainStep(self, obs, next_obs, actions_st, loss_manager, validation_mode=False, noisy_obs=None,
+                  next_noisy_obs=None):
+        """The minibatch-loop body of the reference (models/learner.py:362-497) on device tensors.
+
+        Runs forward, losses, backward (also on validation minibatches, as the reference does), the gradient
+        all-reduce and the Adam step.  Returns the total loss as a 0-dim device tensor; per-loss tensors stay in
+        `loss_manager`.
+        """
+        if validation_mode:
+            self.model.eval()
+        else:
+            self.model.train()
+        self.optimizer.zero_grad()
+        loss_manager.resetLosses()
+
+        decoded_obs = decoded_next_obs = None
+        if self.use_autoencoder:
+            (states, decoded_obs), (next_states, decoded_next_obs) = self.model(obs), self.model(next_obs)
+        elif self.use_dae:
+            (states, decoded_obs), (next_states, decoded_next_obs) = self.model(noisy_obs), self.model(next_noisy_obs)
+        elif self.use_vae:
+            (decoded_obs, mu, logvar), (decoded_next_obs, next_mu, next_logvar) = self.model(obs), self.model(next_obs)
+            states, next_states = self.model.getStates(obs), self.model.getStates(next_obs)
+        else:
+            states, next_states = self.model(obs), self.model(next_obs)
+
+        w = self.losses_weights_dict
+        if self.use_forward_loss:
+            next_states_pred = self.model.forwardModel(states, actions_st)
+            forwardModelLoss(next_states_pred, next_states, weight=w['forward'], loss_manager=loss_manager)
+        if self.use_inverse_loss:
+            actions_pred = self.model.inverseModel(states, next_states)
+            inverseModelLoss(actions_pred, actions_st, weight=w['inverse'], loss_manager=loss_manager)
+        if self.use_autoencoder or self.use_dae:
+            autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs,
+                            weight=w["dae" if self.use_dae else "autoencoder"], loss_manager=loss_manager)
+        if self.use_vae:
+            kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager=loss_manager, beta=self.beta)
+            generationLoss(decoded_obs, decoded_next_obs, obs, next_obs, weight=w['vae'], loss_manager=loss_manager)
+
+        loss = loss_manager.computeTotalLoss()
+        loss.backward()  # the reference backpropagates on validation minibatches too (learner.py:487-489)
+        if not validation_mode:
+            grad_scale = optim.allreduce_gradients(self.flat_params)
+            self.optimizer.step(grad_scale)
+        self._last_obs = obs
+        return loss
+
+    def learn(self, images_path, actions, rewards, episode_starts):
+        """
+        Learn a state representation.
+        :param images_path: (numpy 1D array)
+        :param actions: (np.ndarray)
+        :param rewards: (numpy 1D array)
+        :param episode_starts: (numpy 1D array) True where an episode starts
+        :return: (loss_history dict, learned states np.ndarray [N, state_dim], [(loss name, weight)])
+        """
+        print("\nYour are using the following weights for the losses:")
+        pprint(self.losses_weights_dict)
+
+        # ---- minibatches: every index whose successor belongs to the same episode, shuffled, full batches, sorted
+        num_samples = images_path.shape[0] - 1
+        indices = np.array([i for i in range(num_samples) if not episode_starts[i + 1]], dtype='int64')
+        np.random.shuffle(indices)
+        minibatchlist = [np.array(sorted(indices[start_idx:start_idx + self.batch_size]))
+                         for start_idx in range(0, len(indices) - self.batch_size + 1, self.batch_size)]
+        test_minibatchlist = DataLoader.createTestMinibatchList(len(images_path), MAX_BATCH_SIZE_GPU)
+
+        n_val_batches = np.round(VALIDATION_SIZE * len(minibatchlist)).astype(np.int64)
+        val_indices = np.random.permutation(len(minibatchlist))[:n_val_batches]
+        print("{} minibatches for training, {} samples".format(len(minibatchlist) - n_val_batches,
+                                                               (len(minibatchlist) - n_val_batches) * BATCH_SIZE))
+        print("{} minibatches for validation, {} samples".format(n_val_batches, n_val_batches * BATCH_SIZE))
+        assert n_val_batches > 0, "Not enough sample to create a validation set"
+
+        n_actions = int(np.max(actions) + 1)
+        print("{} unique actions / {} actions".format(len(set(actions)), n_actions))
+        print("Number of observations per action")
+        print(np.array([np.sum(actions == i) for i in range(n_actions)], dtype=np.int64))
+
+        data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
+                                 use_triplets=False, is_training=True, apply_occlusion=self.use_dae,
+                                 occlusion_percentage=self.occlusion_percentage, rank=self.rank,
+                                 world_size=self.world_size, val_indices=val_indices)
+        test_data_loader = DataLoader(test_minibatchlist, images_path, n_workers=N_WORKERS,
+                                      multi_view=self.multi_view, use_triplets=False, max_queue_len=1,
+                                      is_training=False, apply_occlusion=self.use_dae,
+                                      occlusion_percentage=self.occlusion_percentage)
+
+        loss_history = defaultdict(list)
+        loss_manager = LossManager(self.model, loss_history)
+        best_error = np.inf
+        best_model_path = "{}/srl_model.pth".format(self.log_folder)
+        start_time = time.time()
+
+        n_epochs = N_EPOCHS
+        if len(self.losses) == 1 and self.losses[0] == 'random':
+            n_epochs = 0
+            printYellow("Skipping training because using random features")
+            self.saveModel(best_model_path)
+
+        val_set = set(int(i) for i in val_indices)
+        for epoch in range(n_epochs):
+            epoch_loss, epoch_batches, val_loss, val_batches = 0.0, 0, 0.0, 0
+            for minibatch_num, (minibatch_idx, obs, next_obs, noisy_obs, next_noisy_obs) in enumerate(data_loader):
+                validation_mode = int(minibatch_idx) in val_set
+                if self.use_dae:
+                    noisy_obs = noisy_obs.to(self.device, non_blocking=True)
+                    next_noisy_obs = next_noisy_obs.to(self.device, non_blocking=True)
+                obs, next_obs = obs.to(self.device, non_blocking=True), next_obs.to(self.device, non_blocking=True)
+                actions_st = th.from_numpy(actions[minibatchlist[minibatch_idx]]).view(-1, 1).to(self.device)
+
+                loss = self.trainStep(obs, next_obs, actions_st, loss_manager, validation_mode, noisy_obs,
+                                      next_noisy_obs)
+                # one D2H copy for every scalar of this step
+                values = th.stack([l.detach().reshape(()) for l in loss_manager.losses] + [loss.detach()]).tolist()
+                loss_manager.updateLossHistory(values[:-1])
+                if validation_mode:
+                    val_loss += values[-1]
+                    val_batches += 1
+                else:
+                    epoch_loss += values[-1]
+                    epoch_batches += 1
+
+            train_loss = epoch_loss / float(max(epoch_batches, 1))
+            val_loss /= float(max(val_batches, 1)) if self.world_size > 1 else float(n_val_batches)
+            loss_history = loss_manager.loss_history
+            loss_history['train_loss'].append(train_loss)
+            loss_history['val_loss'].append(val_loss)
+            for key in loss_history.keys():
+                if key in ['train_loss', 'val_loss']:
+                    continue
+                loss_history[key][-1] /= max(epoch_batches, 1)
+                if epoch + 1 < n_epochs:
+                    loss_history[key].append(0)
+
+            if val_loss < best_error:
+                best_error = val_loss
+                if self.rank == 0:
+                    self.saveModel(best_model_path)
+
+            if np.isnan(train_loss):
+                printRed("NaN Loss, consider increasing NOISE_STD in the gaussian noise layer")
+                sys.exit(NAN_ERROR)
+
+            if (epoch + 1) % EPOCH_FLAG == 0:
+                print("Epoch {:3}/{}, train_loss:{:.4f} val_loss:{:.4f}".format(epoch + 1, n_epochs, train_loss,
+                                                                                val_loss))
+                print("{:.2f}s/epoch".format((time.time() - start_time) / (epoch + 1)))
+
+        if self.world_size > 1:
+            th.distributed.barrier()
+        self.model.load_state_dict(th.load(best_model_path, map_location=self.device))
+
+        print("Predicting states for all the observations...")
+        self.model.eval()
+        with th.no_grad():
+            pred_states = self.predStatesWithDataLoader(test_data_loader)
+        pairs_loss_weight = [k for k in zip(loss_manager.names, loss_manager.weights)]
+        return loss_history, pred_states, pairs_loss_weight

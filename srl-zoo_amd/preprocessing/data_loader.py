@@ -1,0 +1,242 @@
+"""Per-GPU minibatch stream (reference preprocessing/data_loader.py:38-65, 68-280).
+
+Same contract as the reference's DataLoader: a daemon producer process decodes and normalises images with a small
+thread pool and pushes minibatches through a bounded queue; the training iterator yields
+``(minibatch_idx, obs, next_obs, noisy_obs, next_noisy_obs)`` and ends each epoch with a ``None`` sentinel
+(-> StopIteration); the test iterator yields single observation tensors.  Tensors are float32 CPU, reference layout
+[B, C, W, H] (``transpose(0, 3, 2, 1)`` of an (H, W, C) image, reference :255).
+
+Additions for data parallelism: ``rank`` / ``world_size`` — every rank draws the SAME per-epoch
+permutation (same seed, same RNG state at fork) and consumes entries ``rank::world_size`` of it; the ragged tail is
+dropped so all ranks run the same number of steps.
+
+Image decoding is host-side I/O, not a kernel: OpenCV is used when importable (as in the reference), otherwise Pillow
+(identical RGB pixels for the 224x224 JPEGs the datasets ship; INTER_AREA is approximated by a box filter otherwise).
+"""
+from __future__ import print_function, division, absolute_import
+
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+try:
+    import queue
+except ImportError:  # python 2
+    import Queue as queue
+
+import numpy as np
+import torch as th
+from torch.multiprocessing import Queue, Process
+
+from .preprocess import IMAGE_WIDTH, IMAGE_HEIGHT
+from .utils import preprocessInput
+
+try:
+    import cv2
+    _HAVE_CV2 = True
+except ImportError:
+    cv2 = None
+    _HAVE_CV2 = False
+
+
+def _imread_rgb(path):
+    """Decode an image file to an RGB uint8 (H, W, 3) array resized to the network input; None if unreadable."""
+    if _HAVE_CV2:
+        im = cv2.imread(path)
+        if im is None:
+            return None
+        im = cv2.resize(im, (IMAGE_WIDTH, IMAGE_HEIGHT), interpolation=cv2.INTER_AREA)
+        return cv2.cvtColor(im, cv2.COLOR_BGR2RGB)
+    from PIL import Image
+    try:
+        with Image.open(path) as f:
+            im = f.convert("RGB")
+            if im.size != (IMAGE_WIDTH, IMAGE_HEIGHT):
+                im = im.resize((IMAGE_WIDTH, IMAGE_HEIGHT), Image.BOX)
+            return np.asarray(im)
+    except (IOError, OSError):
+        return None
+
+
+def sample_coordinates(coord_1, max_distance, percentage):
+    """Second coordinate within [coord_1 -/+ max_distance*percentage], clipped to the axis (reference :23-35)."""
+    low = max(0, coord_1 - max_distance * percentage)
+    high = min(coord_1 + max_distance * percentage, max_distance)
+    coord_2 = np.random.randint(low=low, high=high)
+    return min(coord_1, coord_2), max(coord_1, coord_2)
+
+
+def preprocessImage(image, convert_to_rgb=True, apply_occlusion=False, occlusion_percentage=0.5):
+    """(H, W, 3) image -> normalised float32 (224, 224, 3); optional random rectangular occlusion (DAE).
+
+    With OpenCV the input is BGR (cv2.imread) and is resized / converted here exactly as the reference does; without
+    OpenCV the caller passes RGB and `convert_to_rgb` only applies to BGR inputs.
+    """
+    if _HAVE_CV2:
+        im = cv2.resize(image, (IMAGE_WIDTH, IMAGE_HEIGHT), interpolation=cv2.INTER_AREA)
+        if convert_to_rgb:
+            im = cv2.cvtColor(im, cv2.COLOR_BGR2RGB)
+    else:
+        im = np.asarray(image)
+        if convert_to_rgb:
+            im = im[..., ::-1]
+        if im.shape[:2] != (IMAGE_HEIGHT, IMAGE_WIDTH):
+            from PIL import Image
+            im = np.asarray(Image.fromarray(np.ascontiguousarray(im)).resize((IMAGE_WIDTH, IMAGE_HEIGHT), Image.BOX))
+    im = preprocessInput(np.array(im, dtype=np.float32), mode="image_net")
+    if apply_occlusion:
+        h_1 = np.random.randint(IMAGE_HEIGHT)
+        h_1, h_2 = sample_coordinates(h_1, IMAGE_HEIGHT, percentage=occlusion_percentage)
+        w_1 = np.random.randint(IMAGE_WIDTH)
+        w_1, w_2 = sample_coordinates(w_1, IMAGE_WIDTH, percentage=occlusion_percentage)
+        im[h_1:h_2, w_1:w_2, :] = 0.
+    return im
+
+
+def _normalised(rgb, apply_occlusion, occlusion_percentage):
+    # rgb: uint8 RGB already at network size
+    return preprocessImage(rgb, convert_to_rgb=False, apply_occlusion=apply_occlusion,
+                           occlusion_percentage=occlusion_percentage)
+
+
+def shardOrder(order, rank, world_size, val_indices=None):
+    """This rank's slice of a per-epoch minibatch order.  world_size 1: the order itself.  Otherwise training and
+    validation minibatches are sharded separately (entries rank::world_size, ragged tails dropped, train first) so
+    every rank runs the same number of optimisation steps and the gradient all-reduce never waits on a rank that is
+    validating."""
+    order = np.asarray(order, dtype=np.int64)
+    if world_size == 1:
+        return order
+    val = val_indices if val_indices is not None else set()
+    parts = []
+    for keep_val in (False, True):
+        sel = np.array([i for i in order if (int(i) in val) == keep_val], dtype=np.int64)
+        usable = (len(sel) // world_size) * world_size
+        parts.append(sel[:usable][rank::world_size])
+    return np.concatenate(parts)
+
+
+class DataLoader(object):
+    def __init__(self, minibatchlist, images_path, n_workers=1, multi_view=False, use_triplets=False,
+                 infinite_loop=True, max_queue_len=4, is_training=False, apply_occlusion=False,
+                 occlusion_percentage=0.5, rank=0, world_size=1, val_indices=None):
+        """
+        :param minibatchlist: ([np.array]) observation indices grouped per minibatch
+        :param images_path: (np.array) image paths (without the 'data/' prefix)
+        :param n_workers: (int) decoding threads
+        :param multi_view: (bool) stack the two camera views along channels
+        :param use_triplets: (bool) out of scope (needs the ResNet path); rejected
+        :param infinite_loop: (bool) restart after each epoch
+        :param max_queue_len: (int) minibatches prepared ahead
+        :param is_training: (bool) True: yield (idx, obs, next_obs, noisy, next_noisy) in shuffled order;
+                            False: yield obs tensors in order
+        :param apply_occlusion: (bool) also produce occluded copies (DAE)
+        :param occlusion_percentage: (float)
+        :param rank, world_size: data-parallel shard of the per-epoch permutation
+        :param val_indices: minibatch ids used for validation; with world_size > 1 training and validation
+                            minibatches are sharded separately (train first) so all ranks stay in lock-step
+        """
+        super(DataLoader, self).__init__()
+        if use_triplets:
+            raise NotImplementedError("triplet loading is outside the MI355X hot-path build")
+        self.n_workers = n_workers
+        self.infinite_loop = infinite_loop
+        self.n_minibatches = len(minibatchlist)
+        self.minibatchlist = minibatchlist
+        self.images_path = images_path
+        self.shuffle = is_training
+        self.queue = Queue(max_queue_len)
+        self.process = None
+        self.multi_view = multi_view
+        self.apply_occlusion = apply_occlusion
+        self.occlusion_percentage = occlusion_percentage
+        self.rank, self.world_size = rank, world_size
+        self.val_indices = None if val_indices is None else set(int(i) for i in val_indices)
+        self.startProcess()
+
+    @staticmethod
+    def createTestMinibatchList(n_samples, batch_size):
+        """Index ranges of at most batch_size covering n_samples (the last one may be empty, as in the reference)."""
+        return [np.arange(i * batch_size, min(n_samples, (i + 1) * batch_size))
+                for i in range(n_samples // batch_size + 1)]
+
+    def stepsPerEpoch(self):
+        """Minibatches this rank yields per epoch."""
+        return len(shardOrder(np.arange(self.n_minibatches), self.rank, self.world_size, self.val_indices)) \
+            if self.shuffle else self.n_minibatches
+
+    def startProcess(self):
+        self.process = Process(target=self._run)
+        self.process.daemon = True  # dies with the trainer
+        self.process.start()
+
+    def _epochOrder(self):
+        if not self.shuffle:
+            return np.arange(self.n_minibatches, dtype=np.int64)
+        order = np.random.permutation(self.n_minibatches).astype(np.int64)
+        return shardOrder(order, self.rank, self.world_size, self.val_indices)
+
+    def _run(self):
+        pool = ThreadPoolExecutor(max_workers=max(1, self.n_workers))
+        first = True
+        while first or self.infinite_loop:
+            first = False
+            for minibatch_idx in self._epochOrder():
+                idx = self.minibatchlist[minibatch_idx]
+                if self.shuffle:
+                    paths = np.concatenate((self.images_path[idx], self.images_path[idx + 1]))
+                else:
+                    paths = self.images_path[idx]
+                clean = list(pool.map(lambda p: self._makeBatchElement(p, self.multi_view), paths))
+                batch = th.cat(clean, dim=0) if clean else th.zeros(0)
+                noisy = None
+                if self.apply_occlusion:
+                    occl = list(pool.map(lambda p: self._makeBatchElement(
+                        p, self.multi_view, apply_occlusion=True, occlusion_percentage=self.occlusion_percentage), paths))
+                    noisy = th.cat(occl, dim=0)
+                if self.shuffle:
+                    half = len(paths) // 2
+                    item = (minibatch_idx, batch[:half], batch[half:],
+                            None if noisy is None else noisy[:half], None if noisy is None else noisy[half:])
+                else:
+                    item = batch
+                self.queue.put(item)
+            self.queue.put(None)  # end-of-epoch sentinel
+
+    @classmethod
+    def _makeBatchElement(cls, image_path, multi_view=False, use_triplets=False, apply_occlusion=False,
+                          occlusion_percentage=None):
+        """One image path (without 'data/' prefix, '.jpg' optional) -> float32 tensor [1, C, W, H]."""
+        stem = 'data/' + image_path.split('.jpg')[0]
+        names = ["{}_{}.jpg".format(stem, i + 1) for i in range(2)] if multi_view else ["{}.jpg".format(stem)]
+        views = []
+        for name in names:
+            rgb = _imread_rgb(name)
+            if rgb is None:
+                raise ValueError("tried to load {}, but it was not found".format(name))
+            views.append(_normalised(rgb, apply_occlusion, occlusion_percentage))
+        im = np.dstack(views) if multi_view else views[0]
+        # channel first + batch dim; note the (W, H) order of the last two axes
+        return th.tensor(im.reshape((1,) + im.shape).transpose(0, 3, 2, 1))
+
+    def __len__(self):
+        return self.n_minibatches
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        while True:
+            try:
+                val = self.queue.get_nowait()
+                break
+            except queue.Empty:
+                time.sleep(0.001)
+        if val is None:
+            raise StopIteration
+        return val
+
+    next = __next__
+
+    def __del__(self):
+        if self.process is not None:
+            self.process.terminate()

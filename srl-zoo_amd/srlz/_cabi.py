@@ -1,0 +1,138 @@
+"""ctypes binding of libsrlz_hip.so (the C ABI declared in include/srlz.h).
+
+This is the stub a maintainer of the reference would add: every entry point takes raw device
+pointers (``tensor.data_ptr()``), plain ints/floats, POD descriptors and the HIP stream of the caller.
+There is NO fallback: if the library is missing the import fails loudly, and every non-zero status raises.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_longlong, c_float, c_void_p, c_size_t, c_char_p, POINTER, Structure
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrlz_hip.so")
+
+
+class SrlzError(RuntimeError):
+    pass
+
+
+class Conv64Desc(Structure):
+    _fields_ = [("n", c_int), ("hi", c_int), ("wi", c_int), ("ho", c_int), ("wo", c_int), ("ksize", c_int),
+                ("stride", c_int), ("pad", c_int), ("transposed", c_int)]
+
+
+class SkinnyDesc(Structure):
+    _fields_ = [("n", c_int), ("c", c_int), ("himg", c_int), ("wimg", c_int), ("hf", c_int), ("wf", c_int),
+                ("kind", c_int)]
+
+
+class PoolDesc(Structure):
+    _fields_ = [("n", c_int), ("h", c_int), ("w", c_int), ("hp", c_int), ("wp", c_int), ("pool_pad", c_int),
+                ("out_nchw", c_int)]
+
+
+P = c_void_p
+_C64 = POINTER(Conv64Desc)
+_SK = POINTER(SkinnyDesc)
+_PD = POINTER(PoolDesc)
+
+# name -> (restype, argtypes); restype c_int functions are status-checked
+_PROTOS = {
+    "srlz_version": (c_int, []),
+    "srlz_last_error": (c_char_p, []),
+    "srlz_device_cus": (c_int, []),
+    "srlz_conv64_packed_floats": (c_size_t, []),
+    "srlz_conv64_pack_weights": (c_int, [P, P, P, _C64, P]),
+    "srlz_conv64_fwd_tiles": (c_int, [_C64]),
+    "srlz_conv64_fwd": (c_int, [P, P, P, P, P, _C64, P]),
+    "srlz_conv64_bwd_data": (c_int, [P, P, P, _C64, P]),
+    "srlz_conv64_bwd_weight_workspace": (c_size_t, [_C64]),
+    "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, c_size_t, _C64, P]),
+    "srlz_conv64_debug_program": (c_int, [_C64, c_int, POINTER(c_int), c_int]),
+    "srlz_skinny_tiles": (c_int, [_SK]),
+    "srlz_conv1_fwd": (c_int, [P, P, P, P, _SK, P]),
+    "srlz_skinny_bwd_weight_workspace": (c_size_t, [_SK]),
+    "srlz_conv1_bwd_weight": (c_int, [P, P, P, P, c_size_t, _SK, P]),
+    "srlz_convT_out_fwd": (c_int, [P, P, P, P, _SK, P]),
+    "srlz_convT_out_bwd_data": (c_int, [P, P, P, _SK, P]),
+    "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, c_size_t, _SK, P]),
+    "srlz_bn_finalize": (c_int, [P, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P]),
+    "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),
+    "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),
+    "srlz_bn_relu_pool_fwd": (c_int, [P, P, P, P, _PD, P]),
+    "srlz_bn_bwd_workspace": (c_size_t, [c_longlong]),
+    "srlz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, c_size_t, _PD, P]),
+    "srlz_bn_relu_fwd": (c_int, [P, P, P, c_longlong, P]),
+    "srlz_bn_relu_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, c_longlong, P]),
+    "srlz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srlz_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srlz_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "srlz_linear_bwd_data": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "srlz_linear_bwd_weight": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "srlz_relu_bwd_inplace": (c_int, [P, P, c_longlong, P]),
+    "srlz_reduce_workspace": (c_size_t, [c_longlong]),
+    "srlz_sqdiff_sum": (c_int, [P, P, c_longlong, P, P, c_size_t, P]),
+    "srlz_sqdiff_grad": (c_int, [P, P, P, c_float, P, c_longlong, P]),
+    "srlz_kl_sum": (c_int, [P, P, c_longlong, P, P, c_size_t, P]),
+    "srlz_kl_grad": (c_int, [P, P, P, c_float, P, P, c_longlong, P]),
+    "srlz_reparam_fwd": (c_int, [P, P, P, P, c_longlong, P]),
+    "srlz_reparam_bwd": (c_int, [P, P, P, P, P, c_longlong, P]),
+    "srlz_cross_entropy": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "srlz_concat_onehot": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "srlz_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+}
+
+# entry points whose int return value is data, not a status
+_NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles",
+               "srlz_conv64_debug_program"}
+
+EXPORTED = sorted(_PROTOS.keys())
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise SrlzError(
+            "libsrlz_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C srl-zoo_amd/csrc`). There is no CPU fallback for the srl-zoo_amd hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = _load()
+
+
+def error_text():
+    return _lib.srlz_last_error().decode("utf-8", "replace")
+
+
+def _wrap(name):
+    fn = getattr(_lib, name)
+    if _PROTOS[name][0] is c_int and name not in _NOT_STATUS:
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise SrlzError("%s failed (%d): %s" % (name, rc, error_text()))
+            return rc
+        call.__name__ = name
+        return call
+    return fn
+
+
+for _n in _PROTOS:
+    globals()[_n[len("srlz_"):]] = _wrap(_n)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,63 @@
+"""Composition of the HIP blocks into the reference's two conv stacks.
+
+`encoder_conv` / `decoder_conv` are kept as nn.Sequential containers of standard torch layers (so parameter creation
+order, initialisation and state_dict keys are the reference's, models/models.py:47-83), but they are never *called*:
+the forward below reads their parameters and runs the MI355X kernels.
+"""
+import torch
+
+from . import ops
+
+
+def _bn_args(bn):
+    return bn.weight, bn.bias, bn.running_mean, bn.running_var
+
+
+def _tick(bn, training):
+    # nn.BatchNorm2d increments num_batches_tracked once per training-mode call
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+
+
+def encoder_forward(seq, x, training, stat_sink=None):
+    """models/models.py:47-63.  x: [N,C,H,W] (reference layout) -> [N,64,6,6] (NCHW, ready for .view(N,-1))."""
+    conv1, bn1, conv2, bn2, conv3, bn3 = seq[0], seq[1], seq[4], seq[5], seq[8], seq[9]
+    y, st = ops.Conv1Fn.apply(x, conv1.weight, training)
+    _tick(bn1, training)
+    p = ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink)
+    y, st = ops.Conv64Fn.apply(p, conv2.weight, None, 1, 1, False, training)
+    _tick(bn2, training)
+    p = ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn2), training, 0, False, stat_sink)
+    y, st = ops.Conv64Fn.apply(p, conv3.weight, None, 2, 1, False, training)
+    _tick(bn3, training)
+    return ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn3), training, 0, True, stat_sink)
+
+
+def replay_encoder_bn(seq, stats):
+    """Second train-mode pass over the same batch (VAE getStates quirk, models/learner.py:402): running statistics
+    receive the same batch statistics once more and num_batches_tracked advances; outputs are unchanged."""
+    for bn, st in zip((seq[1], seq[5], seq[9]), stats):
+        ops.bn_replay(st, bn.running_mean, bn.running_var)
+        bn.num_batches_tracked.add_(1)
+
+
+def decoder_forward(seq, z, training):
+    """models/models.py:65-83.  z: [N,64,6,6] NCHW (decoder_fc output viewed) -> [N,C,224,224] NCHW."""
+    a = ops.ToNHWCFn.apply(z)
+    for ci, bi in ((0, 1), (3, 4), (6, 7), (9, 10)):
+        conv, bn = seq[ci], seq[bi]
+        y, st = ops.Conv64Fn.apply(a, conv.weight, conv.bias, 2, 0, True, training)
+        _tick(bn, training)
+        a = ops.BNReLUFn.apply(y, st, *_bn_args(bn), training, None)
+    last = seq[12]
+    return ops.ConvTOutFn.apply(a, last.weight, last.bias)
+
+
+def linear(layer, x, relu=False):
+    return ops.LinearFn.apply(x, layer.weight, layer.bias, relu)
+
+
+def require_gpu(x, what):
+    if not (torch.is_tensor(x) and x.is_cuda):
+        raise RuntimeError("%s: the srl-zoo_amd hot path runs on MI355X only (tensor is on %s); there is no CPU "
+                           "fallback" % (what, x.device if torch.is_tensor(x) else type(x)))

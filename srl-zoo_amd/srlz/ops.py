@@ -1,0 +1,410 @@
+"""Autograd seam between the host-side model classes and the HIP kernels (include/srlz.h).
+
+The reference relies on ``loss.backward()`` (models/learner.py:489); here each fused block is one
+``torch.autograd.Function`` whose forward/backward enqueue C-ABI calls on the current HIP stream.  PyTorch tensors are
+used for storage only: no torch compute op touches an activation.  Activations are NHWC between the first conv and the
+last transposed conv; images and everything the caller sees stay in the reference's NCHW layout.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _cabi as C
+from ._cabi import ptr, stream, Conv64Desc, SkinnyDesc, PoolDesc
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+_workspaces = {}
+
+
+def _ws(nbytes, device, slot=0):
+    """Grow-only scratch buffer per (device, slot); everything runs on one stream, so reuse is ordered."""
+    key = (device.index, slot)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _check(t, name):
+    if t.device.type != "cuda":
+        raise C.SrlzError("%s must live on the GPU: the srl-zoo_amd hot path has no CPU fallback" % name)
+    if t.dtype != torch.float32:
+        raise C.SrlzError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# conv1: nn.Conv2d(C, 64, 7, stride 2, pad 3, bias=False) — models/models.py:49
+# ----------------------------------------------------------------------------------------------------------------
+def _skinny_desc(n, c, himg, wimg, kind):
+    if kind == 0:
+        hf, wf = (himg + 6 - 7) // 2 + 1, (wimg + 6 - 7) // 2 + 1
+    else:
+        hf, wf = (himg - 4) // 2 + 1, (wimg - 4) // 2 + 1
+    return SkinnyDesc(n, c, himg, wimg, hf, wf, kind)
+
+
+class Conv1Fn(Function):
+    @staticmethod
+    def forward(ctx, x, w, want_stats):
+        x, w = _check(x, "conv1 input"), _check(w, "conv1 weight")
+        n, c, h, wd = x.shape
+        d = _skinny_desc(n, c, h, wd, 0)
+        y = torch.empty((n, d.hf, d.wf, 64), dtype=torch.float32, device=x.device)
+        stats = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
+        C.conv1_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), d, stream())
+        ctx.save_for_backward(x, w)
+        ctx.desc = d
+        if stats is None:
+            stats = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, w = ctx.saved_tensors
+        d = ctx.desc
+        dy = _check(dy, "conv1 dy")
+        dw = torch.empty_like(w)
+        nbytes = C.skinny_bwd_weight_workspace(d)
+        ws = _ws(nbytes, x.device)
+        C.conv1_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, d, stream())
+        return None, dw, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# 64 -> 64 convs: conv3x3 (models/models.py:54,59,217-226) and ConvTranspose2d(64,64,3,2) (models.py:66,70,74,78)
+# ----------------------------------------------------------------------------------------------------------------
+def conv64_desc(n, hi, wi, stride, pad, transposed):
+    if transposed:
+        ho, wo = (hi - 1) * stride - 2 * pad + 3, (wi - 1) * stride - 2 * pad + 3
+    else:
+        ho, wo = (hi + 2 * pad - 3) // stride + 1, (wi + 2 * pad - 3) // stride + 1
+    return Conv64Desc(n, hi, wi, ho, wo, 3, stride, pad, 1 if transposed else 0)
+
+
+class Conv64Fn(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, transposed, want_stats):
+        x, w = _check(x, "conv64 input"), _check(w, "conv64 weight")
+        n, hi, wi, ch = x.shape
+        assert ch == 64 and tuple(w.shape) == (64, 64, 3, 3)
+        d = conv64_desc(n, hi, wi, stride, pad, transposed)
+        npk = C.conv64_packed_floats()
+        packs = torch.empty((2, npk), dtype=torch.float32, device=x.device)
+        C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())
+        y = torch.empty((n, d.ho, d.wo, 64), dtype=torch.float32, device=x.device)
+        stats = torch.empty((C.conv64_fwd_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
+        C.conv64_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), d, stream())
+        ctx.save_for_backward(x, packs)
+        ctx.desc = d
+        ctx.has_bias = bias is not None
+        ctx.needs_dx = ctx.needs_input_grad[0]
+        if stats is None:
+            stats = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, packs = ctx.saved_tensors
+        d = ctx.desc
+        dy = _check(dy, "conv64 dy")
+        dx = None
+        if ctx.needs_dx:
+            dx = torch.empty_like(x)
+            C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), d, stream())
+        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=x.device)
+        db = torch.empty(64, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        nbytes = C.conv64_bwd_weight_workspace(d)
+        ws = _ws(nbytes, x.device)
+        C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes, d, stream())
+        return dx, dw, db, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BatchNorm2d + ReLU (+ MaxPool2d(3, 2, pad)) — models/models.py:50-52,55-57,60-62 / 67-68,71-72,75-76,79-80
+# ----------------------------------------------------------------------------------------------------------------
+def _bn_params(stats, count, gamma, beta, running_mean, running_var, training, device):
+    bnp = torch.empty(256, dtype=torch.float32, device=device)
+    batch_stat = None
+    if training:
+        batch_stat = torch.empty(128, dtype=torch.float32, device=device)
+        C.bn_finalize(ptr(stats), stats.shape[0], count, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, 1,
+                      ptr(running_mean), ptr(running_var), ptr(bnp), ptr(batch_stat), stream())
+    else:
+        C.bn_eval_params(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS, ptr(bnp), stream())
+    return bnp, batch_stat
+
+
+class BNReLUPoolFn(Function):
+    """y (raw conv output, NHWC) -> maxpool(relu(bn(y))).  `stats` are the conv's per-tile partial sums."""
+
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, training, pool_pad, out_nchw, stat_sink):
+        y = _check(y, "bn input")
+        n, h, w, _ = y.shape
+        hp, wp = (h + 2 * pool_pad - 3) // 2 + 1, (w + 2 * pool_pad - 3) // 2 + 1
+        d = PoolDesc(n, h, w, hp, wp, pool_pad, 1 if out_nchw else 0)
+        bnp, batch_stat = _bn_params(stats, n * h * w, gamma, beta, running_mean, running_var, training, y.device)
+        if stat_sink is not None and batch_stat is not None:
+            stat_sink.append(batch_stat)
+        shape = (n, 64, hp, wp) if out_nchw else (n, hp, wp, 64)
+        pooled = torch.empty(shape, dtype=torch.float32, device=y.device)
+        need_bwd = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
+        argmax = torch.empty((n, hp, wp, 64), dtype=torch.uint8, device=y.device) if need_bwd else None
+        C.bn_relu_pool_fwd(ptr(y), ptr(bnp), ptr(pooled), ptr(argmax), d, stream())
+        if need_bwd:
+            ctx.save_for_backward(y, bnp, argmax)
+        ctx.desc, ctx.training = d, training
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        y, bnp, argmax = ctx.saved_tensors
+        dpooled = _check(dpooled, "pool grad")
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(64, dtype=torch.float32, device=y.device)
+        dbeta = torch.empty(64, dtype=torch.float32, device=y.device)
+        nbytes = C.bn_bwd_workspace(0)
+        ws = _ws(nbytes, y.device)
+        C.bn_relu_pool_bwd(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(dy), ptr(dgamma), ptr(dbeta),
+                           1 if ctx.training else 0, ptr(ws), nbytes, ctx.desc, stream())
+        return dy, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+class BNReLUFn(Function):
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, training, stat_sink):
+        y = _check(y, "bn input")
+        pixels = y.numel() // 64
+        bnp, batch_stat = _bn_params(stats, pixels, gamma, beta, running_mean, running_var, training, y.device)
+        if stat_sink is not None and batch_stat is not None:
+            stat_sink.append(batch_stat)
+        a = torch.empty_like(y)
+        C.bn_relu_fwd(ptr(y), ptr(bnp), ptr(a), pixels, stream())
+        ctx.save_for_backward(y, bnp)
+        ctx.training = training
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        y, bnp = ctx.saved_tensors
+        da = _check(da, "bn grad")
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(64, dtype=torch.float32, device=y.device)
+        dbeta = torch.empty(64, dtype=torch.float32, device=y.device)
+        nbytes = C.bn_bwd_workspace(0)
+        ws = _ws(nbytes, y.device)
+        C.bn_relu_bwd(ptr(y), ptr(bnp), ptr(da), ptr(dy), ptr(dgamma), ptr(dbeta), 1 if ctx.training else 0, ptr(ws),
+                      nbytes, y.numel() // 64, stream())
+        return dy, None, dgamma, dbeta, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# last layer: nn.ConvTranspose2d(64, C, 4, stride 2) — models/models.py:82 ; output NCHW (the reference's layout)
+# ----------------------------------------------------------------------------------------------------------------
+class ConvTOutFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w = _check(x, "convT_out input"), _check(w, "convT_out weight")
+        n, hf, wf, _ = x.shape
+        c = w.shape[1]
+        d = SkinnyDesc(n, c, (hf - 1) * 2 + 4, (wf - 1) * 2 + 4, hf, wf, 1)
+        y = torch.empty((n, c, d.himg, d.wimg), dtype=torch.float32, device=x.device)
+        C.convT_out_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), d, stream())
+        ctx.save_for_backward(x, w)
+        ctx.desc = d
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        d = ctx.desc
+        dy = _check(dy, "convT_out dy")
+        dx = torch.empty_like(x)
+        C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(dx), d, stream())
+        dw = torch.empty_like(w)
+        db = torch.empty(d.c, dtype=torch.float32, device=x.device)
+        nbytes = C.skinny_bwd_weight_workspace(d)
+        ws = _ws(nbytes, x.device)
+        C.convT_out_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes, d, stream())
+        return dx, dw, db
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# nn.Linear — autoencoders.py:94-100, vae.py:52-57, forward_inverse.py:16,48-55
+# ----------------------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x, w = _check(x, "linear input"), _check(w, "linear weight")
+        m, k = x.shape
+        n = w.shape[0]
+        assert w.shape[1] == k
+        y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        C.linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), m, n, k, 1 if relu else 0, stream())
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.relu, ctx.has_bias, ctx.needs_dx = relu, b is not None, ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _check(dy, "linear dy")
+        m, k = x.shape
+        n = w.shape[0]
+        if ctx.relu:
+            dy = dy.clone()
+            C.relu_bwd_inplace(ptr(y), ptr(dy), dy.numel(), stream())
+        dx = None
+        if ctx.needs_dx:
+            dx = torch.empty_like(x)
+            C.linear_bwd_data(ptr(dy), ptr(w), ptr(dx), m, n, k, stream())
+        dw = torch.empty_like(w)
+        db = torch.empty(n, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        C.linear_bwd_weight(ptr(dy), ptr(x), ptr(dw), ptr(db), m, n, k, stream())
+        return dx, dw, db, None
+
+
+class ToNHWCFn(Function):
+    """[N,C,H,W] -> [N,H,W,C] (the decoder_fc -> view(N,64,6,6) seam, autoencoders.py:116-117)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _check(x, "layout input")
+        n, c, h, w = x.shape
+        y = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+        C.nchw_to_nhwc(ptr(x), ptr(y), n, c, h, w, stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _check(dy, "layout grad")
+        n, h, w, c = dy.shape
+        dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
+        C.nhwc_to_nchw(ptr(dy), ptr(dx), n, c, h, w, stream())
+        return dx
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# losses — losses/losses.py
+# ----------------------------------------------------------------------------------------------------------------
+class SqDiffSumFn(Function):
+    """sum((a-b)^2) — the reduction inside reconstructionLoss (losses.py:181) and F.mse_loss(sum) (losses.py:210)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _check(a, "loss input"), _check(b, "loss target")
+        assert a.shape == b.shape
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        nbytes = C.reduce_workspace(a.numel())
+        ws = _ws(nbytes, a.device)
+        C.sqdiff_sum(ptr(a), ptr(b), a.numel(), ptr(out), ptr(ws), nbytes, stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            C.sqdiff_grad(ptr(a), ptr(b), ptr(g), 2.0, ptr(da), a.numel(), stream())
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(b)
+            C.sqdiff_grad(ptr(a), ptr(b), ptr(g), -2.0, ptr(db), a.numel(), stream())
+        return da, db
+
+
+class KLSumFn(Function):
+    """-0.5 * sum(1 + logvar - mu^2 - exp(logvar)) — losses.py:253."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _check(mu, "mu"), _check(logvar, "logvar")
+        out = torch.empty((), dtype=torch.float32, device=mu.device)
+        nbytes = C.reduce_workspace(mu.numel())
+        ws = _ws(nbytes, mu.device)
+        C.kl_sum(ptr(mu), ptr(logvar), mu.numel(), ptr(out), ptr(ws), nbytes, stream())
+        ctx.save_for_backward(mu, logvar)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        g = g.contiguous()
+        dmu, dlv = torch.zeros_like(mu), torch.zeros_like(logvar)
+        C.kl_grad(ptr(mu), ptr(logvar), ptr(g), 1.0, ptr(dmu), ptr(dlv), mu.numel(), stream())
+        return dmu, dlv
+
+
+class ReparamFn(Function):
+    """z = eps * exp(0.5*logvar) + mu — BaseModelVAE.reparameterize, models/models.py:157-163."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _check(mu, "mu"), _check(logvar, "logvar"), _check(eps, "eps")
+        z = torch.empty_like(mu)
+        C.reparam_fwd(ptr(mu), ptr(logvar), ptr(eps), ptr(z), mu.numel(), stream())
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dz = _check(dz, "dz")
+        dmu, dlv = torch.empty_like(dz), torch.empty_like(dz)
+        C.reparam_bwd(ptr(dz), ptr(logvar), ptr(eps), ptr(dmu), ptr(dlv), dz.numel(), stream())
+        return dmu, dlv, None
+
+
+class CrossEntropyFn(Function):
+    """nn.CrossEntropyLoss()(logits, target) (mean) — inverseModelLoss, losses.py:126-127."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = _check(logits, "logits")
+        target = target.contiguous()
+        assert target.dtype == torch.int64 and target.device == logits.device
+        b, a = logits.shape
+        out = torch.empty((), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        C.cross_entropy(ptr(logits), ptr(target), b, a, ptr(out), ptr(dlogits), stream())
+        ctx.save_for_backward(dlogits)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
+class ConcatOneHotFn(Function):
+    """cat([s, onehot(a)], 1) — forwardModel's input, forward_inverse.py:30 + models/models.py:229-237."""
+
+    @staticmethod
+    def forward(ctx, s, a, n_actions):
+        s = _check(s, "state")
+        a = a.contiguous()
+        assert a.dtype == torch.int64 and a.device == s.device
+        b, sdim = s.shape
+        cat = torch.empty((b, sdim + n_actions), dtype=torch.float32, device=s.device)
+        C.concat_onehot(ptr(s), ptr(a), ptr(cat), b, sdim, n_actions, stream())
+        ctx.sdim = sdim
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        return dcat[:, :ctx.sdim].contiguous(), None, None
+
+
+def adam_step(p, g, m, v, lr, step, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    C.adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, step, grad_scale, stream())
+
+
+def bn_replay(batch_stat, running_mean, running_var):
+    C.bn_replay(ptr(batch_stat), BN_MOMENTUM, ptr(running_mean), ptr(running_var), stream())

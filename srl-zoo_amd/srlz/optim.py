@@ -1,0 +1,80 @@
+"""Flat parameter / gradient buffers, the fused Adam step and the data-parallel gradient exchange.
+
+Replaces ``th.optim.Adam(learnable_params, lr)`` (reference models/learner.py:194-199,495) with ONE kernel over one
+contiguous buffer, and adds what the reference does not have: one RCCL all-reduce (sum) of the flat gradient bucket
+per step across the GPUs of a node.  Parameters stay ``nn.Parameter`` objects (views into the flat
+buffer) so ``state_dict()``, ``named_parameters()`` and LossManager.reg_params keep working.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FlatParams(object):
+    """Re-homes every parameter of `module` into one contiguous fp32 buffer (+ a matching gradient buffer)."""
+
+    ALIGN = 4  # floats (16 bytes)
+
+    def __init__(self, module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("module has no trainable parameter")
+        device = params[0].device
+        offsets, total = [], 0
+        for p in params:
+            offsets.append(total)
+            total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.params, self.offsets = params, offsets
+        with torch.no_grad():
+            for p, off in zip(params, offsets):
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                p.grad = self.grad[off:off + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        # autograd accumulates in place into an existing .grad, so the views persist; re-attach if someone dropped them
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+
+class FusedAdam(object):
+    """torch.optim.Adam semantics (betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad) over a FlatParams.
+
+    Parameters that never receive a gradient keep a zero gradient, zero moments and therefore a zero update — the
+    same end state as torch skipping ``grad is None`` parameters.
+    """
+
+    def __init__(self, flat_params, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.fp = flat_params
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.m = torch.zeros_like(flat_params.flat)
+        self.v = torch.zeros_like(flat_params.flat)
+        self.t = 0
+
+    def zero_grad(self):
+        self.fp.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.t, grad_scale, self.betas, self.eps)
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def allreduce_gradients(flat_params):
+    """One all-reduce (sum) of the whole gradient bucket; returns the scale Adam must apply (1/world_size)."""
+    rank, size = world()
+    if size == 1:
+        return 1.0
+    dist.all_reduce(flat_params.grad, op=dist.ReduceOp.SUM)
+    return 1.0 / size

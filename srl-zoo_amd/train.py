@@ -1,0 +1,181 @@
+"""Command-line trainer — same flags, loss mini-language, outputs and exit codes as the reference train.py:23-212,
+driving the MI355X-native SRL4robotics.  Multi-GPU: launch one process per GPU with
+``python -m torch.distributed.run --nproc-per-node N train.py ...`` (RANK / LOCAL_RANK / WORLD_SIZE are read from the
+environment; backend "nccl" is RCCL on ROCm).
+
+Out of scope of this build (rejected with a clear message): --model-type other than custom_cnn, the losses of other
+SRL methods (priors, reward, triplet, perceptual, episode-prior, reward-prior), split dimensions, plots.
+"""
+from __future__ import print_function, division, absolute_import
+
+import argparse
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch as th
+
+import preprocessing
+import preprocessing.preprocess  # noqa: F401  (N_CHANNELS is set below)
+import models.learner as learner
+from models.learner import SRL4robotics
+from pipeline import getLogFolderName, saveConfig, correlationCall
+from utils import parseDataFolder, createFolder, loadData, buildConfig, parseLossArguments
+
+LOSS_CHOICES = ["forward", "inverse", "reward", "priors", "episode-prior", "reward-prior", "triplet",
+                "autoencoder", "vae", "perceptual", "dae", "random"]
+
+
+def buildParser():
+    parser = argparse.ArgumentParser(description='State Representation Learning on MI355X (srl-zoo hot path)')
+    parser.add_argument('--epochs', type=int, default=30, metavar='N', help='number of epochs to train (default: 30)')
+    parser.add_argument('--seed', type=int, default=1, metavar='S', help='random seed (default: 1)')
+    parser.add_argument('--state-dim', type=int, default=2, help='state dimension (default: 2)')
+    parser.add_argument('-bs', '--batch-size', type=int, default=32, help='batch_size (default: 32)')
+    parser.add_argument('--val-size', type=float, default=0.2, help='Validation set size in percentage (default: 0.2)')
+    parser.add_argument('--training-set-size', type=int, default=-1,
+                        help='Limit size (number of samples) of the training set (default: -1)')
+    parser.add_argument('-lr', '--learning-rate', type=float, default=0.005, help='learning rate (default: 0.005)')
+    parser.add_argument('--l1-reg', type=float, default=0.0, help='L1 regularization coeff (default: 0.0)')
+    parser.add_argument('--l2-reg', type=float, default=0.0, help='L2 regularization coeff (default: 0.0)')
+    parser.add_argument('--no-cuda', action='store_true', default=False, help='disables CUDA training')
+    parser.add_argument('--no-display-plots', action='store_true', default=False,
+                        help='disables live plots of the representation learned')
+    parser.add_argument('--model-type', type=str, default="custom_cnn", choices=['custom_cnn', 'resnet', 'mlp', 'linear'],
+                        help='Model architecture (default: "custom_cnn")')
+    parser.add_argument('--inverse-model-type', type=str, default="linear", choices=['mlp', 'linear'],
+                        help='Inverse model s architecture (default: "linear")')
+    parser.add_argument('--data-folder', type=str, default="", help='Dataset folder', required=True)
+    parser.add_argument('--log-folder', type=str, default="",
+                        help='Folder where the experiment model and plots will be saved. By default '
+                             'logs/DatasetName/YY-MM-DD_HHhMM_SS_ModelType_ST_DIMN_LOSSES')
+    parser.add_argument('--multi-view', action='store_true', default=False, help='Enable use of multiple camera')
+    parser.add_argument('--balanced-sampling', action='store_true', default=False,
+                        help='Force balanced sampling for episode independent prior instead of uniform')
+    parser.add_argument('--losses', nargs='+', default=["inverse"], **parseLossArguments(
+        choices=LOSS_CHOICES,
+        help='The wanted losses. One may also want to specify a weight and dimension '
+             'that apply as follows: "<name>:<weight>:<dimension>".'))
+    parser.add_argument('--beta', type=float, default=1.0,
+                        help='(For beta-VAE only) Factor on the KL divergence, higher value means more disentangling.')
+    parser.add_argument('--path-to-dae', type=str, default="",
+                        help='Path to a pre-trained dae model when using the perceptual loss with VAE')
+    parser.add_argument('--state-dim-dae', type=int, default=200, help='state dimension of the pre-trained dae (default: 200)')
+    parser.add_argument('--occlusion-percentage', type=float, default=0.5,
+                        help='Max percentage of input occlusion for masks when using DAE')
+    return parser
+
+
+def resolveLosses(raw_losses, multi_view):
+    """The loss mini-language of the reference (train.py:79-115): plain names, or all '<name>:<weight>[:<dim>]'.
+    :return: (losses, losses_weights_dict, split_dimensions)"""
+    described = [isinstance(loss, tuple) for loss in raw_losses]
+    if any(described) and not all(described):
+        raise ValueError("Either no losses have a defined weight or dimension, or all losses have a defined weight. "
+                         "{}".format(raw_losses))
+    if not all(described):
+        return list(set(raw_losses)), None, -1
+    losses_weights_dict, split_dimensions = OrderedDict(), OrderedDict()
+    for loss, weight, split_dim in raw_losses:
+        losses_weights_dict[loss] = weight
+        split_dimensions[loss] = split_dim
+    losses = list(losses_weights_dict.keys())
+    assert not ("triplet" in losses and not multi_view), \
+        "Triplet loss with single view is not supported, please use the --multi-view option"
+    return losses, losses_weights_dict, split_dimensions
+
+
+def initDistributed():
+    """One process per GPU when launched by torch.distributed.run; returns (rank, world_size)."""
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size == 1:
+        return 0, 1
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    th.cuda.set_device(local_rank)
+    th.distributed.init_process_group(backend="nccl")
+    return th.distributed.get_rank(), world_size
+
+
+if __name__ == '__main__':
+    args = buildParser().parse_args()
+    args.cuda = not args.no_cuda and th.cuda.is_available()
+    args.data_folder = parseDataFolder(args.data_folder)
+    learner.DISPLAY_PLOTS = False  # plotting is out of scope
+    learner.N_EPOCHS = args.epochs
+    learner.BATCH_SIZE = args.batch_size
+    learner.VALIDATION_SIZE = args.val_size
+    learner.BALANCED_SAMPLING = args.balanced_sampling
+
+    losses, losses_weights_dict, split_dimensions = resolveLosses(args.losses, args.multi_view)
+    args.losses = losses
+    args.split_dimensions = split_dimensions
+    if args.multi_view is True:
+        # two stacked camera views (three with triplets) -> input layers take 6 (9) channels
+        preprocessing.preprocess.N_CHANNELS = 9 if "triplet" in losses else 6
+
+    assert not ("autoencoder" in losses and "vae" in losses), "Model cannot be both an Autoencoder and a VAE (come on!)"
+    assert not (("autoencoder" in losses or "vae" in losses)
+                and args.model_type == "resnet"), "Model cannot be an Autoencoder or VAE using ResNet Architecture !"
+    assert not ("vae" in losses and args.model_type == "linear"), "Model cannot be VAE using Linear Architecture !"
+    assert not (args.multi_view and args.model_type == "resnet"), \
+        "Default ResNet input layer is not suitable for stacked images!"
+    assert not (args.path_to_dae == "" and "vae" in losses and "perceptual" in losses), \
+        "To use the perceptual loss with a VAE, please specify a path to a pre-trained DAE model"
+    assert not ("dae" in losses and "perceptual" in losses), \
+        "Please learn the DAE before learning a VAE with the perceptual loss "
+
+    rank, world_size = initDistributed()
+
+    print('Loading data ... ')
+    training_data, ground_truth, _, _ = loadData(args.data_folder)
+    rewards, episode_starts = training_data['rewards'], training_data['episode_starts']
+    actions = training_data['actions']
+    n_actions = int(np.max(actions) + 1)  # actions are assumed to be integers
+    try:
+        images_path = np.array([path.decode("utf-8") for path in ground_truth['images_path']])
+    except AttributeError:
+        images_path = ground_truth['images_path']
+
+    exp_config = buildConfig(args)
+    if args.log_folder == "":
+        createFolder("logs/{}".format(exp_config['data-folder']), "Dataset log folder already exist")
+        log_folder, experiment_name = getLogFolderName(exp_config)
+        args.log_folder = log_folder
+    else:
+        createFolder(args.log_folder, "Log folder already exist")
+        experiment_name = "{}_{}".format(args.model_type, losses)
+
+    exp_config['log-folder'] = args.log_folder
+    exp_config['experiment-name'] = experiment_name
+    exp_config['n_actions'] = n_actions
+    exp_config['multi-view'] = args.multi_view
+    if "dae" in losses:
+        exp_config['occlusion-percentage'] = args.occlusion_percentage
+    print('Log folder: {}'.format(args.log_folder))
+
+    print('Learning a state representation ... ')
+    srl = SRL4robotics(args.state_dim, model_type=args.model_type, inverse_model_type=args.inverse_model_type,
+                       seed=args.seed, log_folder=args.log_folder, learning_rate=args.learning_rate,
+                       l1_reg=args.l1_reg, l2_reg=args.l2_reg, cuda=args.cuda, multi_view=args.multi_view,
+                       losses=losses, losses_weights_dict=losses_weights_dict, n_actions=n_actions, beta=args.beta,
+                       split_dimensions=split_dimensions, path_to_dae=args.path_to_dae,
+                       state_dim_dae=args.state_dim_dae, occlusion_percentage=args.occlusion_percentage)
+
+    if args.training_set_size > 0:
+        limit = args.training_set_size
+        actions, images_path = actions[:limit], images_path[:limit]
+        rewards, episode_starts = rewards[:limit], episode_starts[:limit]
+
+    if rank == 0:
+        saveConfig(exp_config, print_config=True)
+
+    loss_history, learned_states, pairs_name_weights = srl.learn(images_path, actions, rewards, episode_starts)
+
+    if rank == 0:
+        exp_config['losses_weights'] = pairs_name_weights
+        saveConfig(exp_config, print_config=True)
+        srl.saveStates(learned_states, images_path, rewards, args.log_folder)
+        np.savez('{}/loss_history.npz'.format(args.log_folder), **loss_history)
+        correlationCall(exp_config, plot=False)
+    if world_size > 1:
+        th.distributed.destroy_process_group()

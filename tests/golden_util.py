@@ -1,0 +1,69 @@
+"""Shared helpers for the golden fixtures (used by tools/make_golden.py and by the tests).
+
+Inputs are never stored: they are regenerated from a seed here, so a fixture holds only
+expected outputs.  `tensor_digest` is the reduced form an output tensor is stored in.
+"""
+import os
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SUB = 97  # stride of the flat subsample kept for big tensors
+
+_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
+_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+
+
+def synthetic_obs(B, C, seed):
+    """uint8 noise image -> /255 -> ImageNet mean/std -> reference tensor layout [B,C,W,H].
+
+    Mirrors what preprocessing/data_loader.py:38-65,255 + preprocessing/utils.py:20-32 do to a
+    decoded frame (SURVEY §8d "Configs 2-4"): per RGB triple normalisation, then
+    transpose(0,3,2,1).  Returns (obs, next_obs) float32.
+    """
+    rs = np.random.RandomState(seed)
+    raw = rs.randint(0, 256, (2, B, 224, 224, C)).astype(np.float32) / np.float32(255.0)
+    reps = C // 3
+    raw = (raw - np.tile(_MEAN, reps)) / np.tile(_STD, reps)
+    x = np.ascontiguousarray(raw.transpose(0, 1, 4, 3, 2)).astype(np.float32)
+    return x[0], x[1]
+
+
+def golden_inputs(B, C, A, seed=1234):
+    obs, next_obs = synthetic_obs(B, C, seed)
+    actions = np.random.RandomState(seed + 77).randint(0, A, (B,)).astype(np.int64)
+    return obs, next_obs, actions
+
+
+def tensor_digest(t):
+    """sum, abs-sum, L2 norm (float64) and a strided flat subsample of a tensor/ndarray."""
+    if hasattr(t, "detach"):
+        t = t.detach().cpu().double().numpy()
+    a = np.asarray(t, dtype=np.float64).reshape(-1)
+    return {
+        "sum": np.array(a.sum()),
+        "abs": np.array(np.abs(a).sum()),
+        "l2": np.array(np.sqrt((a * a).sum())),
+        "sub": a[::SUB].copy() if a.size > 4096 else a.copy(),
+    }
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+
+def check_digest(t, g, prefix, rtol=1e-4, atol_scale=1e-5):
+    """Assert tensor `t` matches the stored digest g[prefix+/...]; returns worst relative error."""
+    d = tensor_digest(t)
+    ref_sub = g[prefix + "/sub"]
+    scale = max(float(np.abs(ref_sub).max()), 1e-30)
+    err_sub = float(np.abs(d["sub"] - ref_sub).max()) / scale
+    n = max(d["sub"].size, 1)
+    l2 = float(g[prefix + "/l2"])
+    err_l2 = abs(float(d["l2"]) - l2) / max(l2, 1e-30)
+    ab = float(g[prefix + "/abs"])
+    err_sum = abs(float(d["sum"]) - float(g[prefix + "/sum"])) / max(ab, 1e-30)
+    worst = max(err_sub, err_l2, err_sum)
+    assert err_sub <= rtol, "%s: subsample rel err %.3e > %.1e" % (prefix, err_sub, rtol)
+    assert err_l2 <= rtol, "%s: l2 rel err %.3e" % (prefix, err_l2)
+    assert err_sum <= rtol, "%s: sum err (rel. to abs-sum) %.3e" % (prefix, err_sum)
+    return worst

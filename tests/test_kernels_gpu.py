@@ -1,0 +1,396 @@
+"""Kernel-level parity (GPU): every C-ABI entry point against the CPU oracle on the same seeded inputs.
+
+Oracle = torch CPU fp32/fp64 functional ops (the third-party library the reference's arithmetic lives in) — see
+oracle/torch_twin.py header.  Tolerance: fp32, 1e-4 relative (BASELINE.json north_star); most ops hold 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    scale = ref.abs().max().item()
+    return (got - ref).abs().max().item() / max(scale, 1e-30)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.fixture(scope="module")
+def C():
+    from srlz import _cabi
+    assert torch.cuda.is_available()
+    return _cabi
+
+
+def out_size(hi, s, p, t):
+    return (hi - 1) * s - 2 * p + 3 if t else (hi + 2 * p - 3) // s + 1
+
+
+CONV64 = [(3, 56, 1, 1, 0), (3, 27, 2, 1, 0), (5, 6, 2, 0, 1), (3, 13, 2, 0, 1), (2, 27, 2, 0, 1), (2, 55, 2, 0, 1),
+          (1, 9, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("n,hi,s,p,t", CONV64)
+def test_conv64_forward_backward(C, n, hi, s, p, t):
+    g = torch.Generator().manual_seed(hi * 13 + s)
+    ho = out_size(hi, s, p, t)
+    x = torch.randn(n, 64, hi, hi, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(64, generator=g) if t else None
+    dy = torch.randn(n, 64, ho, ho, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if t else None
+    if t:
+        yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=p)
+    else:
+        yr = F.conv2d(xr, wr, None, stride=s, padding=p)
+    yr.backward(dy.double())
+
+    d = C.Conv64Desc(n, hi, hi, ho, ho, 3, s, p, t)
+    st = C.stream()
+    xd, wd, dyd = nhwc(x).to(DEV), w.to(DEV), nhwc(dy).to(DEV)
+    bd = b.to(DEV) if t else None
+    packs = torch.empty(2, C.conv64_packed_floats(), device=DEV)
+    C.conv64_pack_weights(C.ptr(wd), C.ptr(packs[0]), C.ptr(packs[1]), d, st)
+    y = torch.full((n, ho, ho, 64), float("nan"), device=DEV)
+    ntiles = C.conv64_fwd_tiles(d)
+    stats = torch.empty(ntiles, 128, device=DEV)
+    C.conv64_fwd(C.ptr(xd), C.ptr(packs[0]), C.ptr(bd), C.ptr(y), C.ptr(stats), d, st)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y), yr) < 2e-5
+    # BatchNorm partial sums
+    s_tot = stats.double().sum(0).cpu()
+    yr_flat = yr.detach().permute(1, 0, 2, 3).reshape(64, -1)
+    assert rel_err(s_tot[:64], yr_flat.sum(1)) < 1e-4 or (s_tot[:64] - yr_flat.sum(1)).abs().max() < 1e-2
+    assert rel_err(s_tot[64:], (yr_flat ** 2).sum(1)) < 2e-5
+
+    dx = torch.full((n, hi, hi, 64), float("nan"), device=DEV)
+    C.conv64_bwd_data(C.ptr(dyd), C.ptr(packs[1]), C.ptr(dx), d, st)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx), xr.grad) < 2e-5
+
+    nbytes = C.conv64_bwd_weight_workspace(d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, 64, 3, 3), float("nan"), device=DEV)
+    db = torch.full((64,), float("nan"), device=DEV)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(db), C.ptr(ws), nbytes, d, st)
+    torch.cuda.synchronize()
+    assert rel_err(dw, wr.grad) < 2e-5
+    ref_db = dy.double().sum((0, 2, 3))
+    assert rel_err(db, ref_db) < 2e-5
+
+
+def test_conv64_deterministic(C):
+    """Two runs of the weight gradient are bit-identical (fixed-order split-K reduction; learner.py:62)."""
+    n, hi = 4, 27
+    g = torch.Generator().manual_seed(5)
+    d = C.Conv64Desc(n, hi, hi, 55, 55, 3, 2, 0, 1)
+    x = torch.randn(n, hi, hi, 64, generator=g).to(DEV)
+    dy = torch.randn(n, 55, 55, 64, generator=g).to(DEV)
+    nbytes = C.conv64_bwd_weight_workspace(d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.empty(64, 64, 3, 3, device=DEV)
+        C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), None, C.ptr(ws), nbytes, d, C.stream())
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("n,c,h", [(2, 3, 224), (1, 6, 224), (2, 3, 64)])
+def test_conv1(C, n, c, h):
+    g = torch.Generator().manual_seed(c * 100 + h)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(64, c, 7, 7, generator=g) * 0.1
+    hf = (h + 6 - 7) // 2 + 1
+    dy = torch.randn(n, 64, hf, hf, generator=g)
+    wr = w.double().requires_grad_(True)
+    yr = F.conv2d(x.double(), wr, None, stride=2, padding=3)
+    yr.backward(dy.double())
+    d = C.SkinnyDesc(n, c, h, h, hf, hf, 0)
+    st = C.stream()
+    xd, wd, dyd = x.to(DEV), w.to(DEV), nhwc(dy).to(DEV)
+    y = torch.full((n, hf, hf, 64), float("nan"), device=DEV)
+    stats = torch.empty(C.skinny_tiles(d), 128, device=DEV)
+    C.conv1_fwd(C.ptr(xd), C.ptr(wd), C.ptr(y), C.ptr(stats), d, st)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y), yr) < 2e-5
+    s_tot = stats.double().sum(0).cpu()
+    yr_flat = yr.detach().permute(1, 0, 2, 3).reshape(64, -1)
+    assert rel_err(s_tot[64:], (yr_flat ** 2).sum(1)) < 2e-5
+    assert (s_tot[:64] - yr_flat.sum(1)).abs().max() < 1e-3 * yr_flat.abs().sum(1).max()
+    nbytes = C.skinny_bwd_weight_workspace(d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, c, 7, 7), float("nan"), device=DEV)
+    C.conv1_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(ws), nbytes, d, st)
+    torch.cuda.synchronize()
+    assert rel_err(dw, wr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("n,c,hf", [(2, 3, 111), (1, 6, 111), (3, 3, 20)])
+def test_convT_out(C, n, c, hf):
+    g = torch.Generator().manual_seed(c * 10 + hf)
+    himg = (hf - 1) * 2 + 4
+    x = torch.randn(n, 64, hf, hf, generator=g)
+    w = torch.randn(64, c, 4, 4, generator=g) * 0.1
+    b = torch.randn(c, generator=g)
+    dy = torch.randn(n, c, himg, himg, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    yr.backward(dy.double())
+    d = C.SkinnyDesc(n, c, himg, himg, hf, hf, 1)
+    st = C.stream()
+    xd, wd, bd, dyd = nhwc(x).to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    y = torch.full((n, c, himg, himg), float("nan"), device=DEV)
+    C.convT_out_fwd(C.ptr(xd), C.ptr(wd), C.ptr(bd), C.ptr(y), d, st)
+    torch.cuda.synchronize()
+    assert rel_err(y, yr) < 2e-5
+    dx = torch.full((n, hf, hf, 64), float("nan"), device=DEV)
+    C.convT_out_bwd_data(C.ptr(dyd), C.ptr(wd), C.ptr(dx), d, st)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx), xr.grad) < 2e-5
+    nbytes = C.skinny_bwd_weight_workspace(d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, c, 4, 4), float("nan"), device=DEV)
+    db = torch.full((c,), float("nan"), device=DEV)
+    C.convT_out_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(db), C.ptr(ws), nbytes, d, st)
+    torch.cuda.synchronize()
+    assert rel_err(dw, wr.grad) < 2e-5
+    assert rel_err(db, br.grad) < 2e-5
+
+
+def _bn_setup(g, shape):
+    y = torch.randn(*shape, generator=g) * 1.7 + 0.3
+    gamma = torch.rand(64, generator=g) + 0.5
+    beta = torch.randn(64, generator=g) * 0.2
+    rm = torch.randn(64, generator=g) * 0.1
+    rv = torch.rand(64, generator=g) + 0.5
+    return y, gamma, beta, rm, rv
+
+
+def _partials(y_nhwc, rows_per=100):
+    """Per-tile partial sums as a conv epilogue would produce them (any tiling sums to the same statistics)."""
+    flat = y_nhwc.reshape(-1, 64).double()
+    chunks = torch.split(flat, rows_per)
+    return torch.stack([torch.cat((c.sum(0), (c * c).sum(0))) for c in chunks]).float()
+
+
+@pytest.mark.parametrize("n,h,pad,out_nchw,training", [(2, 112, 1, 0, 1), (3, 56, 0, 0, 1), (4, 14, 0, 1, 1),
+                                                       (2, 56, 0, 0, 0), (2, 14, 0, 1, 0)])
+def test_bn_relu_pool(C, n, h, pad, out_nchw, training):
+    g = torch.Generator().manual_seed(h + pad)
+    y, gamma, beta, rm, rv = _bn_setup(g, (n, 64, h, h))
+    hp = (h + 2 * pad - 3) // 2 + 1
+    dp = torch.randn(n, 64, hp, hp, generator=g)
+    yr = y.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    z = F.batch_norm(yr, rm_r, rv_r, gr, br, bool(training), 0.1, 1e-5)
+    pr = F.max_pool2d(F.relu(z), 3, 2, pad)
+    pr.backward(dp.double())
+
+    st = C.stream()
+    yd = nhwc(y).to(DEV)
+    gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    bnp = torch.empty(256, device=DEV)
+    if training:
+        parts = _partials(nhwc(y)).to(DEV)
+        bstat = torch.empty(128, device=DEV)
+        C.bn_finalize(C.ptr(parts), parts.shape[0], n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
+                      C.ptr(rvd), C.ptr(bnp), C.ptr(bstat), st)
+        torch.cuda.synchronize()
+        assert rel_err(rmd, rm_r) < 1e-5 and rel_err(rvd, rv_r) < 1e-5
+    else:
+        C.bn_eval_params(C.ptr(gd), C.ptr(bd), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(bnp), st)
+    d = C.PoolDesc(n, h, h, hp, hp, pad, out_nchw)
+    pooled = torch.full((n, 64, hp, hp) if out_nchw else (n, hp, hp, 64), float("nan"), device=DEV)
+    arg = torch.empty(n, hp, hp, 64, dtype=torch.uint8, device=DEV)
+    C.bn_relu_pool_fwd(C.ptr(yd), C.ptr(bnp), C.ptr(pooled), C.ptr(arg), d, st)
+    torch.cuda.synchronize()
+    got = pooled if out_nchw else nchw(pooled)
+    assert rel_err(got, pr) < 1e-5
+    dpd = (dp if out_nchw else nhwc(dp)).to(DEV)
+    dy = torch.full((n, h, h, 64), float("nan"), device=DEV)
+    dgm, dbt = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    nbytes = C.bn_bwd_workspace(0)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    C.bn_relu_pool_bwd(C.ptr(yd), C.ptr(bnp), C.ptr(arg), C.ptr(dpd), C.ptr(dy), C.ptr(dgm), C.ptr(dbt), training,
+                       C.ptr(ws), nbytes, d, st)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dy), yr.grad) < 5e-5
+    assert rel_err(dgm, gr.grad) < 5e-5 and rel_err(dbt, br.grad) < 5e-5
+
+
+@pytest.mark.parametrize("n,h,training", [(2, 111, 1), (3, 13, 1), (2, 27, 0)])
+def test_bn_relu(C, n, h, training):
+    g = torch.Generator().manual_seed(h)
+    y, gamma, beta, rm, rv = _bn_setup(g, (n, 64, h, h))
+    da = torch.randn(n, 64, h, h, generator=g)
+    yr = y.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ar = F.relu(F.batch_norm(yr, rm.double().clone(), rv.double().clone(), gr, br, bool(training), 0.1, 1e-5))
+    ar.backward(da.double())
+    st = C.stream()
+    yd, dad = nhwc(y).to(DEV), nhwc(da).to(DEV)
+    gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    bnp = torch.empty(256, device=DEV)
+    if training:
+        parts = _partials(nhwc(y)).to(DEV)
+        C.bn_finalize(C.ptr(parts), parts.shape[0], n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
+                      C.ptr(rvd), C.ptr(bnp), None, st)
+    else:
+        C.bn_eval_params(C.ptr(gd), C.ptr(bd), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(bnp), st)
+    a = torch.full((n, h, h, 64), float("nan"), device=DEV)
+    C.bn_relu_fwd(C.ptr(yd), C.ptr(bnp), C.ptr(a), n * h * h, st)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(a), ar) < 1e-5
+    dy = torch.full((n, h, h, 64), float("nan"), device=DEV)
+    dgm, dbt = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    nbytes = C.bn_bwd_workspace(0)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    C.bn_relu_bwd(C.ptr(yd), C.ptr(bnp), C.ptr(dad), C.ptr(dy), C.ptr(dgm), C.ptr(dbt), training, C.ptr(ws), nbytes,
+                  n * h * h, st)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dy), yr.grad) < 5e-5
+    assert rel_err(dgm, gr.grad) < 5e-5 and rel_err(dbt, br.grad) < 5e-5
+
+
+def test_bn_replay_and_repeat(C):
+    g = torch.Generator().manual_seed(3)
+    stat = torch.randn(128, generator=g).abs()
+    rm, rv = torch.randn(64, generator=g), torch.rand(64, generator=g)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    C.bn_replay(C.ptr(stat.to(DEV)), 0.1, C.ptr(rmd), C.ptr(rvd), C.stream())
+    torch.cuda.synchronize()
+    assert rel_err(rmd, 0.9 * rm + 0.1 * stat[:64]) < 1e-6
+    assert rel_err(rvd, 0.9 * rv + 0.1 * stat[64:]) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(32, 200, 2304, 0), (7, 2304, 200, 0), (5, 6, 400, 0), (64, 128, 400, 1),
+                                        (3, 200, 206, 0), (130, 70, 33, 1)])
+def test_linear(C, M, N, K, relu):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(dy.double())
+    st = C.stream()
+    xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    C.linear_fwd(C.ptr(xd), C.ptr(wd), C.ptr(bd), C.ptr(y), M, N, K, relu, st)
+    torch.cuda.synchronize()
+    assert rel_err(y, yr) < 2e-5
+    if relu:
+        C.relu_bwd_inplace(C.ptr(y), C.ptr(dyd), M * N, st)
+    dx = torch.full((M, K), float("nan"), device=DEV)
+    C.linear_bwd_data(C.ptr(dyd), C.ptr(wd), C.ptr(dx), M, N, K, st)
+    dw = torch.full((N, K), float("nan"), device=DEV)
+    db = torch.full((N,), float("nan"), device=DEV)
+    C.linear_bwd_weight(C.ptr(dyd), C.ptr(xd), C.ptr(dw), C.ptr(db), M, N, K, st)
+    torch.cuda.synchronize()
+    assert rel_err(dx, xr.grad) < 2e-5 and rel_err(dw, wr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
+
+
+def test_layout_seams(C):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 64, 6, 6, generator=g)
+    xd = x.to(DEV)
+    y = torch.empty(5, 6, 6, 64, device=DEV)
+    C.nchw_to_nhwc(C.ptr(xd), C.ptr(y), 5, 64, 6, 6, C.stream())
+    back = torch.empty(5, 64, 6, 6, device=DEV)
+    C.nhwc_to_nchw(C.ptr(y), C.ptr(back), 5, 64, 6, 6, C.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), nhwc(x)) and torch.equal(back.cpu(), x)
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 2 * 3 * 224 * 224 + 3])
+def test_loss_reductions(C, n):
+    g = torch.Generator().manual_seed(n)
+    a, b = torch.randn(n + 4, generator=g)[:n].contiguous(), torch.randn(n, generator=g)
+    st = C.stream()
+    ad, bd = a.to(DEV), b.to(DEV)
+    out = torch.empty((), device=DEV)
+    nbytes = C.reduce_workspace(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    C.sqdiff_sum(C.ptr(ad), C.ptr(bd), n, C.ptr(out), C.ptr(ws), nbytes, st)
+    ref = ((a.double() - b.double()) ** 2).sum()
+    assert abs(out.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    coef = torch.tensor(0.37, device=DEV)
+    da = torch.empty(n, device=DEV)
+    C.sqdiff_grad(C.ptr(ad), C.ptr(bd), C.ptr(coef), 2.0, C.ptr(da), n, st)
+    assert rel_err(da, 0.37 * 2.0 * (a.double() - b.double())) < 1e-6
+    lv = (b * 0.3).contiguous()
+    lvd = lv.to(DEV)
+    C.kl_sum(C.ptr(ad), C.ptr(lvd), n, C.ptr(out), C.ptr(ws), nbytes, st)
+    ref = -0.5 * (1 + lv.double() - a.double() ** 2 - lv.double().exp()).sum()
+    assert abs(out.item() - ref.item()) <= 2e-6 * max(abs(ref.item()), 1.0)
+    dmu, dlv = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    C.kl_grad(C.ptr(ad), C.ptr(lvd), C.ptr(coef), 1.0, C.ptr(dmu), C.ptr(dlv), n, st)
+    assert rel_err(dmu, 0.37 * a.double()) < 1e-6
+    assert rel_err(dlv, 0.37 * 0.5 * (lv.double().exp() - 1)) < 1e-5
+
+
+def test_reparam_ce_onehot(C):
+    g = torch.Generator().manual_seed(21)
+    B, S, A = 9, 200, 6
+    mu, lv, eps = torch.randn(B, S, generator=g), torch.randn(B, S, generator=g) * 0.4, torch.randn(B, S, generator=g)
+    dz = torch.randn(B, S, generator=g)
+    st = C.stream()
+    mud, lvd, epsd, dzd = mu.to(DEV), lv.to(DEV), eps.to(DEV), dz.to(DEV)
+    z = torch.empty(B, S, device=DEV)
+    C.reparam_fwd(C.ptr(mud), C.ptr(lvd), C.ptr(epsd), C.ptr(z), B * S, st)
+    assert rel_err(z, eps.double() * (0.5 * lv.double()).exp() + mu.double()) < 1e-6
+    dmu, dlv = torch.empty(B, S, device=DEV), torch.empty(B, S, device=DEV)
+    C.reparam_bwd(C.ptr(dzd), C.ptr(lvd), C.ptr(epsd), C.ptr(dmu), C.ptr(dlv), B * S, st)
+    assert rel_err(dmu, dz) < 1e-7
+    assert rel_err(dlv, dz.double() * eps.double() * 0.5 * (0.5 * lv.double()).exp()) < 1e-6
+    logits = torch.randn(B, A, generator=g) * 2
+    tgt = torch.randint(0, A, (B,), generator=g)
+    lr = logits.double().requires_grad_(True)
+    ref = F.cross_entropy(lr, tgt)
+    ref.backward()
+    out = torch.empty((), device=DEV)
+    dl = torch.empty(B, A, device=DEV)
+    C.cross_entropy(C.ptr(logits.to(DEV)), C.ptr(tgt.to(DEV)), B, A, C.ptr(out), C.ptr(dl), st)
+    assert abs(out.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    assert rel_err(dl, lr.grad) < 1e-5
+    cat = torch.empty(B, S + A, device=DEV)
+    C.concat_onehot(C.ptr(mud), C.ptr(tgt.to(DEV)), C.ptr(cat), B, S, A, st)
+    ref_cat = torch.cat((mu, F.one_hot(tgt, A).float()), 1)
+    assert torch.equal(cat.cpu(), ref_cat)
+
+
+def test_adam(C):
+    g = torch.Generator().manual_seed(33)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=5e-3)
+    pd = p0.to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * (10.0 ** -step)
+        pr.grad = gr.clone()
+        opt.step()
+        C.adam_step(C.ptr(pd), C.ptr((gr * 4).to(DEV)), C.ptr(m), C.ptr(v), n, 5e-3, 0.9, 0.999, 1e-8, step, 0.25,
+                    C.stream())
+    assert rel_err(pd, pr) < 1e-6

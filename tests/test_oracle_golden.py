@@ -1,0 +1,166 @@
+"""Pins the CPU oracle (oracle/torch_twin.py) and the build's parameter construction against the golden fixtures that
+tools/make_golden.py captured from the UNMODIFIED reference (/root/reference, imported in the build container).
+
+Runs anywhere (no GPU, no /root/reference needed): this is what makes the oracle trustworthy on the GPU box.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import torch_twin as T
+
+RTOL = 2e-5
+
+
+def build(losses, C=3, S=200, A=6, seed=1, inverse="linear"):
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModules
+    pre.N_CHANNELS = C
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return SRLModules(state_dim=S, action_dim=A, cuda=False, model_type="custom_cnn", losses=losses,
+                      inverse_model_type=inverse)
+
+
+@pytest.mark.parametrize("tag,losses,C", [("ae_c3", ["autoencoder"], 3), ("vae_c3", ["vae"], 3),
+                                          ("ae_c6", ["autoencoder"], 6), ("cnn_c3", ["inverse"], 3)])
+def test_seeded_construction_reproduces_reference_init(tag, losses, C):
+    """Same constructors, same order => same RNG stream => the reference's initial state_dict."""
+    g = gu.load("init_" + tag)
+    sd = build(losses, C=C).state_dict()
+    assert list(sd.keys()) == [str(n) for n in g["names"]]
+    for i, (k, v) in enumerate(sd.items()):
+        assert str(list(v.shape)).replace(" ", "") == str(g["shapes"][i]).replace(" ", ""), k
+        assert abs(float(v.double().sum()) - g["sums"][i]) <= 1e-9 * max(1.0, g["abss"][i]), k
+        assert abs(float(v.double().abs().sum()) - g["abss"][i]) <= 1e-9 * max(1.0, g["abss"][i]), k
+
+
+CASES = [("step_ae_b2", ["autoencoder"], 2, 3, "linear"),
+         ("step_ae_b4", ["autoencoder"], 4, 3, "linear"),
+         ("step_vae_b2", ["vae"], 2, 3, "linear"),
+         ("step_vae_b4", ["vae"], 4, 3, "linear"),
+         ("step_aeif_b2", ["autoencoder", "inverse", "forward"], 2, 3, "linear"),
+         ("step_aeif_mlp_b2", ["autoencoder", "inverse", "forward"], 2, 3, "mlp"),
+         ("step_ae_c6_b2", ["autoencoder"], 2, 6, "linear"),
+         ("step_vae_c6_b2", ["vae"], 2, 6, "linear"),
+         ("step_cnn_if_b2", ["inverse", "forward"], 2, 3, "linear")]
+
+
+def run_twin(losses, B, C, inverse, n_steps=1, lr=None):
+    torch.set_num_threads(1)
+    model = build(losses, C=C, inverse=inverse)
+    sd = T.clone_state(model.state_dict())
+    opt = T.TwinAdam(sd, lr) if lr is not None else None
+    outs = []
+    for step in range(n_steps):
+        obs, next_obs, actions = gu.golden_inputs(B, C, 6, seed=1234 + step)
+        eps = [None, None]
+        if "vae" in losses:
+            torch.manual_seed(99 + step)
+            eps = [torch.randn(B, 200), torch.randn(B, 200)]
+        out = T.train_step(sd, losses, torch.from_numpy(obs), torch.from_numpy(next_obs), torch.from_numpy(actions),
+                           eps=eps[0], next_eps=eps[1])
+        outs.append(out)
+        if opt is not None:
+            opt.step(sd)
+    return sd, outs
+
+
+@pytest.mark.parametrize("name,losses,B,C,inverse", CASES)
+def test_twin_step_matches_reference_golden(name, losses, B, C, inverse):
+    g = gu.load(name)
+    sd, outs = run_twin(losses, B, C, inverse)
+    out = outs[0]
+    for k in [f for f in g.files if f.startswith("loss/")]:
+        nm = k[len("loss/"):]
+        v = float(g[k])
+        got = out["total"] if nm == "total" else out["losses"][nm]
+        assert abs(got - v) <= RTOL * max(abs(v), 1e-6), (k, got, v)
+    gu.check_digest(out["states"], g, "states", rtol=RTOL)
+    gu.check_digest(out["next_states"], g, "next_states", rtol=RTOL)
+    if out["decoded"] is not None:
+        gu.check_digest(out["decoded"], g, "decoded", rtol=RTOL)
+        gu.check_digest(out["next_decoded"], g, "next_decoded", rtol=RTOL)
+    if out["logvar"] is not None:
+        gu.check_digest(out["logvar"], g, "logvar", rtol=RTOL)
+    for k, grad in out["grads"].items():
+        if ("grad/" + k + "/none") in g.files:
+            assert grad is None, k
+        elif k.endswith(("decoder_conv.0.bias", "decoder_conv.3.bias", "decoder_conv.6.bias", "decoder_conv.9.bias")):
+            continue  # analytically zero gradients (bias feeding a train-mode BN): pure summation noise
+        else:
+            gu.check_digest(grad, g, "grad/" + k, rtol=1e-4)
+    for k in [f for f in g.files if f.startswith("bn/")]:
+        ref = np.asarray(g[k], dtype=np.float64)
+        got = sd[k[len("bn/"):]].double().numpy()
+        np.testing.assert_allclose(got, ref, rtol=RTOL, atol=1e-7)
+    kind = "ae" if "autoencoder" in losses else ("vae" if "vae" in losses else "cnn")
+    obs, _, _ = gu.golden_inputs(B, C, 6, seed=1234)
+    st = T.get_states(sd, torch.from_numpy(obs), kind)
+    np.testing.assert_allclose(st.double().numpy(), g["eval_states/full"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,losses", [("trace_ae_b2", ["autoencoder"]), ("trace_vae_b2", ["vae"]),
+                                         ("trace_aeif_b2", ["autoencoder", "inverse", "forward"])])
+def test_twin_adam_trace_matches_reference(name, losses):
+    """Three optimisation steps (Adam, lr 1e-4): per-step losses follow the reference."""
+    g = gu.load(name)
+    sd, outs = run_twin(losses, 2, 3, "linear", n_steps=3, lr=1e-4)
+    names = [str(n) for n in g["trace/names"]]
+    for step, out in enumerate(outs):
+        for j, nm in enumerate(names):
+            v = float(g["trace/values"][step, j])
+            got = out["total"] if nm == "total" else out["losses"][nm]
+            assert abs(got - v) <= 5e-4 * max(abs(v), 1e-6), (step, nm, got, v)
+
+
+def test_loss_kats():
+    """reconstruction / generation / KL / forward / inverse on small tensors (reference losses.py free functions)."""
+    g = gu.load("loss_kats")
+    Tn = lambda k: torch.from_numpy(g["in/" + k])
+    a, b, c, d = Tn("a"), Tn("b"), Tn("c"), Tn("d")
+    assert abs(T.reconstruction_loss(a, b).item() - float(g["reconstruction"])) < 1e-6
+    ae = T.reconstruction_loss(a, b) + T.reconstruction_loss(c, d)
+    assert abs(ae.item() - float(g["autoencoder_w1"])) < 1e-6
+    kl = 2.0 * (T.kl_loss(Tn("mu"), Tn("lv")) + T.kl_loss(Tn("nmu"), Tn("nlv")))
+    assert abs(kl.item() - float(g["kl_beta2"])) < 1e-4
+    fw = T.reconstruction_loss(Tn("mu"), Tn("nmu"))
+    assert abs(fw.item() - float(g["forward_w1"])) < 1e-6
+    inv = 2.0 * torch.nn.functional.cross_entropy(Tn("logits"), Tn("act").view(-1))
+    assert abs(inv.item() - float(g["inverse_w2"])) < 1e-6
+
+
+def test_head_kats():
+    g = gu.load("head_kats")
+    s, ns, act = torch.from_numpy(g["in/s"]), torch.from_numpy(g["in/ns"]), torch.from_numpy(g["in/act"])
+    for inv in ("linear", "mlp"):
+        sd = T.clone_state(build(["autoencoder", "inverse", "forward"], inverse=inv).state_dict(), requires_grad=False)
+        np.testing.assert_allclose(T.forward_model(sd, s, act, 6).numpy(), g[inv + "/forward"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(T.inverse_model(sd, s, ns).numpy(), g[inv + "/inverse"], rtol=1e-5, atol=1e-6)
+
+
+def test_layer_trace():
+    """Per-layer forward digests of the AE (conv outputs / pooled maps), B=2."""
+    g = gu.load("layers_ae_b2")
+    torch.set_num_threads(1)
+    sd = T.clone_state(build(["autoencoder"]).state_dict(), requires_grad=False)
+    obs, _, _ = gu.golden_inputs(2, 3, 6, seed=1234)
+    taps = {}
+    T.ae_forward(sd, torch.from_numpy(obs), True, taps=taps)
+    checked = 0
+    for k, v in taps.items():
+        key = k[len("model."):]
+        if (key + "/sum") in g.files:
+            gu.check_digest(v, g, key, rtol=RTOL)
+            checked += 1
+    assert checked >= 10
+
+
+def test_product_has_no_cpu_path():
+    model = build(["autoencoder"])
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 224, 224))
+    from models.learner import SRL4robotics
+    with pytest.raises(RuntimeError):
+        SRL4robotics(10, model_type="custom_cnn", losses=["autoencoder"], cuda=False)

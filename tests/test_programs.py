@@ -1,0 +1,115 @@
+"""Host logic of the 64->64 convolution family: the virtual-grid programs built by csrc/conv64.hip::build_program
+(dumped through srlz_conv64_debug_program, a host-only call) are interpreted here in numpy and must reproduce
+torch's conv2d / conv_transpose2d and their data gradients for every layer shape of the network."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+# (hi, stride, pad, transposed) of every 64->64 layer: conv2, conv3, ConvT1..4 (reference models/models.py:54-78)
+LAYERS = [(56, 1, 1, 0), (27, 2, 1, 0), (6, 2, 0, 1), (13, 2, 0, 1), (27, 2, 0, 1), (55, 2, 0, 1),
+          (9, 1, 1, 0), (10, 2, 1, 0), (7, 2, 0, 1)]
+
+
+def out_size(hi, s, p, t):
+    return (hi - 1) * s - 2 * p + 3 if t else (hi + 2 * p - 3) // s + 1
+
+
+def get_program(cabi, n, hi, s, p, t, backward):
+    d = cabi.Conv64Desc(n, hi, hi, out_size(hi, s, p, t), out_size(hi, s, p, t), 3, s, p, t)
+    buf = (ctypes.c_int * 64)()
+    cnt = cabi.conv64_debug_program(d, backward, buf, 64)
+    assert cnt == 48, cabi.error_text()
+    v = list(buf)[:cnt]
+    keys = ["N", "PH", "PW", "ss", "Hs", "Ws", "ds", "Hd", "Wd", "min_off", "span", "s2"]
+    P = dict(zip(keys, v[:12]))
+    P["taps"] = [tuple(v[12 + 4 * i: 16 + 4 * i]) for i in range(9)]  # (src, dst, off, w)
+    return P
+
+
+def interpret(P, src, Wg):
+    """src [N,Hs,Ws,Cin], Wg [9][Cin][Cout] -> dst [N,Hd,Wd,Cout] following the program semantics."""
+    N, PH, PW = P["N"], P["PH"], P["PW"]
+    total = N * PH * PW
+    cout = Wg.shape[2]
+    dst = np.full((N, P["Hd"], P["Wd"], cout), np.nan, dtype=np.float64)
+    q = np.arange(total)
+    n, rem = q // (PH * PW), q % (PH * PW)
+    a, b = rem // PW, rem % PW
+    for d in sorted(set(t[1] for t in P["taps"])):
+        acc = np.zeros((total, cout))
+        for (c, dd, off, w) in P["taps"]:
+            if dd != d:
+                continue
+            q2 = q + off
+            ok = (q2 >= 0) & (q2 < total)
+            q2c = np.clip(q2, 0, total - 1)
+            n2, rem2 = q2c // (PH * PW), q2c % (PH * PW)
+            y = (rem2 // PW) * P["ss"] + (c >> 1)
+            x = (rem2 % PW) * P["ss"] + (c & 1)
+            ok &= (y < P["Hs"]) & (x < P["Ws"])
+            vals = np.where(ok[:, None], src[n2, np.minimum(y, P["Hs"] - 1), np.minimum(x, P["Ws"] - 1), :], 0.0)
+            acc += vals @ Wg[w]
+        oy, ox = a * P["ds"] + (d >> 1), b * P["ds"] + (d & 1)
+        ok = (oy < P["Hd"]) & (ox < P["Wd"])
+        assert not np.isfinite(dst[n[ok], oy[ok], ox[ok], 0]).any(), "an output position is produced twice"
+        dst[n[ok], oy[ok], ox[ok], :] = acc[ok]
+    assert np.isfinite(dst).all(), "some output position is never produced"
+    return dst
+
+
+@pytest.mark.parametrize("hi,s,p,t", LAYERS)
+def test_forward_program_matches_torch(cabi, hi, s, p, t):
+    rs = np.random.RandomState(hi * 10 + s)
+    N, C = 2, 3
+    x = rs.randn(N, hi, hi, C)
+    Wg = rs.randn(9, C, C)  # [tap][cin][cout]
+    P = get_program(cabi, N, hi, s, p, t, 0)
+    got = interpret(P, x, Wg)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    if t:
+        w = torch.from_numpy(Wg.reshape(3, 3, C, C)).permute(2, 3, 0, 1).contiguous()  # [ci,co,ky,kx]
+        ref = F.conv_transpose2d(xt, w, stride=s, padding=p)
+    else:
+        w = torch.from_numpy(Wg.reshape(3, 3, C, C)).permute(3, 2, 0, 1).contiguous()  # [co,ci,ky,kx]
+        ref = F.conv2d(xt, w, stride=s, padding=p)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("hi,s,p,t", LAYERS)
+def test_backward_data_program_matches_autograd(cabi, hi, s, p, t):
+    rs = np.random.RandomState(hi * 7 + s + 100)
+    N, C = 2, 3
+    ho = out_size(hi, s, p, t)
+    x = torch.from_numpy(rs.randn(N, C, hi, hi)).requires_grad_(True)
+    dy = rs.randn(N, ho, ho, C)
+    Wg = rs.randn(9, C, C)  # forward slabs [tap][cin][cout]
+    if t:
+        w = torch.from_numpy(Wg.reshape(3, 3, C, C)).permute(2, 3, 0, 1).contiguous()
+        y = F.conv_transpose2d(x, w, stride=s, padding=p)
+    else:
+        w = torch.from_numpy(Wg.reshape(3, 3, C, C)).permute(3, 2, 0, 1).contiguous()
+        y = F.conv2d(x, w, stride=s, padding=p)
+    y.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1).numpy()
+    P = get_program(cabi, N, hi, s, p, t, 1)
+    got = interpret(P, dy, Wg.transpose(0, 2, 1))  # data-gradient slabs map cout -> cin
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("hi,s,p,t", LAYERS)
+def test_program_tap_grouping(cabi, hi, s, p, t):
+    """Stride-2 programs group taps {4,2,2,1} by class (the weight-gradient kernel relies on it)."""
+    for backward in (0, 1):
+        P = get_program(cabi, 1, hi, s, p, t, backward)
+        key = [(c, d) for (c, d, _, _) in P["taps"]]
+        if P["s2"]:
+            assert key[0] == key[1] == key[2] == key[3] and key[4] == key[5] and key[6] == key[7]
+            assert len(set(key)) == 4
+        else:
+            assert len(set(key)) == 1
+        assert sorted(w for (_, _, _, w) in P["taps"]) == list(range(9))

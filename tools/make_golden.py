@@ -1,0 +1,290 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box).  The
+reference is imported, never copied: four absent third-party modules are stubbed in
+sys.modules (torchvision, cv2, termcolor, seaborn) exactly as SURVEY.md §8c describes.
+
+Every fixture is DATA: inputs are regenerated from a seed by `golden_inputs()` (shared with
+the tests through tests/golden_util.py), outputs are stored as sums, norms and strided
+subsamples so the files stay small.
+
+    python tools/make_golden.py            # writes tests/golden/*.npz
+"""
+from __future__ import print_function
+import os
+import sys
+import types
+import json
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def _stub_modules():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvm.resnet18 = lambda *a, **k: None
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+    tc = types.ModuleType("termcolor")
+    tc.colored = lambda s, *a, **k: s
+    sys.modules["termcolor"] = tc
+    sb = types.ModuleType("seaborn")
+    sb.set = lambda *a, **k: None
+    sys.modules["seaborn"] = sb
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+def import_reference():
+    _stub_modules()
+    sys.path.insert(0, REF)
+    import torch as th
+    th.set_num_threads(1)  # single-threaded: deterministic summation order
+    import preprocessing.preprocess as ref_pre
+    from models.modules import SRLModules
+    import losses.losses as ref_losses
+    return th, ref_pre, SRLModules, ref_losses
+
+
+from golden_util import golden_inputs, tensor_digest, SUB  # noqa: E402
+
+
+def digest_state_dict(sd):
+    names, shapes, sums, abss = [], [], [], []
+    for k, v in sd.items():
+        names.append(k)
+        shapes.append(list(v.shape))
+        vv = v.double()
+        sums.append(float(vv.sum()))
+        abss.append(float(vv.abs().sum()))
+    return dict(names=np.array(names), shapes=np.array([json.dumps(s) for s in shapes]),
+                sums=np.array(sums), abss=np.array(abss))
+
+
+def build(th, ref_pre, SRLModules, losses, S=200, A=6, C=3, seed=1, inverse="linear"):
+    ref_pre.N_CHANNELS = C
+    np.random.seed(seed)
+    th.manual_seed(seed)
+    return SRLModules(state_dim=S, action_dim=A, cuda=False, model_type="custom_cnn",
+                      losses=losses, inverse_model_type=inverse)
+
+
+def grads_digest(model, out, prefix="grad/"):
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            out[prefix + name + "/none"] = np.array(1)
+            continue
+        for k, v in tensor_digest(p.grad).items():
+            out[prefix + name + "/" + k] = v
+
+
+def bn_digest(model, out, prefix="bn/"):
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            out[prefix + k] = v.detach().double().numpy().copy()
+
+
+def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1, lr=None,
+              eps_seed=99, beta=1.0, inverse="linear", weights=None):
+    """One (or several) loop bodies of models/learner.py:373-497 driven on the reference classes."""
+    model = build(th, ref_pre, SRLModules, losses, S=S, A=A, C=C, inverse=inverse)
+    w = {"forward": 1.0, "inverse": 2.0, "autoencoder": 1.0, "vae": 0.5e-6}
+    if weights:
+        w.update(weights)
+    out = {}
+    opt = None
+    if lr is not None:
+        opt = th.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr)
+    history = {}
+    lm = RL.LossManager(model, None)
+    trace = []
+    for step in range(n_steps):
+        obs, next_obs, actions = golden_inputs(B, C, A, seed=1234 + step)
+        obs, next_obs = th.from_numpy(obs), th.from_numpy(next_obs)
+        act = th.from_numpy(actions).view(-1, 1)
+        model.train()
+        if opt is not None:
+            opt.zero_grad()
+        lm.resetLosses()
+        mu = logvar = None
+        if "autoencoder" in losses:
+            (states, dec), (next_states, next_dec) = model(obs), model(next_obs)
+        elif "vae" in losses:
+            th.manual_seed(eps_seed + step)
+            (dec, mu, logvar), (next_dec, next_mu, next_logvar) = model(obs), model(next_obs)
+            states, next_states = model.getStates(obs), model.getStates(next_obs)
+        else:
+            states, next_states = model(obs), model(next_obs)
+            dec = next_dec = None
+        if "forward" in losses:
+            pred = model.forwardModel(states, act)
+            RL.forwardModelLoss(pred, next_states, weight=w["forward"], loss_manager=lm)
+        if "inverse" in losses:
+            logits = model.inverseModel(states, next_states)
+            RL.inverseModelLoss(logits, act, weight=w["inverse"], loss_manager=lm)
+        if "autoencoder" in losses:
+            RL.autoEncoderLoss(obs, dec, next_obs, next_dec, weight=w["autoencoder"], loss_manager=lm)
+        if "vae" in losses:
+            RL.kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager=lm, beta=beta)
+            RL.generationLoss(dec, next_dec, obs, next_obs, weight=w["vae"], loss_manager=lm)
+        loss = lm.computeTotalLoss()
+        loss.backward()
+        rec = {n: float(l.item()) for n, l in zip(lm.names, lm.losses)}
+        rec["total"] = float(loss.item())
+        trace.append(rec)
+        if step == 0:
+            for n, v in rec.items():
+                out["loss/" + n] = np.array(v)
+            for k, v in tensor_digest(states).items():
+                out["states/" + k] = v
+            for k, v in tensor_digest(next_states).items():
+                out["next_states/" + k] = v
+            if dec is not None:
+                for k, v in tensor_digest(dec).items():
+                    out["decoded/" + k] = v
+                for k, v in tensor_digest(next_dec).items():
+                    out["next_decoded/" + k] = v
+            if mu is not None:
+                for k, v in tensor_digest(logvar).items():
+                    out["logvar/" + k] = v
+                for k, v in tensor_digest(next_logvar).items():
+                    out["next_logvar/" + k] = v
+            grads_digest(model, out)
+            bn_digest(model, out)
+        if opt is not None:
+            opt.step()
+    if n_steps > 1 or opt is not None:
+        names = sorted(trace[0].keys())
+        out["trace/names"] = np.array(names)
+        out["trace/values"] = np.array([[t[n] for n in names] for t in trace])
+        sd = digest_state_dict(model.state_dict())
+        out["final/names"], out["final/sums"], out["final/abss"] = sd["names"], sd["sums"], sd["abss"]
+        bn_digest(model, out, prefix="final_bn/")
+    # eval-mode states on the (possibly updated) model: the "learned states" output (learner.py:67-88)
+    model.eval()
+    with th.no_grad():
+        obs, _, _ = golden_inputs(B, C, A, seed=1234)
+        st = model.getStates(th.from_numpy(obs))
+    out["eval_states/full"] = st.double().numpy()
+    return out
+
+
+def layer_trace(th, ref_pre, SRLModules):
+    """Per-layer forward digests of the AE (train mode, B=2) via forward hooks."""
+    model = build(th, ref_pre, SRLModules, ["autoencoder"])
+    obs, _, _ = golden_inputs(2, 3, 6, seed=1234)
+    out = {}
+    hooks = []
+
+    def mk(name):
+        def hook(_m, _i, o):
+            for k, v in tensor_digest(o).items():
+                out[name + "/" + k] = v
+        return hook
+    for name, mod in model.model.named_modules():
+        if name.count(".") == 1 and (name.startswith("encoder_conv") or name.startswith("decoder_conv")
+                                     or name.startswith("encoder_fc") or name.startswith("decoder_fc")):
+            hooks.append(mod.register_forward_hook(mk(name)))
+    model.train()
+    model(th.from_numpy(obs))
+    for h in hooks:
+        h.remove()
+    return out
+
+
+def loss_kats(th, RL):
+    """Known-answer vectors for the free loss functions (losses/losses.py:102-129,172-214,239-256)."""
+    rs = np.random.RandomState(7)
+    out = {}
+    a = rs.randn(4, 3, 8, 8).astype(np.float32)
+    b = rs.randn(4, 3, 8, 8).astype(np.float32)
+    c = rs.randn(4, 3, 8, 8).astype(np.float32)
+    d = rs.randn(4, 3, 8, 8).astype(np.float32)
+    mu, nmu = rs.randn(4, 10).astype(np.float32), rs.randn(4, 10).astype(np.float32)
+    lv, nlv = (0.3 * rs.randn(4, 10)).astype(np.float32), (0.3 * rs.randn(4, 10)).astype(np.float32)
+    logits = rs.randn(4, 6).astype(np.float32)
+    act = rs.randint(0, 6, (4, 1)).astype(np.int64)
+    for k, v in dict(a=a, b=b, c=c, d=d, mu=mu, nmu=nmu, lv=lv, nlv=nlv, logits=logits, act=act).items():
+        out["in/" + k] = v
+    T = th.from_numpy
+
+    class M(th.nn.Module):
+        pass
+    lm = RL.LossManager(M(), {})
+    lm.loss_history = __import__("collections").defaultdict(list)
+    out["reconstruction"] = np.array(RL.reconstructionLoss(T(a), T(b)).item())
+    out["autoencoder_w1"] = np.array(RL.autoEncoderLoss(T(a), T(b), T(c), T(d), 1.0, lm).item())
+    out["generation_w"] = np.array(RL.generationLoss(T(b), T(d), T(a), T(c), 0.5e-6, lm).item())
+    out["kl_beta2"] = np.array(RL.kullbackLeiblerLoss(T(mu), T(nmu), T(lv), T(nlv), lm, beta=2.0).item())
+    out["forward_w1"] = np.array(RL.forwardModelLoss(T(mu), T(nmu), 1.0, lm).item())
+    out["inverse_w2"] = np.array(RL.inverseModelLoss(T(logits), T(act), 2.0, lm).item())
+    out["total"] = np.array(lm.computeTotalLoss().item())
+    lm.updateLossHistory()
+    lm.updateLossHistory()
+    out["history/names"] = np.array(list(lm.loss_history.keys()))
+    out["history/values"] = np.array([lm.loss_history[k][-1] for k in lm.loss_history.keys()])
+    out["names"] = np.array(lm.names)
+    out["weights"] = np.array(lm.weights, dtype=np.float64)
+    return out
+
+
+def head_kats(th, ref_pre, SRLModules):
+    """forwardModel / inverseModel (linear + mlp) outputs (models/forward_inverse.py:21-31,62-70)."""
+    out = {}
+    rs = np.random.RandomState(11)
+    s = rs.randn(5, 200).astype(np.float32)
+    ns = rs.randn(5, 200).astype(np.float32)
+    act = rs.randint(0, 6, (5, 1)).astype(np.int64)
+    out["in/s"], out["in/ns"], out["in/act"] = s, ns, act
+    for inv in ("linear", "mlp"):
+        m = build(th, ref_pre, SRLModules, ["autoencoder", "inverse", "forward"], inverse=inv)
+        out[inv + "/forward"] = m.forwardModel(th.from_numpy(s), th.from_numpy(act)).detach().numpy()
+        out[inv + "/inverse"] = m.inverseModel(th.from_numpy(s), th.from_numpy(ns)).detach().numpy()
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    th, ref_pre, SRLModules, RL = import_reference()
+
+    def save(name, d):
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **d)
+        print("wrote %-28s %6.1f KB  (%d arrays)" % (name + ".npz", os.path.getsize(path) / 1024.0, len(d)))
+
+    # (1) init KATs: same seed + same constructor order => identical parameters
+    for tag, losses, C in (("ae_c3", ["autoencoder"], 3), ("vae_c3", ["vae"], 3), ("ae_c6", ["autoencoder"], 6),
+                           ("cnn_c3", ["inverse"], 3)):
+        save("init_" + tag, digest_state_dict(build(th, ref_pre, SRLModules, losses, C=C).state_dict()))
+    # (2) single train-mode steps
+    save("step_ae_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2))
+    save("step_ae_b4", step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=4))
+    save("step_vae_b2", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2))
+    save("step_vae_b4", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=4))
+    save("step_aeif_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2))
+    save("step_aeif_mlp_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2,
+                                       inverse="mlp"))
+    save("step_ae_c6_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, C=6))
+    save("step_vae_c6_b2", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, C=6))
+    save("step_cnn_if_b2", step_case(th, ref_pre, SRLModules, RL, ["inverse", "forward"], B=2))
+    # (3) short optimisation traces (Adam, lr 1e-4)
+    save("trace_ae_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, n_steps=3, lr=1e-4))
+    save("trace_vae_b2", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, n_steps=3, lr=1e-4))
+    save("trace_aeif_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2,
+                                    n_steps=3, lr=1e-4))
+    # (4) per-layer forward digests, loss KATs, head KATs
+    save("layers_ae_b2", layer_trace(th, ref_pre, SRLModules))
+    save("loss_kats", loss_kats(th, RL))
+    save("head_kats", head_kats(th, ref_pre, SRLModules))
+
+
+if __name__ == "__main__":
+    main()
