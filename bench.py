@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py — images/s of the srl-zoo image-representation TRAIN STEP on MI355X (BASELINE.json metric).
+
+One "step" = one body of the reference's minibatch loop (models/learner.py:362-497) on one synthetic minibatch that
+is already resident in HBM: forward of obs and next_obs through the conv auto-encoder, reconstruction loss, backward,
+(one RCCL all-reduce of the flat gradient bucket when N > 1) and the fused Adam step.  Workload at N=1 =
+BASELINE.json configs[1]: synthetic 224x224x3 observations, --losses autoencoder, custom_cnn, state-dim 200, bs=256.
+`--losses vae` / `--losses autoencoder inverse forward` select configs[2] / configs[3]'s per-GPU workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+Prints ONE JSON line (rank 0).  value = 2*B*N*K / t  (both frames of a sample go through forward+backward), with t the
+max over ranks of the wall time of exactly K steps bracketed by barrier + synchronize.
+"roofline" is measured live with HIP events on the stream the kernels are launched on, over the timed region, for the
+MFMA implicit-GEMM convolution kernel (conv64_fwd_kernel); "cpu_baseline" times the CPU oracle (plain torch fp32 twin
+of the reference path) on the host cores for a bounded sample — a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(REPO, "srl-zoo_amd"), REPO, os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(B, C, seed, device):
+    """uint8 noise -> /255 -> ImageNet mean/std -> reference layout."""
+    from golden_util import synthetic_obs
+    obs, next_obs = synthetic_obs(B, C, seed)
+    actions = np.random.RandomState(seed + 77).randint(0, 6, (B,)).astype(np.int64)
+    return (torch.from_numpy(obs).to(device), torch.from_numpy(next_obs).to(device),
+            torch.from_numpy(actions).view(-1, 1).to(device))
+
+
+def cpu_baseline(losses, sample_b=64, steps=2):
+    """The CPU oracle (oracle/torch_twin.py: the reference's torch ops, fp32) timed on this box's host cores."""
+    from oracle import torch_twin as T
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModules
+    from golden_util import synthetic_obs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pre.N_CHANNELS = 3
+    np.random.seed(1)
+    torch.manual_seed(1)
+    model = SRLModules(state_dim=200, action_dim=6, cuda=False, model_type="custom_cnn", losses=losses)
+    sd = T.clone_state(model.state_dict())
+    opt = T.TwinAdam(sd, 0.005)
+    obs, next_obs = synthetic_obs(sample_b, 3, 4321)
+    obs, next_obs = torch.from_numpy(obs), torch.from_numpy(next_obs)
+    actions = torch.randint(0, 6, (sample_b,))
+    eps = [torch.randn(sample_b, 200), torch.randn(sample_b, 200)] if "vae" in losses else [None, None]
+
+    def one():
+        T.train_step(sd, losses, obs, next_obs, actions, eps=eps[0], next_eps=eps[1])
+        opt.step(sd)
+    one()  # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        one()
+    dt = (time.time() - t0) / steps
+    return {"value": round(2 * sample_b / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps of the same train step at bs=%d (%d images each) after 1 warm-up; torch %s CPU fp32, "
+                      "%d threads; %.2f s/step" % (steps, sample_b, 2 * sample_b, torch.__version__,
+                                                   torch.get_num_threads(), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=256, help="per-GPU minibatch (samples; 2 frames each)")
+    ap.add_argument("--losses", nargs="+", default=["autoencoder"])
+    ap.add_argument("--state-dim", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl")  # RCCL over xGMI
+
+    import models.learner as learner
+    from models.learner import SRL4robotics
+    from losses.losses import LossManager
+    from srlz import ops
+
+    B = args.batch_size
+    learner.BATCH_SIZE = B
+    quiet = open(os.devnull, "w")
+    stdout, sys.stdout = sys.stdout, quiet  # the learner prints its banner; keep stdout to the JSON line
+    try:
+        srl = SRL4robotics(args.state_dim, model_type="custom_cnn", seed=1, learning_rate=0.005, cuda=True,
+                           losses=list(args.losses), n_actions=6, beta=1.0, log_folder="/tmp")
+    finally:
+        sys.stdout = stdout
+    loss_manager = LossManager(srl.model, None)
+    obs, next_obs, actions = synthetic_batch(B, 3, 1234 + rank, device)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    totals = []
+    for _ in range(args.warmup):
+        srl.trainStep(obs, next_obs, actions, loss_manager)
+    sync()
+    if not args.no_kernel_timers:
+        ops.timers_enable(True)
+    t0 = time.time()
+    for _ in range(args.steps):
+        totals.append(srl.trainStep(obs, next_obs, actions, loss_manager).detach())
+    sync()
+    dt = time.time() - t0
+    ops.timers_enable(False)
+    last_losses = torch.stack(totals).tolist()
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        images = 2 * B * world * args.steps
+        out = {
+            "metric": "images/sec (224x224x3) AE+VAE train step", "value": round(images / dt, 1), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "samples_per_s": round(B * world * args.steps / dt, 1),
+            "config": {"workload": "synthetic 224x224x3 obs, --losses %s, custom_cnn, state-dim %d, bs=%d per GPU "
+                                   "(%d frames fwd+bwd per step per GPU), Adam lr 0.005, data resident in HBM"
+                                   % (" ".join(args.losses), args.state_dim, B, 2 * B),
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "final_loss": round(last_losses[-1], 6)},
+        }
+        rep = ops.timers_report()
+        k = rep.get("conv64_fwd_kernel")
+        if k and k["ms"] > 0:
+            tf = k["flop"] / (k["ms"] * 1e-3) / 1e12
+            layers = {}
+            for name, v in sorted(rep.items()):
+                if name.startswith("conv64_fwd_kernel/") and v["ms"] > 0:
+                    layers[name.split("/", 1)[1]] = {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                                                     "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
+            out["roofline"] = {"kernel": "conv64_fwd_kernel (3x3 64->64 conv / convT forward and data-gradient, all layers)",
+                               "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
+                               "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),
+                               "layers": layers}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(list(args.losses))
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

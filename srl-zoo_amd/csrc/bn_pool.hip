@@ -106,18 +106,37 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
   }
 }
 
+// Per-block combine of the 16 pixel-rows' fp64 partial sums; partial[block][128] (fp64): [0,64) s1, [64,128) s2.
+// The two BatchNorm-backward sums feed dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)): an error in either mean is a
+// per-channel CONSTANT added to every dy element, which the following weight-gradient sums coherently over all
+// (non-negative, post-ReLU) inputs.  fp32 accumulation here costs 1e-3..1e-2 of relative accuracy in dW; fp64 is free
+// in an HBM-bound kernel.
+__device__ __forceinline__ void block_reduce_store(const double (&s1)[4], const double (&s2)[4], double* __restrict__ partial) {
+  __shared__ double sm[16][128];
+  const int c4 = threadIdx.x & 15, prow = threadIdx.x >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sm[prow][c4 * 4 + j] = s1[j]; sm[prow][64 + c4 * 4 + j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += sm[r][threadIdx.x];
+    partial[(size_t)blockIdx.x * 128 + threadIdx.x] = s;
+  }
+}
+
 // ---- backward, stage 1: per-channel sums of dz and dz*xhat over the pooled outputs (dz lives at the argmax) ----
 // partial[block][128]: [0,64) sum dz, [64,128) sum dz*xhat
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __restrict__ y, const float* __restrict__ bnp,
                                                               const uint8_t* __restrict__ argmax,
-                                                              const float* __restrict__ dpooled, float* __restrict__ partial,
+                                                              const float* __restrict__ dpooled, double* __restrict__ partial,
                                                               int N, int H, int W, int HP, int WP, int pad, int dp_nchw) {
   const int c4 = threadIdx.x & 15;
   const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
   const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
   const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
   const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   const long long npix = (long long)N * HP * WP;
   for (long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long long)gridDim.x * 16) {
     const int px = (int)(pix % WP);
@@ -139,30 +158,20 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
       const float v = y[((size_t)(n * H + iy) * W + ix) * 64 + c4 * 4 + j];
       const float z = v * sc[j] + sh[j];
       if (z > 0.f) {
-        s1[j] += dp[j];
-        s2[j] += dp[j] * (v - mean[j]) * invstd[j];
+        s1[j] += (double)dp[j];
+        s2[j] += (double)(dp[j] * ((v - mean[j]) * invstd[j]));
       }
     }
   }
-  __shared__ float sm[16][128];
-  const int prow = threadIdx.x >> 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { sm[prow][c4 * 4 + j] = s1[j]; sm[prow][64 + c4 * 4 + j] = s2[j]; }
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += sm[r][threadIdx.x];
-    partial[(size_t)blockIdx.x * 128 + threadIdx.x] = s;
-  }
+  block_reduce_store(s1, s2, partial);
 }
 
 // sums[0..64) = sum dz (= dbeta), sums[64..128) = sum dz*xhat (= dgamma); also written to dgamma/dbeta
-__global__ void bn_bwd_finalize(const float* __restrict__ partial, int nblocks, float* __restrict__ sums,
+__global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblocks, float* __restrict__ sums,
                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = threadIdx.x;  // 128 threads
   double s = 0.0;
-  for (int i = 0; i < nblocks; ++i) s += (double)partial[(size_t)i * 128 + c];
+  for (int i = 0; i < nblocks; ++i) s += partial[(size_t)i * 128 + c];
   sums[c] = (float)s;
   if (c < 64) { if (dbeta) dbeta[c] = (float)s; } else { if (dgamma) dgamma[c - 64] = (float)s; }
 }
@@ -245,34 +254,24 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce(const float* __restrict__ y, const float* __restrict__ bnp,
-                                                         const float* __restrict__ da, float* __restrict__ partial,
+                                                         const float* __restrict__ da, double* __restrict__ partial,
                                                          long long pixels) {
   const int c4 = threadIdx.x & 15;
   const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
   const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
   const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
   const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   for (long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < pixels; pix += (long long)gridDim.x * 16) {
     const f32x4 v = *(const f32x4*)(y + pix * 64 + c4 * 4);
     const f32x4 d = *(const f32x4*)(da + pix * 64 + c4 * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float z = v[j] * sc[j] + sh[j];
-      if (z > 0.f) { s1[j] += d[j]; s2[j] += d[j] * (v[j] - mean[j]) * invstd[j]; }
+      if (z > 0.f) { s1[j] += (double)d[j]; s2[j] += (double)(d[j] * ((v[j] - mean[j]) * invstd[j])); }
     }
   }
-  __shared__ float sm[16][128];
-  const int prow = threadIdx.x >> 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { sm[prow][c4 * 4 + j] = s1[j]; sm[prow][64 + c4 * 4 + j] = s2[j]; }
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += sm[r][threadIdx.x];
-    partial[(size_t)blockIdx.x * 128 + threadIdx.x] = s;
-  }
+  block_reduce_store(s1, s2, partial);
 }
 
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply(const float* __restrict__ y, const float* __restrict__ bnp,
@@ -385,7 +384,7 @@ extern "C" int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* po
 
 extern "C" size_t srlz_bn_bwd_workspace(long long elems) {
   (void)elems;
-  return (size_t)(RED_BLOCKS * 128 + 128) * sizeof(float);
+  return (size_t)RED_BLOCKS * 128 * sizeof(double) + 128 * sizeof(float);
 }
 
 extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
@@ -395,8 +394,8 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   SRLZ_REQUIRE(y && bnp && argmax && dpooled && dy && ws, SRLZ_ERR_NULL, "bn_relu_pool_bwd: null pointer");
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
-  float* partial = (float*)ws;
-  float* sums = partial + RED_BLOCKS * 128;
+  double* partial = (double*)ws;
+  float* sums = (float*)(partial + RED_BLOCKS * 128);
   const long long npix = (long long)d->n * d->hp * d->wp;
   int nb = (int)((npix + 15) / 16);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
@@ -425,8 +424,8 @@ extern "C" int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* d
   SRLZ_REQUIRE(y && bnp && da && dy && ws, SRLZ_ERR_NULL, "bn_relu_bwd: null pointer");
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
-  float* partial = (float*)ws;
-  float* sums = partial + RED_BLOCKS * 128;
+  double* partial = (double*)ws;
+  float* sums = (float*)(partial + RED_BLOCKS * 128);
   int nb = (int)((pixels + 15) / 16);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   hipLaunchKernelGGL(bn_relu_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, da, partial, pixels);

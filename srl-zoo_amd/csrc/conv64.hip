@@ -353,17 +353,17 @@ __global__ void conv64_wgrad_reduce(const float* __restrict__ partial, int nwg, 
                                     float* __restrict__ dbias, int transposed) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id < NTAPS * 4096) {
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * (NTAPS * 4096) + id];
+    double s = 0.0;
+    for (int w = 0; w < nwg; ++w) s += (double)partial[(size_t)w * (NTAPS * 4096) + id];
     const int tap = id >> 12, ci = (id >> 6) & 63, co = id & 63;
     const int o = transposed ? ((ci * 64 + co) * 9 + tap) : ((co * 64 + ci) * 9 + tap);
-    dw_ref[o] = s;
+    dw_ref[o] = (float)s;
   } else if (id < NTAPS * 4096 + 64 && dbias) {
     const int c = id - NTAPS * 4096;
     const float* b = partial + (size_t)nwg * (NTAPS * 4096);
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += b[(size_t)w * 64 + c];
-    dbias[c] = s;
+    double s = 0.0;
+    for (int w = 0; w < nwg; ++w) s += (double)b[(size_t)w * 64 + c];
+    dbias[c] = (float)s;
   }
 }
 

@@ -232,9 +232,9 @@ __global__ void skinny_wgrad_reduce(const float* __restrict__ partial, int nwg, 
   const int cg = id / (64 * KT);
   const int rem = id - cg * 64 * KT;
   const int ch = rem / KT, k = rem - ch * KT;
-  float s = 0.f;
-  for (int w = 0; w < nwg; ++w) s += partial[((size_t)cg * nwg + w) * (64 * NTW) + ch * NTW + k];
-  dw_ref[((size_t)ch * C + cg * 3) * KK + k] = s;
+  double s = 0.0;
+  for (int w = 0; w < nwg; ++w) s += (double)partial[((size_t)cg * nwg + w) * (64 * NTW) + ch * NTW + k];
+  dw_ref[((size_t)ch * C + cg * 3) * KK + k] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -109,6 +109,9 @@ def error_text():
     return _lib.srlz_last_error().decode("utf-8", "replace")
 
 
+_DEBUG_SYNC = bool(os.environ.get("SRLZ_SYNC"))  # debugging aid: device-synchronise after every call
+
+
 def _wrap(name):
     fn = getattr(_lib, name)
     if _PROTOS[name][0] is c_int and name not in _NOT_STATUS:
@@ -116,6 +119,9 @@ def _wrap(name):
             rc = fn(*a)
             if rc != 0:
                 raise SrlzError("%s failed (%d): %s" % (name, rc, error_text()))
+            if _DEBUG_SYNC:
+                import torch
+                torch.cuda.synchronize()
             return rc
         call.__name__ = name
         return call

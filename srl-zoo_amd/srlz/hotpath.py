@@ -8,6 +8,18 @@ import torch
 
 from . import ops
 
+# Debug / test hook: when set to a dict, every intermediate activation of the two conv stacks is recorded under the
+# reference's layer name (e.g. "encoder_conv.4" = raw output of conv2) with retain_grad(), so parity tests can compare
+# activation gradients layer by layer.  None (default) = no overhead.
+TAPS = None
+
+
+def _tap(prefix, idx, t):
+    if TAPS is not None and t.requires_grad:
+        t.retain_grad()
+        TAPS["%s.%d" % (prefix, idx)] = t
+    return t
+
 
 def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var
@@ -19,18 +31,21 @@ def _tick(bn, training):
         bn.num_batches_tracked.add_(1)
 
 
-def encoder_forward(seq, x, training, stat_sink=None):
+def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
     """models/models.py:47-63.  x: [N,C,H,W] (reference layout) -> [N,64,6,6] (NCHW, ready for .view(N,-1))."""
     conv1, bn1, conv2, bn2, conv3, bn3 = seq[0], seq[1], seq[4], seq[5], seq[8], seq[9]
     y, st = ops.Conv1Fn.apply(x, conv1.weight, training)
+    _tap(name, 0, y)
     _tick(bn1, training)
-    p = ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink)
+    p = _tap(name, 3, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink))
     y, st = ops.Conv64Fn.apply(p, conv2.weight, None, 1, 1, False, training)
+    _tap(name, 4, y)
     _tick(bn2, training)
-    p = ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn2), training, 0, False, stat_sink)
+    p = _tap(name, 7, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn2), training, 0, False, stat_sink))
     y, st = ops.Conv64Fn.apply(p, conv3.weight, None, 2, 1, False, training)
+    _tap(name, 8, y)
     _tick(bn3, training)
-    return ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn3), training, 0, True, stat_sink)
+    return _tap(name, 11, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn3), training, 0, True, stat_sink))
 
 
 def replay_encoder_bn(seq, stats):
@@ -47,10 +62,11 @@ def decoder_forward(seq, z, training):
     for ci, bi in ((0, 1), (3, 4), (6, 7), (9, 10)):
         conv, bn = seq[ci], seq[bi]
         y, st = ops.Conv64Fn.apply(a, conv.weight, conv.bias, 2, 0, True, training)
+        _tap("decoder_conv", ci, y)
         _tick(bn, training)
-        a = ops.BNReLUFn.apply(y, st, *_bn_args(bn), training, None)
+        a = _tap("decoder_conv", bi + 1, ops.BNReLUFn.apply(y, st, *_bn_args(bn), training, None))
     last = seq[12]
-    return ops.ConvTOutFn.apply(a, last.weight, last.bias)
+    return _tap("decoder_conv", 12, ops.ConvTOutFn.apply(a, last.weight, last.bias))
 
 
 def linear(layer, x, relu=False):

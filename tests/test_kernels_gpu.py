@@ -274,7 +274,8 @@ def test_bn_replay_and_repeat(C):
     stat = torch.randn(128, generator=g).abs()
     rm, rv = torch.randn(64, generator=g), torch.rand(64, generator=g)
     rmd, rvd = rm.to(DEV), rv.to(DEV)
-    C.bn_replay(C.ptr(stat.to(DEV)), 0.1, C.ptr(rmd), C.ptr(rvd), C.stream())
+    stat_d = stat.to(DEV)
+    C.bn_replay(C.ptr(stat_d), 0.1, C.ptr(rmd), C.ptr(rvd), C.stream())
     torch.cuda.synchronize()
     assert rel_err(rmd, 0.9 * rm + 0.1 * stat[:64]) < 1e-6
     assert rel_err(rvd, 0.9 * rv + 0.1 * stat[64:]) < 1e-6
@@ -370,11 +371,12 @@ def test_reparam_ce_onehot(C):
     ref.backward()
     out = torch.empty((), device=DEV)
     dl = torch.empty(B, A, device=DEV)
-    C.cross_entropy(C.ptr(logits.to(DEV)), C.ptr(tgt.to(DEV)), B, A, C.ptr(out), C.ptr(dl), st)
+    logits_d, tgt_d = logits.to(DEV), tgt.to(DEV)  # keep the device copies alive while the kernel runs
+    C.cross_entropy(C.ptr(logits_d), C.ptr(tgt_d), B, A, C.ptr(out), C.ptr(dl), st)
     assert abs(out.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
     assert rel_err(dl, lr.grad) < 1e-5
     cat = torch.empty(B, S + A, device=DEV)
-    C.concat_onehot(C.ptr(mud), C.ptr(tgt.to(DEV)), C.ptr(cat), B, S, A, st)
+    C.concat_onehot(C.ptr(mud), C.ptr(tgt_d), C.ptr(cat), B, S, A, st)
     ref_cat = torch.cat((mu, F.one_hot(tgt, A).float()), 1)
     assert torch.equal(cat.cpu(), ref_cat)
 
@@ -391,6 +393,6 @@ def test_adam(C):
         gr = torch.randn(n, generator=g) * (10.0 ** -step)
         pr.grad = gr.clone()
         opt.step()
-        C.adam_step(C.ptr(pd), C.ptr((gr * 4).to(DEV)), C.ptr(m), C.ptr(v), n, 5e-3, 0.9, 0.999, 1e-8, step, 0.25,
-                    C.stream())
+        g_d = (gr * 4).to(DEV)
+        C.adam_step(C.ptr(pd), C.ptr(g_d), C.ptr(m), C.ptr(v), n, 5e-3, 0.9, 0.999, 1e-8, step, 0.25, C.stream())
     assert rel_err(pd, pr) < 1e-6

@@ -164,3 +164,38 @@ def test_product_has_no_cpu_path():
     from models.learner import SRL4robotics
     with pytest.raises(RuntimeError):
         SRL4robotics(10, model_type="custom_cnn", losses=["autoencoder"], cuda=False)
+
+
+def test_pinned_decisions_reproduce_unpinned_gradient():
+    """The oracle's decision-pinned mode (used by the GPU gradient parity test) fed with the oracle's OWN decisions
+    gives the oracle's own gradient."""
+    import torch.nn.functional as F
+    torch.set_num_threads(4)
+    model = build(["autoencoder"])
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    obs, next_obs, actions = gu.golden_inputs(2, 3, 6, seed=1234)
+    obs, next_obs, actions = torch.from_numpy(obs), torch.from_numpy(next_obs), torch.from_numpy(actions)
+    base = T.train_step(T.clone_state(init), ["autoencoder"], obs, next_obs, actions)
+
+    def decisions(x):
+        taps = {}
+        sd = T.clone_state(init, requires_grad=False)
+        T.ae_forward(sd, x, True, taps=taps)
+        pins = {}
+        for conv, bn, pool, pad in ((0, 1, 3, 1), (4, 5, 7, 0), (8, 9, 11, 0)):
+            y = taps["model.encoder_conv.%d" % conv]
+            z = F.batch_norm(y, None, None, sd["model.encoder_conv.%d.weight" % bn], sd["model.encoder_conv.%d.bias" % bn],
+                             True, 0.1, 1e-5)
+            pz, idx = F.max_pool2d(F.relu(z), 3, 2, pad, return_indices=True)
+            pins["encoder_conv.%d" % pool] = (idx, pz > 0)
+        for i in (2, 5, 8, 11):
+            pins["decoder_conv.%d" % i] = taps["model.decoder_conv.%d" % i] > 0
+        return pins
+    pinned = T.train_step(T.clone_state(init), ["autoencoder"], obs, next_obs, actions,
+                          pins=(decisions(obs), decisions(next_obs)))
+    assert abs(pinned["total"] - base["total"]) < 1e-6 * abs(base["total"])
+    for k, g in base["grads"].items():
+        if g is None or k.endswith(("decoder_conv.0.bias", "decoder_conv.3.bias", "decoder_conv.6.bias", "decoder_conv.9.bias")):
+            continue
+        e = (pinned["grads"][k] - g).abs().max().item() / g.abs().max().item()
+        assert e < 1e-5, (k, e)

