@@ -42,13 +42,25 @@ def synthetic_batch(B, C, seed, device):
             torch.from_numpy(actions).view(-1, 1).to(device))
 
 
+def host_cores():
+    """CPUs this process may actually use: min(affinity, cgroup cpu.max quota) — the GPU box's container is capped."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (IOError, OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(losses, sample_b=64, steps=2):
     """The CPU oracle (oracle/torch_twin.py: the reference's torch ops, fp32) timed on this box's host cores."""
     from oracle import torch_twin as T
     import preprocessing.preprocess as pre
     from models.modules import SRLModules
     from golden_util import synthetic_obs
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     pre.N_CHANNELS = 3
     np.random.seed(1)

@@ -120,10 +120,11 @@ int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* 
 /* Training-mode statistics from the convolution's per-tile partials: fills bnp and applies `repeat` momentum
  * updates of running_mean / running_var (momentum, unbiased variance — torch defaults eps 1e-5, momentum 0.1).
  * batch_stat[2][64] (may be NULL) receives {mean, unbiased var} so the update can be replayed (VAE getStates quirk,
- * models/learner.py:402). */
+ * models/learner.py:402).  ws: srlz_bn_bwd_workspace(0) bytes of scratch (two-stage fp64 reduction of the partials). */
 int srlz_bn_finalize(const float* stats_partial, int n_partials, long long count, const float* gamma,
                      const float* beta, float eps, float momentum, int repeat, float* running_mean,
-                     float* running_var, float* bnp, float* batch_stat, srlz_stream_t stream);
+                     float* running_var, float* bnp, float* batch_stat, void* ws, size_t ws_bytes,
+                     srlz_stream_t stream);
 /* Eval-mode bnp from running statistics. */
 int srlz_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, float* bnp, srlz_stream_t stream);
@@ -159,13 +160,17 @@ int srlz_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, 
  * Linear layers — nn.Linear: autoencoders.py:94-100, vae.py:52-57, forward_inverse.py:16,48-55.
  * y[M,N] = x[M,K] . w[N,K]^T + b[N]   (w in torch [out,in] layout), optional ReLU on y.
  * ------------------------------------------------------------------------------------------------------------ */
+/* ws (may be NULL): srlz_linear_workspace bytes; lets skinny GEMMs split their reduction over more workgroups
+ * (deterministic two-stage sum). */
+size_t srlz_linear_workspace(int M, int N, int K);
 int srlz_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,
-                    srlz_stream_t stream);
+                    void* ws, size_t ws_bytes, srlz_stream_t stream);
 /* dx[M,K] = dy[M,N] . w[N,K] */
-int srlz_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, srlz_stream_t stream);
+int srlz_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, void* ws, size_t ws_bytes,
+                         srlz_stream_t stream);
 /* dw[N,K] = dy^T . x ; db[N] = column sums of dy (may be NULL) */
 int srlz_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
-                           srlz_stream_t stream);
+                           void* ws, size_t ws_bytes, srlz_stream_t stream);
 /* dy *= (y > 0)  — backward of the fused ReLU */
 int srlz_relu_bwd_inplace(const float* y, float* dy, long long n, srlz_stream_t stream);
 

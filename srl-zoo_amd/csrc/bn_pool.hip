@@ -6,8 +6,38 @@
 
 namespace {
 
+constexpr int STAGE_ROWS = 128;  // rows of the intermediate [STAGE_ROWS][128] fp64 buffer
+
+// Stage A of every per-channel reduction: rows[nrows][128] (fp32 or fp64) -> out[gridDim.x][128] fp64.
+// Block b sums rows b*2+half, stepping 2*gridDim.x; fixed assignment -> deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const T* __restrict__ rows, int nrows, double* __restrict__ out) {
+  const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const int step = 2 * gridDim.x;
+  int r = blockIdx.x * 2 + half;
+  for (; r + 3 * step < nrows; r += 4 * step) {
+    a0 += (double)rows[(size_t)r * 128 + col];
+    a1 += (double)rows[(size_t)(r + step) * 128 + col];
+    a2 += (double)rows[(size_t)(r + 2 * step) * 128 + col];
+    a3 += (double)rows[(size_t)(r + 3 * step) * 128 + col];
+  }
+  for (; r < nrows; r += step) a0 += (double)rows[(size_t)r * 128 + col];
+  __shared__ double sm[128];
+  const double s = (a0 + a1) + (a2 + a3);
+  if (half) sm[col] = s;
+  __syncthreads();
+  if (!half) out[(size_t)blockIdx.x * 128 + col] = s + sm[col];
+}
+
+static int stage_blocks(int nrows) {
+  int g = (nrows + 7) / 8;
+  if (g > STAGE_ROWS) g = STAGE_ROWS;
+  return g < 1 ? 1 : g;
+}
+
 // bnp record: [0,64) mean, [64,128) invstd, [128,192) scale, [192,256) shift
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int n_partials, double count,
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int n_partials, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, int repeat, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ bnp,
@@ -16,8 +46,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int n_part
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
   double s = 0.0, q = 0.0;
   for (int i = part; i < n_partials; i += 4) {
-    s += (double)partial[(size_t)i * 128 + c];
-    q += (double)partial[(size_t)i * 128 + 64 + c];
+    s += partial[(size_t)i * 128 + c];
+    q += partial[(size_t)i * 128 + 64 + c];
   }
   __shared__ double sm[2][4][64];
   sm[0][part][c] = s; sm[1][part][c] = q;
@@ -345,10 +375,16 @@ static int check_pool(const srlz_pool_desc* d) {
 
 extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, long long count, const float* gamma,
                                 const float* beta, float eps, float momentum, int repeat, float* running_mean,
-                                float* running_var, float* bnp, float* batch_stat, srlz_stream_t stream) {
-  SRLZ_REQUIRE(stats_partial && gamma && beta && bnp, SRLZ_ERR_NULL, "bn_finalize: null pointer");
+                                float* running_var, float* bnp, float* batch_stat, void* ws, size_t ws_bytes,
+                                srlz_stream_t stream) {
+  SRLZ_REQUIRE(stats_partial && gamma && beta && bnp && ws, SRLZ_ERR_NULL, "bn_finalize: null pointer");
   SRLZ_REQUIRE(n_partials > 0 && count > 0, SRLZ_ERR_BAD_DESC, "bn_finalize: empty reduction");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), stats_partial, n_partials, (double)count,
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_finalize: workspace too small");
+  double* staged = (double*)ws;
+  const int g = stage_blocks(n_partials);
+  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g), dim3(256), 0, as_stream(stream), stats_partial, n_partials, staged);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double*)staged, g, (double)count,
                      gamma, beta, eps, momentum, repeat, running_mean, running_var, bnp, batch_stat);
   SRLZ_LAUNCHED();
   return 0;
@@ -384,7 +420,7 @@ extern "C" int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* po
 
 extern "C" size_t srlz_bn_bwd_workspace(long long elems) {
   (void)elems;
-  return (size_t)RED_BLOCKS * 128 * sizeof(double) + 128 * sizeof(float);
+  return (size_t)(RED_BLOCKS + STAGE_ROWS) * 128 * sizeof(double) + 128 * sizeof(float);
 }
 
 extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
@@ -395,14 +431,18 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
   double* partial = (double*)ws;
-  float* sums = (float*)(partial + RED_BLOCKS * 128);
+  double* staged = partial + RED_BLOCKS * 128;
+  float* sums = (float*)(staged + STAGE_ROWS * 128);
   const long long npix = (long long)d->n * d->hp * d->wp;
   int nb = (int)((npix + 15) / 16);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   hipLaunchKernelGGL(bn_relu_pool_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, argmax, dpooled, partial, d->n, d->h, d->w,
                      d->hp, d->wp, d->pool_pad, d->out_nchw);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, partial, nb, sums, dgamma, dbeta);
+  const int sg = stage_blocks(nb);
+  hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(sg), dim3(256), 0, st, (const double*)partial, nb, staged);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
   SRLZ_LAUNCHED();
   const long long items = (long long)d->n * d->h * d->w * 16;
   const float inv_count = 1.0f / (float)((double)d->n * d->h * d->w);
@@ -425,12 +465,16 @@ extern "C" int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* d
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
   double* partial = (double*)ws;
-  float* sums = (float*)(partial + RED_BLOCKS * 128);
+  double* staged = partial + RED_BLOCKS * 128;
+  float* sums = (float*)(staged + STAGE_ROWS * 128);
   int nb = (int)((pixels + 15) / 16);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   hipLaunchKernelGGL(bn_relu_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, da, partial, pixels);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, partial, nb, sums, dgamma, dbeta);
+  const int sg = stage_blocks(nb);
+  hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(sg), dim3(256), 0, st, (const double*)partial, nb, staged);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
   SRLZ_LAUNCHED();
   const float inv_count = 1.0f / (float)(double)pixels;
   hipLaunchKernelGGL(bn_relu_bwd_apply, dim3(grid_for(pixels * 16, 256)), dim3(256), 0, st, y, bnp, da, sums, dy, pixels,

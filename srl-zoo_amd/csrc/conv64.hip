@@ -353,8 +353,16 @@ __global__ void conv64_wgrad_reduce(const float* __restrict__ partial, int nwg, 
                                     float* __restrict__ dbias, int transposed) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id < NTAPS * 4096) {
-    double s = 0.0;
-    for (int w = 0; w < nwg; ++w) s += (double)partial[(size_t)w * (NTAPS * 4096) + id];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int w = 0;
+    for (; w + 3 < nwg; w += 4) {
+      s0 += (double)partial[(size_t)w * (NTAPS * 4096) + id];
+      s1 += (double)partial[(size_t)(w + 1) * (NTAPS * 4096) + id];
+      s2 += (double)partial[(size_t)(w + 2) * (NTAPS * 4096) + id];
+      s3 += (double)partial[(size_t)(w + 3) * (NTAPS * 4096) + id];
+    }
+    for (; w < nwg; ++w) s0 += (double)partial[(size_t)w * (NTAPS * 4096) + id];
+    const double s = (s0 + s1) + (s2 + s3);
     const int tap = id >> 12, ci = (id >> 6) & 63, co = id & 63;
     const int o = transposed ? ((ci * 64 + co) * 9 + tap) : ((co * 64 + ci) * 9 + tap);
     dw_ref[o] = (float)s;

@@ -14,10 +14,12 @@ namespace {
 constexpr int BR = 16;
 constexpr int LD = 68;  // 64 + 4 padding floats
 
+// blockIdx.z = split of the reduction range [z*rchunk, min(R, (z+1)*rchunk)); with gridDim.z > 1 the kernel writes
+// raw partial tiles to C + z*I*J (bias / ReLU are applied by splitk_combine_kernel).
 __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restrict__ A, long long sai, long long sar,
                                                           const float* __restrict__ B, long long sbr, long long sbj,
                                                           const float* __restrict__ bias, float* __restrict__ C, int I,
-                                                          int J, int R, int relu) {
+                                                          int J, int R, int relu, int rchunk) {
   __shared__ float As[BR][LD];
   __shared__ float Bs[BR][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -28,7 +30,10 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int r0 = 0; r0 < R; r0 += BR) {
+  const int rbeg = blockIdx.z * rchunk;
+  const int rend = (rbeg + rchunk < R) ? rbeg + rchunk : R;
+  C += (size_t)blockIdx.z * I * J;
+  for (int r0 = rbeg; r0 < rend; r0 += BR) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -36,12 +41,12 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
       int i, r;
       if (sar == 1) { i = e >> 4; r = e & 15; } else { r = e >> 6; i = e & 63; }
       float v = 0.f;
-      if (i0 + i < I && r0 + r < R) v = A[(long long)(i0 + i) * sai + (long long)(r0 + r) * sar];
+      if (i0 + i < I && r0 + r < rend) v = A[(long long)(i0 + i) * sai + (long long)(r0 + r) * sar];
       As[r][i] = v;
       int j, rb;
       if (sbr == 1) { j = e >> 4; rb = e & 15; } else { rb = e >> 6; j = e & 63; }
       float w = 0.f;
-      if (j0 + j < J && r0 + rb < R) w = B[(long long)(r0 + rb) * sbr + (long long)(j0 + j) * sbj];
+      if (j0 + j < J && r0 + rb < rend) w = B[(long long)(r0 + rb) * sbr + (long long)(j0 + j) * sbj];
       Bs[rb][j] = w;
     }
     __syncthreads();
@@ -65,6 +70,18 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
   }
 }
 
+// C[e] = sum_z partial[z][e] (+ bias[e % J]) (+ ReLU), fixed order
+__global__ void splitk_combine_kernel(const float* __restrict__ partial, int nsplit, const float* __restrict__ bias,
+                                      float* __restrict__ C, int I, int J, int relu) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= I * J) return;
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += partial[(size_t)z * I * J + e];
+  if (bias) s += bias[e % J];
+  if (relu) s = s > 0.f ? s : 0.f;
+  C[e] = s;
+}
+
 // db[n] = sum_m dy[m][n]
 __global__ void colsum_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,32 +96,66 @@ __global__ void relu_bwd_kernel(const float* __restrict__ y, float* __restrict__
     if (!(y[i] > 0.f)) dy[i] = 0.f;
 }
 
+// Few output tiles + a long reduction (e.g. Linear(2304, 200) at batch 256: 16 tiles, R = 2304) would leave most CUs
+// idle: split the reduction over blockIdx.z into `ws` and combine in a fixed order (deterministic, no atomics).
+static int choose_splits(int I, int J, int R, size_t ws_bytes) {
+  const int tiles = ((I + 63) / 64) * ((J + 63) / 64);
+  if (tiles >= 96 || R < 512) return 1;
+  int s = 256 / tiles;
+  if (s > R / 128) s = R / 128;
+  if (s > 16) s = 16;
+  while (s > 1 && (size_t)s * I * J * sizeof(float) > ws_bytes) --s;
+  return s < 1 ? 1 : s;
+}
+
 static int launch(const float* A, long long sai, long long sar, const float* B, long long sbr, long long sbj,
-                  const float* bias, float* C, int I, int J, int R, int relu, hipStream_t st) {
+                  const float* bias, float* C, int I, int J, int R, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
   SRLZ_REQUIRE(I > 0 && J > 0 && R > 0, SRLZ_ERR_BAD_DESC, "linear: empty GEMM %dx%dx%d", I, J, R);
-  hipLaunchKernelGGL(gemm_strided_kernel, dim3((J + 63) / 64, (I + 63) / 64), dim3(256), 0, st, A, sai, sar, B, sbr, sbj,
-                     bias, C, I, J, R, relu);
+  const int splits = ws ? choose_splits(I, J, R, ws_bytes) : 1;
+  if (splits == 1) {
+    hipLaunchKernelGGL(gemm_strided_kernel, dim3((J + 63) / 64, (I + 63) / 64, 1), dim3(256), 0, st, A, sai, sar, B, sbr,
+                       sbj, bias, C, I, J, R, relu, R);
+    SRLZ_LAUNCHED();
+    return 0;
+  }
+  int rchunk = (R + splits - 1) / splits;
+  rchunk = (rchunk + BR - 1) / BR * BR;
+  const int nz = (R + rchunk - 1) / rchunk;
+  hipLaunchKernelGGL(gemm_strided_kernel, dim3((J + 63) / 64, (I + 63) / 64, nz), dim3(256), 0, st, A, sai, sar, B, sbr,
+                     sbj, (const float*)nullptr, (float*)ws, I, J, R, 0, rchunk);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(splitk_combine_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, (const float*)ws, nz, bias, C, I, J,
+                     relu);
   SRLZ_LAUNCHED();
   return 0;
 }
 
 }  // namespace
 
-extern "C" int srlz_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,
-                               srlz_stream_t stream) {
-  SRLZ_REQUIRE(x && w && y, SRLZ_ERR_NULL, "linear_fwd: null pointer");
-  return launch(x, K, 1, w, 1, K, b, y, M, N, K, relu, as_stream(stream));
+extern "C" size_t srlz_linear_workspace(int M, int N, int K) {
+  // enough for 16 split-K partial copies of the largest of the three results (y[M,N], dx[M,K], dw[N,K])
+  size_t a = (size_t)M * N, b = (size_t)M * K, c = (size_t)N * K;
+  size_t m = a > b ? a : b;
+  if (c > m) m = c;
+  return 16 * m * sizeof(float);
 }
 
-extern "C" int srlz_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, srlz_stream_t stream) {
+extern "C" int srlz_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,
+                               void* ws, size_t ws_bytes, srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && w && y, SRLZ_ERR_NULL, "linear_fwd: null pointer");
+  return launch(x, K, 1, w, 1, K, b, y, M, N, K, relu, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int srlz_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, void* ws,
+                                    size_t ws_bytes, srlz_stream_t stream) {
   SRLZ_REQUIRE(dy && w && dx, SRLZ_ERR_NULL, "linear_bwd_data: null pointer");
-  return launch(dy, N, 1, w, K, 1, nullptr, dx, M, K, N, 0, as_stream(stream));
+  return launch(dy, N, 1, w, K, 1, nullptr, dx, M, K, N, 0, ws, ws_bytes, as_stream(stream));
 }
 
 extern "C" int srlz_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
-                                      srlz_stream_t stream) {
+                                      void* ws, size_t ws_bytes, srlz_stream_t stream) {
   SRLZ_REQUIRE(dy && x && dw, SRLZ_ERR_NULL, "linear_bwd_weight: null pointer");
-  if (int rc = launch(dy, 1, N, x, K, 1, nullptr, dw, N, K, M, 0, as_stream(stream))) return rc;
+  if (int rc = launch(dy, 1, N, x, K, 1, nullptr, dw, N, K, M, 0, ws, ws_bytes, as_stream(stream))) return rc;
   if (db) {
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), dy, db, M, N);
     SRLZ_LAUNCHED();

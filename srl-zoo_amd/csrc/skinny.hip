@@ -232,8 +232,17 @@ __global__ void skinny_wgrad_reduce(const float* __restrict__ partial, int nwg, 
   const int cg = id / (64 * KT);
   const int rem = id - cg * 64 * KT;
   const int ch = rem / KT, k = rem - ch * KT;
-  double s = 0.0;
-  for (int w = 0; w < nwg; ++w) s += (double)partial[((size_t)cg * nwg + w) * (64 * NTW) + ch * NTW + k];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const float* base = partial + (size_t)cg * nwg * (64 * NTW) + ch * NTW + k;
+  int w = 0;
+  for (; w + 3 < nwg; w += 4) {
+    s0 += (double)base[(size_t)w * (64 * NTW)];
+    s1 += (double)base[(size_t)(w + 1) * (64 * NTW)];
+    s2 += (double)base[(size_t)(w + 2) * (64 * NTW)];
+    s3 += (double)base[(size_t)(w + 3) * (64 * NTW)];
+  }
+  for (; w < nwg; ++w) s0 += (double)base[(size_t)w * (64 * NTW)];
+  const double s = (s0 + s1) + (s2 + s3);
   dw_ref[((size_t)ch * C + cg * 3) * KK + k] = (float)s;
 }
 
@@ -327,27 +336,31 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
   }
 }
 
-// per-channel sum of an NCHW tensor (bias gradient of the last ConvTranspose): partial then final, fixed order.
-__global__ void nchw_chan_sum_partial(const float* __restrict__ x, int N, int C, int HW, double* __restrict__ partial) {
-  // grid (64, C): block (bx, c) sums elements of channel c with stride 64 blocks over (n, hw)
-  const int c = blockIdx.y;
-  const long long total = (long long)N * HW;
-  double s = 0.0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long n = i / HW, r = i - n * HW;
-    s += (double)x[((size_t)n * C + c) * HW + r];
+// per-channel sum of an NCHW tensor (bias gradient of the last ConvTranspose): one block per (n, c) plane with float4
+// loads -> partial[c][n] (fp64), then one thread per channel sums over n in a fixed order.
+__global__ __launch_bounds__(256) void nchw_chan_sum_partial(const float* __restrict__ x, int C, int HW, double* __restrict__ partial,
+                                                            int N) {
+  const int n = blockIdx.x / C, c = blockIdx.x % C;
+  const float* plane = x + (size_t)blockIdx.x * HW;
+  float s = 0.f;
+  const int hw4 = HW >> 2;
+  for (int i = threadIdx.x; i < hw4; i += 256) {
+    const f32x4 v = *(const f32x4*)(plane + i * 4);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
   }
-  s = wave_sum_d(s);
+  for (int i = hw4 * 4 + threadIdx.x; i < HW; i += 256) s += plane[i];
+  double d = wave_sum_d((double)s);
   __shared__ double sm[4];
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = d;
   __syncthreads();
-  if (threadIdx.x == 0) partial[c * gridDim.x + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+  if (threadIdx.x == 0) partial[(size_t)c * N + n] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
-__global__ void nchw_chan_sum_final(const double* __restrict__ partial, int nb, float* __restrict__ out) {
-  const int c = threadIdx.x;
+__global__ void nchw_chan_sum_final(const double* __restrict__ partial, int N, float* __restrict__ out) {
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int i = 0; i < nb; ++i) s += partial[c * nb + i];
-  out[c] = (float)s;
+  for (int i = threadIdx.x; i < N; i += 64) s += partial[(size_t)c * N + i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 static int check_skinny(const srlz_skinny_desc* d) {
@@ -390,7 +403,7 @@ static size_t wgrad_ws(const srlz_skinny_desc* d) {
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int g = persistent_grid(d->n * ty * tx);
-  return (size_t)(d->c / 3) * g * 64 * NT * 32 * sizeof(float) + 64 * 16 * sizeof(double);
+  return (size_t)(d->c / 3) * g * 64 * NT * 32 * sizeof(float) + (size_t)d->n * d->c * sizeof(double);
 }
 
 template <int K, int PAD>
@@ -472,11 +485,13 @@ extern "C" int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nc
   // dw_ref[ci,co,ky,kx] = sum_{n,iy,ix} x[n,iy,ix,ci] * dy[n,co,2iy+ky,2ix+kx]
   if (int rc = launch_wgrad<4, 0>(dy_nchw, x_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream))) return rc;
   if (dbias) {
-    double* part = (double*)((char*)ws + wgrad_ws<4>(d) - 64 * 16 * sizeof(double));
-    hipLaunchKernelGGL(nchw_chan_sum_partial, dim3(64, d->c), dim3(256), 0, as_stream(stream), dy_nchw, d->n, d->c,
-                       d->himg * d->wimg, part);
+    double* part = (double*)((char*)ws + wgrad_ws<4>(d) - (size_t)d->n * d->c * sizeof(double));
+    SRLZ_REQUIRE((((uintptr_t)part) & 7) == 0 && ((d->himg * d->wimg) & 3) == 0, SRLZ_ERR_BAD_DESC,
+                 "convT_out_bwd_weight: unaligned workspace / image plane");
+    hipLaunchKernelGGL(nchw_chan_sum_partial, dim3(d->n * d->c), dim3(256), 0, as_stream(stream), dy_nchw, d->c,
+                       d->himg * d->wimg, part, d->n);
     SRLZ_LAUNCHED();
-    hipLaunchKernelGGL(nchw_chan_sum_final, dim3(1), dim3(d->c), 0, as_stream(stream), part, 64, dbias);
+    hipLaunchKernelGGL(nchw_chan_sum_final, dim3(d->c), dim3(64), 0, as_stream(stream), part, d->n, dbias);
     SRLZ_LAUNCHED();
   }
   return 0;

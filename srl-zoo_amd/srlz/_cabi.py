@@ -56,7 +56,7 @@ _PROTOS = {
     "srlz_convT_out_fwd": (c_int, [P, P, P, P, _SK, P]),
     "srlz_convT_out_bwd_data": (c_int, [P, P, P, _SK, P]),
     "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, c_size_t, _SK, P]),
-    "srlz_bn_finalize": (c_int, [P, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P]),
+    "srlz_bn_finalize": (c_int, [P, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),
     "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),
     "srlz_bn_relu_pool_fwd": (c_int, [P, P, P, P, _PD, P]),
@@ -66,9 +66,10 @@ _PROTOS = {
     "srlz_bn_relu_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, c_longlong, P]),
     "srlz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srlz_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    "srlz_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "srlz_linear_bwd_data": (c_int, [P, P, P, c_int, c_int, c_int, P]),
-    "srlz_linear_bwd_weight": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "srlz_linear_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "srlz_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "srlz_linear_bwd_data": (c_int, [P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "srlz_linear_bwd_weight": (c_int, [P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     "srlz_relu_bwd_inplace": (c_int, [P, P, c_longlong, P]),
     "srlz_reduce_workspace": (c_size_t, [c_longlong]),
     "srlz_sqdiff_sum": (c_int, [P, P, c_longlong, P, P, c_size_t, P]),

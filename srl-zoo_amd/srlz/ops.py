@@ -16,6 +16,52 @@ BN_MOMENTUM = 0.1
 
 _workspaces = {}
 
+# ---- optional per-launch timing (bench.py's roofline leg): HIP events recorded on the stream the kernels run on ----
+_timers_on = False
+_timer_events = []  # (kernel symbol, layer key, algorithmic flop, start event, end event)
+
+
+def timers_enable(flag):
+    global _timers_on
+    _timers_on = bool(flag)
+    if flag:
+        del _timer_events[:]
+
+
+def _launch(kernel, key, flop, fn):
+    if not _timers_on:
+        return fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    out = fn()
+    end.record()
+    _timer_events.append((kernel, key, flop, start, end))
+    return out
+
+
+def timers_report():
+    """{kernel or kernel/layer: {"ms", "launches", "flop"}} over everything recorded since timers_enable(True)."""
+    torch.cuda.synchronize()
+    rep = {}
+    for kernel, key, flop, start, end in _timer_events:
+        ms = start.elapsed_time(end)
+        for name in (kernel, "%s/%s" % (kernel, key)):
+            r = rep.setdefault(name, {"ms": 0.0, "launches": 0, "flop": 0.0})
+            r["ms"] += ms
+            r["launches"] += 1
+            r["flop"] += flop
+    return rep
+
+
+def _conv64_flop(d):
+    # algorithmic FLOP (2 x MAC) of the layer: 9 taps x 64 x 64 per position of the low-resolution side
+    pos = d.n * (d.hi * d.wi if d.transposed else d.ho * d.wo)
+    return 2.0 * 9 * 64 * 64 * pos
+
+
+def _conv64_key(d, what):
+    return "%s s%d %dx%d->%dx%d %s" % ("convT" if d.transposed else "conv", d.stride, d.hi, d.wi, d.ho, d.wo, what)
+
 
 def _ws(nbytes, device, slot=0):
     """Grow-only scratch buffer per (device, slot); everything runs on one stream, so reuse is ordered."""
@@ -97,7 +143,8 @@ class Conv64Fn(Function):
         C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())
         y = torch.empty((n, d.ho, d.wo, 64), dtype=torch.float32, device=x.device)
         stats = torch.empty((C.conv64_fwd_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
-        C.conv64_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), d, stream())
+        _launch("conv64_fwd_kernel", _conv64_key(d, "fwd"), _conv64_flop(d),
+                lambda: C.conv64_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), d, stream()))
         ctx.save_for_backward(x, packs)
         ctx.desc = d
         ctx.has_bias = bias is not None
@@ -115,12 +162,14 @@ class Conv64Fn(Function):
         dx = None
         if ctx.needs_dx:
             dx = torch.empty_like(x)
-            C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), d, stream())
+            _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                    lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), d, stream()))
         dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=x.device)
         db = torch.empty(64, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         nbytes = C.conv64_bwd_weight_workspace(d)
         ws = _ws(nbytes, x.device)
-        C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes, d, stream())
+        _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes, d, stream()))
         return dx, dw, db, None, None, None, None
 
 
@@ -132,8 +181,10 @@ def _bn_params(stats, count, gamma, beta, running_mean, running_var, training, d
     batch_stat = None
     if training:
         batch_stat = torch.empty(128, dtype=torch.float32, device=device)
+        nbytes = C.bn_bwd_workspace(0)
+        ws = _ws(nbytes, device)
         C.bn_finalize(ptr(stats), stats.shape[0], count, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, 1,
-                      ptr(running_mean), ptr(running_var), ptr(bnp), ptr(batch_stat), stream())
+                      ptr(running_mean), ptr(running_var), ptr(bnp), ptr(batch_stat), ptr(ws), nbytes, stream())
     else:
         C.bn_eval_params(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS, ptr(bnp), stream())
     return bnp, batch_stat
@@ -245,7 +296,9 @@ class LinearFn(Function):
         n = w.shape[0]
         assert w.shape[1] == k
         y = torch.empty((m, n), dtype=torch.float32, device=x.device)
-        C.linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), m, n, k, 1 if relu else 0, stream())
+        nbytes = C.linear_workspace(m, n, k)
+        ws = _ws(nbytes, x.device)
+        C.linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), m, n, k, 1 if relu else 0, ptr(ws), nbytes, stream())
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.relu, ctx.has_bias, ctx.needs_dx = relu, b is not None, ctx.needs_input_grad[0]
         return y
@@ -259,13 +312,15 @@ class LinearFn(Function):
         if ctx.relu:
             dy = dy.clone()
             C.relu_bwd_inplace(ptr(y), ptr(dy), dy.numel(), stream())
+        nbytes = C.linear_workspace(m, n, k)
+        ws = _ws(nbytes, x.device)
         dx = None
         if ctx.needs_dx:
             dx = torch.empty_like(x)
-            C.linear_bwd_data(ptr(dy), ptr(w), ptr(dx), m, n, k, stream())
+            C.linear_bwd_data(ptr(dy), ptr(w), ptr(dx), m, n, k, ptr(ws), nbytes, stream())
         dw = torch.empty_like(w)
         db = torch.empty(n, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        C.linear_bwd_weight(ptr(dy), ptr(x), ptr(dw), ptr(db), m, n, k, stream())
+        C.linear_bwd_weight(ptr(dy), ptr(x), ptr(dw), ptr(db), m, n, k, ptr(ws), nbytes, stream())
         return dx, dw, db, None
 
 

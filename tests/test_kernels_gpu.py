@@ -210,8 +210,9 @@ def test_bn_relu_pool(C, n, h, pad, out_nchw, training):
     if training:
         parts = _partials(nhwc(y)).to(DEV)
         bstat = torch.empty(128, device=DEV)
+        fws = torch.empty(C.bn_bwd_workspace(0), dtype=torch.uint8, device=DEV)
         C.bn_finalize(C.ptr(parts), parts.shape[0], n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
-                      C.ptr(rvd), C.ptr(bnp), C.ptr(bstat), st)
+                      C.ptr(rvd), C.ptr(bnp), C.ptr(bstat), C.ptr(fws), fws.numel(), st)
         torch.cuda.synchronize()
         assert rel_err(rmd, rm_r) < 1e-5 and rel_err(rvd, rv_r) < 1e-5
     else:
@@ -250,8 +251,9 @@ def test_bn_relu(C, n, h, training):
     bnp = torch.empty(256, device=DEV)
     if training:
         parts = _partials(nhwc(y)).to(DEV)
+        fws = torch.empty(C.bn_bwd_workspace(0), dtype=torch.uint8, device=DEV)
         C.bn_finalize(C.ptr(parts), parts.shape[0], n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
-                      C.ptr(rvd), C.ptr(bnp), None, st)
+                      C.ptr(rvd), C.ptr(bnp), None, C.ptr(fws), fws.numel(), st)
     else:
         C.bn_eval_params(C.ptr(gd), C.ptr(bd), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(bnp), st)
     a = torch.full((n, h, h, 64), float("nan"), device=DEV)
@@ -282,7 +284,8 @@ def test_bn_replay_and_repeat(C):
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(32, 200, 2304, 0), (7, 2304, 200, 0), (5, 6, 400, 0), (64, 128, 400, 1),
-                                        (3, 200, 206, 0), (130, 70, 33, 1)])
+                                        (3, 200, 206, 0), (130, 70, 33, 1), (256, 200, 2304, 0), (256, 2304, 200, 0),
+                                        (256, 128, 1000, 1)])
 def test_linear(C, M, N, K, relu):
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)
@@ -297,16 +300,18 @@ def test_linear(C, M, N, K, relu):
     st = C.stream()
     xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
     y = torch.full((M, N), float("nan"), device=DEV)
-    C.linear_fwd(C.ptr(xd), C.ptr(wd), C.ptr(bd), C.ptr(y), M, N, K, relu, st)
+    nb = C.linear_workspace(M, N, K)
+    lws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    C.linear_fwd(C.ptr(xd), C.ptr(wd), C.ptr(bd), C.ptr(y), M, N, K, relu, C.ptr(lws), nb, st)
     torch.cuda.synchronize()
     assert rel_err(y, yr) < 2e-5
     if relu:
         C.relu_bwd_inplace(C.ptr(y), C.ptr(dyd), M * N, st)
     dx = torch.full((M, K), float("nan"), device=DEV)
-    C.linear_bwd_data(C.ptr(dyd), C.ptr(wd), C.ptr(dx), M, N, K, st)
+    C.linear_bwd_data(C.ptr(dyd), C.ptr(wd), C.ptr(dx), M, N, K, C.ptr(lws), nb, st)
     dw = torch.full((N, K), float("nan"), device=DEV)
     db = torch.full((N,), float("nan"), device=DEV)
-    C.linear_bwd_weight(C.ptr(dyd), C.ptr(xd), C.ptr(dw), C.ptr(db), M, N, K, st)
+    C.linear_bwd_weight(C.ptr(dyd), C.ptr(xd), C.ptr(dw), C.ptr(db), M, N, K, None, 0, st)
     torch.cuda.synchronize()
     assert rel_err(dx, xr.grad) < 2e-5 and rel_err(dw, wr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
 
