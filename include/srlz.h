@@ -210,6 +210,15 @@ int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, int B, int 
 int srlz_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale, srlz_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Debug / calibration hooks (not on the product path).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* Host-only: dump the virtual-grid program of a 64->64 convolution (tests interpret it on the CPU).
+ * out: N,PH,PW,ss,Hs,Ws,ds,Hd,Wd,min_off,span,s2, then 9 x {src class, dst class, flat offset, weight tap}. */
+int srlz_conv64_debug_program(const srlz_conv64_desc* d, int backward_data, int* out, int cap);
+/* Back-to-back fp32 MFMA on random operands (no memory traffic): the matrix rate the chip sustains under load. */
+int srlz_debug_mfma_peak(float* out, int blocks, int iters, srlz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

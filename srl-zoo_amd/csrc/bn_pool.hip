@@ -94,14 +94,13 @@ __global__ void bn_replay_kernel(const float* batch_stat, float momentum, float*
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                               float* __restrict__ pooled, uint8_t* __restrict__ argmax,
                                                               int N, int H, int W, int HP, int WP, int pad, int out_nchw) {
-  const long long total = (long long)N * HP * WP * 16;
-  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(id & 15);
-    const long long pix = id >> 4;
-    const int px = (int)(pix % WP);
-    const long long t = pix / WP;
-    const int py = (int)(t % HP);
-    const int n = (int)(t / HP);
+  // grid: x covers (px, c4) of one pooled row, y = n*HP + py  -> no per-thread integer division
+  {
+    const int c4 = threadIdx.x & 15;
+    const int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (px >= WP) return;
+    const int n = blockIdx.y / HP, py = blockIdx.y - n * HP;
+    const long long pix = ((long long)n * HP + py) * WP + px;
     const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
     const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
     f32x4 best = {-1.f, -1.f, -1.f, -1.f};  // relu output is >= 0, so -1 marks "nothing seen yet"
@@ -161,35 +160,37 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
                                                               const uint8_t* __restrict__ argmax,
                                                               const float* __restrict__ dpooled, double* __restrict__ partial,
                                                               int N, int H, int W, int HP, int WP, int pad, int dp_nchw) {
+  // dz is non-zero only at a window's argmax and only if the pooled value is positive; there z = scale*v + shift is
+  // re-read from y (one 4-byte gather per pooled element, the expensive part of this kernel).
   const int c4 = threadIdx.x & 15;
   const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
   const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
   const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
   const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  const long long npix = (long long)N * HP * WP;
-  for (long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long long)gridDim.x * 16) {
-    const int px = (int)(pix % WP);
-    const long long t = pix / WP;
-    const int py = (int)(t % HP);
-    const int n = (int)(t / HP);
-    const uint32_t packed = *(const uint32_t*)(argmax + (size_t)pix * 64 + c4 * 4);
-    f32x4 dp;
-    if (dp_nchw) {
+  // block b walks pooled rows b, b + gridDim.x, ... (row = n*HP + py); 16 pixel-lanes x 16 channel-quads per block
+  for (int row = blockIdx.x; row < N * HP; row += gridDim.x) {
+    const int n = row / HP, py = row - n * HP;
+    for (int px = threadIdx.x >> 4; px < WP; px += 16) {
+      const long long pix = (long long)row * WP + px;
+      const uint32_t packed = *(const uint32_t*)(argmax + (size_t)pix * 64 + c4 * 4);
+      f32x4 dp;
+      if (dp_nchw) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dp[j] = dpooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px];
-    } else {
-      dp = *(const f32x4*)(dpooled + (size_t)pix * 64 + c4 * 4);
-    }
+        for (int j = 0; j < 4; ++j) dp[j] = dpooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px];
+      } else {
+        dp = *(const f32x4*)(dpooled + (size_t)pix * 64 + c4 * 4);
+      }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int a = (packed >> (8 * j)) & 0xff;
-      const int iy = py * 2 - pad + a / 3, ix = px * 2 - pad + a % 3;
-      const float v = y[((size_t)(n * H + iy) * W + ix) * 64 + c4 * 4 + j];
-      const float z = v * sc[j] + sh[j];
-      if (z > 0.f) {
-        s1[j] += (double)dp[j];
-        s2[j] += (double)(dp[j] * ((v - mean[j]) * invstd[j]));
+      for (int j = 0; j < 4; ++j) {
+        const int a = (packed >> (8 * j)) & 0xff;
+        const int iy = py * 2 - pad + a / 3, ix = px * 2 - pad + a % 3;
+        const float v = y[((size_t)(n * H + iy) * W + ix) * 64 + c4 * 4 + j];
+        const float z = v * sc[j] + sh[j];
+        if (z > 0.f) {
+          s1[j] += (double)dp[j];
+          s2[j] += (double)(dp[j] * ((v - mean[j]) * invstd[j]));
+        }
       }
     }
   }
@@ -207,63 +208,87 @@ __global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblocks,
 }
 
 // ---- backward, stage 2: dy = scale * (dz - m1 - xhat*m2) (training) or scale * dz (eval) for every y element ----
+// One thread owns a 2x2 block of y positions x 4 channels.  With kernel 3 / stride 2 the block whose top-left corner
+// has (iy + pad) even is covered by exactly the four pooling windows (py-1..py, px-1..px), py = (iy+pad)/2: the
+// (even,even) corner belongs to all four, the two mixed corners to two each, the (odd,odd) corner to one.  So one
+// thread loads 4 argmax words + 4 dp vectors (unconditionally, 16-byte) and resolves 9 membership tests for 4 outputs.
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply(const float* __restrict__ y, const float* __restrict__ bnp,
                                                              const uint8_t* __restrict__ argmax,
                                                              const float* __restrict__ dpooled, const float* __restrict__ sums,
                                                              float* __restrict__ dy, int N, int H, int W, int HP, int WP,
                                                              int pad, int dp_nchw, int training, float inv_count) {
-  const long long total = (long long)N * H * W * 16;
-  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(id & 15);
-    const long long pix = id >> 4;
-    const int ix = (int)(pix % W);
-    const long long t = pix / W;
-    const int iy = (int)(t % H);
-    const int n = (int)(t / H);
+  // block grid over (by, bx): iy = 2*by - pad .. +1, ix = 2*bx - pad .. +1 ; by in [0, HB), bx in [0, WB)
+  const int HB = (H + pad + 1) / 2, WB = (W + pad + 1) / 2;
+  // grid: x covers (bx, c4) of one block-row, y = n*HB + by
+  {
+    const int c4 = threadIdx.x & 15;
+    const int bx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (bx >= WB) return;
+    const int n = blockIdx.y / HB, by = blockIdx.y - n * HB;
     const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
     const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
     const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
     const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
-    const f32x4 v = *(const f32x4*)(y + (size_t)pix * 64 + c4 * 4);
-    f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-    // pooled outputs whose window contains (iy,ix): py with py*2 - pad + ky == iy, ky in 0..2
+    // the four windows (wy, wx) in {by-1, by} x {bx-1, bx}
+    uint32_t am[2][2];
+    f32x4 dp[2][2];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int ty = iy + pad - ky;
-      if (ty < 0 || (ty & 1)) continue;
-      const int py = ty >> 1;
-      if (py >= HP) continue;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int tx = ix + pad - kx;
-        if (tx < 0 || (tx & 1)) continue;
-        const int px = tx >> 1;
-        if (px >= WP) continue;
-        const size_t pp = ((size_t)(n * HP + py) * WP + px);
-        const uint32_t packed = *(const uint32_t*)(argmax + pp * 64 + c4 * 4);
-        const int me = ky * 3 + kx;
+      for (int b = 0; b < 2; ++b) {
+        const int py = by - 1 + a, px = bx - 1 + b;
+        am[a][b] = 0xffffffffu;  // matches no window index
+        dp[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (py >= 0 && py < HP && px >= 0 && px < WP) {
+          const size_t pp = ((size_t)(n * HP + py) * WP + px);
+          am[a][b] = *(const uint32_t*)(argmax + pp * 64 + c4 * 4);
+          if (dp_nchw) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if ((int)((packed >> (8 * j)) & 0xff) == me) {
-            dz[j] += dp_nchw ? dpooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px]
-                             : dpooled[pp * 64 + c4 * 4 + j];
+            for (int j = 0; j < 4; ++j) dp[a][b][j] = dpooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px];
+          } else {
+            dp[a][b] = *(const f32x4*)(dpooled + pp * 64 + c4 * 4);
           }
         }
       }
-    }
-    f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float z = v[j] * sc[j] + sh[j];
-      const float d = z > 0.f ? dz[j] : 0.f;
-      if (training) {
-        const float xh = (v[j] - mean[j]) * invstd[j];
-        o[j] = sc[j] * (d - sums[c4 * 4 + j] * inv_count - xh * sums[64 + c4 * 4 + j] * inv_count);
-      } else {
-        o[j] = sc[j] * d;
+    for (int ry = 0; ry < 2; ++ry) {
+      const int iy = 2 * by - pad + ry;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int rx = 0; rx < 2; ++rx) {
+        const int ix = 2 * bx - pad + rx;
+        if (ix < 0 || ix >= W) continue;
+        const size_t pix = ((size_t)(n * H + iy) * W + ix);
+        const f32x4 v = *(const f32x4*)(y + pix * 64 + c4 * 4);
+        f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+        // row ry = 0: windows by-1 (ky = 2) and by (ky = 0); ry = 1: window by only (ky = 1)
+#pragma unroll
+        for (int a = (ry ? 1 : 0); a < 2; ++a) {
+          const int ky = ry ? 1 : (a ? 0 : 2);
+#pragma unroll
+          for (int b = (rx ? 1 : 0); b < 2; ++b) {
+            const int kx = rx ? 1 : (b ? 0 : 2);
+            const uint32_t me = (uint32_t)(ky * 3 + kx);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (((am[a][b] >> (8 * j)) & 0xffu) == me) dz[j] += dp[a][b][j];
+          }
+        }
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = v[j] * sc[j] + sh[j];
+          const float d = z > 0.f ? dz[j] : 0.f;
+          if (training) {
+            const float xh = (v[j] - mean[j]) * invstd[j];
+            o[j] = sc[j] * (d - sums[c4 * 4 + j] * inv_count - xh * sums[64 + c4 * 4 + j] * inv_count);
+          } else {
+            o[j] = sc[j] * d;
+          }
+        }
+        *(f32x4*)(dy + pix * 64 + c4 * 4) = o;
       }
     }
-    *(f32x4*)(dy + (size_t)pix * 64 + c4 * 4) = o;
   }
 }
 
@@ -411,8 +436,8 @@ extern "C" int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* po
                                      const srlz_pool_desc* d, srlz_stream_t stream) {
   if (int rc = check_pool(d)) return rc;
   SRLZ_REQUIRE(y && bnp && pooled, SRLZ_ERR_NULL, "bn_relu_pool_fwd: null pointer");
-  const long long items = (long long)d->n * d->hp * d->wp * 16;
-  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(grid_for(items, 256)), dim3(256), 0, as_stream(stream), y, bnp, pooled,
+  SRLZ_REQUIRE((long long)d->n * d->hp <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*hp too large for one launch");
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((d->wp * 16 + 255) / 256, d->n * d->hp), dim3(256), 0, as_stream(stream), y, bnp, pooled,
                      argmax, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw);
   SRLZ_LAUNCHED();
   return 0;
@@ -433,8 +458,7 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   double* partial = (double*)ws;
   double* staged = partial + RED_BLOCKS * 128;
   float* sums = (float*)(staged + STAGE_ROWS * 128);
-  const long long npix = (long long)d->n * d->hp * d->wp;
-  int nb = (int)((npix + 15) / 16);
+  int nb = d->n * d->hp;
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   hipLaunchKernelGGL(bn_relu_pool_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, argmax, dpooled, partial, d->n, d->h, d->w,
                      d->hp, d->wp, d->pool_pad, d->out_nchw);
@@ -444,9 +468,10 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
   SRLZ_LAUNCHED();
-  const long long items = (long long)d->n * d->h * d->w * 16;
+  const int HB = (d->h + d->pool_pad + 1) / 2, WB = (d->w + d->pool_pad + 1) / 2;
+  SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
   const float inv_count = 1.0f / (float)((double)d->n * d->h * d->w);
-  hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3(grid_for(items, 256)), dim3(256), 0, st, y, bnp, argmax, dpooled, sums, dy,
+  hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3((WB * 16 + 255) / 256, d->n * HB), dim3(256), 0, st, y, bnp, argmax, dpooled, sums, dy,
                      d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count);
   SRLZ_LAUNCHED();
   return 0;

@@ -22,6 +22,7 @@
 // with (row & 15) so a 16-lane ds_read_b128 group (consecutive rows, same k) covers all 64 banks.
 // LDS: (128+116)*256 + 16384 + 1536 = 80.4 KB for conv2 -> 2 workgroups per CU, which is what hides the staging.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -36,6 +37,7 @@ struct ConvProg {
   int tsrc[NTAPS], tdst[NTAPS], toff[NTAPS], tw[NTAPS];
   int min_off, span;
   int s2;          // 1 if taps are grouped {4,2,2,1} by class, 0 if a single group of 9
+  int dbg;         // ablation switches for tools/kbench.py (env SRLZ_ABLATE): 1 skip A staging, 2 skip epilogue, 4 skip B staging
 };
 
 struct Axis {
@@ -114,6 +116,7 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
   if (nt != NTAPS) return -1;
   P->span = max_off - P->min_off;
   P->s2 = (stride == 2);
+  { const char* e = getenv("SRLZ_ABLATE"); P->dbg = e ? atoi(e) : 0; }
   if (P->s2 && !(cnt[order[0]] == 4 && cnt[order[1]] == 2 && cnt[order[2]] == 2 && cnt[order[3]] == 1)) return -1;
   return 0;
 }
@@ -124,24 +127,44 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
 // ---------------------------------------------------------------------------------------------------------------
 template <bool SWZ>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
-                                           int stride, int cls, int PW, int PHW, int total_q, int qstart,
+                                           int stride, int cls, int PW, int PH, int total_q, int qstart,
                                            int nrows) {
+  // Loads are issued in batches of 8 rows per thread before any LDS store, so the HBM/L2 latency is paid once per
+  // batch instead of once per row; (n, a, b) of a thread's rows are advanced incrementally (rows are 16 apart), the
+  // only integer divisions are the two for its first row.
+  constexpr int BATCH = 8;
   const int t = threadIdx.x;
   const int slot = t & 15;
   const int cy = cls >> 1, cx = cls & 1;
-  for (int R = t >> 4; R < nrows; R += 16) {
-    const int q = qstart + R;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q >= 0 && q < total_q) {
-      const int n = q / PHW;
-      const int rem = q - n * PHW;
-      const int a = rem / PW;
-      const int b = rem - a * PW;
+  const int PHW = PH * PW;
+  const int sa = 16 / PW, sb = 16 - sa * PW;
+  // shift by one image so the first rows of the first tile (negative q) stay non-negative: n1 = n + 1
+  const int qq = qstart + (t >> 4) + PHW;
+  int n1 = qq / PHW;
+  int rem = qq - n1 * PHW;
+  int a = rem / PW;
+  int b = rem - a * PW;
+  const int N1max = total_q / PHW;  // images
+  for (int base = t >> 4; base < nrows; base += 16 * BATCH) {
+    f32x4 v[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int y = a * stride + cy, x = b * stride + cx;
-      if (y < H && x < W) v = *(const f32x4*)(src + ((size_t)(n * H + y) * W + x) * 64 + slot * 4);
+      if (base + 16 * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W)
+        v[j] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
+      b += sb; a += sa;
+      if (b >= PW) { b -= PW; ++a; }
+      if (a >= PH) { a -= PH; ++n1; }
     }
-    const int sl = SWZ ? (slot ^ (R & 15)) : slot;
-    *(f32x4*)(lds + R * 64 + sl * 4) = v;
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int R = base + 16 * j;
+      if (R < nrows) {
+        const int sl = SWZ ? (slot ^ (R & 15)) : slot;
+        *(f32x4*)(lds + R * 64 + sl * 4) = v[j];
+      }
+    }
   }
 }
 
@@ -185,6 +208,10 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
   int cur_src = -1, cur_dst = -1;
 
   auto flush = [&](int d) {
+    if (P.dbg & 2) {  // ablation: keep the accumulators live, write nothing
+      if (acc0[0] + acc1[5] == 123.456f) dst[tid] = acc0[1];
+      return;
+    }
     const int dy = d >> 1, dx = d & 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -200,6 +227,14 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
     }
   };
 
+  // The weight slab of tap t+1 is fetched into registers while tap t's MFMAs run, and written to LDS between the two
+  // barriers of the next iteration: the L2 latency of the slab never sits between barriers.
+  f32x4 breg[4];
+  {
+    const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[0] * 4096);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) breg[i] = wsrc[i * 256 + tid];
+  }
 #pragma unroll
   for (int ti = 0; ti < NTAPS; ++ti) {
     const int tsrc = P.tsrc[ti], tdst = P.tdst[ti];
@@ -211,38 +246,53 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
       cur_dst = tdst;
     }
     if (tsrc != cur_src) {
-      stage_rows<true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PHW, P.total_q, q0 + P.min_off, TM + P.span);
+      if (!(P.dbg & 1))
+        stage_rows<true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span);
       cur_src = tsrc;
     }
-    {  // weight slab: 16 KB linear copy
-      const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[ti] * 4096);
+    if (!(P.dbg & 4)) {
       f32x4* wdst = (f32x4*)Bs;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wdst[i * 256 + tid] = wsrc[i * 256 + tid];
+      for (int i = 0; i < 4; ++i) wdst[i * 256 + tid] = breg[i];
     }
     __syncthreads();
+    if (ti + 1 < NTAPS && !(P.dbg & 4)) {
+      const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[ti + 1] * 4096);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) breg[i] = wsrc[i * 256 + tid];
+    }
     const int R = wave * 32 + l31 + P.toff[ti] - P.min_off;
     const float* arow = As + R * 64;
     const int akey = R & 15;
     const float* brow0 = Bs + l31 * 64;
     const float* brow1 = Bs + (l31 + 32) * 64;
     const int bkey = lane & 15;
+    // operands of chunk kc+1 are read from LDS before chunk kc's eight MFMAs are issued (explicit double buffer),
+    // so the LDS latency is covered by 512 cycles of matrix work instead of sitting in front of every MFMA group
+    f32x4 a = *(const f32x4*)(arow + ((h ^ akey) << 2));
+    f32x4 b0 = *(const f32x4*)(brow0 + ((h ^ bkey) << 2));
+    f32x4 b1 = *(const f32x4*)(brow1 + ((h ^ bkey) << 2));
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) {
-      const int slot = kc * 2 + h;
-      const f32x4 a = *(const f32x4*)(arow + ((slot ^ akey) << 2));
-      const f32x4 b0 = *(const f32x4*)(brow0 + ((slot ^ bkey) << 2));
-      const f32x4 b1 = *(const f32x4*)(brow1 + ((slot ^ bkey) << 2));
+      f32x4 an = a, b0n = b0, b1n = b1;
+      if (kc < 7) {
+        const int slot = (kc + 1) * 2 + h;
+        an = *(const f32x4*)(arow + ((slot ^ akey) << 2));
+        b0n = *(const f32x4*)(brow0 + ((slot ^ bkey) << 2));
+        b1n = *(const f32x4*)(brow1 + ((slot ^ bkey) << 2));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this chunk's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0[r], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1[r], acc1, 0, 0, 0);
       }
+      a = an; b0 = b0n; b1 = b1n;
     }
   }
   flush(cur_dst);
 
-  if (stats_partial) {
+  if (stats_partial && !(P.dbg & 2)) {
     // lanes l and l+32 hold the same columns; then the 4 waves are combined through LDS
     s0 += __shfl_xor(s0, 32, 64); ss0 += __shfl_xor(ss0, 32, 64);
     s1 += __shfl_xor(s1, 32, 64); ss1 += __shfl_xor(ss1, 32, 64);
@@ -299,12 +349,12 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
       const int cs = P.tsrc[t0], cd = P.tdst[t0];
       __syncthreads();
       if (cs != cur_s) {
-        stage_rows<false>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PHW, P.total_q, q0 + P.min_off, TK + P.span);
+        stage_rows<false>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span);
         cur_s = cs;
       }
       const bool newg = (cd != cur_g);
       if (newg) {
-        stage_rows<false>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PHW, P.total_q, q0, TK);
+        stage_rows<false>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK);
         cur_g = cd;
       }
       __syncthreads();

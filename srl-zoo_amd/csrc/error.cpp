@@ -28,3 +28,31 @@ extern "C" int srlz_device_cus(void) {
   if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
   return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
 }
+
+// ---- calibration micro-benchmark: back-to-back v_mfma_f32_32x32x2_f32 on random operands, no memory traffic ----
+// Used by tools/kbench.py to measure the fp32-MFMA rate this chip actually sustains (clocks under load) so that
+// kernel efficiencies can be read against both the datasheet peak and the sustained one.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, float seed) {
+  const int lane = threadIdx.x;
+  f32x16 a0, a1, a2, a3;
+  for (int r = 0; r < 16; ++r) { a0[r] = seed * (lane + r); a1[r] = seed * (lane - r); a2[r] = seed * r; a3[r] = -seed * r; }
+  float x = 0.37f + 0.001f * lane * seed, y = -0.41f + 0.002f * lane * seed;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Launches `blocks` workgroups of 256 threads, each wave issuing 4*iters MFMAs (4096 FLOP each).  out: blocks*256 floats.
+extern "C" int srlz_debug_mfma_peak(float* out, int blocks, int iters, srlz_stream_t stream) {
+  if (!out || blocks <= 0 || iters <= 0) { srlz_set_error("mfma_peak: bad arguments"); return SRLZ_ERR_BAD_DESC; }
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 1e-3f);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return srlz_hip_fail(e, "mfma_peak launch");
+  return 0;
+}

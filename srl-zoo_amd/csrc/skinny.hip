@@ -36,16 +36,26 @@ __host__ __device__ constexpr int koff(int k) {
 template <int K, int PAD>
 __device__ __forceinline__ void stage_image(float* __restrict__ T, const float* __restrict__ img, int n, int C,
                                             int cg, int H, int W, int oy0, int ox0) {
-  constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS;
+  constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS, TOT = 3 * ROWS * COLS;
+  constexpr int BATCH = 9;  // loads in flight per thread before the first LDS store
   const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
-  for (int idx = threadIdx.x; idx < 3 * ROWS * COLS; idx += 256) {
-    const int c = idx / (ROWS * COLS);
-    const int rem = idx - c * (ROWS * COLS);
-    const int r = rem / COLS, xl = rem - r * COLS;
-    const int iy = iy0 + r, ix = ix0 + xl;
-    float v = 0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix];
-    T[((c * 2 + (xl & 1)) * ROWS + r) * XP + (xl >> 1)] = v;
+  for (int base = threadIdx.x; base < TOT; base += 256 * BATCH) {
+    float v[BATCH];
+    int dst[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int idx = base + 256 * j;
+      const int c = idx / (ROWS * COLS);
+      const int rem = idx - c * (ROWS * COLS);
+      const int r = rem / COLS, xl = rem - r * COLS;
+      const int iy = iy0 + r, ix = ix0 + xl;
+      v[j] = 0.f;
+      if (idx < TOT && iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = img[((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix];
+      dst[j] = ((c * 2 + (xl & 1)) * ROWS + r) * XP + (xl >> 1);
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j)
+      if (base + 256 * j < TOT) T[dst[j]] = v[j];
   }
 }
 
@@ -285,18 +295,19 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
     const int trem = tile - n * (tiles_y * tiles_x);
     const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
     __syncthreads();  // previous tile's gather is done with Tt
-    for (int mtile = wave; mtile < 19; mtile += 4) {
+    auto load_a = [&](int mtile, f32x4 (&a)[4]) {
       const int p = mtile * 16 + li;
       const int ia = p / 17, ib = p - ia * 17;
       const int fy = a0 - 1 + ia, fx = b0 - 1 + ib;
-      const bool ok = (p < 289) && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
+      const bool ok = (mtile < 19) && (p < 289) && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
       const float* src = feat + ((size_t)(n * HF + (ok ? fy : 0)) * WF + (ok ? fx : 0)) * 64 + 4 * kq;
-      f32x4 a[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a[c] = *(const f32x4*)(src + 16 * c);
-        if (!ok) a[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int c = 0; c < 4; ++c) a[c] = ok ? *(const f32x4*)(src + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 a[4], an[4];
+    load_a(wave, a);
+    for (int mtile = wave; mtile < 19; mtile += 4) {
+      load_a(mtile + 4, an);  // next M-tile's fragments travel while this one's MFMAs run
       f32x4 acc[3];
 #pragma unroll
       for (int co = 0; co < 3; ++co) {
@@ -312,6 +323,8 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
       for (int co = 0; co < 3; ++co)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Tt[(mtile * 16 + kq * 4 + r) * TP + co * 16 + li] = acc[co][r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[c] = an[c];
     }
     __syncthreads();
     const int oxl = tid & 31, rg = tid >> 5;
