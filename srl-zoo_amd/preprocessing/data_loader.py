@@ -176,6 +176,9 @@ class DataLoader(object):
         return shardOrder(order, self.rank, self.world_size, self.val_indices)
 
     def _run(self):
+        # forked child: the parent's intra-op (OpenMP) worker threads do not exist here, so torch must not try to use
+        # them — the few tensor ops below (tensor(), cat) run single-threaded; decoding parallelism comes from the pool
+        th.set_num_threads(1)
         pool = ThreadPoolExecutor(max_workers=max(1, self.n_workers))
         first = True
         while first or self.infinite_loop:
@@ -238,5 +241,8 @@ class DataLoader(object):
     next = __next__
 
     def __del__(self):
-        if self.process is not None:
-            self.process.terminate()
+        try:
+            if self.process is not None:
+                self.process.terminate()
+        except Exception:  # interpreter shutdown: multiprocessing internals may already be gone
+            pass

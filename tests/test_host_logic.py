@@ -1,0 +1,140 @@
+"""Host-side logic that mirrors the reference's plugin / CLI surface (no GPU, no kernels)."""
+import argparse
+import json
+import os
+from collections import OrderedDict, defaultdict
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+
+def test_loss_manager_history_and_total_follow_reference():
+    """LossManager semantics on the reference's KAT (tests/golden/loss_kats.npz): names, weights, weighted total and the
+    epoch-history accumulation (weight * value added into the last slot)."""
+    from losses.losses import LossManager
+    g = gu.load("loss_kats")
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super(M, self).__init__()
+            self.lin = torch.nn.Linear(2, 2)
+    hist = defaultdict(list)
+    lm = LossManager(M(), hist)
+    assert [tuple(p.shape) for p in lm.reg_params] == [(2, 2)]  # biases are excluded
+    names = [str(n) for n in g["names"]]
+    weights = g["weights"]
+    # unweighted loss values recovered from the reference's weighted history of ONE update (history holds 2 updates)
+    values = []
+    hn = [str(n) for n in g["history/names"]]
+    for n, w in zip(names, weights):
+        values.append(float(g["history/values"][hn.index(n)]) / 2.0 / w)
+    for n, w, v in zip(names, weights, values):
+        lm.addToLosses(n, float(w), torch.tensor(v, dtype=torch.float32))
+    total = lm.computeTotalLoss()
+    assert abs(float(total) - float(g["total"])) < 1e-4 * abs(float(g["total"]))
+    lm.updateLossHistory()
+    lm.updateLossHistory()
+    for n in names:
+        assert abs(hist[n][-1] - float(g["history/values"][hn.index(n)])) < 1e-4 * abs(float(g["history/values"][hn.index(n)]))
+    lm.resetLosses()
+    assert lm.names == [] and lm.losses == []
+
+
+def test_loss_argument_language():
+    from utils import parseLossArguments
+    kw = parseLossArguments(choices=["autoencoder", "inverse", "vae"], help="h")
+    t = kw["type"]
+    assert t("inverse") == "inverse"
+    assert t("autoencoder:1:10") == ("autoencoder", 1.0, 10)
+    assert t("vae:0.5") == ("vae", 0.5, 0)
+    with pytest.raises(argparse.ArgumentTypeError):
+        t("bogus")
+    with pytest.raises(argparse.ArgumentTypeError):
+        t("inverse:x:1")
+    assert kw["help"].startswith("{autoencoder, inverse, vae}")
+
+
+def test_train_cli_parsing_and_loss_resolution():
+    import train
+    parser = train.buildParser()
+    a = parser.parse_args(["--data-folder", "data/foo/", "--losses", "autoencoder", "inverse", "-bs", "8", "--no-cuda"])
+    assert a.batch_size == 8 and a.state_dim == 2 and a.learning_rate == 0.005 and a.epochs == 30 and a.val_size == 0.2
+    losses, w, split = train.resolveLosses(a.losses, False)
+    assert sorted(losses) == ["autoencoder", "inverse"] and w is None and split == -1
+    b = parser.parse_args(["--data-folder", "x", "--losses", "autoencoder:1:20", "inverse:5:10"])
+    losses, w, split = train.resolveLosses(b.losses, False)
+    assert losses == ["autoencoder", "inverse"] and w == OrderedDict([("autoencoder", 1.0), ("inverse", 5.0)])
+    assert split == OrderedDict([("autoencoder", 20), ("inverse", 10)])
+    with pytest.raises(ValueError):
+        train.resolveLosses(["autoencoder", ("inverse", 1.0, 0)], False)
+
+
+def test_build_config_and_helpers(tmp_path):
+    import train
+    from utils import buildConfig, parseDataFolder
+    from pipeline import getLogFolderName, saveConfig, NAN_ERROR, NO_PAIRS_ERROR
+    assert (NO_PAIRS_ERROR, NAN_ERROR) == (10, 11)
+    assert parseDataFolder("data/kuka_gym_test/") == "kuka_gym_test"
+    a = train.buildParser().parse_args(["--data-folder", "d", "--losses", "vae", "--state-dim", "200"])
+    a.data_folder = parseDataFolder(a.data_folder)
+    a.losses, _, a.split_dimensions = train.resolveLosses(a.losses, False)
+    cfg = buildConfig(a)
+    assert list(cfg.keys()) == ["batch-size", "beta", "data-folder", "epochs", "learning-rate", "training-set-size", "log-folder",
+                                "model-type", "seed", "state-dim", "knn-samples", "knn-seed", "l1-reg", "l2-reg", "losses",
+                                "n-neighbors", "n-to-plot", "split-dimensions", "inverse-model-type"]
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        folder, name = getLogFolderName(cfg)
+        assert folder.startswith("logs/d/") and name.endswith("_custom_cnn_ST_DIM200_vae") and os.path.isdir(folder)
+        cfg["log-folder"] = folder
+        saveConfig(cfg)
+        assert json.load(open(folder + "/exp_config.json"))["state-dim"] == 200
+    finally:
+        os.chdir(cwd)
+
+
+def test_save_states_files(tmp_path):
+    from models.learner import BaseLearner
+    states = np.arange(6, dtype=np.float32).reshape(3, 2)
+    BaseLearner.saveStates(states, ["a", "b", "c"], np.array([0, 1, 0]), str(tmp_path))
+    z = np.load(str(tmp_path / "states_rewards.npz"))
+    assert np.array_equal(z["states"], states) and list(z["rewards"]) == [0, 1, 0]
+    m = json.load(open(str(tmp_path / "image_to_state.json")))
+    assert m["b"] == ["2.0", "3.0"]
+
+
+def test_unsupported_configurations_are_rejected_loudly():
+    from models.modules import SRLModules
+    from models.learner import SRL4robotics
+    with pytest.raises(NotImplementedError):
+        SRLModules(state_dim=3, model_type="resnet", losses=["inverse"])
+    with pytest.raises(NotImplementedError):
+        SRLModules(state_dim=3, model_type="custom_cnn", losses=["triplet"])
+    with pytest.raises(NotImplementedError):
+        SRL4robotics(3, model_type="custom_cnn", losses=["priors"], cuda=True)
+
+
+def test_state_dict_keys_and_flat_params():
+    """Parameters re-homed into one flat buffer stay nn.Parameters with the reference's keys; grads are views."""
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModules
+    from srlz import optim
+    pre.N_CHANNELS = 3
+    m = SRLModules(state_dim=10, action_dim=4, model_type="custom_cnn", losses=["vae"])
+    keys = list(m.state_dict().keys())
+    assert keys[:2] == ["forward_net.weight", "forward_net.bias"] and "model.encoder_fc2.weight" in keys
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = optim.FlatParams(m)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    p = dict(m.named_parameters())["model.encoder_fc1.bias"]
+    assert p.data_ptr() >= flat.flat.data_ptr() and p.grad is not None
+    p.grad.add_(1.0)
+    assert float(flat.grad.sum()) == p.numel()
+    flat.zero_grad()
+    idx = [i for i, q in enumerate(flat.params) if q is p][0]
+    assert float(flat.grad.abs().sum()) == 0.0 and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offsets[idx]

@@ -1,0 +1,66 @@
+"""End-to-end SRL4robotics.learn() on a tiny generated dataset (GPU): loader process, train/validation split,
+best-model checkpoint in the reference's format, learned-states output — and parity of those learned states with the
+CPU oracle evaluated on the saved checkpoint."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dataset_util import make_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    root = tmp_path_factory.mktemp("learn")
+    info = make_dataset(str(root), n_episodes=4, ep_len=26)
+    cwd = os.getcwd()
+    os.chdir(str(root))
+    os.makedirs("logs/run", exist_ok=True)
+    yield info
+    os.chdir(cwd)
+
+
+@pytest.mark.parametrize("losses,kind", [(["autoencoder", "inverse", "forward"], "ae"), (["vae"], "vae")])
+def test_learn_end_to_end(workdir, losses, kind):
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from models.learner import SRL4robotics
+    from oracle import torch_twin as T
+    import golden_util as gu
+    name, paths, actions, rewards, starts = workdir
+    pre.N_CHANNELS = 3
+    learner.N_EPOCHS, learner.BATCH_SIZE, learner.VALIDATION_SIZE, learner.DISPLAY_PLOTS = 3, 8, 0.2, False
+    log = "logs/run_" + kind
+    os.makedirs(log, exist_ok=True)
+    srl = SRL4robotics(12, model_type="custom_cnn", seed=3, learning_rate=1e-3, cuda=True, losses=losses, n_actions=6,
+                       log_folder=log)
+    init_keys = list(srl.model.state_dict().keys())
+    loss_history, states, pairs = srl.learn(paths, actions, rewards, starts)
+    assert states.shape == (len(paths), 12) and np.isfinite(states).all()
+    assert set(n for n, _ in pairs) <= {"forward_loss", "inverse_loss", "reconstruction_loss", "kl_loss", "generation_loss"}
+    for k in ("train_loss", "val_loss"):
+        assert len(loss_history[k]) == 3 and np.isfinite(loss_history[k]).all()
+    assert loss_history["train_loss"][-1] < loss_history["train_loss"][0]  # it learns
+    # checkpoint: reference format (same keys, NCHW shapes), loadable on CPU
+    sd = torch.load(log + "/srl_model.pth", map_location="cpu")
+    assert list(sd.keys()) == init_keys
+    assert tuple(sd["model.encoder_conv.0.weight"].shape) == (64, 3, 7, 7)
+    assert tuple(sd["model.decoder_conv.12.weight"].shape) == (64, 3, 4, 4)
+    # learned states == oracle's eval-mode states on the saved checkpoint (first 8 frames)
+    from preprocessing.data_loader import DataLoader
+    obs = torch.cat([DataLoader._makeBatchElement(p) for p in paths[:8]], 0)
+    ref = T.get_states(T.clone_state(sd, requires_grad=False), obs, kind)
+    err = np.abs(states[:8] - ref.numpy()).max() / np.abs(ref.numpy()).max()
+    assert err < 1e-4, err
+    # loadSavedModel round trip through exp_config.json
+    with open(log + "/exp_config.json", "w") as f:
+        json.dump({"state-dim": 12, "losses": losses, "n_actions": 6, "model-type": "custom_cnn"}, f)
+    srl2, cfg = SRL4robotics.loadSavedModel(log + "/", ["autoencoder", "vae", "inverse", "forward"], cuda=True)
+    srl2.model.eval()
+    with torch.no_grad():
+        st2 = srl2.model.getStates(obs.cuda()).cpu().numpy()
+    assert np.abs(st2 - states[:8]).max() <= 1e-5 * np.abs(states[:8]).max()

@@ -1,0 +1,97 @@
+"""The per-GPU minibatch stream contract (reference preprocessing/data_loader.py:68-280): tuple format, tensor layout,
+normalisation, epoch sentinel, test-mode iteration, data-parallel sharding of the per-epoch order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dataset_util import make_dataset
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    root = tmp_path_factory.mktemp("ds")
+    info = make_dataset(str(root), n_episodes=2, ep_len=10)
+    cwd = os.getcwd()
+    os.chdir(str(root))
+    yield info
+    os.chdir(cwd)
+
+
+def expected_tensor(path):
+    from PIL import Image
+    im = np.asarray(Image.open("data/" + path + ".jpg").convert("RGB")).astype(np.float32) / 255.0
+    im = (im - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)
+    return im.transpose(2, 1, 0)  # (C, W, H): the reference's transpose(0, 3, 2, 1) without the batch axis
+
+
+def test_training_stream_contract(dataset):
+    from preprocessing.data_loader import DataLoader
+    name, paths, actions, rewards, starts = dataset
+    minibatchlist = [np.array([0, 1, 2, 3]), np.array([4, 5, 6, 7]), np.array([10, 11, 12, 13])]
+    loader = DataLoader(minibatchlist, paths, n_workers=2, is_training=True, infinite_loop=True)
+    for epoch in range(2):
+        seen = []
+        for item in loader:
+            idx, obs, next_obs, noisy, next_noisy = item
+            assert noisy is None and next_noisy is None
+            assert obs.dtype == torch.float32 and tuple(obs.shape) == (4, 3, 224, 224) and tuple(next_obs.shape) == (4, 3, 224, 224)
+            mb = minibatchlist[int(idx)]
+            np.testing.assert_allclose(obs[1].numpy(), expected_tensor(paths[mb[1]]), rtol=0, atol=1e-6)
+            np.testing.assert_allclose(next_obs[2].numpy(), expected_tensor(paths[mb[2] + 1]), rtol=0, atol=1e-6)
+            seen.append(int(idx))
+        assert sorted(seen) == [0, 1, 2]  # every minibatch exactly once per epoch, then the None sentinel
+    lo, hi = float(obs.min()), float(obs.max())
+    assert lo >= -2.1180 and hi <= 2.6401  # value range of ImageNet-normalised pixels
+    del loader
+
+
+def test_test_stream_and_minibatch_list(dataset):
+    from preprocessing.data_loader import DataLoader
+    name, paths, *_ = dataset
+    ml = DataLoader.createTestMinibatchList(len(paths), 8)
+    assert [len(m) for m in ml] == [8, 8, 4]
+    assert [len(m) for m in DataLoader.createTestMinibatchList(16, 8)] == [8, 8, 0]  # trailing empty range, as the reference
+    loader = DataLoader(ml, paths, n_workers=2, is_training=False, max_queue_len=1, infinite_loop=False)
+    batches = list(loader)
+    assert [b.shape[0] for b in batches] == [8, 8, 4]
+    np.testing.assert_allclose(batches[1][3].numpy(), expected_tensor(paths[11]), atol=1e-6)
+
+
+def test_missing_image_raises(dataset):
+    from preprocessing.data_loader import DataLoader
+    with pytest.raises(ValueError):
+        DataLoader._makeBatchElement("tiny_test/record_000/frame999999")
+
+
+def test_preprocess_image_and_denormalize():
+    from preprocessing.data_loader import preprocessImage
+    from preprocessing.utils import deNormalize, preprocessInput
+    rgb = np.random.RandomState(0).randint(0, 256, (224, 224, 3)).astype(np.uint8)
+    out = preprocessImage(rgb, convert_to_rgb=False)
+    ref = (rgb.astype(np.float32) / 255.0 - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)
+    np.testing.assert_allclose(out, ref, atol=1e-6)
+    back = deNormalize(out.transpose(2, 1, 0).copy())  # (3, W, H) -> (H, W, 3) in [0, 1]
+    np.testing.assert_allclose(back, rgb / 255.0, atol=1e-6)
+    x = np.full((2, 2, 3), 255.0, np.float32)
+    assert np.allclose(preprocessInput(x.copy(), mode="tf"), 1.0)
+    np.random.seed(0)
+    occl = preprocessImage(rgb, convert_to_rgb=False, apply_occlusion=True, occlusion_percentage=0.5)
+    assert (occl == 0).all(axis=2).any()  # a zeroed rectangle exists
+
+
+def test_shard_order_lockstep():
+    from preprocessing.data_loader import shardOrder
+    order = np.random.RandomState(1).permutation(23)
+    val = {3, 7, 11, 19, 22}
+    assert np.array_equal(shardOrder(order, 0, 1, val), order)
+    shards = [shardOrder(order, r, 4, val) for r in range(4)]
+    assert len({len(s) for s in shards}) == 1  # same number of steps on every rank
+    flat = np.concatenate(shards)
+    assert len(set(flat.tolist())) == len(flat)  # disjoint
+    for step in range(len(shards[0])):
+        kinds = {int(s[step]) in val for s in shards}
+        assert len(kinds) == 1  # all ranks train, or all ranks validate, at every step
+    n_train = sum(1 for i in shards[0] if int(i) not in val)
+    assert all(int(i) not in val for i in shards[0][:n_train]) and all(int(i) in val for i in shards[0][n_train:])
