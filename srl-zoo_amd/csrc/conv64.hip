@@ -399,29 +399,40 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
 }
 
 // dw_ref[...] = sum over workgroups (fixed order); layout: conv [co][ci][3][3], convT [ci][co][3][3].
-__global__ void conv64_wgrad_reduce(const float* __restrict__ partial, int nwg, float* __restrict__ dw_ref,
-                                    float* __restrict__ dbias, int transposed) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id < NTAPS * 4096) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int w = 0;
-    for (; w + 3 < nwg; w += 4) {
-      s0 += (double)partial[(size_t)w * (NTAPS * 4096) + id];
-      s1 += (double)partial[(size_t)(w + 1) * (NTAPS * 4096) + id];
-      s2 += (double)partial[(size_t)(w + 2) * (NTAPS * 4096) + id];
-      s3 += (double)partial[(size_t)(w + 3) * (NTAPS * 4096) + id];
+// 1024 threads per block: 256 outputs x 4 slices of the workgroup range, 4 loads in flight per thread, fp64 combine.
+__global__ __launch_bounds__(1024) void conv64_wgrad_reduce(const float* __restrict__ partial, int nwg,
+                                                           float* __restrict__ dw_ref, float* __restrict__ dbias,
+                                                           int transposed) {
+  const int o = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int id = blockIdx.x * 256 + o;
+  constexpr int TOT = NTAPS * 4096;
+  const int per = (nwg + 3) / 4;
+  const int w0 = part * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (id < TOT + 64) {
+    // bias partials live after all workgroups' tap blocks: [nwg][64]
+    const float* base = (id < TOT) ? partial + id : partial + (size_t)nwg * TOT + (id - TOT);
+    const size_t stride = (id < TOT) ? (size_t)TOT : 64;
+    int w = w0;
+    for (; w + 3 < w1; w += 4) {
+      s0 += (double)base[(size_t)w * stride];
+      s1 += (double)base[(size_t)(w + 1) * stride];
+      s2 += (double)base[(size_t)(w + 2) * stride];
+      s3 += (double)base[(size_t)(w + 3) * stride];
     }
-    for (; w < nwg; ++w) s0 += (double)partial[(size_t)w * (NTAPS * 4096) + id];
-    const double s = (s0 + s1) + (s2 + s3);
-    const int tap = id >> 12, ci = (id >> 6) & 63, co = id & 63;
-    const int o = transposed ? ((ci * 64 + co) * 9 + tap) : ((co * 64 + ci) * 9 + tap);
-    dw_ref[o] = (float)s;
-  } else if (id < NTAPS * 4096 + 64 && dbias) {
-    const int c = id - NTAPS * 4096;
-    const float* b = partial + (size_t)nwg * (NTAPS * 4096);
-    double s = 0.0;
-    for (int w = 0; w < nwg; ++w) s += (double)b[(size_t)w * 64 + c];
-    dbias[c] = (float)s;
+    for (; w < w1; ++w) s0 += (double)base[(size_t)w * stride];
+  }
+  __shared__ double sm[4][256];
+  sm[part][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part == 0 && id < TOT + 64) {
+    const double s = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+    if (id < TOT) {
+      const int tap = id >> 12, ci = (id >> 6) & 63, co = id & 63;
+      dw_ref[transposed ? ((ci * 64 + co) * 9 + tap) : ((co * 64 + ci) * 9 + tap)] = (float)s;
+    } else if (dbias) {
+      dbias[id - TOT] = (float)s;
+    }
   }
 }
 
@@ -555,7 +566,7 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
     hipLaunchKernelGGL(conv64_wgrad_kernel<false>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks);
   }
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(256), 0, st, partial, grid,
+  hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(1024), 0, st, partial, grid,
                      dw_ref, dbias, d->transposed);
   SRLZ_LAUNCHED();
   return 0;

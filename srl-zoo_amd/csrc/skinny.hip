@@ -21,7 +21,10 @@ struct Geo {
   static constexpr int COLS = 30 + K;
   static constexpr int KT = 3 * K * K;             // taps per channel group
   static constexpr int KS = (KT + 1) / 2;          // MFMA k-steps (2 taps per step)
-  static constexpr int TILE_FLOATS = 3 * 2 * ROWS * XP;
+  // pitch of one (channel, column-parity) plane: ROWS*XP rounded so that PP % 32 == 4 — the weight-gradient kernel
+  // reads 32 different taps per instruction, and a pitch congruent to XP (24) folds them onto 4 banks
+  static constexpr int PP = ((ROWS * XP + 31) / 32) * 32 + 4;
+  static constexpr int TILE_FLOATS = 3 * 2 * PP;
 };
 
 template <int K>
@@ -29,7 +32,7 @@ __host__ __device__ constexpr int koff(int k) {
   // LDS offset of tap k = (c,ky,kx) relative to the pixel base (2*ty*XP + tx)
   const int kk = (k < Geo<K>::KT) ? k : 0;
   const int c = kk / (K * K), ky = (kk / K) % K, kx = kk % K;
-  return ((c * 2 + (kx & 1)) * Geo<K>::ROWS + ky) * XP + (kx >> 1);
+  return (c * 2 + (kx & 1)) * Geo<K>::PP + ky * XP + (kx >> 1);
 }
 
 // Stage channels [3cg, 3cg+3) of the image window of output tile (oy0, ox0) into LDS.
@@ -51,7 +54,7 @@ __device__ __forceinline__ void stage_image(float* __restrict__ T, const float* 
       const int iy = iy0 + r, ix = ix0 + xl;
       v[j] = 0.f;
       if (idx < TOT && iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = img[((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix];
-      dst[j] = ((c * 2 + (xl & 1)) * ROWS + r) * XP + (xl >> 1);
+      dst[j] = (c * 2 + (xl & 1)) * Geo<K>::PP + r * XP + (xl >> 1);
     }
 #pragma unroll
     for (int j = 0; j < BATCH; ++j)
@@ -155,8 +158,10 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------------------------
 // dW[ch][k] = sum_{n,pix} feat[n,pix,ch] * im2col(img)[n,pix,k]     ch in [0,64), k = (c,ky,kx) of channel group cg.
 // GEMM view: M = 64 feature channels (2 M-tiles), N = KT taps (NT tiles of 32), K = pixels.
-// Wave w owns M-tile (w&1) and N-tiles (w>>1), (w>>1)+2, ...; every wave walks all 256 pixels of a tile.
-// Persistent over tiles; per-workgroup partial [64][NT*32] -> skinny_wgrad_reduce (fixed order).
+// Per 16x16-pixel tile the image window is staged in LDS (T) and the 64-channel feature rows are staged in two halves
+// of 128 pixels (F, 32 KB) with 16-byte coalesced loads — a dword-per-lane fragment load straight from HBM is
+// address-path bound (measured 2 TB/s).  Wave w owns M-tile (w&1), ALL N-tiles and 64 of a half's 128 pixels.
+// Persistent over tiles; each (workgroup, w>>1) writes its own partial [64][NT*32] -> skinny_wgrad_reduce.
 // ------------------------------------------------------------------------------------------------------------------
 template <int K, int PAD>
 __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __restrict__ img,
@@ -165,70 +170,73 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
                                                              int HF, int WF, int tiles_y, int tiles_x) {
   constexpr int KT = Geo<K>::KT;
   constexpr int NT = (KT + 31) / 32;
-  constexpr int MAXJ = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* T = (float*)smem;
+  float* T = (float*)smem;                  // image window
+  float* F = T + Geo<K>::TILE_FLOATS;       // [128 pixels][64 channels] feature rows of the current half tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int mt = wave & 1, nt0 = wave >> 1;
+  const int mt = wave & 1, sub = wave >> 1;
   const int cg = blockIdx.y;
   const int ntiles = N * tiles_y * tiles_x;
 
-  int kb[MAXJ];  // per-lane LDS offset of this lane's tap in N-tile j (+h: the odd pixel of a k-step is one column on)
+  int kb[NT];  // per-lane LDS offset of this lane's tap in N-tile j (+h: the odd pixel of a k-step is one column on)
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const int k = (nt0 + 2 * j) * 32 + l31;
+  for (int j = 0; j < NT; ++j) {
+    const int k = j * 32 + l31;
     const int kk = (k < KT) ? k : 0;
     const int c = kk / (K * K), ky = (kk / K) % K, kx = kk % K;
-    kb[j] = ((c * 2 + (kx & 1)) * Geo<K>::ROWS + ky) * XP + (kx >> 1) + h;
+    kb[j] = (c * 2 + (kx & 1)) * Geo<K>::PP + ky * XP + (kx >> 1) + h;
   }
-  f32x16 acc[MAXJ];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+  const int slot = tid & 15, prow = tid >> 4;  // feature staging: 16 lanes per pixel row (256 B), 16 pixels per pass
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_y * tiles_x);
     const int trem = tile - n * (tiles_y * tiles_x);
     const int oy0 = (trem / tiles_x) * 16, ox0 = (trem % tiles_x) * 16;
-    __syncthreads();
-    stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
-    __syncthreads();
-    // 128 k-steps: step s covers pixels (ty = s>>3, tx = 2*(s&7) + h)
 #pragma unroll 1
-    for (int sb = 0; sb < 128; sb += 8) {
-      float a[8];
-      const int ty = sb >> 3;
-      const int oy = oy0 + ty;
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if (half == 0) stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
+      {
+        f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int ox = ox0 + 2 * u + h;
-        a[u] = (oy < HF && ox < WF) ? feat[((size_t)(n * HF + oy) * WF + ox) * 64 + mt * 32 + l31] : 0.f;
+        for (int j = 0; j < 8; ++j) {  // pixel p = 16*j + prow of the half: tile row 8*half + j, column prow
+          const int oy = oy0 + 8 * half + j, ox = ox0 + prow;
+          v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (oy < HF && ox < WF) v[j] = *(const f32x4*)(feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + slot * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = v[j];
       }
-      const int base = 2 * ty * XP;
+      __syncthreads();
+      // 32 k-steps per wave: step s covers pixels (row 4*sub + (s>>3) of the half, column 2*(s&7) + h)
+      const float* fcol = F + mt * 32 + l31;
+#pragma unroll 4
+      for (int s = 0; s < 32; ++s) {
+        const int lrow = 4 * sub + (s >> 3), tx = 2 * (s & 7);
+        const float a = fcol[(lrow * 16 + tx + h) * 64];
+        const int base = 2 * (8 * half + lrow) * XP + tx;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-          if (nt0 + 2 * j < NT) {
-            const float b = T[base + 2 * u + kb[j]];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b, acc[j], 0, 0, 0);
-          }
+        for (int j = 0; j < NT; ++j) {
+          const float b = T[base + kb[j]];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
         }
       }
     }
   }
-  float* out = partial + ((size_t)cg * gridDim.x + blockIdx.x) * (64 * NT * 32);
+  float* out = partial + (((size_t)cg * gridDim.x + blockIdx.x) * 2 + sub) * (64 * NT * 32);
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    if (nt0 + 2 * j < NT) {
+  for (int j = 0; j < NT; ++j) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        out[row * (NT * 32) + (nt0 + 2 * j) * 32 + l31] = acc[j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[row * (NT * 32) + j * 32 + l31] = acc[j][r];
     }
   }
 }
@@ -416,7 +424,7 @@ static size_t wgrad_ws(const srlz_skinny_desc* d) {
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int g = persistent_grid(d->n * ty * tx);
-  return (size_t)(d->c / 3) * g * 64 * NT * 32 * sizeof(float) + (size_t)d->n * d->c * sizeof(double);
+  return (size_t)(d->c / 3) * g * 2 * 64 * NT * 32 * sizeof(float) + (size_t)d->n * d->c * sizeof(double);
 }
 
 template <int K, int PAD>
@@ -427,13 +435,13 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
   const int ntiles = d->n * ty * tx;
   const int g = persistent_grid(ntiles);
   SRLZ_REQUIRE(ws_bytes >= wgrad_ws<K>(d), SRLZ_ERR_WORKSPACE, "skinny wgrad: workspace too small (%zu)", ws_bytes);
-  const size_t lds = (size_t)Geo<K>::TILE_FLOATS * 4;
+  const size_t lds = (size_t)(Geo<K>::TILE_FLOATS + 128 * 64) * 4;
   float* partial = (float*)ws;
   hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
                      d->himg, d->wimg, d->hf, d->wf, ty, tx);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
-  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, st, partial, g, d->c, K * K, Geo<K>::KT,
+  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
                      NT * 32, dw);
   SRLZ_LAUNCHED();
   return 0;
