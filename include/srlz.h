@@ -146,8 +146,9 @@ size_t srlz_bn_bwd_workspace(long long elems);
 /* dy (same shape as y) and dgamma[64], dbeta[64] from dpooled.  training != 0: batch-statistics backward;
  * training == 0: running-statistics backward (validation minibatches, models/learner.py:362-364,489). */
 int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
-                          float* dy, float* dgamma, float* dbeta, int training, void* ws, size_t ws_bytes,
-                          const srlz_pool_desc* d, srlz_stream_t stream);
+                          const float* pooled /* forward output, may be NULL (slower) */, float* dy, float* dgamma,
+                          float* dbeta, int training, void* ws, size_t ws_bytes, const srlz_pool_desc* d,
+                          srlz_stream_t stream);
 /* a = relu(y*scale+shift) over `pixels` x 64 */
 int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long long pixels, srlz_stream_t stream);
 int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* da, float* dy, float* dgamma, float* dbeta,

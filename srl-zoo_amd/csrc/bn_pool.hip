@@ -158,10 +158,12 @@ __device__ __forceinline__ void block_reduce_store(const double (&s1)[4], const 
 // partial[block][128]: [0,64) sum dz, [64,128) sum dz*xhat
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __restrict__ y, const float* __restrict__ bnp,
                                                               const uint8_t* __restrict__ argmax,
-                                                              const float* __restrict__ dpooled, double* __restrict__ partial,
+                                                              const float* __restrict__ dpooled,
+                                                              const float* __restrict__ pooled, double* __restrict__ partial,
                                                               int N, int H, int W, int HP, int WP, int pad, int dp_nchw) {
-  // dz is non-zero only at a window's argmax and only if the pooled value is positive; there z = scale*v + shift is
-  // re-read from y (one 4-byte gather per pooled element, the expensive part of this kernel).
+  // dz is non-zero only at a window's argmax and only if the pooled value is positive.  The pooled value IS
+  // z = scale*v + shift at that position, so xhat = ((z - shift)/scale - mean)*invstd needs no access to y — unless
+  // `pooled` is not supplied or scale == 0, where v is gathered from y (one scattered 4-byte read per element).
   const int c4 = threadIdx.x & 15;
   const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
   const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
@@ -181,12 +183,27 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
       } else {
         dp = *(const f32x4*)(dpooled + (size_t)pix * 64 + c4 * 4);
       }
+      f32x4 pz = {0.f, 0.f, 0.f, 0.f};
+      if (pooled) {
+        if (dp_nchw) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pz[j] = pooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px];
+        } else {
+          pz = *(const f32x4*)(pooled + (size_t)pix * 64 + c4 * 4);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int a = (packed >> (8 * j)) & 0xff;
-        const int iy = py * 2 - pad + a / 3, ix = px * 2 - pad + a % 3;
-        const float v = y[((size_t)(n * H + iy) * W + ix) * 64 + c4 * 4 + j];
-        const float z = v * sc[j] + sh[j];
+        float v, z;
+        if (pooled && sc[j] != 0.f) {
+          z = pz[j];
+          v = (z - sh[j]) / sc[j];
+        } else {
+          const int a = (packed >> (8 * j)) & 0xff;
+          const int iy = py * 2 - pad + a / 3, ix = px * 2 - pad + a % 3;
+          v = y[((size_t)(n * H + iy) * W + ix) * 64 + c4 * 4 + j];
+          z = v * sc[j] + sh[j];
+        }
         if (z > 0.f) {
           s1[j] += (double)dp[j];
           s2[j] += (double)(dp[j] * ((v - mean[j]) * invstd[j]));
@@ -197,14 +214,21 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
   block_reduce_store(s1, s2, partial);
 }
 
-// sums[0..64) = sum dz (= dbeta), sums[64..128) = sum dz*xhat (= dgamma); also written to dgamma/dbeta
-__global__ void bn_bwd_finalize(const double* __restrict__ partial, int nblocks, float* __restrict__ sums,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = threadIdx.x;  // 128 threads
+// sums[0..64) = sum dz (= dbeta), sums[64..128) = sum dz*xhat (= dgamma); also written to dgamma/dbeta.
+// 1024 threads: 8 row slices x 128 columns, combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize(const double* __restrict__ partial, int nblocks, float* __restrict__ sums,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = threadIdx.x & 127, part = threadIdx.x >> 7;
   double s = 0.0;
-  for (int i = 0; i < nblocks; ++i) s += partial[(size_t)i * 128 + c];
-  sums[c] = (float)s;
-  if (c < 64) { if (dbeta) dbeta[c] = (float)s; } else { if (dgamma) dgamma[c - 64] = (float)s; }
+  for (int i = part; i < nblocks; i += 8) s += partial[(size_t)i * 128 + c];
+  __shared__ double sm[8][128];
+  sm[part][c] = s;
+  __syncthreads();
+  if (part == 0) {
+    s = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) + ((sm[4][c] + sm[5][c]) + (sm[6][c] + sm[7][c]));
+    sums[c] = (float)s;
+    if (c < 64) { if (dbeta) dbeta[c] = (float)s; } else { if (dgamma) dgamma[c - 64] = (float)s; }
+  }
 }
 
 // ---- backward, stage 2: dy = scale * (dz - m1 - xhat*m2) (training) or scale * dz (eval) for every y element ----
@@ -449,8 +473,8 @@ extern "C" size_t srlz_bn_bwd_workspace(long long elems) {
 }
 
 extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
-                                     float* dy, float* dgamma, float* dbeta, int training, void* ws, size_t ws_bytes,
-                                     const srlz_pool_desc* d, srlz_stream_t stream) {
+                                     const float* pooled, float* dy, float* dgamma, float* dbeta, int training, void* ws,
+                                     size_t ws_bytes, const srlz_pool_desc* d, srlz_stream_t stream) {
   if (int rc = check_pool(d)) return rc;
   SRLZ_REQUIRE(y && bnp && argmax && dpooled && dy && ws, SRLZ_ERR_NULL, "bn_relu_pool_bwd: null pointer");
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
@@ -460,13 +484,13 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   float* sums = (float*)(staged + STAGE_ROWS * 128);
   int nb = d->n * d->hp;
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-  hipLaunchKernelGGL(bn_relu_pool_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, argmax, dpooled, partial, d->n, d->h, d->w,
+  hipLaunchKernelGGL(bn_relu_pool_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, argmax, dpooled, pooled, partial, d->n, d->h, d->w,
                      d->hp, d->wp, d->pool_pad, d->out_nchw);
   SRLZ_LAUNCHED();
   const int sg = stage_blocks(nb);
   hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(sg), dim3(256), 0, st, (const double*)partial, nb, staged);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
   SRLZ_LAUNCHED();
   const int HB = (d->h + d->pool_pad + 1) / 2, WB = (d->w + d->pool_pad + 1) / 2;
   SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
@@ -499,7 +523,7 @@ extern "C" int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* d
   const int sg = stage_blocks(nb);
   hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(sg), dim3(256), 0, st, (const double*)partial, nb, staged);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(128), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
   SRLZ_LAUNCHED();
   const float inv_count = 1.0f / (float)(double)pixels;
   hipLaunchKernelGGL(bn_relu_bwd_apply, dim3(grid_for(pixels * 16, 256)), dim3(256), 0, st, y, bnp, da, sums, dy, pixels,

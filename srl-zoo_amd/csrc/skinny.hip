@@ -241,27 +241,36 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   }
 }
 
-// dw_ref[ch][cg*3+c][ky][kx] = sum over workgroups of partial[cg][wg][ch][k]
-__global__ void skinny_wgrad_reduce(const float* __restrict__ partial, int nwg, int C, int KK, int KT, int NTW,
-                                    float* __restrict__ dw_ref) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+// dw_ref[ch][cg*3+c][ky][kx] = sum over workgroups of partial[cg][wg][ch][k]; 256 outputs x 4 slices of the
+// workgroup range per 1024-thread block, fp64, fixed order.
+__global__ __launch_bounds__(1024) void skinny_wgrad_reduce(const float* __restrict__ partial, int nwg, int C, int KK, int KT,
+                                                           int NTW, float* __restrict__ dw_ref) {
+  const int o = threadIdx.x & 255, part = threadIdx.x >> 8;
+  const int id = blockIdx.x * 256 + o;
   const int ncg = C / 3;
-  if (id >= ncg * 64 * KT) return;
-  const int cg = id / (64 * KT);
-  const int rem = id - cg * 64 * KT;
-  const int ch = rem / KT, k = rem - ch * KT;
+  const bool live = id < ncg * 64 * KT;
+  int cg = 0, ch = 0, k = 0;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  const float* base = partial + (size_t)cg * nwg * (64 * NTW) + ch * NTW + k;
-  int w = 0;
-  for (; w + 3 < nwg; w += 4) {
-    s0 += (double)base[(size_t)w * (64 * NTW)];
-    s1 += (double)base[(size_t)(w + 1) * (64 * NTW)];
-    s2 += (double)base[(size_t)(w + 2) * (64 * NTW)];
-    s3 += (double)base[(size_t)(w + 3) * (64 * NTW)];
+  if (live) {
+    cg = id / (64 * KT);
+    const int rem = id - cg * 64 * KT;
+    ch = rem / KT; k = rem - ch * KT;
+    const float* base = partial + (size_t)cg * nwg * (64 * NTW) + ch * NTW + k;
+    const int per = (nwg + 3) / 4;
+    const int w0 = part * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
+    int w = w0;
+    for (; w + 3 < w1; w += 4) {
+      s0 += (double)base[(size_t)w * (64 * NTW)];
+      s1 += (double)base[(size_t)(w + 1) * (64 * NTW)];
+      s2 += (double)base[(size_t)(w + 2) * (64 * NTW)];
+      s3 += (double)base[(size_t)(w + 3) * (64 * NTW)];
+    }
+    for (; w < w1; ++w) s0 += (double)base[(size_t)w * (64 * NTW)];
   }
-  for (; w < nwg; ++w) s0 += (double)base[(size_t)w * (64 * NTW)];
-  const double s = (s0 + s1) + (s2 + s3);
-  dw_ref[((size_t)ch * C + cg * 3) * KK + k] = (float)s;
+  __shared__ double sm[4][256];
+  sm[part][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part == 0 && live) dw_ref[((size_t)ch * C + cg * 3) * KK + k] = (float)((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -441,7 +450,7 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
                      d->himg, d->wimg, d->hf, d->wf, ty, tx);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
-  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(256), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
+  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
                      NT * 32, dw);
   SRLZ_LAUNCHED();
   return 0;

@@ -62,7 +62,7 @@ _PROTOS = {
     "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),
     "srlz_bn_relu_pool_fwd": (c_int, [P, P, P, P, _PD, P]),
     "srlz_bn_bwd_workspace": (c_size_t, [c_longlong]),
-    "srlz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, c_size_t, _PD, P]),
+    "srlz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, c_size_t, _PD, P]),
     "srlz_bn_relu_fwd": (c_int, [P, P, P, c_longlong, P]),
     "srlz_bn_relu_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, c_longlong, P]),
     "srlz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

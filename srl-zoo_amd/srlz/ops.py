@@ -208,20 +208,20 @@ class BNReLUPoolFn(Function):
         argmax = torch.empty((n, hp, wp, 64), dtype=torch.uint8, device=y.device) if need_bwd else None
         C.bn_relu_pool_fwd(ptr(y), ptr(bnp), ptr(pooled), ptr(argmax), d, stream())
         if need_bwd:
-            ctx.save_for_backward(y, bnp, argmax)
+            ctx.save_for_backward(y, bnp, argmax, pooled)
         ctx.desc, ctx.training = d, training
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        y, bnp, argmax = ctx.saved_tensors
+        y, bnp, argmax, pooled = ctx.saved_tensors
         dpooled = _check(dpooled, "pool grad")
         dy = torch.empty_like(y)
         dgamma = torch.empty(64, dtype=torch.float32, device=y.device)
         dbeta = torch.empty(64, dtype=torch.float32, device=y.device)
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, y.device)
-        C.bn_relu_pool_bwd(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(dy), ptr(dgamma), ptr(dbeta),
+        C.bn_relu_pool_bwd(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(dy), ptr(dgamma), ptr(dbeta),
                            1 if ctx.training else 0, ptr(ws), nbytes, ctx.desc, stream())
         return dy, None, dgamma, dbeta, None, None, None, None, None, None
 

@@ -229,7 +229,7 @@ def test_bn_relu_pool(C, n, h, pad, out_nchw, training):
     dgm, dbt = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
     nbytes = C.bn_bwd_workspace(0)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    C.bn_relu_pool_bwd(C.ptr(yd), C.ptr(bnp), C.ptr(arg), C.ptr(dpd), C.ptr(dy), C.ptr(dgm), C.ptr(dbt), training,
+    C.bn_relu_pool_bwd(C.ptr(yd), C.ptr(bnp), C.ptr(arg), C.ptr(dpd), C.ptr(pooled), C.ptr(dy), C.ptr(dgm), C.ptr(dbt), training,
                        C.ptr(ws), nbytes, d, st)
     torch.cuda.synchronize()
     assert rel_err(nchw(dy), yr.grad) < 5e-5

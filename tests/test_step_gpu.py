@@ -92,7 +92,7 @@ def pins_from_taps(taps):
     pins = {}
     for name, pad in (("encoder_conv.3", 1), ("encoder_conv.7", 0), ("encoder_conv.11", 0)):
         t = taps[name]
-        y, _bnp, arg = t.grad_fn.saved_tensors
+        y, _bnp, arg = t.grad_fn.saved_tensors[:3]
         n, h, w, _ = y.shape
         a = arg.long().cpu().permute(0, 3, 1, 2)  # [n, c, hp, wp] window index ky*3+kx
         hp, wp = a.shape[2], a.shape[3]

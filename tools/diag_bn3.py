@@ -38,7 +38,7 @@ print("pooled rel err", S.rel(pooled, p))
 dp = p.grad.float().contiguous().cuda()
 dy = torch.empty(n, h, h, 64).cuda(); dg = torch.empty(64).cuda(); db = torch.empty(64).cuda()
 nb = C.bn_bwd_workspace(0); ws = torch.empty(nb, dtype=torch.uint8).cuda()
-C.bn_relu_pool_bwd(C.ptr(yd), C.ptr(bnp), C.ptr(arg), C.ptr(dp), C.ptr(dy), C.ptr(dg), C.ptr(db), 1, C.ptr(ws), nb, d, st)
+C.bn_relu_pool_bwd(C.ptr(yd), C.ptr(bnp), C.ptr(arg), C.ptr(dp), C.ptr(pooled), C.ptr(dy), C.ptr(dg), C.ptr(db), 1, C.ptr(ws), nb, d, st)
 torch.cuda.synchronize()
 ref = y.grad.permute(0, 2, 3, 1)
 got = dy.double().cpu()

@@ -14,7 +14,7 @@ hotpath.TAPS = {}
 lm = L.LossManager(model, None); model.train()
 st, dec = model(o); first = dict(hotpath.TAPS); hotpath.TAPS = None
 node = first["encoder_conv.11"].grad_fn
-y_s, bnp_s, arg_s = node.saved_tensors
+y_s, bnp_s, arg_s = node.saved_tensors[:3]
 y_s, bnp_s, arg_s = y_s.clone(), bnp_s.clone(), arg_s.clone()
 nst, ndec = model(no)
 L.forwardModelLoss(model.forwardModel(st, act), nst, 1.0, lm)
@@ -30,7 +30,7 @@ n, h = 2, 14
 d = C.PoolDesc(n, h, h, 6, 6, 0, 1)
 dy = torch.empty(n, h, h, 64).cuda(); dg = torch.empty(64).cuda(); db = torch.empty(64).cuda()
 nb = C.bn_bwd_workspace(0); ws = torch.empty(nb, dtype=torch.uint8).cuda()
-C.bn_relu_pool_bwd(C.ptr(y_s), C.ptr(bnp_s), C.ptr(arg_s), C.ptr(dp), C.ptr(dy), C.ptr(dg), C.ptr(db), 1, C.ptr(ws), nb, d, C.stream())
+C.bn_relu_pool_bwd(C.ptr(y_s), C.ptr(bnp_s), C.ptr(arg_s), C.ptr(dp), None, C.ptr(dy), C.ptr(dg), C.ptr(db), 1, C.ptr(ws), nb, d, C.stream())
 torch.cuda.synchronize()
 print("recomputed dy vs pipeline dy: rel", S.rel(dy, dy_pipe), " max|dy| %.3e" % dy_pipe.abs().max().item())
 print("is dy_pipe exactly 2x or sum? ratio stats", (dy_pipe / (dy + 1e-30))[dy.abs() > 1e-6].median().item())

@@ -125,7 +125,7 @@ def bench_bn(sel):
                    bytes_=4.0 * y.numel() + 5.0 * pooled.numel())
         C.bn_relu_pool_fwd(C.ptr(y), C.ptr(bnp), C.ptr(pooled), C.ptr(arg), d, st)
         if sel("pool bwd"):
-            report(label + " bwd (reduce+apply)", *timeit(lambda: C.bn_relu_pool_bwd(C.ptr(y), C.ptr(bnp), C.ptr(arg), C.ptr(dp), C.ptr(dy), C.ptr(dg), C.ptr(db), 1, C.ptr(ws), nbw, d, st)),
+            report(label + " bwd (reduce+apply)", *timeit(lambda: C.bn_relu_pool_bwd(C.ptr(y), C.ptr(bnp), C.ptr(arg), C.ptr(dp), C.ptr(pooled), C.ptr(dy), C.ptr(dg), C.ptr(db), 1, C.ptr(ws), nbw, d, st)),
                    bytes_=8.0 * y.numel() + 5.0 * pooled.numel())
     for label, h in (("bn+relu 111x111", 111), ("bn+relu 55x55", 55)):
         y, da = rnd(N, h, h, 64), rnd(N, h, h, 64)
