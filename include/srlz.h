@@ -68,9 +68,12 @@ int srlz_conv64_pack_weights(const float* w_ref, float* wpack_fwd, float* wpack_
 /* number of per-tile BatchNorm partial records forward() writes (each record = 128 floats: sum[64], sumsq[64]) */
 int srlz_conv64_fwd_tiles(const srlz_conv64_desc* d);
 /* y = conv(x) (+bias).  bias may be NULL.  stats_partial may be NULL; otherwise receives
- * srlz_conv64_fwd_tiles(d) x 128 floats of per-tile sum / sum-of-squares per channel over y (BatchNorm input). */
+ * srlz_conv64_fwd_tiles(d) x 128 floats of per-tile sum / sum-of-squares per channel over y (BatchNorm input).
+ * x_bnp (may be NULL): x is the RAW output of the previous convolution and the layer input is relu(batchnorm(x)) with
+ * this 4x64 record (srlz_bn_finalize / srlz_bn_eval_params) — nn.BatchNorm2d + nn.ReLU of models/models.py:67-80 fused
+ * into the operand load, so the activated tensor is never written to memory. */
 int srlz_conv64_fwd(const float* x, const float* wpack_fwd, const float* bias, float* y, float* stats_partial,
-                    const srlz_conv64_desc* d, srlz_stream_t stream);
+                    const float* x_bnp, const srlz_conv64_desc* d, srlz_stream_t stream);
 /* dx = d(loss)/d(x) from dy. */
 int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx,
                          const srlz_conv64_desc* d, srlz_stream_t stream);
@@ -78,8 +81,8 @@ int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx,
 size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d);
 /* dw_ref (reference layout) = d(loss)/d(w); dbias[64] = sum of dy over n,h,w (may be NULL).
  * Deterministic: split-K partials in `ws`, fixed-order second-stage reduction (learner.py:62 asks cuDNN for the same). */
-int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float* dbias, void* ws, size_t ws_bytes,
-                           const srlz_conv64_desc* d, srlz_stream_t stream);
+int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float* dbias, const float* x_bnp /* as above */,
+                           void* ws, size_t ws_bytes, const srlz_conv64_desc* d, srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * "Skinny" convolutions: one side has C in {3,6,9} image channels stored NCHW, the other 64 channels NHWC.
@@ -104,13 +107,15 @@ int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, float* dw_r
                           const srlz_skinny_desc* d, srlz_stream_t stream);
 /* kind 1 forward: x_nhwc [N,hf,wf,64] -> y_nchw [N,C,H,W] = convT(x) + bias; w_ref [64,C,4,4]. */
 int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
-                       const srlz_skinny_desc* d, srlz_stream_t stream);
+                       const float* x_bnp /* may be NULL, see srlz_conv64_fwd */, const srlz_skinny_desc* d,
+                       srlz_stream_t stream);
 /* kind 1 data gradient: dx_nhwc [N,hf,wf,64] from dy_nchw. */
 int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc,
                             const srlz_skinny_desc* d, srlz_stream_t stream);
 /* kind 1 weight gradient: dw_ref [64,C,4,4], dbias [C]. */
 int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias,
-                              void* ws, size_t ws_bytes, const srlz_skinny_desc* d, srlz_stream_t stream);
+                              const float* x_bnp, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
+                              srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BatchNorm2d(64) (+ ReLU (+ MaxPool 3x3 s2)) — nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d,

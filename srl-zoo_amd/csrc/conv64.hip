@@ -125,10 +125,13 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
 // Tile staging: rows [qstart, qstart+nrows) of class `cls` of an NHWC/64 tensor -> LDS (256 B per row).
 // 16 lanes fetch one row (256 contiguous bytes); out-of-range rows are zero-filled.
 // ---------------------------------------------------------------------------------------------------------------
+// With `bnp` != NULL the source is the RAW output of a convolution and the consumer wants relu(batchnorm(.)): the affine
+// (scale = bnp[128..], shift = bnp[192..]) and the ReLU are applied to in-bounds rows on the way into LDS, so the
+// activated tensor is never materialised in HBM (padding rows stay exactly zero).
 template <bool SWZ>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
                                            int stride, int cls, int PW, int PH, int total_q, int qstart,
-                                           int nrows) {
+                                           int nrows, const float* __restrict__ bnp = nullptr) {
   // Loads are issued in batches of 8 rows per thread before any LDS store, so the HBM/L2 latency is paid once per
   // batch instead of once per row; (n, a, b) of a thread's rows are advanced incrementally (rows are 16 apart), the
   // only integer divisions are the two for its first row.
@@ -145,13 +148,17 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
   int a = rem / PW;
   int b = rem - a * PW;
   const int N1max = total_q / PHW;  // images
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
   for (int base = t >> 4; base < nrows; base += 16 * BATCH) {
     f32x4 v[BATCH];
+    bool ok[BATCH];
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int y = a * stride + cy, x = b * stride + cx;
-      if (base + 16 * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W)
+      ok[j] = base + 16 * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W;
+      if (ok[j])
         v[j] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
       b += sb; a += sa;
       if (b >= PW) { b -= PW; ++a; }
@@ -161,6 +168,10 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
     for (int j = 0; j < BATCH; ++j) {
       const int R = base + 16 * j;
       if (R < nrows) {
+        if (bnp && ok[j]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = z > 0.f ? z : 0.f; }
+        }
         const int sl = SWZ ? (slot ^ (R & 15)) : slot;
         *(f32x4*)(lds + R * 64 + sl * 4) = v[j];
       }
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
                                                            const float* __restrict__ wpack,
                                                            const float* __restrict__ bias, float* __restrict__ dst,
                                                            float* __restrict__ stats_partial, const ConvProg P,
-                                                           int ntiles) {
+                                                           int ntiles, const float* __restrict__ src_bnp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* As = (float*)smem;                 // (TM + span) x 64, swizzled
   float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap, pre-swizzled in global
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
     }
     if (tsrc != cur_src) {
       if (!(P.dbg & 1))
-        stage_rows<true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span);
+        stage_rows<true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span, src_bnp);
       cur_src = tsrc;
     }
     if (!(P.dbg & 4)) {
@@ -320,7 +331,7 @@ template <bool S2>
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ g,
                                                              float* __restrict__ partial, const ConvProg P,
-                                                             int nchunks) {
+                                                             int nchunks, const float* __restrict__ x_bnp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Ss = (float*)smem;              // (TK + span) x 64
   float* Gs = Ss + (TK + P.span) * 64;   // TK x 64
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
       const int cs = P.tsrc[t0], cd = P.tdst[t0];
       __syncthreads();
       if (cs != cur_s) {
-        stage_rows<false>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span);
+        stage_rows<false>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span, x_bnp);
         cur_s = cs;
       }
       const bool newg = (cd != cur_g);
@@ -481,12 +492,12 @@ static size_t fwd_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) * 
 static size_t wgrad_lds_bytes(const ConvProg& P) { return (size_t)(TK + P.span + TK) * 256; }
 
 static int launch_fwd(const float* src, const float* wpack, const float* bias, float* dst, float* stats,
-                      const ConvProg& P, hipStream_t st) {
+                      const ConvProg& P, hipStream_t st, const float* src_bnp = nullptr) {
   const int ntiles = (P.total_q + TM - 1) / TM;
   const size_t lds = fwd_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64: tile needs %zu bytes of LDS", lds);
   SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(conv64_fwd_kernel, dim3(ntiles), dim3(256), lds, st, src, wpack, bias, dst, stats, P, ntiles);
+  hipLaunchKernelGGL(conv64_fwd_kernel, dim3(ntiles), dim3(256), lds, st, src, wpack, bias, dst, stats, P, ntiles, src_bnp);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -520,12 +531,13 @@ extern "C" int srlz_conv64_fwd_tiles(const srlz_conv64_desc* d) {
 }
 
 extern "C" int srlz_conv64_fwd(const float* x, const float* wpack_fwd, const float* bias, float* y,
-                               float* stats_partial, const srlz_conv64_desc* d, srlz_stream_t stream) {
+                               float* stats_partial, const float* x_bnp, const srlz_conv64_desc* d,
+                               srlz_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   SRLZ_REQUIRE(x && wpack_fwd && y, SRLZ_ERR_NULL, "conv64_fwd: null pointer");
   ConvProg P;
   if (int rc = program_for(&P, d, 0)) return rc;
-  return launch_fwd(x, wpack_fwd, bias, y, stats_partial, P, as_stream(stream));
+  return launch_fwd(x, wpack_fwd, bias, y, stats_partial, P, as_stream(stream), x_bnp);
 }
 
 extern "C" int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx, const srlz_conv64_desc* d,
@@ -544,8 +556,8 @@ extern "C" size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d) {
   return (size_t)wgrad_grid(P) * (NTAPS * 4096 + 64) * sizeof(float);
 }
 
-extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float* dbias, void* ws,
-                                      size_t ws_bytes, const srlz_conv64_desc* d, srlz_stream_t stream) {
+extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float* dbias, const float* x_bnp,
+                                      void* ws, size_t ws_bytes, const srlz_conv64_desc* d, srlz_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   SRLZ_REQUIRE(x && dy && dw_ref && ws, SRLZ_ERR_NULL, "conv64_bwd_weight: null pointer");
   ConvProg P;
@@ -560,10 +572,10 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   float* partial = (float*)ws;
   if (P.s2) {
     SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(conv64_wgrad_kernel<true>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks);
+    hipLaunchKernelGGL(conv64_wgrad_kernel<true>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, x_bnp);
   } else {
     SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(conv64_wgrad_kernel<false>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks);
+    hipLaunchKernelGGL(conv64_wgrad_kernel<false>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, x_bnp);
   }
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(1024), 0, st, partial, grid,

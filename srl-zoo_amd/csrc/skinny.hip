@@ -167,7 +167,8 @@ template <int K, int PAD>
 __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __restrict__ img,
                                                              const float* __restrict__ feat,
                                                              float* __restrict__ partial, int N, int C, int H, int W,
-                                                             int HF, int WF, int tiles_y, int tiles_x) {
+                                                             int HF, int WF, int tiles_y, int tiles_x,
+                                                             const float* __restrict__ feat_bnp) {
   constexpr int KT = Geo<K>::KT;
   constexpr int NT = (KT + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -195,6 +196,9 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int slot = tid & 15, prow = tid >> 4;  // feature staging: 16 lanes per pixel row (256 B), 16 pixels per pass
+  // feat_bnp != NULL: `feat` is a raw convolution output and the operand is relu(batchnorm(feat)) (fused, see conv64.hip)
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (feat_bnp) { sc4 = *(const f32x4*)(feat_bnp + 128 + slot * 4); sh4 = *(const f32x4*)(feat_bnp + 192 + slot * 4); }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_y * tiles_x);
     const int trem = tile - n * (tiles_y * tiles_x);
@@ -210,6 +214,14 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
           const int oy = oy0 + 8 * half + j, ox = ox0 + prow;
           v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (oy < HF && ox < WF) v[j] = *(const f32x4*)(feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + slot * 4);
+        }
+        if (feat_bnp) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool ok = (oy0 + 8 * half + j < HF) && (ox0 + prow < WF);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = (ok && z > 0.f) ? z : 0.f; }
+          }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = v[j];
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
                                                           const float* __restrict__ w_ref,
                                                           const float* __restrict__ bias, float* __restrict__ img,
                                                           int N, int C, int H, int W, int HF, int WF, int tiles_y,
-                                                          int tiles_x) {
+                                                          int tiles_x, const float* __restrict__ feat_bnp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Tt = (float*)smem;  // [304][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -306,6 +318,13 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
   float bs[3];
 #pragma unroll
   for (int co = 0; co < 3; ++co) bs[co] = bias ? bias[cg * 3 + co] : 0.f;
+  // feat_bnp != NULL: the operand is relu(batchnorm(feat)); this lane's channels are 16c + 4kq + r
+  f32x4 fsc[4], fsh[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    fsc[c] = f32x4{1.f, 1.f, 1.f, 1.f}; fsh[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (feat_bnp) { fsc[c] = *(const f32x4*)(feat_bnp + 128 + 16 * c + 4 * kq); fsh[c] = *(const f32x4*)(feat_bnp + 192 + 16 * c + 4 * kq); }
+  }
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_y * tiles_x);
@@ -319,7 +338,13 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
       const bool ok = (mtile < 19) && (p < 289) && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
       const float* src = feat + ((size_t)(n * HF + (ok ? fy : 0)) * WF + (ok ? fx : 0)) * 64 + 4 * kq;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a[c] = ok ? *(const f32x4*)(src + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 4; ++c) {
+        a[c] = ok ? *(const f32x4*)(src + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (feat_bnp && ok) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float z = a[c][e] * fsc[c][e] + fsh[c][e]; a[c][e] = z > 0.f ? z : 0.f; }
+        }
+      }
     };
     f32x4 a[4], an[4];
     load_a(wave, a);
@@ -438,7 +463,7 @@ static size_t wgrad_ws(const srlz_skinny_desc* d) {
 
 template <int K, int PAD>
 static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
-                        hipStream_t st) {
+                        hipStream_t st, const float* feat_bnp = nullptr) {
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
@@ -447,7 +472,7 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
   const size_t lds = (size_t)(Geo<K>::TILE_FLOATS + 128 * 64) * 4;
   float* partial = (float*)ws;
   hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                     d->himg, d->wimg, d->hf, d->wf, ty, tx);
+                     d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
@@ -485,7 +510,7 @@ extern "C" int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, 
 }
 
 extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
-                                  const srlz_skinny_desc* d, srlz_stream_t stream) {
+                                  const float* x_bnp, const srlz_skinny_desc* d, srlz_stream_t stream) {
   if (int rc = check_skinny(d)) return rc;
   SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_fwd: descriptor kind must be 1");
   SRLZ_REQUIRE(x_nhwc && w_ref && y_nchw, SRLZ_ERR_NULL, "convT_out_fwd: null pointer");
@@ -493,7 +518,7 @@ extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const
   const int ntiles = d->n * ty * tx;
   const size_t lds = (size_t)304 * TP * 4;
   hipLaunchKernelGGL(convT_out_kernel, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
-                     w_ref, bias, y_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx);
+                     w_ref, bias, y_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -507,13 +532,14 @@ extern "C" int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref,
   return launch_conv<4, 0>(dy_nchw, w_ref, dx_nhwc, nullptr, d, as_stream(stream));
 }
 
-extern "C" int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias, void* ws,
-                                         size_t ws_bytes, const srlz_skinny_desc* d, srlz_stream_t stream) {
+extern "C" int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias,
+                                         const float* x_bnp, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
+                                         srlz_stream_t stream) {
   if (int rc = check_skinny(d)) return rc;
   SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_bwd_weight: descriptor kind must be 1");
   SRLZ_REQUIRE(x_nhwc && dy_nchw && dw_ref && ws, SRLZ_ERR_NULL, "convT_out_bwd_weight: null pointer");
   // dw_ref[ci,co,ky,kx] = sum_{n,iy,ix} x[n,iy,ix,ci] * dy[n,co,2iy+ky,2ix+kx]
-  if (int rc = launch_wgrad<4, 0>(dy_nchw, x_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream))) return rc;
+  if (int rc = launch_wgrad<4, 0>(dy_nchw, x_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream), x_bnp)) return rc;
   if (dbias) {
     double* part = (double*)((char*)ws + wgrad_ws<4>(d) - (size_t)d->n * d->c * sizeof(double));
     SRLZ_REQUIRE((((uintptr_t)part) & 7) == 0 && ((d->himg * d->wimg) & 3) == 0, SRLZ_ERR_BAD_DESC,

@@ -44,19 +44,19 @@ _PROTOS = {
     "srlz_conv64_packed_floats": (c_size_t, []),
     "srlz_conv64_pack_weights": (c_int, [P, P, P, _C64, P]),
     "srlz_conv64_fwd_tiles": (c_int, [_C64]),
-    "srlz_conv64_fwd": (c_int, [P, P, P, P, P, _C64, P]),
+    "srlz_conv64_fwd": (c_int, [P, P, P, P, P, P, _C64, P]),
     "srlz_conv64_bwd_data": (c_int, [P, P, P, _C64, P]),
     "srlz_conv64_bwd_weight_workspace": (c_size_t, [_C64]),
-    "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, c_size_t, _C64, P]),
+    "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _C64, P]),
     "srlz_conv64_debug_program": (c_int, [_C64, c_int, POINTER(c_int), c_int]),
     "srlz_debug_mfma_peak": (c_int, [P, c_int, c_int, P]),
     "srlz_skinny_tiles": (c_int, [_SK]),
     "srlz_conv1_fwd": (c_int, [P, P, P, P, _SK, P]),
     "srlz_skinny_bwd_weight_workspace": (c_size_t, [_SK]),
     "srlz_conv1_bwd_weight": (c_int, [P, P, P, P, c_size_t, _SK, P]),
-    "srlz_convT_out_fwd": (c_int, [P, P, P, P, _SK, P]),
+    "srlz_convT_out_fwd": (c_int, [P, P, P, P, P, _SK, P]),
     "srlz_convT_out_bwd_data": (c_int, [P, P, P, _SK, P]),
-    "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, c_size_t, _SK, P]),
+    "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _SK, P]),
     "srlz_bn_finalize": (c_int, [P, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),
     "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),

@@ -57,16 +57,34 @@ def replay_encoder_bn(seq, stats):
 
 
 def decoder_forward(seq, z, training):
-    """models/models.py:65-83.  z: [N,64,6,6] NCHW (decoder_fc output viewed) -> [N,C,224,224] NCHW."""
+    """models/models.py:65-83.  z: [N,64,6,6] NCHW (decoder_fc output viewed) -> [N,C,224,224] NCHW.
+
+    Each BatchNorm-apply + ReLU is fused into the operand load of the transposed convolution that consumes it
+    (ops.DecBlockFn / ops.DecOutFn): only the raw convolution outputs y1..y4 exist in memory."""
     a = ops.ToNHWCFn.apply(z)
-    for ci, bi in ((0, 1), (3, 4), (6, 7), (9, 10)):
-        conv, bn = seq[ci], seq[bi]
-        y, st = ops.Conv64Fn.apply(a, conv.weight, conv.bias, 2, 0, True, training)
-        _tap("decoder_conv", ci, y)
+    y, st = ops.Conv64Fn.apply(a, seq[0].weight, seq[0].bias, 2, 0, True, training)
+    _tap("decoder_conv", 0, y)
+    for bi, ci in ((1, 3), (4, 6), (7, 9)):
+        bn, conv = seq[bi], seq[ci]
         _tick(bn, training)
-        a = _tap("decoder_conv", bi + 1, ops.BNReLUFn.apply(y, st, *_bn_args(bn), training, None))
-    last = seq[12]
-    return _tap("decoder_conv", 12, ops.ConvTOutFn.apply(a, last.weight, last.bias))
+        if TAPS is not None:
+            _record_activation(bi + 1, y, st, bn, training)
+        y, st = ops.DecBlockFn.apply(y, st, *_bn_args(bn), training, conv.weight, conv.bias, training)
+        _tap("decoder_conv", ci, y)
+    bn, last = seq[10], seq[12]
+    _tick(bn, training)
+    if TAPS is not None:
+        _record_activation(11, y, st, bn, training)
+    return _tap("decoder_conv", 12, ops.DecOutFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias))
+
+
+def _record_activation(idx, y, st, bn, training):
+    """TAPS only: materialise relu(bn(y)) with the same kernel arithmetic the fused loaders use, WITHOUT touching the
+    running statistics (a throw-away copy of them is updated instead)."""
+    with torch.no_grad():
+        rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+        bnp, _ = ops._bn_params(st, y.numel() // 64, bn.weight, bn.bias, rm, rv, training, y.device)
+        TAPS["decoder_conv.%d" % idx] = ops.bn_relu_materialise(y.detach(), bnp)
 
 
 def linear(layer, x, relu=False):

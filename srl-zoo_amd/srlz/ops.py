@@ -144,7 +144,7 @@ class Conv64Fn(Function):
         y = torch.empty((n, d.ho, d.wo, 64), dtype=torch.float32, device=x.device)
         stats = torch.empty((C.conv64_fwd_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
         _launch("conv64_fwd_kernel", _conv64_key(d, "fwd"), _conv64_flop(d),
-                lambda: C.conv64_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), d, stream()))
+                lambda: C.conv64_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), None, d, stream()))
         ctx.save_for_backward(x, packs)
         ctx.desc = d
         ctx.has_bias = bias is not None
@@ -169,7 +169,7 @@ class Conv64Fn(Function):
         nbytes = C.conv64_bwd_weight_workspace(d)
         ws = _ws(nbytes, x.device)
         _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
-                lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes, d, stream()))
+                lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, ptr(ws), nbytes, d, stream()))
         return dx, dw, db, None, None, None, None
 
 
@@ -255,34 +255,98 @@ class BNReLUFn(Function):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# last layer: nn.ConvTranspose2d(64, C, 4, stride 2) — models/models.py:82 ; output NCHW (the reference's layout)
+# Decoder blocks with the BatchNorm-apply + ReLU fused into the NEXT layer's operand load
+# (models/models.py:67-82: BatchNorm2d -> ReLU -> ConvTranspose2d).  Input = RAW output of the previous transposed
+# convolution + its BatchNorm statistics; the activated tensor relu(bn(y)) is never written to memory.
 # ----------------------------------------------------------------------------------------------------------------
-class ConvTOutFn(Function):
+def _bn_relu_backward(y, bnp, da, training):
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(64, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(64, dtype=torch.float32, device=y.device)
+    nbytes = C.bn_bwd_workspace(0)
+    ws = _ws(nbytes, y.device)
+    C.bn_relu_bwd(ptr(y), ptr(bnp), ptr(da), ptr(dy), ptr(dgamma), ptr(dbeta), 1 if training else 0, ptr(ws), nbytes,
+                  y.numel() // 64, stream())
+    return dy, dgamma, dbeta
+
+
+class DecBlockFn(Function):
+    """(y_prev raw, stats_prev, gamma, beta, running stats) -> y = ConvTranspose2d(64,64,3,2)(relu(bn(y_prev))) + stats."""
+
     @staticmethod
-    def forward(ctx, x, w, bias):
-        x, w = _check(x, "convT_out input"), _check(w, "convT_out weight")
-        n, hf, wf, _ = x.shape
+    def forward(ctx, y_prev, stats_prev, gamma, beta, running_mean, running_var, training, w, bias, want_stats):
+        y_prev, w = _check(y_prev, "decoder block input"), _check(w, "convT weight")
+        n, hi, wi, _ = y_prev.shape
+        bnp, _ = _bn_params(stats_prev, n * hi * wi, gamma, beta, running_mean, running_var, training, y_prev.device)
+        d = conv64_desc(n, hi, wi, 2, 0, True)
+        packs = torch.empty((2, C.conv64_packed_floats()), dtype=torch.float32, device=y_prev.device)
+        C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())
+        y = torch.empty((n, d.ho, d.wo, 64), dtype=torch.float32, device=y_prev.device)
+        stats = torch.empty((C.conv64_fwd_tiles(d), 128), dtype=torch.float32, device=y_prev.device) if want_stats else None
+        _launch("conv64_fwd_kernel", _conv64_key(d, "fwd"), _conv64_flop(d),
+                lambda: C.conv64_fwd(ptr(y_prev), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), ptr(bnp), d, stream()))
+        ctx.save_for_backward(y_prev, bnp, packs)
+        ctx.desc, ctx.training = d, training
+        if stats is None:
+            stats = torch.empty(0, device=y_prev.device)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        y_prev, bnp, packs = ctx.saved_tensors
+        d = ctx.desc
+        dy = _check(dy, "decoder block dy")
+        da = torch.empty_like(y_prev)
+        _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(da), d, stream()))
+        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=dy.device)
+        db = torch.empty(64, dtype=torch.float32, device=dy.device)
+        nbytes = C.conv64_bwd_weight_workspace(d)
+        ws = _ws(nbytes, dy.device)
+        _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                lambda: C.conv64_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream()))
+        dy_prev, dgamma, dbeta = _bn_relu_backward(y_prev, bnp, da, ctx.training)
+        return dy_prev, None, dgamma, dbeta, None, None, None, dw, db, None
+
+
+class DecOutFn(Function):
+    """(y_prev raw, stats, BN params) -> ConvTranspose2d(64, C, 4, 2)(relu(bn(y_prev))), NCHW (models/models.py:79-82)."""
+
+    @staticmethod
+    def forward(ctx, y_prev, stats_prev, gamma, beta, running_mean, running_var, training, w, bias):
+        y_prev, w = _check(y_prev, "decoder output input"), _check(w, "convT_out weight")
+        n, hf, wf, _ = y_prev.shape
+        bnp, _ = _bn_params(stats_prev, n * hf * wf, gamma, beta, running_mean, running_var, training, y_prev.device)
         c = w.shape[1]
         d = SkinnyDesc(n, c, (hf - 1) * 2 + 4, (wf - 1) * 2 + 4, hf, wf, 1)
-        y = torch.empty((n, c, d.himg, d.wimg), dtype=torch.float32, device=x.device)
-        C.convT_out_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), d, stream())
-        ctx.save_for_backward(x, w)
-        ctx.desc = d
+        y = torch.empty((n, c, d.himg, d.wimg), dtype=torch.float32, device=y_prev.device)
+        C.convT_out_fwd(ptr(y_prev), ptr(w), ptr(bias), ptr(y), ptr(bnp), d, stream())
+        ctx.save_for_backward(y_prev, bnp, w)
+        ctx.desc, ctx.training = d, training
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        y_prev, bnp, w = ctx.saved_tensors
         d = ctx.desc
-        dy = _check(dy, "convT_out dy")
-        dx = torch.empty_like(x)
-        C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(dx), d, stream())
+        dy = _check(dy, "decoder output dy")
+        da = torch.empty_like(y_prev)
+        C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), d, stream())
         dw = torch.empty_like(w)
-        db = torch.empty(d.c, dtype=torch.float32, device=x.device)
+        db = torch.empty(d.c, dtype=torch.float32, device=dy.device)
         nbytes = C.skinny_bwd_weight_workspace(d)
-        ws = _ws(nbytes, x.device)
-        C.convT_out_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes, d, stream())
-        return dx, dw, db
+        ws = _ws(nbytes, dy.device)
+        C.convT_out_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream())
+        dy_prev, dgamma, dbeta = _bn_relu_backward(y_prev, bnp, da, ctx.training)
+        return dy_prev, None, dgamma, dbeta, None, None, None, dw, db
+
+
+def bn_relu_materialise(y, bnp_source):
+    """relu(bn(y)) as a tensor — debug / test helper only (the product path fuses it into the consumer)."""
+    a = torch.empty_like(y)
+    C.bn_relu_fwd(ptr(y), ptr(bnp_source), ptr(a), y.numel() // 64, stream())
+    return a
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -69,7 +69,7 @@ def test_conv64_forward_backward(C, n, hi, s, p, t):
     y = torch.full((n, ho, ho, 64), float("nan"), device=DEV)
     ntiles = C.conv64_fwd_tiles(d)
     stats = torch.empty(ntiles, 128, device=DEV)
-    C.conv64_fwd(C.ptr(xd), C.ptr(packs[0]), C.ptr(bd), C.ptr(y), C.ptr(stats), d, st)
+    C.conv64_fwd(C.ptr(xd), C.ptr(packs[0]), C.ptr(bd), C.ptr(y), C.ptr(stats), None, d, st)
     torch.cuda.synchronize()
     assert rel_err(nchw(y), yr) < 2e-5
     # BatchNorm partial sums
@@ -87,7 +87,7 @@ def test_conv64_forward_backward(C, n, hi, s, p, t):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     dw = torch.full((64, 64, 3, 3), float("nan"), device=DEV)
     db = torch.full((64,), float("nan"), device=DEV)
-    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(db), C.ptr(ws), nbytes, d, st)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(db), None, C.ptr(ws), nbytes, d, st)
     torch.cuda.synchronize()
     assert rel_err(dw, wr.grad) < 2e-5
     ref_db = dy.double().sum((0, 2, 3))
@@ -106,7 +106,7 @@ def test_conv64_deterministic(C):
     outs = []
     for _ in range(2):
         dw = torch.empty(64, 64, 3, 3, device=DEV)
-        C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), None, C.ptr(ws), nbytes, d, C.stream())
+        C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), None, None, C.ptr(ws), nbytes, d, C.stream())
         outs.append(dw.cpu())
     assert torch.equal(outs[0], outs[1])
 
@@ -156,7 +156,7 @@ def test_convT_out(C, n, c, hf):
     st = C.stream()
     xd, wd, bd, dyd = nhwc(x).to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
     y = torch.full((n, c, himg, himg), float("nan"), device=DEV)
-    C.convT_out_fwd(C.ptr(xd), C.ptr(wd), C.ptr(bd), C.ptr(y), d, st)
+    C.convT_out_fwd(C.ptr(xd), C.ptr(wd), C.ptr(bd), C.ptr(y), None, d, st)
     torch.cuda.synchronize()
     assert rel_err(y, yr) < 2e-5
     dx = torch.full((n, hf, hf, 64), float("nan"), device=DEV)
@@ -167,7 +167,7 @@ def test_convT_out(C, n, c, hf):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     dw = torch.full((64, c, 4, 4), float("nan"), device=DEV)
     db = torch.full((c,), float("nan"), device=DEV)
-    C.convT_out_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(db), C.ptr(ws), nbytes, d, st)
+    C.convT_out_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(db), None, C.ptr(ws), nbytes, d, st)
     torch.cuda.synchronize()
     assert rel_err(dw, wr.grad) < 2e-5
     assert rel_err(db, br.grad) < 2e-5
@@ -401,3 +401,56 @@ def test_adam(C):
         g_d = (gr * 4).to(DEV)
         C.adam_step(C.ptr(pd), C.ptr(g_d), C.ptr(m), C.ptr(v), n, 5e-3, 0.9, 0.999, 1e-8, step, 0.25, C.stream())
     assert rel_err(pd, pr) < 1e-6
+
+
+def test_fused_bn_relu_operand(C):
+    """x_bnp: the layer input is relu(x*scale+shift), applied inside the operand load (never materialised)."""
+    g = torch.Generator().manual_seed(77)
+    n, hi = 2, 13
+    ho = (hi - 1) * 2 + 3
+    x = torch.randn(n, 64, hi, hi, generator=g)
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    bnp = torch.cat((torch.zeros(64), torch.ones(64), scale, shift))
+    w, b = torch.randn(64, 64, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g)
+    dy = torch.randn(n, 64, ho, ho, generator=g)
+    a = F.relu(x.double() * scale.double().view(1, 64, 1, 1) + shift.double().view(1, 64, 1, 1))
+    wr = w.double().requires_grad_(True)
+    yr = F.conv_transpose2d(a, wr, b.double(), stride=2)
+    yr.backward(dy.double())
+    d = C.Conv64Desc(n, hi, hi, ho, ho, 3, 2, 0, 1)
+    st = C.stream()
+    xd, wd, bd, dyd, bnpd = nhwc(x).to(DEV), w.to(DEV), b.to(DEV), nhwc(dy).to(DEV), bnp.to(DEV)
+    packs = torch.empty(2, C.conv64_packed_floats(), device=DEV)
+    C.conv64_pack_weights(C.ptr(wd), C.ptr(packs[0]), C.ptr(packs[1]), d, st)
+    y = torch.full((n, ho, ho, 64), float("nan"), device=DEV)
+    C.conv64_fwd(C.ptr(xd), C.ptr(packs[0]), C.ptr(bd), C.ptr(y), None, C.ptr(bnpd), d, st)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y), yr) < 2e-5
+    nbytes = C.conv64_bwd_weight_workspace(d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, 64, 3, 3), float("nan"), device=DEV)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), None, C.ptr(bnpd), C.ptr(ws), nbytes, d, st)
+    torch.cuda.synchronize()
+    assert rel_err(dw, wr.grad) < 2e-5
+    # last layer (64 -> 3, 4x4 s2)
+    hf = 20
+    himg = (hf - 1) * 2 + 4
+    xf = torch.randn(n, 64, hf, hf, generator=g)
+    wt, bt = torch.randn(64, 3, 4, 4, generator=g) * 0.1, torch.randn(3, generator=g)
+    dimg = torch.randn(n, 3, himg, himg, generator=g)
+    af = F.relu(xf.double() * scale.double().view(1, 64, 1, 1) + shift.double().view(1, 64, 1, 1))
+    wtr = wt.double().requires_grad_(True)
+    out = F.conv_transpose2d(af, wtr, bt.double(), stride=2)
+    out.backward(dimg.double())
+    d1 = C.SkinnyDesc(n, 3, himg, himg, hf, hf, 1)
+    xfd, wtd, btd, dimgd = nhwc(xf).to(DEV), wt.to(DEV), bt.to(DEV), dimg.to(DEV)
+    img = torch.full((n, 3, himg, himg), float("nan"), device=DEV)
+    C.convT_out_fwd(C.ptr(xfd), C.ptr(wtd), C.ptr(btd), C.ptr(img), C.ptr(bnpd), d1, st)
+    torch.cuda.synchronize()
+    assert rel_err(img, out) < 2e-5
+    nb1 = C.skinny_bwd_weight_workspace(d1)
+    ws1 = torch.empty(nb1, dtype=torch.uint8, device=DEV)
+    dwt, dbt = torch.full((64, 3, 4, 4), float("nan"), device=DEV), torch.empty(3, device=DEV)
+    C.convT_out_bwd_weight(C.ptr(xfd), C.ptr(dimgd), C.ptr(dwt), C.ptr(dbt), C.ptr(bnpd), C.ptr(ws1), nb1, d1, st)
+    torch.cuda.synchronize()
+    assert rel_err(dwt, wtr.grad) < 2e-5

@@ -69,11 +69,11 @@ def bench_conv64(sel):
         ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
         dw, db = torch.empty(64, 64, 3, 3, device=DEV), torch.empty(64, device=DEV)
         if sel("fwd"):
-            report(label + " fwd", *timeit(lambda: C.conv64_fwd(C.ptr(x), C.ptr(packs[0]), None, C.ptr(y), C.ptr(stats), d, st)), flop=flop)
+            report(label + " fwd", *timeit(lambda: C.conv64_fwd(C.ptr(x), C.ptr(packs[0]), None, C.ptr(y), C.ptr(stats), None, d, st)), flop=flop)
         if sel("dgrad"):
             report(label + " dgrad", *timeit(lambda: C.conv64_bwd_data(C.ptr(dy), C.ptr(packs[1]), C.ptr(dx), d, st)), flop=flop)
         if sel("wgrad"):
-            report(label + " wgrad(+reduce)", *timeit(lambda: C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), C.ptr(db), C.ptr(ws), nb, d, st)), flop=flop)
+            report(label + " wgrad(+reduce)", *timeit(lambda: C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), C.ptr(db), None, C.ptr(ws), nb, d, st)), flop=flop)
 
 
 def bench_skinny(sel):
@@ -95,7 +95,7 @@ def bench_skinny(sel):
     img, dimg = torch.empty(N, 3, 224, 224, device=DEV), rnd(N, 3, 224, 224)
     flop1 = 2.0 * 48 * 64 * N * 111 * 111
     if sel("convT5 fwd"):
-        report("convT5 4x4 s2 fwd", *timeit(lambda: C.convT_out_fwd(C.ptr(xf), C.ptr(wt), C.ptr(b), C.ptr(img), d1, st)), flop=flop1,
+        report("convT5 4x4 s2 fwd", *timeit(lambda: C.convT_out_fwd(C.ptr(xf), C.ptr(wt), C.ptr(b), C.ptr(img), None, d1, st)), flop=flop1,
                bytes_=4.0 * N * (111 * 111 * 64 + 3 * 224 * 224))
     dxf = torch.empty(N, 111, 111, 64, device=DEV)
     if sel("convT5 dgrad"):
@@ -105,7 +105,7 @@ def bench_skinny(sel):
     ws1 = torch.empty(nb1, dtype=torch.uint8, device=DEV)
     dwt, dbt = torch.empty(64, 3, 4, 4, device=DEV), torch.empty(3, device=DEV)
     if sel("convT5 wgrad"):
-        report("convT5 4x4 s2 wgrad(+reduce+dbias)", *timeit(lambda: C.convT_out_bwd_weight(C.ptr(xf), C.ptr(dimg), C.ptr(dwt), C.ptr(dbt), C.ptr(ws1), nb1, d1, st)), flop=flop1,
+        report("convT5 4x4 s2 wgrad(+reduce+dbias)", *timeit(lambda: C.convT_out_bwd_weight(C.ptr(xf), C.ptr(dimg), C.ptr(dwt), C.ptr(dbt), None, C.ptr(ws1), nb1, d1, st)), flop=flop1,
                bytes_=4.0 * N * (111 * 111 * 64 + 3 * 224 * 224))
 
 
