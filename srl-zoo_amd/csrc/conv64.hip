@@ -27,7 +27,6 @@
 namespace {
 
 constexpr int TM = 128;       // grid positions per forward tile
-constexpr int TK = 64;        // grid positions per weight-gradient chunk
 constexpr int NTAPS = 9;
 
 struct ConvProg {
@@ -128,14 +127,13 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
 // With `bnp` != NULL the source is the RAW output of a convolution and the consumer wants relu(batchnorm(.)): the affine
 // (scale = bnp[128..], shift = bnp[192..]) and the ReLU are applied to in-bounds rows on the way into LDS, so the
 // activated tensor is never materialised in HBM (padding rows stay exactly zero).
-template <bool SWZ>
+template <bool SWZ, int BATCH = 8>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
                                            int stride, int cls, int PW, int PH, int total_q, int qstart,
                                            int nrows, const float* __restrict__ bnp = nullptr) {
   // Loads are issued in batches of 8 rows per thread before any LDS store, so the HBM/L2 latency is paid once per
   // batch instead of once per row; (n, a, b) of a thread's rows are advanced incrementally (rows are 16 apart), the
   // only integer divisions are the two for its first row.
-  constexpr int BATCH = 8;
   const int t = threadIdx.x;
   const int slot = t & 15;
   const int cy = cls >> 1, cx = cls & 1;
@@ -152,13 +150,14 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
   if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
   for (int base = t >> 4; base < nrows; base += 16 * BATCH) {
     f32x4 v[BATCH];
-    bool ok[BATCH];
+    unsigned okmask = 0;
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int y = a * stride + cy, x = b * stride + cx;
-      ok[j] = base + 16 * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W;
-      if (ok[j])
+      const bool ok = base + 16 * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W;
+      okmask |= (ok ? 1u : 0u) << j;
+      if (ok)
         v[j] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
       b += sb; a += sa;
       if (b >= PW) { b -= PW; ++a; }
@@ -168,7 +167,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
     for (int j = 0; j < BATCH; ++j) {
       const int R = base + 16 * j;
       if (R < nrows) {
-        if (bnp && ok[j]) {
+        if (bnp && ((okmask >> j) & 1u)) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = z > 0.f ? z : 0.f; }
         }
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
 // (144 accumulator registers); persistent over K-chunks of 64 positions; per-workgroup partials are reduced by
 // conv64_wgrad_reduce in a fixed order (deterministic).
 // ---------------------------------------------------------------------------------------------------------------
-template <bool S2>
+template <bool S2, int TK>
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ g,
                                                              float* __restrict__ partial, const ConvProg P,
@@ -360,19 +359,19 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
       const int cs = P.tsrc[t0], cd = P.tdst[t0];
       __syncthreads();
       if (cs != cur_s) {
-        stage_rows<false>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span, x_bnp);
+        stage_rows<false, 4>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span, x_bnp);
         cur_s = cs;
       }
       const bool newg = (cd != cur_g);
       if (newg) {
-        stage_rows<false>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK);
+        stage_rows<false, 4>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK);
         cur_g = cd;
       }
       __syncthreads();
       if (newg) {
         const int col = tid & 63, part = tid >> 6;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bsum += Gs[(part * 16 + r) * 64 + col];
+        for (int r = 0; r < TK / 4; ++r) bsum += Gs[(part * (TK / 4) + r) * 64 + col];
       }
       const float* gcol = Gs + nj * 32 + l31;
       const float* scol = Ss + mi * 32 + l31;
@@ -489,7 +488,8 @@ static int program_for(ConvProg* P, const srlz_conv64_desc* d, int backward_data
 }
 
 static size_t fwd_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) * 256 + 16384 + 3 * TM * 4; }
-static size_t wgrad_lds_bytes(const ConvProg& P) { return (size_t)(TK + P.span + TK) * 256; }
+static size_t wgrad_lds_bytes(const ConvProg& P, int tk) { return (size_t)(tk + P.span + tk) * 256; }
+static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried: the extra staging registers spill
 
 static int launch_fwd(const float* src, const float* wpack, const float* bias, float* dst, float* stats,
                       const ConvProg& P, hipStream_t st, const float* src_bnp = nullptr) {
@@ -503,7 +503,8 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
 }
 
 static int wgrad_grid(const ConvProg& P) {
-  const int nchunks = (P.total_q + TK - 1) / TK;
+  const int tk = wgrad_tk(P);
+  const int nchunks = (P.total_q + tk - 1) / tk;
   int g = 2 * srlz_device_cus();
   if (g > nchunks) g = nchunks;
   return g < 1 ? 1 : g;
@@ -565,18 +566,21 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   const int grid = wgrad_grid(P);
   SRLZ_REQUIRE(ws_bytes >= (size_t)grid * (NTAPS * 4096 + 64) * sizeof(float), SRLZ_ERR_WORKSPACE,
                "conv64_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
-  const int nchunks = (P.total_q + TK - 1) / TK;
-  const size_t lds = wgrad_lds_bytes(P);
+  const int tk = wgrad_tk(P);
+  const int nchunks = (P.total_q + tk - 1) / tk;
+  const size_t lds = wgrad_lds_bytes(P, tk);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64 wgrad: chunk needs %zu bytes of LDS", lds);
   hipStream_t st = as_stream(stream);
   float* partial = (float*)ws;
-  if (P.s2) {
-    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(conv64_wgrad_kernel<true>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, x_bnp);
-  } else {
-    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(conv64_wgrad_kernel<false>, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, x_bnp);
-  }
+#define SRLZ_WGRAD_LAUNCH(S2V, TKV)                                                                                        \
+  do {                                                                                                                     \
+    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<S2V, TKV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)lds));                                                                               \
+    hipLaunchKernelGGL((conv64_wgrad_kernel<S2V, TKV>), dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, x_bnp); \
+  } while (0)
+  if (P.s2) SRLZ_WGRAD_LAUNCH(true, 64);
+  else SRLZ_WGRAD_LAUNCH(false, 64);
+#undef SRLZ_WGRAD_LAUNCH
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(1024), 0, st, partial, grid,
                      dw_ref, dbias, d->transposed);

@@ -73,6 +73,56 @@ def _ws(nbytes, device, slot=0):
     return buf
 
 
+# ---- side stream: weight gradients are off the critical path of backward (nothing downstream of a layer's dW until the
+# optimiser), so they run on a second HIP stream concurrently with the data-gradient chain and, above all, with the
+# HBM-bound BatchNorm-backward kernels that follow it on the main stream (MFMA-bound + HBM-bound work co-resident on
+# the same CUs).  SRLZ_SIDE_STREAM=0 disables it.
+import os as _os
+_USE_SIDE = _os.environ.get("SRLZ_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device.index] = s
+    return s
+
+
+class _OnSide(object):
+    """with _OnSide(device, tensors...) as active: launches inside run on the side stream after everything already
+    enqueued on the current stream; join() makes the current stream wait for them."""
+
+    def __init__(self, device, *tensors):
+        self.device, self.tensors = device, [t for t in tensors if t is not None]
+        self.side = _side_stream(device) if _USE_SIDE else None
+
+    def __enter__(self):
+        if self.side is None:
+            return self
+        main = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side.wait_event(ev)
+        for t in self.tensors:
+            t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+            self.done = torch.cuda.Event()
+            self.done.record(self.side)
+        return False
+
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.done)
+
+
 def _check(t, name):
     if t.device.type != "cuda":
         raise C.SrlzError("%s must live on the GPU: the srl-zoo_amd hot path has no CPU fallback" % name)
@@ -159,17 +209,20 @@ class Conv64Fn(Function):
         x, packs = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "conv64 dy")
+        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=x.device)
+        db = torch.empty(64, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        nbytes = C.conv64_bwd_weight_workspace(d)
+        ws = _ws(nbytes, x.device, slot=1)
+        with _OnSide(x.device, x, dy, dw, db, ws) as side:
+            _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                    lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, ptr(ws), nbytes, d, stream()))
         dx = None
         if ctx.needs_dx:
             dx = torch.empty_like(x)
             _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
                     lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), d, stream()))
-        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=x.device)
-        db = torch.empty(64, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        nbytes = C.conv64_bwd_weight_workspace(d)
-        ws = _ws(nbytes, x.device)
-        _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
-                lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, ptr(ws), nbytes, d, stream()))
+        ctx_side = side
+        ctx_side.join()
         return dx, dw, db, None, None, None, None
 
 
@@ -297,16 +350,18 @@ class DecBlockFn(Function):
         y_prev, bnp, packs = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "decoder block dy")
-        da = torch.empty_like(y_prev)
-        _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
-                lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(da), d, stream()))
         dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=dy.device)
         db = torch.empty(64, dtype=torch.float32, device=dy.device)
         nbytes = C.conv64_bwd_weight_workspace(d)
-        ws = _ws(nbytes, dy.device)
-        _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
-                lambda: C.conv64_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream()))
+        ws = _ws(nbytes, dy.device, slot=1)
+        with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
+            _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                    lambda: C.conv64_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream()))
+        da = torch.empty_like(y_prev)
+        _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(da), d, stream()))
         dy_prev, dgamma, dbeta = _bn_relu_backward(y_prev, bnp, da, ctx.training)
+        side.join()
         return dy_prev, None, dgamma, dbeta, None, None, None, dw, db, None
 
 
@@ -331,14 +386,16 @@ class DecOutFn(Function):
         y_prev, bnp, w = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "decoder output dy")
-        da = torch.empty_like(y_prev)
-        C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), d, stream())
         dw = torch.empty_like(w)
         db = torch.empty(d.c, dtype=torch.float32, device=dy.device)
         nbytes = C.skinny_bwd_weight_workspace(d)
-        ws = _ws(nbytes, dy.device)
-        C.convT_out_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream())
+        ws = _ws(nbytes, dy.device, slot=1)
+        with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
+            C.convT_out_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream())
+        da = torch.empty_like(y_prev)
+        C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), d, stream())
         dy_prev, dgamma, dbeta = _bn_relu_backward(y_prev, bnp, da, ctx.training)
+        side.join()
         return dy_prev, None, dgamma, dbeta, None, None, None, dw, db
 
 
