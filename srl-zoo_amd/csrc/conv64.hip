@@ -127,18 +127,19 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
 // With `bnp` != NULL the source is the RAW output of a convolution and the consumer wants relu(batchnorm(.)): the affine
 // (scale = bnp[128..], shift = bnp[192..]) and the ReLU are applied to in-bounds rows on the way into LDS, so the
 // activated tensor is never materialised in HBM (padding rows stay exactly zero).
-template <bool SWZ, int BATCH = 8>
+template <bool SWZ, int BATCH = 8, int NTHREADS = 256>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
                                            int stride, int cls, int PW, int PH, int total_q, int qstart,
                                            int nrows, const float* __restrict__ bnp = nullptr) {
   // Loads are issued in batches of 8 rows per thread before any LDS store, so the HBM/L2 latency is paid once per
-  // batch instead of once per row; (n, a, b) of a thread's rows are advanced incrementally (rows are 16 apart), the
+  // batch instead of once per row; (n, a, b) of a thread's rows are advanced incrementally (rows are NTHREADS/16 apart), the
   // only integer divisions are the two for its first row.
   const int t = threadIdx.x;
   const int slot = t & 15;
   const int cy = cls >> 1, cx = cls & 1;
   const int PHW = PH * PW;
-  const int sa = 16 / PW, sb = 16 - sa * PW;
+  constexpr int RP = NTHREADS / 16;  // rows per pass
+  const int sa = RP / PW, sb = RP - sa * PW;
   // shift by one image so the first rows of the first tile (negative q) stay non-negative: n1 = n + 1
   const int qq = qstart + (t >> 4) + PHW;
   int n1 = qq / PHW;
@@ -148,14 +149,14 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
   const int N1max = total_q / PHW;  // images
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
-  for (int base = t >> 4; base < nrows; base += 16 * BATCH) {
+  for (int base = t >> 4; base < nrows; base += RP * BATCH) {
     f32x4 v[BATCH];
     unsigned okmask = 0;
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int y = a * stride + cy, x = b * stride + cx;
-      const bool ok = base + 16 * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W;
+      const bool ok = base + RP * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W;
       okmask |= (ok ? 1u : 0u) << j;
       if (ok)
         v[j] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
@@ -165,7 +166,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
     }
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
-      const int R = base + 16 * j;
+      const int R = base + RP * j;
       if (R < nrows) {
         if (bnp && ((okmask >> j) & 1u)) {
 #pragma unroll
@@ -179,13 +180,19 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Forward / data-gradient kernel
+// Forward / data-gradient kernel.  NW = waves per workgroup: 4 (wave = 32 rows x 64 columns, two accumulators) or
+// 8 (wave = 32 rows x 32 columns, one accumulator; twice the waves per SIMD to hide barriers, LDS and staging latency).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restrict__ src,
-                                                           const float* __restrict__ wpack,
-                                                           const float* __restrict__ bias, float* __restrict__ dst,
-                                                           float* __restrict__ stats_partial, const ConvProg P,
-                                                           int ntiles, const float* __restrict__ src_bnp) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float* __restrict__ src,
+                                                                    const float* __restrict__ wpack,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ dst,
+                                                                    float* __restrict__ stats_partial,
+                                                                    const ConvProg P, int ntiles,
+                                                                    const float* __restrict__ src_bnp) {
+  constexpr int NT = NW * 64;      // threads
+  constexpr int NACC = 8 / NW;     // 32-column tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* As = (float*)smem;                 // (TM + span) x 64, swizzled
   float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap, pre-swizzled in global
@@ -193,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave & 3, wcol = wave >> 2;  // row group (32 rows), first column tile
   const int h = lane >> 5, l31 = lane & 31;
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int q0 = tile * TM;
@@ -210,40 +218,48 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
     rowinfo[tid] = n; rowinfo[TM + tid] = ya; rowinfo[2 * TM + tid] = xb;
   }
 
-  f32x16 acc0, acc1;
-  float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;  // BatchNorm partials (columns l31 and l31+32)
-  const float bias0 = bias ? bias[l31] : 0.f;
-  const float bias1 = bias ? bias[l31 + 32] : 0.f;
+  f32x16 acc[NACC];
+  float sum[NACC], sq[NACC];  // BatchNorm partials of this lane's columns
+  float bcol[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) {
+    sum[j] = 0.f; sq[j] = 0.f;
+    bcol[j] = bias ? bias[(wcol * NACC + j) * 32 + l31] : 0.f;
+  }
 
   int cur_src = -1, cur_dst = -1;
 
   auto flush = [&](int d) {
     if (P.dbg & 2) {  // ablation: keep the accumulators live, write nothing
-      if (acc0[0] + acc1[5] == 123.456f) dst[tid] = acc0[1];
+      if (acc[0][0] + acc[NACC - 1][5] == 123.456f) dst[tid] = acc[0][1];
       return;
     }
     const int dy = d >> 1, dx = d & 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int row = wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const int n = rowinfo[row];
       const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
       if (n >= 0 && y < P.Hd && x < P.Wd) {
-        const float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
-        float* o = dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 + l31;
-        o[0] = v0; o[32] = v1;
-        s0 += v0; ss0 += v0 * v0; s1 += v1; ss1 += v1 * v1;
+        float* o = dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 + wcol * NACC * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+          const float v = acc[j][r] + bcol[j];
+          o[32 * j] = v;
+          sum[j] += v; sq[j] += v * v;
+        }
       }
     }
   };
 
   // The weight slab of tap t+1 is fetched into registers while tap t's MFMAs run, and written to LDS between the two
   // barriers of the next iteration: the L2 latency of the slab never sits between barriers.
-  f32x4 breg[4];
+  constexpr int BV = 1024 / NT;  // 16-byte vectors of the 16 KB slab per thread
+  f32x4 breg[BV];
   {
     const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[0] * 4096);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) breg[i] = wsrc[i * 256 + tid];
+    for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
   }
 #pragma unroll
   for (int ti = 0; ti < NTAPS; ++ti) {
@@ -252,65 +268,72 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
     if (tdst != cur_dst) {
       if (cur_dst >= 0) flush(cur_dst);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       cur_dst = tdst;
     }
     if (tsrc != cur_src) {
       if (!(P.dbg & 1))
-        stage_rows<true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span, src_bnp);
+        stage_rows<true, (NW == 4 ? 8 : 4), NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off,
+                                                TM + P.span, src_bnp);
       cur_src = tsrc;
     }
     if (!(P.dbg & 4)) {
       f32x4* wdst = (f32x4*)Bs;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wdst[i * 256 + tid] = breg[i];
+      for (int i = 0; i < BV; ++i) wdst[i * NT + tid] = breg[i];
     }
     __syncthreads();
     if (ti + 1 < NTAPS && !(P.dbg & 4)) {
       const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[ti + 1] * 4096);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) breg[i] = wsrc[i * 256 + tid];
+      for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
     }
-    const int R = wave * 32 + l31 + P.toff[ti] - P.min_off;
+    const int R = wrow * 32 + l31 + P.toff[ti] - P.min_off;
     const float* arow = As + R * 64;
     const int akey = R & 15;
-    const float* brow0 = Bs + l31 * 64;
-    const float* brow1 = Bs + (l31 + 32) * 64;
+    const float* brow = Bs + (wcol * NACC * 32 + l31) * 64;  // column tile j is 32 rows (2048 floats) further
     const int bkey = lane & 15;
-    // operands of chunk kc+1 are read from LDS before chunk kc's eight MFMAs are issued (explicit double buffer),
-    // so the LDS latency is covered by 512 cycles of matrix work instead of sitting in front of every MFMA group
     f32x4 a = *(const f32x4*)(arow + ((h ^ akey) << 2));
-    f32x4 b0 = *(const f32x4*)(brow0 + ((h ^ bkey) << 2));
-    f32x4 b1 = *(const f32x4*)(brow1 + ((h ^ bkey) << 2));
+    f32x4 b[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) b[j] = *(const f32x4*)(brow + j * 2048 + ((h ^ bkey) << 2));
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) {
-      f32x4 an = a, b0n = b0, b1n = b1;
+      f32x4 an = a, bn[NACC];
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) bn[j] = b[j];
       if (kc < 7) {
         const int slot = (kc + 1) * 2 + h;
         an = *(const f32x4*)(arow + ((slot ^ akey) << 2));
-        b0n = *(const f32x4*)(brow0 + ((slot ^ bkey) << 2));
-        b1n = *(const f32x4*)(brow1 + ((slot ^ bkey) << 2));
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) bn[j] = *(const f32x4*)(brow + j * 2048 + ((slot ^ bkey) << 2));
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this chunk's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0[r], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1[r], acc1, 0, 0, 0);
-      }
-      a = an; b0 = b0n; b1 = b1n;
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[j][r], acc[j], 0, 0, 0);
+      a = an;
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) b[j] = bn[j];
     }
   }
   flush(cur_dst);
 
   if (stats_partial && !(P.dbg & 2)) {
-    // lanes l and l+32 hold the same columns; then the 4 waves are combined through LDS
-    s0 += __shfl_xor(s0, 32, 64); ss0 += __shfl_xor(ss0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64); ss1 += __shfl_xor(ss1, 32, 64);
+    // lanes l and l+32 hold the same columns; then the 4 row groups are combined through LDS
     __syncthreads();
-    float* red = Bs;  // [4 waves][128]
-    if (h == 0) {
-      red[wave * 128 + l31] = s0; red[wave * 128 + 32 + l31] = s1;
-      red[wave * 128 + 64 + l31] = ss0; red[wave * 128 + 96 + l31] = ss1;
+    float* red = Bs;  // [4 row groups][128]
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+      sum[j] += __shfl_xor(sum[j], 32, 64);
+      sq[j] += __shfl_xor(sq[j], 32, 64);
+      if (h == 0) {
+        red[wrow * 128 + (wcol * NACC + j) * 32 + l31] = sum[j];
+        red[wrow * 128 + 64 + (wcol * NACC + j) * 32 + l31] = sq[j];
+      }
     }
     __syncthreads();
     if (tid < 128) {
@@ -496,8 +519,16 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
   const int ntiles = (P.total_q + TM - 1) / TM;
   const size_t lds = fwd_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64: tile needs %zu bytes of LDS", lds);
-  SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(conv64_fwd_kernel, dim3(ntiles), dim3(256), lds, st, src, wpack, bias, dst, stats, P, ntiles, src_bnp);
+  // 4 waves (32x64 per wave) is the default; SRLZ_NW=8 selects 8 waves of 32x32 (measured within +-3 %: the kernel is
+  // bound by the power-limited matrix rate, not by latency hiding)
+  static const int nw = [] { const char* e = getenv("SRLZ_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
+  if (nw == 8) {
+    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv64_fwd_kernel<8>, dim3(ntiles), dim3(512), lds, st, src, wpack, bias, dst, stats, P, ntiles, src_bnp);
+  } else {
+    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv64_fwd_kernel<4>, dim3(ntiles), dim3(256), lds, st, src, wpack, bias, dst, stats, P, ntiles, src_bnp);
+  }
   SRLZ_LAUNCHED();
   return 0;
 }

@@ -26,9 +26,10 @@ def _bn_args(bn):
 
 
 def _tick(bn, training):
-    # nn.BatchNorm2d increments num_batches_tracked once per training-mode call
+    # nn.BatchNorm2d increments num_batches_tracked once per training-mode call (ordered with the other stream's
+    # updates of the same layer when the two frames of a step run on two streams)
     if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        ops._ordered_bn_update(bn.running_mean, lambda: bn.num_batches_tracked.add_(1))
 
 
 def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
@@ -52,8 +53,10 @@ def replay_encoder_bn(seq, stats):
     """Second train-mode pass over the same batch (VAE getStates quirk, models/learner.py:402): running statistics
     receive the same batch statistics once more and num_batches_tracked advances; outputs are unchanged."""
     for bn, st in zip((seq[1], seq[5], seq[9]), stats):
-        ops.bn_replay(st, bn.running_mean, bn.running_var)
-        bn.num_batches_tracked.add_(1)
+        def update(bn=bn, st=st):
+            ops.bn_replay(st, bn.running_mean, bn.running_var)
+            bn.num_batches_tracked.add_(1)
+        ops._ordered_bn_update(bn.running_mean, update)
 
 
 def decoder_forward(seq, z, training):

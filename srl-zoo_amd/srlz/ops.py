@@ -64,8 +64,9 @@ def _conv64_key(d, what):
 
 
 def _ws(nbytes, device, slot=0):
-    """Grow-only scratch buffer per (device, slot); everything runs on one stream, so reuse is ordered."""
-    key = (device.index, slot)
+    """Grow-only scratch buffer per (device, current stream, slot): work on one stream is ordered, so a buffer is only
+    ever shared by launches of the stream that owns it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, slot)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -83,10 +84,12 @@ _side_streams = {}
 
 
 def _side_stream(device):
-    s = _side_streams.get(device.index)
+    """The side stream paired with the CURRENT stream (each main stream gets its own)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    s = _side_streams.get(key)
     if s is None:
         s = torch.cuda.Stream(device=device)
-        _side_streams[device.index] = s
+        _side_streams[key] = s
     return s
 
 
@@ -229,15 +232,38 @@ class Conv64Fn(Function):
 # ----------------------------------------------------------------------------------------------------------------
 # BatchNorm2d + ReLU (+ MaxPool2d(3, 2, pad)) — models/models.py:50-52,55-57,60-62 / 67-68,71-72,75-76,79-80
 # ----------------------------------------------------------------------------------------------------------------
-def _bn_params(stats, count, gamma, beta, running_mean, running_var, training, device):
+# When the two frames of a step are encoded on two different streams (learner.trainStep), the momentum updates of one
+# BatchNorm layer's running statistics must still happen in program order (obs, then next_obs): every update waits for
+# the event the previous update of the same buffers recorded.
+_bn_last_update = {}
+
+
+def _ordered_bn_update(running_mean, fn):
+    key = running_mean.data_ptr()
+    cur = torch.cuda.current_stream(running_mean.device)
+    prev = _bn_last_update.get(key)
+    if prev is not None and prev[0] != cur.cuda_stream:
+        cur.wait_event(prev[1])
+    fn()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _bn_last_update[key] = (cur.cuda_stream, ev)
+
+
+def _bn_params(stats, count, gamma, beta, running_mean, running_var, training, device, tick=None):
     bnp = torch.empty(256, dtype=torch.float32, device=device)
     batch_stat = None
     if training:
         batch_stat = torch.empty(128, dtype=torch.float32, device=device)
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, device)
-        C.bn_finalize(ptr(stats), stats.shape[0], count, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, 1,
-                      ptr(running_mean), ptr(running_var), ptr(bnp), ptr(batch_stat), ptr(ws), nbytes, stream())
+
+        def update():
+            if tick is not None:
+                tick.add_(1)  # num_batches_tracked
+            C.bn_finalize(ptr(stats), stats.shape[0], count, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, 1,
+                          ptr(running_mean), ptr(running_var), ptr(bnp), ptr(batch_stat), ptr(ws), nbytes, stream())
+        _ordered_bn_update(running_mean, update)
     else:
         C.bn_eval_params(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS, ptr(bnp), stream())
     return bnp, batch_stat
