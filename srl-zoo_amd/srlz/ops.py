@@ -77,9 +77,11 @@ def _ws(nbytes, device, slot=0):
 # ---- side stream: weight gradients are off the critical path of backward (nothing downstream of a layer's dW until the
 # optimiser), so they run on a second HIP stream concurrently with the data-gradient chain and, above all, with the
 # HBM-bound BatchNorm-backward kernels that follow it on the main stream (MFMA-bound + HBM-bound work co-resident on
-# the same CUs).  SRLZ_SIDE_STREAM=0 disables it.
+# the same CUs).  Opt-in with SRLZ_SIDE_STREAM=1: measured +2 % step throughput on MI355X (the big kernels already
+# fill every CU's LDS), at the price of per-kernel timings that no longer describe a kernel running alone — so the
+# default keeps one stream, which is also what bench.py's roofline leg and the rocprofv3 summaries in profiles/ assume.
 import os as _os
-_USE_SIDE = _os.environ.get("SRLZ_SIDE_STREAM", "1") != "0"
+_USE_SIDE = _os.environ.get("SRLZ_SIDE_STREAM", "0") != "0"
 _side_streams = {}
 
 
