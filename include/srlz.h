@@ -210,6 +210,13 @@ int srlz_cross_entropy(const float* logits, const int64_t* target, int B, int A,
 int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, int B, int S, int A, srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Input pipeline tail: decoded uint8 frames [N,H,W,C] (RGB per 3-group) -> normalised fp32 [N,C,W,H]
+ * = preprocessInput(x, "image_net") (preprocessing/utils.py:20-32) + the loader's transpose(0,3,2,1)
+ * (preprocessing/data_loader.py:255), bit-identical to the host arithmetic.  Lets the loader ship uint8 over PCIe.
+ * ------------------------------------------------------------------------------------------------------------ */
+int srlz_normalize_u8(const uint8_t* img_nhwc, float* out_ncwh, int n, int h, int w, int c, srlz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Adam over one flat parameter buffer — th.optim.Adam(params, lr) models/learner.py:199,495 (torch defaults).
  * step is 1-based; grad_scale multiplies g first (1/world_size after the RCCL sum).
  * ------------------------------------------------------------------------------------------------------------ */

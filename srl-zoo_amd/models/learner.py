@@ -38,6 +38,8 @@ BATCH_SIZE = 256
 N_EPOCHS = 1
 VALIDATION_SIZE = 0.2
 BALANCED_SAMPLING = False
+# build-specific: ship decoded frames as uint8 and normalise on the GPU (bit-identical, 4x less PCIe traffic)
+RAW_UINT8_INPUT = True
 
 SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "random"}
 
@@ -71,6 +73,15 @@ class BaseLearner(object):
             th.cuda.manual_seed(seed)
         self.device = th.device("cuda" if th.cuda.is_available() and cuda else "cpu")
 
+    def _toDevice(self, frames):
+        """Loader minibatch -> observation tensor on the device.  uint8 frames (DataLoader(raw_uint8=True)) are
+        normalised and laid out by the GPU; float tensors are the reference's ready-made observations."""
+        frames = frames.to(self.device, non_blocking=True)
+        if frames.dtype == th.uint8:
+            from srlz import ops
+            frames = ops.normalize_u8(frames)
+        return frames
+
     def _predFn(self, observations):
         """Observations -> states (np.ndarray), model in whatever mode the caller set."""
         return detachToNumpy(self.model.getStates(observations))
@@ -81,7 +92,7 @@ class BaseLearner(object):
         for obs_var in data_loader:
             if obs_var.shape[0] == 0:  # the test minibatch list may end with an empty range
                 continue
-            predictions.append(self._predFn(obs_var.to(self.device)))
+            predictions.append(self._predFn(self._toDevice(obs_var)))
         return np.concatenate(predictions, axis=0)
 
     def learn(self, *args, **kwargs):
@@ -303,11 +314,12 @@ class SRL4robotics(BaseLearner):
         data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
                                  use_triplets=False, is_training=True, apply_occlusion=self.use_dae,
                                  occlusion_percentage=self.occlusion_percentage, rank=self.rank,
-                                 world_size=self.world_size, val_indices=val_indices)
+                                 world_size=self.world_size, val_indices=val_indices, raw_uint8=RAW_UINT8_INPUT and not self.use_dae)
         test_data_loader = DataLoader(test_minibatchlist, images_path, n_workers=N_WORKERS,
                                       multi_view=self.multi_view, use_triplets=False, max_queue_len=1,
                                       is_training=False, apply_occlusion=self.use_dae,
-                                      occlusion_percentage=self.occlusion_percentage)
+                                      occlusion_percentage=self.occlusion_percentage,
+                                      raw_uint8=RAW_UINT8_INPUT and not self.use_dae)
 
         loss_history = defaultdict(list)
         loss_manager = LossManager(self.model, loss_history)
@@ -327,9 +339,8 @@ class SRL4robotics(BaseLearner):
             for minibatch_num, (minibatch_idx, obs, next_obs, noisy_obs, next_noisy_obs) in enumerate(data_loader):
                 validation_mode = int(minibatch_idx) in val_set
                 if self.use_dae:
-                    noisy_obs = noisy_obs.to(self.device, non_blocking=True)
-                    next_noisy_obs = next_noisy_obs.to(self.device, non_blocking=True)
-                obs, next_obs = obs.to(self.device, non_blocking=True), next_obs.to(self.device, non_blocking=True)
+                    noisy_obs, next_noisy_obs = self._toDevice(noisy_obs), self._toDevice(next_noisy_obs)
+                obs, next_obs = self._toDevice(obs), self._toDevice(next_obs)
                 actions_st = th.from_numpy(actions[minibatchlist[minibatch_idx]]).view(-1, 1).to(self.device)
 
                 loss = self.trainStep(obs, next_obs, actions_st, loss_manager, validation_mode, noisy_obs,

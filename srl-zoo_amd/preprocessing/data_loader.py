@@ -118,7 +118,7 @@ def shardOrder(order, rank, world_size, val_indices=None):
 class DataLoader(object):
     def __init__(self, minibatchlist, images_path, n_workers=1, multi_view=False, use_triplets=False,
                  infinite_loop=True, max_queue_len=4, is_training=False, apply_occlusion=False,
-                 occlusion_percentage=0.5, rank=0, world_size=1, val_indices=None):
+                 occlusion_percentage=0.5, rank=0, world_size=1, val_indices=None, raw_uint8=False):
         """
         :param minibatchlist: ([np.array]) observation indices grouped per minibatch
         :param images_path: (np.array) image paths (without the 'data/' prefix)
@@ -132,6 +132,9 @@ class DataLoader(object):
         :param apply_occlusion: (bool) also produce occluded copies (DAE)
         :param occlusion_percentage: (float)
         :param rank, world_size: data-parallel shard of the per-epoch permutation
+        :param raw_uint8: yield the decoded frames as uint8 [B, H, W, C] instead of normalised float32 [B, C, W, H]:
+                          the learner then normalises / transposes on the GPU (srlz_normalize_u8, bit-identical) and
+                          only a quarter of the bytes cross PCIe.  Not available with occlusion (DAE).
         :param val_indices: minibatch ids used for validation; with world_size > 1 training and validation
                             minibatches are sharded separately (train first) so all ranks stay in lock-step
         """
@@ -151,6 +154,9 @@ class DataLoader(object):
         self.occlusion_percentage = occlusion_percentage
         self.rank, self.world_size = rank, world_size
         self.val_indices = None if val_indices is None else set(int(i) for i in val_indices)
+        if raw_uint8 and apply_occlusion:
+            raise ValueError("raw_uint8 frames cannot carry the (normalised-space) occlusion of the DAE loader")
+        self.raw_uint8 = raw_uint8
         self.startProcess()
 
     @staticmethod
@@ -189,7 +195,7 @@ class DataLoader(object):
                     paths = np.concatenate((self.images_path[idx], self.images_path[idx + 1]))
                 else:
                     paths = self.images_path[idx]
-                clean = list(pool.map(lambda p: self._makeBatchElement(p, self.multi_view), paths))
+                clean = list(pool.map(lambda p: self._makeBatchElement(p, self.multi_view, raw_uint8=self.raw_uint8), paths))
                 batch = th.cat(clean, dim=0) if clean else th.zeros(0)
                 noisy = None
                 if self.apply_occlusion:
@@ -204,11 +210,16 @@ class DataLoader(object):
                     item = batch
                 self.queue.put(item)
             self.queue.put(None)  # end-of-epoch sentinel
+        # one-shot loader: stay alive until terminated — tensors travel through the queue as shared-memory handles and
+        # the sender must outlive their reception
+        while True:
+            time.sleep(0.05)
 
     @classmethod
     def _makeBatchElement(cls, image_path, multi_view=False, use_triplets=False, apply_occlusion=False,
-                          occlusion_percentage=None):
-        """One image path (without 'data/' prefix, '.jpg' optional) -> float32 tensor [1, C, W, H]."""
+                          occlusion_percentage=None, raw_uint8=False):
+        """One image path (without 'data/' prefix, '.jpg' optional) -> float32 tensor [1, C, W, H]
+        (raw_uint8: the decoded RGB frame(s) as uint8 [1, H, W, C])."""
         stem = 'data/' + image_path.split('.jpg')[0]
         names = ["{}_{}.jpg".format(stem, i + 1) for i in range(2)] if multi_view else ["{}.jpg".format(stem)]
         views = []
@@ -216,8 +227,10 @@ class DataLoader(object):
             rgb = _imread_rgb(name)
             if rgb is None:
                 raise ValueError("tried to load {}, but it was not found".format(name))
-            views.append(_normalised(rgb, apply_occlusion, occlusion_percentage))
+            views.append(np.ascontiguousarray(rgb) if raw_uint8 else _normalised(rgb, apply_occlusion, occlusion_percentage))
         im = np.dstack(views) if multi_view else views[0]
+        if raw_uint8:
+            return th.from_numpy(np.ascontiguousarray(im).reshape((1,) + im.shape))
         # channel first + batch dim; note the (W, H) order of the last two axes
         return th.tensor(im.reshape((1,) + im.shape).transpose(0, 3, 2, 1))
 

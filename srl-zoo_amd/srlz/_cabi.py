@@ -81,6 +81,7 @@ _PROTOS = {
     "srlz_reparam_bwd": (c_int, [P, P, P, P, P, c_longlong, P]),
     "srlz_cross_entropy": (c_int, [P, P, c_int, c_int, P, P, P]),
     "srlz_concat_onehot": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "srlz_normalize_u8": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srlz_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, P]),
 }
 

@@ -606,6 +606,17 @@ class ConcatOneHotFn(Function):
         return dcat[:, :ctx.sdim].contiguous(), None, None
 
 
+def normalize_u8(frames):
+    """uint8 [N,H,W,C] device tensor -> normalised fp32 [N,C,W,H] (the reference's observation tensor)."""
+    if frames.device.type != "cuda" or frames.dtype != torch.uint8:
+        raise C.SrlzError("normalize_u8 expects a uint8 tensor on the GPU")
+    frames = frames.contiguous()
+    n, h, w, c = frames.shape
+    out = torch.empty((n, c, w, h), dtype=torch.float32, device=frames.device)
+    C.normalize_u8(ptr(frames), ptr(out), n, h, w, c, stream())
+    return out
+
+
 def adam_step(p, g, m, v, lr, step, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
     C.adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, step, grad_scale, stream())
 

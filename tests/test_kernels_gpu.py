@@ -454,3 +454,16 @@ def test_fused_bn_relu_operand(C):
     C.convT_out_bwd_weight(C.ptr(xfd), C.ptr(dimgd), C.ptr(dwt), C.ptr(dbt), C.ptr(bnpd), C.ptr(ws1), nb1, d1, st)
     torch.cuda.synchronize()
     assert rel_err(dwt, wtr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("n,c", [(3, 3), (2, 6)])
+def test_normalize_u8_bit_exact(C, n, c):
+    """uint8 frames -> normalised fp32 [N,C,W,H]: bit-identical to the host arithmetic of the reference's loader."""
+    from preprocessing.utils import preprocessInput
+    from srlz import ops
+    rs = np.random.RandomState(n + c)
+    frames = rs.randint(0, 256, (n, 224, 224, c)).astype(np.uint8)
+    ref = np.stack([np.dstack([preprocessInput(f[..., 3 * v:3 * v + 3].astype(np.float32)) for v in range(c // 3)])
+                    .transpose(2, 1, 0) for f in frames])
+    got = ops.normalize_u8(torch.from_numpy(frames).to(DEV)).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)

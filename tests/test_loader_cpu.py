@@ -95,3 +95,19 @@ def test_shard_order_lockstep():
         assert len(kinds) == 1  # all ranks train, or all ranks validate, at every step
     n_train = sum(1 for i in shards[0] if int(i) not in val)
     assert all(int(i) not in val for i in shards[0][:n_train]) and all(int(i) in val for i in shards[0][n_train:])
+
+
+def test_raw_uint8_stream(dataset):
+    """raw_uint8=True yields the decoded frames themselves; normalising them on the host reproduces the float stream."""
+    from preprocessing.data_loader import DataLoader
+    from preprocessing.utils import preprocessInput
+    name, paths, *_ = dataset
+    ml = [np.array([0, 1, 2]), np.array([4, 5, 6])]
+    raw = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8=True)
+    idx, obs, next_obs, noisy, next_noisy = next(iter(raw))
+    assert obs.dtype == torch.uint8 and tuple(obs.shape) == (3, 224, 224, 3) and noisy is None
+    ref = preprocessInput(obs[1].numpy().astype(np.float32), mode="image_net").transpose(2, 1, 0)
+    np.testing.assert_array_equal(ref, expected_tensor(paths[ml[int(idx)][1]]))
+    with pytest.raises(ValueError):
+        DataLoader(ml, paths, is_training=True, raw_uint8=True, apply_occlusion=True)
+    del raw
