@@ -105,6 +105,14 @@ size_t srlz_skinny_bwd_weight_workspace(const srlz_skinny_desc* d);
 /* kind 0 weight gradient: dw_ref [64,C,7,7] from x_nchw and dy_nhwc. */
 int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, float* dw_ref, void* ws, size_t ws_bytes,
                           const srlz_skinny_desc* d, srlz_stream_t stream);
+/* kind 0 weight gradient with the BatchNorm + ReLU + MaxPool backward of the FOLLOWING block fused into the operand load:
+ * dy = d(loss)/d(conv1 output) is never materialised (it has no other consumer: conv1 needs no data gradient).
+ * y_nhwc / bnp / argmax as in srlz_bn_relu_pool_fwd, dpooled = gradient of the pooled map (NHWC),
+ * sums = output of srlz_bn_relu_pool_bwd_sums; pd describes that pooling layer. */
+int srlz_conv1_bwd_weight_fused(const float* x_nchw, const float* y_nhwc, const float* bnp, const uint8_t* argmax,
+                                const float* dpooled, const float* sums, int training, float* dw_ref, void* ws,
+                                size_t ws_bytes, const srlz_skinny_desc* d, const struct srlz_pool_desc_s* pd,
+                                srlz_stream_t stream);
 /* kind 1 forward: x_nhwc [N,hf,wf,64] -> y_nchw [N,C,H,W] = convT(x) + bias; w_ref [64,C,4,4]. */
 int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
                        const float* x_bnp /* may be NULL, see srlz_conv64_fwd */, const srlz_skinny_desc* d,
@@ -137,7 +145,7 @@ int srlz_bn_eval_params(const float* gamma, const float* beta, const float* runn
 int srlz_bn_replay(const float* batch_stat, float momentum, float* running_mean, float* running_var,
                    srlz_stream_t stream);
 
-typedef struct {
+typedef struct srlz_pool_desc_s {
   int n, h, w;      /* input  [N,h,w,64] */
   int hp, wp;       /* pooled [N,hp,wp,64] */
   int pool_pad;     /* 0 or 1 (kernel 3, stride 2) */
@@ -148,6 +156,10 @@ typedef struct {
 int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* pooled, uint8_t* argmax,
                           const srlz_pool_desc* d, srlz_stream_t stream);
 size_t srlz_bn_bwd_workspace(long long elems);
+/* First half of the backward below: sums[128] = {sum dz[64], sum dz*xhat[64]} (= dbeta, dgamma). */
+int srlz_bn_relu_pool_bwd_sums(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
+                               const float* pooled, float* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                               const srlz_pool_desc* d, srlz_stream_t stream);
 /* dy (same shape as y) and dgamma[64], dbeta[64] from dpooled.  training != 0: batch-statistics backward;
  * training == 0: running-statistics backward (validation minibatches, models/learner.py:362-364,489). */
 int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,

@@ -472,16 +472,11 @@ extern "C" size_t srlz_bn_bwd_workspace(long long elems) {
   return (size_t)(RED_BLOCKS + STAGE_ROWS) * 128 * sizeof(double) + 128 * sizeof(float);
 }
 
-extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
-                                     const float* pooled, float* dy, float* dgamma, float* dbeta, int training, void* ws,
-                                     size_t ws_bytes, const srlz_pool_desc* d, srlz_stream_t stream) {
-  if (int rc = check_pool(d)) return rc;
-  SRLZ_REQUIRE(y && bnp && argmax && dpooled && dy && ws, SRLZ_ERR_NULL, "bn_relu_pool_bwd: null pointer");
-  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
-  hipStream_t st = as_stream(stream);
+// stage 1 of the pooled-block backward: sums[0..64) = sum dz, sums[64..128) = sum dz*xhat (also dbeta / dgamma)
+static int pool_bwd_sums(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled, const float* pooled,
+                         float* sums, float* dgamma, float* dbeta, void* ws, const srlz_pool_desc* d, hipStream_t st) {
   double* partial = (double*)ws;
   double* staged = partial + RED_BLOCKS * 128;
-  float* sums = (float*)(staged + STAGE_ROWS * 128);
   int nb = d->n * d->hp;
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   hipLaunchKernelGGL(bn_relu_pool_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, argmax, dpooled, pooled, partial, d->n, d->h, d->w,
@@ -492,6 +487,27 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
   SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_bn_relu_pool_bwd_sums(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
+                                          const float* pooled, float* sums, float* dgamma, float* dbeta, void* ws,
+                                          size_t ws_bytes, const srlz_pool_desc* d, srlz_stream_t stream) {
+  if (int rc = check_pool(d)) return rc;
+  SRLZ_REQUIRE(y && bnp && argmax && dpooled && sums && ws, SRLZ_ERR_NULL, "bn_relu_pool_bwd_sums: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_pool_bwd_sums: workspace too small");
+  return pool_bwd_sums(y, bnp, argmax, dpooled, pooled, sums, dgamma, dbeta, ws, d, as_stream(stream));
+}
+
+extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
+                                     const float* pooled, float* dy, float* dgamma, float* dbeta, int training, void* ws,
+                                     size_t ws_bytes, const srlz_pool_desc* d, srlz_stream_t stream) {
+  if (int rc = check_pool(d)) return rc;
+  SRLZ_REQUIRE(y && bnp && argmax && dpooled && dy && ws, SRLZ_ERR_NULL, "bn_relu_pool_bwd: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  float* sums = (float*)((double*)ws + (RED_BLOCKS + STAGE_ROWS) * 128);
+  if (int rc = pool_bwd_sums(y, bnp, argmax, dpooled, pooled, sums, dgamma, dbeta, ws, d, st)) return rc;
   const int HB = (d->h + d->pool_pad + 1) / 2, WB = (d->w + d->pool_pad + 1) / 2;
   SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
   const float inv_count = 1.0f / (float)((double)d->n * d->h * d->w);

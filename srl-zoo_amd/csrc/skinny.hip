@@ -27,6 +27,20 @@ struct Geo {
   static constexpr int TILE_FLOATS = 3 * 2 * PP;
 };
 
+// Optional fusion for conv1's weight gradient: its feature-side operand dy1 = d(loss)/d(conv1 output) is the output of the
+// BatchNorm + ReLU + MaxPool backward and has NO other consumer (conv1 needs no data gradient), so instead of writing
+// dy1 (0.82 GB per 256 images) and reading it back, the staging code of the wgrad kernel computes it on the fly from
+// y1, the pooling argmax, the pooled-output gradient and the two BatchNorm-backward sums.
+struct PoolFuse {
+  const float* y;          // raw conv output [N,HF,WF,64]; NULL = fusion off
+  const uint8_t* argmax;   // [N,HP,WP,64] window index of the maximum
+  const float* dpooled;    // [N,HP,WP,64]
+  const float* bnp;        // mean / invstd / scale / shift
+  const float* sums;       // [128] sum dz, sum dz*xhat
+  int HP, WP, pad, training;
+  float inv_count;
+};
+
 template <int K>
 __host__ __device__ constexpr int koff(int k) {
   // LDS offset of tap k = (c,ky,kx) relative to the pixel base (2*ty*XP + tx)
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
                                                              const float* __restrict__ feat,
                                                              float* __restrict__ partial, int N, int C, int H, int W,
                                                              int HF, int WF, int tiles_y, int tiles_x,
-                                                             const float* __restrict__ feat_bnp) {
+                                                             const float* __restrict__ feat_bnp, const PoolFuse pf) {
   constexpr int KT = Geo<K>::KT;
   constexpr int NT = (KT + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -207,7 +221,72 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
     for (int half = 0; half < 2; ++half) {
       __syncthreads();
       if (half == 0) stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
-      {
+      if (K == 7 && pf.y) {
+        // Fused BatchNorm + ReLU + MaxPool(3,2,pad=1) backward for this lane's column of 8 output rows (oy0 + 8*half + j,
+        // ox) x 4 channels.  oy0 is a multiple of 8, so the pooling windows that can have picked one of these rows are
+        // the 5 window rows pb..pb+4 (pb = first_row/2): an even row r is only the centre (ky=1) of window r/2, an odd
+        // row is ky=0 of window (r+1)/2 and ky=2 of window (r-1)/2; same along x with the parity of ox.  All <=10
+        // windows are loaded up front (independent loads), then the 8 rows are resolved from registers.
+        const f32x4 mean = *(const f32x4*)(pf.bnp + slot * 4), invstd = *(const f32x4*)(pf.bnp + 64 + slot * 4);
+        const f32x4 sc = *(const f32x4*)(pf.bnp + 128 + slot * 4), sh = *(const f32x4*)(pf.bnp + 192 + slot * 4);
+        f32x4 m1 = *(const f32x4*)(pf.sums + slot * 4), m2 = *(const f32x4*)(pf.sums + 64 + slot * 4);
+        if (!pf.training) m1 = m2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int oyb = oy0 + 8 * half, ox = ox0 + prow, pb = oyb >> 1;
+        const bool xodd = ox & 1, xin = ox < WF;
+        // window columns: c0 = (ox+1)>>1 seen through kx = (xodd ? 0 : 1); c1 = (ox-1)>>1 through kx = 2 (odd ox only)
+        const int c0 = (ox + 1) >> 1, c1 = (ox - 1) >> 1;
+        const bool c0ok = xin && c0 < pf.WP, c1ok = xin && xodd && c1 < pf.WP;
+        const uint32_t kx0 = xodd ? 0u : 1u;
+        f32x4 yv[8], dpv[5][2];
+        uint32_t am[5][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          yv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (xin && oyb + j < HF) yv[j] = *(const f32x4*)(pf.y + ((size_t)(n * HF + oyb + j) * WF + ox) * 64 + slot * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const bool rok = pb + r < pf.HP;
+          const size_t rowbase = (size_t)(n * pf.HP + pb + r) * pf.WP;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const bool ok = rok && (c ? c1ok : c0ok);
+            am[r][c] = 0xffffffffu;  // matches no window position
+            dpv[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+              const size_t pp = (rowbase + (c ? c1 : c0)) * 64 + slot * 4;
+              am[r][c] = *(const uint32_t*)(pf.argmax + pp);
+              dpv[r][c] = *(const f32x4*)(pf.dpooled + pp);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+          // (window row, ky) pairs for row j: even j -> (j/2, 1); odd j -> ((j+1)/2, 0) and ((j-1)/2, 2)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if ((j & 1) == 0 && t == 1) continue;
+            const int r = (j & 1) ? (t == 0 ? (j + 1) / 2 : (j - 1) / 2) : j / 2;
+            const uint32_t ky = (j & 1) ? (t == 0 ? 0u : 2u) : 1u;
+            const uint32_t me0 = ky * 3 + kx0, me1 = ky * 3 + 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (((am[r][0] >> (8 * e)) & 0xffu) == me0) dz[e] += dpv[r][0][e];
+              if (((am[r][1] >> (8 * e)) & 0xffu) == me1) dz[e] += dpv[r][1][e];
+            }
+          }
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = yv[j][e] * sc[e] + sh[e];
+            const float d = z > 0.f ? dz[e] : 0.f;
+            o[e] = sc[e] * (d - m1[e] * pf.inv_count - (yv[j][e] - mean[e]) * invstd[e] * m2[e] * pf.inv_count);
+          }
+          if (!(xin && oyb + j < HF)) o = f32x4{0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = o;
+        }
+      } else {
         f32x4 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {  // pixel p = 16*j + prow of the half: tile row 8*half + j, column prow
@@ -463,7 +542,7 @@ static size_t wgrad_ws(const srlz_skinny_desc* d) {
 
 template <int K, int PAD>
 static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
-                        hipStream_t st, const float* feat_bnp = nullptr) {
+                        hipStream_t st, const float* feat_bnp = nullptr, const PoolFuse* pfuse = nullptr) {
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
@@ -471,8 +550,10 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
   SRLZ_REQUIRE(ws_bytes >= wgrad_ws<K>(d), SRLZ_ERR_WORKSPACE, "skinny wgrad: workspace too small (%zu)", ws_bytes);
   const size_t lds = (size_t)(Geo<K>::TILE_FLOATS + 128 * 64) * 4;
   float* partial = (float*)ws;
+  PoolFuse pf = {};
+  if (pfuse) pf = *pfuse;
   hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                     d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp);
+                     d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
@@ -507,6 +588,23 @@ extern "C" int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, 
   SRLZ_REQUIRE(d->kind == 0, SRLZ_ERR_BAD_DESC, "conv1_bwd_weight: descriptor kind must be 0");
   SRLZ_REQUIRE(x_nchw && dy_nhwc && dw_ref && ws, SRLZ_ERR_NULL, "conv1_bwd_weight: null pointer");
   return launch_wgrad<7, 3>(x_nchw, dy_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream));
+}
+
+extern "C" int srlz_conv1_bwd_weight_fused(const float* x_nchw, const float* y_nhwc, const float* bnp, const uint8_t* argmax,
+                                           const float* dpooled, const float* sums, int training, float* dw_ref, void* ws,
+                                           size_t ws_bytes, const srlz_skinny_desc* d, const srlz_pool_desc* pd,
+                                           srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 0 && pd, SRLZ_ERR_BAD_DESC, "conv1_bwd_weight_fused: descriptor kind must be 0");
+  SRLZ_REQUIRE(x_nchw && y_nhwc && bnp && argmax && dpooled && sums && dw_ref && ws, SRLZ_ERR_NULL,
+               "conv1_bwd_weight_fused: null pointer");
+  SRLZ_REQUIRE(pd->n == d->n && pd->h == d->hf && pd->w == d->wf && !pd->out_nchw && pd->pool_pad == 1, SRLZ_ERR_BAD_DESC,
+               "conv1_bwd_weight_fused: pooling descriptor does not match conv1's output");
+  PoolFuse pf;
+  pf.y = y_nhwc; pf.argmax = argmax; pf.dpooled = dpooled; pf.bnp = bnp; pf.sums = sums;
+  pf.HP = pd->hp; pf.WP = pd->wp; pf.pad = pd->pool_pad; pf.training = training;
+  pf.inv_count = 1.0f / (float)((double)d->n * d->hf * d->wf);
+  return launch_wgrad<7, 3>(x_nchw, y_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream), nullptr, &pf);
 }
 
 extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,

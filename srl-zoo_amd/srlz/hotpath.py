@@ -4,6 +4,7 @@
 order, initialisation and state_dict keys are the reference's, models/models.py:47-83), but they are never *called*:
 the forward below reads their parameters and runs the MI355X kernels.
 """
+import os
 import torch
 
 from . import ops
@@ -21,6 +22,10 @@ def _tap(prefix, idx, t):
     return t
 
 
+# A/B switch for the fused first-block backward (ops.EncInFn); the fused form is the product path
+_FUSE_ENC_IN = os.environ.get("SRLZ_FUSE_ENC_IN", "1") != "0"
+
+
 def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var
 
@@ -35,10 +40,15 @@ def _tick(bn, training):
 def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
     """models/models.py:47-63.  x: [N,C,H,W] (reference layout) -> [N,64,6,6] (NCHW, ready for .view(N,-1))."""
     conv1, bn1, conv2, bn2, conv3, bn3 = seq[0], seq[1], seq[4], seq[5], seq[8], seq[9]
-    y, st = ops.Conv1Fn.apply(x, conv1.weight, training)
-    _tap(name, 0, y)
     _tick(bn1, training)
-    p = _tap(name, 3, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink))
+    if _FUSE_ENC_IN:
+        p, y = ops.EncInFn.apply(x, conv1.weight, *_bn_args(bn1), training, 1, stat_sink)
+        _tap(name, 0, y)
+        _tap(name, 3, p)
+    else:
+        y, st = ops.Conv1Fn.apply(x, conv1.weight, training)
+        _tap(name, 0, y)
+        p = _tap(name, 3, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink))
     y, st = ops.Conv64Fn.apply(p, conv2.weight, None, 1, 1, False, training)
     _tap(name, 4, y)
     _tick(bn2, training)

@@ -307,6 +307,55 @@ class BNReLUPoolFn(Function):
         return dy, None, dgamma, dbeta, None, None, None, None, None, None
 
 
+class EncInFn(Function):
+    """First encoder block as ONE autograd node: Conv2d(C,64,7,2,3,bias=False) -> BatchNorm2d -> ReLU -> MaxPool(3,2,1)
+    (models/models.py:49-52).  Forward = Conv1Fn + BNReLUPoolFn; backward never writes d(loss)/d(conv output): the
+    weight-gradient kernel rebuilds it from (y, argmax, dpooled, BN sums) while staging its operand
+    (srlz_conv1_bwd_weight_fused).  Saved tensors start with (y, bnp, argmax) like BNReLUPoolFn's."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, training, pool_pad, stat_sink):
+        x, w = _check(x, "conv1 input"), _check(w, "conv1 weight")
+        n, c, h, wd = x.shape
+        d = _skinny_desc(n, c, h, wd, 0)
+        y = torch.empty((n, d.hf, d.wf, 64), dtype=torch.float32, device=x.device)
+        stats = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=x.device) if training else None
+        C.conv1_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), d, stream())
+        hp, wp = (d.hf + 2 * pool_pad - 3) // 2 + 1, (d.wf + 2 * pool_pad - 3) // 2 + 1
+        pd = PoolDesc(n, d.hf, d.wf, hp, wp, pool_pad, 0)
+        bnp, batch_stat = _bn_params(stats, n * d.hf * d.wf, gamma, beta, running_mean, running_var, training, x.device)
+        if stat_sink is not None and batch_stat is not None:
+            stat_sink.append(batch_stat)
+        pooled = torch.empty((n, hp, wp, 64), dtype=torch.float32, device=x.device)
+        need_bwd = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        argmax = torch.empty((n, hp, wp, 64), dtype=torch.uint8, device=x.device) if need_bwd else None
+        C.bn_relu_pool_fwd(ptr(y), ptr(bnp), ptr(pooled), ptr(argmax), pd, stream())
+        if need_bwd:
+            ctx.save_for_backward(y, bnp, argmax, pooled, x, w)
+        ctx.desc, ctx.pdesc, ctx.training = d, pd, training
+        ctx.mark_non_differentiable(y)
+        return pooled, y
+
+    @staticmethod
+    def backward(ctx, dpooled, _dy):
+        y, bnp, argmax, pooled, x, w = ctx.saved_tensors
+        dpooled = _check(dpooled, "pool grad")
+        dev = y.device
+        dgamma = torch.empty(64, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(64, dtype=torch.float32, device=dev)
+        sums = torch.empty(128, dtype=torch.float32, device=dev)
+        nbytes = C.bn_bwd_workspace(0)
+        ws = _ws(nbytes, dev)
+        C.bn_relu_pool_bwd_sums(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(sums), ptr(dgamma), ptr(dbeta),
+                                ptr(ws), nbytes, ctx.pdesc, stream())
+        dw = torch.empty_like(w)
+        nbytes = C.skinny_bwd_weight_workspace(ctx.desc)
+        ws = _ws(nbytes, dev)
+        C.conv1_bwd_weight_fused(ptr(x), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums), 1 if ctx.training else 0,
+                                 ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc, stream())
+        return None, dw, dgamma, dbeta, None, None, None, None, None
+
+
 class BNReLUFn(Function):
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, running_mean, running_var, training, stat_sink):

@@ -467,3 +467,33 @@ def test_normalize_u8_bit_exact(C, n, c):
                     .transpose(2, 1, 0) for f in frames])
     got = ops.normalize_u8(torch.from_numpy(frames).to(DEV)).cpu().numpy()
     assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("n,c,h,training", [(2, 3, 224, True), (1, 6, 224, True), (3, 3, 50, True), (2, 3, 64, False)])
+def test_encoder_input_block_fused_backward(C, n, c, h, training):
+    """srlz_conv1_bwd_weight_fused (dy rebuilt in the operand load) == conv1 -> BN -> ReLU -> MaxPool(3,2,1) in fp64."""
+    from srlz import ops
+    g = torch.Generator().manual_seed(7 * h + c)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(64, c, 7, 7, generator=g) * 0.1
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    rm, rv = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
+    hf = (h + 6 - 7) // 2 + 1
+    hp = (hf + 2 - 3) // 2 + 1
+    dp = torch.randn(n, 64, hp, hp, generator=g)
+
+    wr, gr, br = (t.double().requires_grad_(True) for t in (w, gamma, beta))
+    yr = F.conv2d(x.double(), wr, None, stride=2, padding=3)
+    zr = F.batch_norm(yr, rm.double().clone(), rv.double().clone(), gr, br, training, 0.1, 1e-5)
+    pr = F.max_pool2d(F.relu(zr), 3, 2, 1)
+    pr.backward(dp.double())
+
+    xd = x.to(DEV)
+    wd, gd, bd = (t.to(DEV).requires_grad_(True) for t in (w, gamma, beta))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    pooled, y = ops.EncInFn.apply(xd, wd, gd, bd, rmd, rvd, training, 1, None)
+    assert rel_err(nchw(y), yr) < 2e-5 and rel_err(nchw(pooled), pr) < 2e-5
+    pooled.backward(nhwc(dp).to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(wd.grad, wr.grad) < 5e-5
+    assert rel_err(gd.grad, gr.grad) < 5e-5 and rel_err(bd.grad, br.grad) < 5e-5
