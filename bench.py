@@ -175,12 +175,19 @@ def main():
                 if name.startswith("conv64_fwd_kernel/") and v["ms"] > 0:
                     layers[name.split("/", 1)[1]] = {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                                                      "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
-            out["roofline"] = {"kernel": "conv64_fwd_kernel (3x3 64->64 conv / convT forward and data-gradient, all layers)",
+            fused = {}
+            for name, v in sorted(rep.items()):
+                if name.startswith("conv64_fwd_kernel<bn-bwd operand>/") and v["ms"] > 0:
+                    fused[name.split("/", 1)[1]] = {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                                                    "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
+            out["roofline"] = {"kernel": "conv64_fwd_kernel<4,false> (3x3 64->64 conv / convT forward and data-gradient, all "
+                                         "layers; the <4,true> instantiation = data-gradient with the BatchNorm backward "
+                                         "fused into its operand load is listed under fused_dgrad_layers)",
                                "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                                "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),
-                               "layers": layers}
+                               "layers": layers, "fused_dgrad_layers": fused}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(list(args.losses))
         print(json.dumps(out))

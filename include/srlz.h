@@ -74,14 +74,31 @@ int srlz_conv64_fwd_tiles(const srlz_conv64_desc* d);
  * into the operand load, so the activated tensor is never written to memory. */
 int srlz_conv64_fwd(const float* x, const float* wpack_fwd, const float* bias, float* y, float* stats_partial,
                     const float* x_bnp, const srlz_conv64_desc* d, srlz_stream_t stream);
-/* dx = d(loss)/d(x) from dy. */
-int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx,
+/* Fused BatchNorm + ReLU BACKWARD operand.  Wherever a `dy` argument is followed by a `const srlz_bn_bwd_operand* dy_bn`,
+ * a non-NULL record means: the convolution whose gradient is being taken was followed by BatchNorm2d + ReLU
+ * (models/models.py:67-80), `dy` actually holds dA = d(loss)/d(relu(bn(y))), and the kernel rebuilds
+ *   d(loss)/dy = scale * ( dA*[bn(y)>0] - sums[c]/count - xhat*sums[64+c]/count )      (training; eval: scale*dA*[..])
+ * while loading its operand, so d(loss)/dy is never written to memory.  y = the raw convolution output (same shape as
+ * dA), bnp = its 4x64 BatchNorm record, sums = output of srlz_bn_relu_bwd_sums, count = N*H*W of y.
+ * dy_out (srlz_conv64_bwd_data only, may be NULL): the rebuilt d(loss)/dy is also stored there, every element exactly
+ * once, as a by-product of the operand staging — the weight-gradient kernel then reads it as a plain dy. */
+typedef struct {
+  const float* y;
+  const float* bnp;
+  const float* sums;
+  long long count;
+  int training;
+  float* dy_out;
+} srlz_bn_bwd_operand;
+/* dx = d(loss)/d(x) from dy (dy_bn may be NULL: dy is then the plain gradient). */
+int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx, const srlz_bn_bwd_operand* dy_bn,
                          const srlz_conv64_desc* d, srlz_stream_t stream);
 /* workspace (bytes) for bwd_weight */
 size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d);
 /* dw_ref (reference layout) = d(loss)/d(w); dbias[64] = sum of dy over n,h,w (may be NULL).
  * Deterministic: split-K partials in `ws`, fixed-order second-stage reduction (learner.py:62 asks cuDNN for the same). */
 int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float* dbias, const float* x_bnp /* as above */,
+                           const srlz_bn_bwd_operand* dy_bn /* may be NULL */,
                            void* ws, size_t ws_bytes, const srlz_conv64_desc* d, srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -168,6 +185,9 @@ int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argma
                           srlz_stream_t stream);
 /* a = relu(y*scale+shift) over `pixels` x 64 */
 int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long long pixels, srlz_stream_t stream);
+/* First half of srlz_bn_relu_bwd: sums[128] = {sum dz[64], sum dz*xhat[64]} (= dbeta, dgamma), for srlz_bn_bwd_operand. */
+int srlz_bn_relu_bwd_sums(const float* y, const float* bnp, const float* da, float* sums, float* dgamma, float* dbeta,
+                          void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream);
 int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* da, float* dy, float* dgamma, float* dbeta,
                      int training, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream);
 /* [N,C,H,W] <-> [N,H,W,C] for the two 6x6x64 seams around the FC layers (autoencoders.py:107-108,116-117). */

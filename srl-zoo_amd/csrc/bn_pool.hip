@@ -524,14 +524,10 @@ extern "C" int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long
   return 0;
 }
 
-extern "C" int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* da, float* dy, float* dgamma, float* dbeta,
-                                int training, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream) {
-  SRLZ_REQUIRE(y && bnp && da && dy && ws, SRLZ_ERR_NULL, "bn_relu_bwd: null pointer");
-  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
-  hipStream_t st = as_stream(stream);
+static int bn_relu_bwd_sums_launch(const float* y, const float* bnp, const float* da, float* sums, float* dgamma, float* dbeta,
+                                   void* ws, long long pixels, hipStream_t st) {
   double* partial = (double*)ws;
   double* staged = partial + RED_BLOCKS * 128;
-  float* sums = (float*)(staged + STAGE_ROWS * 128);
   int nb = (int)((pixels + 15) / 16);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
   hipLaunchKernelGGL(bn_relu_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, da, partial, pixels);
@@ -541,6 +537,23 @@ extern "C" int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* d
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
   SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_bn_relu_bwd_sums(const float* y, const float* bnp, const float* da, float* sums, float* dgamma,
+                                     float* dbeta, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream) {
+  SRLZ_REQUIRE(y && bnp && da && sums && ws, SRLZ_ERR_NULL, "bn_relu_bwd_sums: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_bwd_sums: workspace too small");
+  return bn_relu_bwd_sums_launch(y, bnp, da, sums, dgamma, dbeta, ws, pixels, as_stream(stream));
+}
+
+extern "C" int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* da, float* dy, float* dgamma, float* dbeta,
+                                int training, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream) {
+  SRLZ_REQUIRE(y && bnp && da && dy && ws, SRLZ_ERR_NULL, "bn_relu_bwd: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  float* sums = (float*)((double*)ws + (RED_BLOCKS + STAGE_ROWS) * 128);
+  if (int rc = bn_relu_bwd_sums_launch(y, bnp, da, sums, dgamma, dbeta, ws, pixels, st)) return rc;
   const float inv_count = 1.0f / (float)(double)pixels;
   hipLaunchKernelGGL(bn_relu_bwd_apply, dim3(grid_for(pixels * 16, 256)), dim3(256), 0, st, y, bnp, da, sums, dy, pixels,
                      training, inv_count);

@@ -124,13 +124,31 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
 // Tile staging: rows [qstart, qstart+nrows) of class `cls` of an NHWC/64 tensor -> LDS (256 B per row).
 // 16 lanes fetch one row (256 contiguous bytes); out-of-range rows are zero-filled.
 // ---------------------------------------------------------------------------------------------------------------
-// With `bnp` != NULL the source is the RAW output of a convolution and the consumer wants relu(batchnorm(.)): the affine
-// (scale = bnp[128..], shift = bnp[192..]) and the ReLU are applied to in-bounds rows on the way into LDS, so the
-// activated tensor is never materialised in HBM (padding rows stay exactly zero).
-template <bool SWZ, int BATCH = 8, int NTHREADS = 256>
+// How raw rows become the operand (OpFuse):
+//  * bnp != NULL, y == NULL: the source is the RAW output of a convolution and the consumer wants relu(batchnorm(.)):
+//    the affine (scale = bnp[128..], shift = bnp[192..]) and the ReLU are applied to in-bounds rows on the way into
+//    LDS, so the activated tensor is never materialised in HBM (padding rows stay exactly zero).
+//  * y != NULL: the source is dA = d(loss)/d(relu(bn(y))) and the consumer wants dy = d(loss)/dy, the BatchNorm + ReLU
+//    BACKWARD: dy = scale*(dA*[bn(y)>0] - S1/count - xhat*S2/count) = scale*dz - (c0 + c1*y), rebuilt from (dA, y) and
+//    the two per-channel sums of srlz_bn_relu_bwd_sums, so dy is never materialised either.
+//    With dy_out != NULL every rebuilt element whose grid position lies in this tile's own range [core_lo, core_lo+TM)
+//    is also written to dy_out (each element exactly once across the launch): the data-gradient kernel materialises
+//    the tensor for the weight-gradient kernel as a by-product of its staging, replacing the separate apply pass.
+struct OpFuse {
+  const float* bnp;
+  const float* y;
+  const float* sums;
+  float inv_count;
+  int training;
+  float* dy_out;
+};
+#define SRLZ_NO_FUSE OpFuse{nullptr, nullptr, nullptr, 0.f, 0, nullptr}
+
+template <bool SWZ, int BATCH = 8, int NTHREADS = 256, bool BWD = false>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
                                            int stride, int cls, int PW, int PH, int total_q, int qstart,
-                                           int nrows, const float* __restrict__ bnp = nullptr) {
+                                           int nrows, const OpFuse f = SRLZ_NO_FUSE, int core_lo = 0, int core_n = 0) {
+  const float* __restrict__ bnp = f.bnp;
   // Loads are issued in batches of 8 rows per thread before any LDS store, so the HBM/L2 latency is paid once per
   // batch instead of once per row; (n, a, b) of a thread's rows are advanced incrementally (rows are NTHREADS/16 apart), the
   // only integer divisions are the two for its first row.
@@ -148,9 +166,20 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
   int b = rem - a * PW;
   const int N1max = total_q / PHW;  // images
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
   if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
+  if (BWD && f.training) {
+    const f32x4 mean = *(const f32x4*)(bnp + slot * 4), invstd = *(const f32x4*)(bnp + 64 + slot * 4);
+    const f32x4 m1 = *(const f32x4*)(f.sums + slot * 4), m2 = *(const f32x4*)(f.sums + 64 + slot * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      c1[e] = sc4[e] * invstd[e] * m2[e] * f.inv_count;
+      c0[e] = sc4[e] * m1[e] * f.inv_count - c1[e] * mean[e];
+    }
+  }
   for (int base = t >> 4; base < nrows; base += RP * BATCH) {
-    f32x4 v[BATCH];
+    f32x4 v[BATCH], yv[BWD ? BATCH : 1];
+    size_t offs[BWD ? BATCH : 1];
     unsigned okmask = 0;
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
@@ -158,8 +187,11 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
       const int y = a * stride + cy, x = b * stride + cx;
       const bool ok = base + RP * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W;
       okmask |= (ok ? 1u : 0u) << j;
-      if (ok)
-        v[j] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
+      if (ok) {
+        const size_t off = ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4;
+        v[j] = *(const f32x4*)(src + off);
+        if (BWD) { yv[j] = *(const f32x4*)(f.y + off); offs[j] = off; }
+      }
       b += sb; a += sa;
       if (b >= PW) { b -= PW; ++a; }
       if (a >= PH) { a -= PH; ++n1; }
@@ -169,8 +201,18 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
       const int R = base + RP * j;
       if (R < nrows) {
         if (bnp && ((okmask >> j) & 1u)) {
+          if (BWD) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = z > 0.f ? z : 0.f; }
+            for (int e = 0; e < 4; ++e) {
+              const float z = yv[j][e] * sc4[e] + sh4[e];
+              const float dz = z > 0.f ? v[j][e] : 0.f;
+              v[j][e] = sc4[e] * dz - (c0[e] + c1[e] * yv[j][e]);
+            }
+            if (f.dy_out && (unsigned)(R - core_lo) < (unsigned)core_n) *(f32x4*)(f.dy_out + offs[j]) = v[j];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = z > 0.f ? z : 0.f; }
+          }
         }
         const int sl = SWZ ? (slot ^ (R & 15)) : slot;
         *(f32x4*)(lds + R * 64 + sl * 4) = v[j];
@@ -183,14 +225,16 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
 // Forward / data-gradient kernel.  NW = waves per workgroup: 4 (wave = 32 rows x 64 columns, two accumulators) or
 // 8 (wave = 32 rows x 32 columns, one accumulator; twice the waves per SIMD to hide barriers, LDS and staging latency).
 // ---------------------------------------------------------------------------------------------------------------
-template <int NW>
+// BWD = true is the data-gradient launch whose operand is rebuilt from (dA, y) by the fused BatchNorm+ReLU backward (and
+// optionally stored): a separate instantiation, so the plain kernel keeps its register budget and shows up under its own
+// name in rocprof.
+template <int NW, bool BWD = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float* __restrict__ src,
                                                                     const float* __restrict__ wpack,
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ dst,
                                                                     float* __restrict__ stats_partial,
-                                                                    const ConvProg P, int ntiles,
-                                                                    const float* __restrict__ src_bnp) {
+                                                                    const ConvProg P, int ntiles, const OpFuse src_fuse) {
   constexpr int NT = NW * 64;      // threads
   constexpr int NACC = 8 / NW;     // 32-column tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -274,9 +318,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
       cur_dst = tdst;
     }
     if (tsrc != cur_src) {
-      if (!(P.dbg & 1))
-        stage_rows<true, (NW == 4 ? 8 : 4), NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off,
-                                                TM + P.span, src_bnp);
+      if (!(P.dbg & 1)) {
+        if (BWD)
+          stage_rows<true, (NW == 4 ? 8 : 2), NT, true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q,
+                                                        q0 + P.min_off, TM + P.span, src_fuse, -P.min_off, TM);
+        else
+          stage_rows<true, (NW == 4 ? 8 : 4), NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off,
+                                                  TM + P.span, src_fuse);
+      }
       cur_src = tsrc;
     }
     if (!(P.dbg & 4)) {
@@ -353,7 +402,7 @@ template <bool S2, int TK>
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ g,
                                                              float* __restrict__ partial, const ConvProg P,
-                                                             int nchunks, const float* __restrict__ x_bnp) {
+                                                             int nchunks, const OpFuse x_fuse, const OpFuse g_fuse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Ss = (float*)smem;              // (TK + span) x 64
   float* Gs = Ss + (TK + P.span) * 64;   // TK x 64
@@ -382,12 +431,13 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
       const int cs = P.tsrc[t0], cd = P.tdst[t0];
       __syncthreads();
       if (cs != cur_s) {
-        stage_rows<false, 4>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span, x_bnp);
+        stage_rows<false, 4>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span, x_fuse);
         cur_s = cs;
       }
       const bool newg = (cd != cur_g);
       if (newg) {
-        stage_rows<false, 4>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK);
+        if (g_fuse.y) stage_rows<false, 2, 256, true>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK, g_fuse);
+        else stage_rows<false, 4>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK);
         cur_g = cd;
       }
       __syncthreads();
@@ -515,21 +565,40 @@ static size_t wgrad_lds_bytes(const ConvProg& P, int tk) { return (size_t)(tk + 
 static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried: the extra staging registers spill
 
 static int launch_fwd(const float* src, const float* wpack, const float* bias, float* dst, float* stats,
-                      const ConvProg& P, hipStream_t st, const float* src_bnp = nullptr) {
+                      const ConvProg& P, hipStream_t st, const OpFuse src_fuse = SRLZ_NO_FUSE) {
   const int ntiles = (P.total_q + TM - 1) / TM;
   const size_t lds = fwd_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64: tile needs %zu bytes of LDS", lds);
   // 4 waves (32x64 per wave) is the default; SRLZ_NW=8 selects 8 waves of 32x32 (measured within +-3 %: the kernel is
   // bound by the power-limited matrix rate, not by latency hiding)
   static const int nw = [] { const char* e = getenv("SRLZ_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
-  if (nw == 8) {
-    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(conv64_fwd_kernel<8>, dim3(ntiles), dim3(512), lds, st, src, wpack, bias, dst, stats, P, ntiles, src_bnp);
+#define SRLZ_FWD_LAUNCH(NWV, BWDV)                                                                                          \
+  do {                                                                                                                     \
+    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel<NWV, BWDV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                 (int)lds));                                                                               \
+    hipLaunchKernelGGL((conv64_fwd_kernel<NWV, BWDV>), dim3(ntiles), dim3(NWV * 64), lds, st, src, wpack, bias, dst, stats, \
+                       P, ntiles, src_fuse);                                                                               \
+  } while (0)
+  if (src_fuse.y) {
+    if (nw == 8) SRLZ_FWD_LAUNCH(8, true);
+    else SRLZ_FWD_LAUNCH(4, true);
   } else {
-    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(conv64_fwd_kernel<4>, dim3(ntiles), dim3(256), lds, st, src, wpack, bias, dst, stats, P, ntiles, src_bnp);
+    if (nw == 8) SRLZ_FWD_LAUNCH(8, false);
+    else SRLZ_FWD_LAUNCH(4, false);
   }
+#undef SRLZ_FWD_LAUNCH
   SRLZ_LAUNCHED();
+  return 0;
+}
+
+// host view of the fused BatchNorm-backward operand (include/srlz.h: srlz_bn_bwd_operand)
+static int make_bwd_fuse(OpFuse* f, const srlz_bn_bwd_operand* o, const char* who) {
+  *f = SRLZ_NO_FUSE;
+  if (!o) return 0;
+  SRLZ_REQUIRE(o->y && o->bnp && o->sums && o->count > 0, SRLZ_ERR_NULL, "%s: incomplete srlz_bn_bwd_operand", who);
+  f->bnp = o->bnp; f->y = o->y; f->sums = o->sums; f->training = o->training;
+  f->inv_count = 1.0f / (float)(double)o->count;
+  f->dy_out = o->dy_out;
   return 0;
 }
 
@@ -569,16 +638,18 @@ extern "C" int srlz_conv64_fwd(const float* x, const float* wpack_fwd, const flo
   SRLZ_REQUIRE(x && wpack_fwd && y, SRLZ_ERR_NULL, "conv64_fwd: null pointer");
   ConvProg P;
   if (int rc = program_for(&P, d, 0)) return rc;
-  return launch_fwd(x, wpack_fwd, bias, y, stats_partial, P, as_stream(stream), x_bnp);
+  return launch_fwd(x, wpack_fwd, bias, y, stats_partial, P, as_stream(stream), OpFuse{x_bnp, nullptr, nullptr, 0.f, 0, nullptr});
 }
 
-extern "C" int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx, const srlz_conv64_desc* d,
-                                    srlz_stream_t stream) {
+extern "C" int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx, const srlz_bn_bwd_operand* dy_bn,
+                                    const srlz_conv64_desc* d, srlz_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   SRLZ_REQUIRE(dy && wpack_bwd && dx, SRLZ_ERR_NULL, "conv64_bwd_data: null pointer");
   ConvProg P;
   if (int rc = program_for(&P, d, 1)) return rc;
-  return launch_fwd(dy, wpack_bwd, nullptr, dx, nullptr, P, as_stream(stream));
+  OpFuse gf;
+  if (int rc = make_bwd_fuse(&gf, dy_bn, "conv64_bwd_data")) return rc;
+  return launch_fwd(dy, wpack_bwd, nullptr, dx, nullptr, P, as_stream(stream), gf);
 }
 
 extern "C" size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d) {
@@ -589,8 +660,13 @@ extern "C" size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d) {
 }
 
 extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float* dbias, const float* x_bnp,
-                                      void* ws, size_t ws_bytes, const srlz_conv64_desc* d, srlz_stream_t stream) {
+                                      const srlz_bn_bwd_operand* dy_bn, void* ws, size_t ws_bytes,
+                                      const srlz_conv64_desc* d, srlz_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
+  OpFuse gf;
+  if (int rc = make_bwd_fuse(&gf, dy_bn, "conv64_bwd_weight")) return rc;
+  SRLZ_REQUIRE(gf.dy_out == nullptr, SRLZ_ERR_BAD_DESC, "conv64_bwd_weight: dy_out is only produced by srlz_conv64_bwd_data");
+  const OpFuse xf = OpFuse{x_bnp, nullptr, nullptr, 0.f, 0, nullptr};
   SRLZ_REQUIRE(x && dy && dw_ref && ws, SRLZ_ERR_NULL, "conv64_bwd_weight: null pointer");
   ConvProg P;
   if (int rc = program_for(&P, d, 0)) return rc;
@@ -607,7 +683,7 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   do {                                                                                                                     \
     SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<S2V, TKV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)lds));                                                                               \
-    hipLaunchKernelGGL((conv64_wgrad_kernel<S2V, TKV>), dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, x_bnp); \
+    hipLaunchKernelGGL((conv64_wgrad_kernel<S2V, TKV>), dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, xf, gf); \
   } while (0)
   if (P.s2) SRLZ_WGRAD_LAUNCH(true, 64);
   else SRLZ_WGRAD_LAUNCH(false, 64);

@@ -31,7 +31,14 @@ class PoolDesc(Structure):
                 ("out_nchw", c_int)]
 
 
+class BnBwdOperand(Structure):
+    """srlz_bn_bwd_operand: raw device pointers + count; build with bn_bwd_operand() so the tensors stay referenced."""
+    _fields_ = [("y", c_void_p), ("bnp", c_void_p), ("sums", c_void_p), ("count", c_longlong), ("training", c_int),
+                ("dy_out", c_void_p)]
+
+
 P = c_void_p
+_BO = POINTER(BnBwdOperand)
 _C64 = POINTER(Conv64Desc)
 _SK = POINTER(SkinnyDesc)
 _PD = POINTER(PoolDesc)
@@ -45,9 +52,9 @@ _PROTOS = {
     "srlz_conv64_pack_weights": (c_int, [P, P, P, _C64, P]),
     "srlz_conv64_fwd_tiles": (c_int, [_C64]),
     "srlz_conv64_fwd": (c_int, [P, P, P, P, P, P, _C64, P]),
-    "srlz_conv64_bwd_data": (c_int, [P, P, P, _C64, P]),
+    "srlz_conv64_bwd_data": (c_int, [P, P, P, _BO, _C64, P]),
     "srlz_conv64_bwd_weight_workspace": (c_size_t, [_C64]),
-    "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _C64, P]),
+    "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, _BO, P, c_size_t, _C64, P]),
     "srlz_conv64_debug_program": (c_int, [_C64, c_int, POINTER(c_int), c_int]),
     "srlz_debug_mfma_peak": (c_int, [P, c_int, c_int, P]),
     "srlz_skinny_tiles": (c_int, [_SK]),
@@ -66,6 +73,7 @@ _PROTOS = {
     "srlz_bn_bwd_workspace": (c_size_t, [c_longlong]),
     "srlz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, c_size_t, _PD, P]),
     "srlz_bn_relu_fwd": (c_int, [P, P, P, c_longlong, P]),
+    "srlz_bn_relu_bwd_sums": (c_int, [P, P, P, P, P, P, P, c_size_t, c_longlong, P]),
     "srlz_bn_relu_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, c_longlong, P]),
     "srlz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srlz_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

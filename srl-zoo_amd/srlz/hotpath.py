@@ -26,6 +26,10 @@ def _tap(prefix, idx, t):
 _FUSE_ENC_IN = os.environ.get("SRLZ_FUSE_ENC_IN", "1") != "0"
 
 
+# A/B switch for the deferred decoder BatchNorm backward (ops.BwdLink); deferred is the product path
+_DEFER_BN_BWD = os.environ.get("SRLZ_DEFER_BN_BWD", "1") != "0"
+
+
 def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var
 
@@ -77,18 +81,24 @@ def decoder_forward(seq, z, training):
     a = ops.ToNHWCFn.apply(z)
     y, st = ops.Conv64Fn.apply(a, seq[0].weight, seq[0].bias, 2, 0, True, training)
     _tap("decoder_conv", 0, y)
+    # BatchNorm backward deferred into the producing block's kernels (ops.BwdLink); with TAPS on, every d(loss)/dy_k is
+    # materialised instead so that retain_grad() on the taps shows true gradients.
+    defer = _DEFER_BN_BWD and TAPS is None
+    in_link = None  # the first transposed convolution is a plain Conv64Fn: its BatchNorm backward is materialised
     for bi, ci in ((1, 3), (4, 6), (7, 9)):
         bn, conv = seq[bi], seq[ci]
         _tick(bn, training)
         if TAPS is not None:
             _record_activation(bi + 1, y, st, bn, training)
-        y, st = ops.DecBlockFn.apply(y, st, *_bn_args(bn), training, conv.weight, conv.bias, training)
+        out_link = ops.BwdLink() if defer else None
+        y, st = ops.DecBlockFn.apply(y, st, *_bn_args(bn), training, conv.weight, conv.bias, training, in_link, out_link)
+        in_link = out_link
         _tap("decoder_conv", ci, y)
     bn, last = seq[10], seq[12]
     _tick(bn, training)
     if TAPS is not None:
         _record_activation(11, y, st, bn, training)
-    return _tap("decoder_conv", 12, ops.DecOutFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias))
+    return _tap("decoder_conv", 12, ops.DecOutFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias, in_link))
 
 
 def _record_activation(idx, y, st, bn, training):

@@ -79,7 +79,7 @@ def test_conv64_forward_backward(C, n, hi, s, p, t):
     assert rel_err(s_tot[64:], (yr_flat ** 2).sum(1)) < 2e-5
 
     dx = torch.full((n, hi, hi, 64), float("nan"), device=DEV)
-    C.conv64_bwd_data(C.ptr(dyd), C.ptr(packs[1]), C.ptr(dx), d, st)
+    C.conv64_bwd_data(C.ptr(dyd), C.ptr(packs[1]), C.ptr(dx), None, d, st)
     torch.cuda.synchronize()
     assert rel_err(nchw(dx), xr.grad) < 2e-5
 
@@ -87,7 +87,7 @@ def test_conv64_forward_backward(C, n, hi, s, p, t):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     dw = torch.full((64, 64, 3, 3), float("nan"), device=DEV)
     db = torch.full((64,), float("nan"), device=DEV)
-    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(db), None, C.ptr(ws), nbytes, d, st)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(db), None, None, C.ptr(ws), nbytes, d, st)
     torch.cuda.synchronize()
     assert rel_err(dw, wr.grad) < 2e-5
     ref_db = dy.double().sum((0, 2, 3))
@@ -106,7 +106,7 @@ def test_conv64_deterministic(C):
     outs = []
     for _ in range(2):
         dw = torch.empty(64, 64, 3, 3, device=DEV)
-        C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), None, None, C.ptr(ws), nbytes, d, C.stream())
+        C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), None, None, None, C.ptr(ws), nbytes, d, C.stream())
         outs.append(dw.cpu())
     assert torch.equal(outs[0], outs[1])
 
@@ -429,7 +429,7 @@ def test_fused_bn_relu_operand(C):
     nbytes = C.conv64_bwd_weight_workspace(d)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     dw = torch.full((64, 64, 3, 3), float("nan"), device=DEV)
-    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), None, C.ptr(bnpd), C.ptr(ws), nbytes, d, st)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), None, C.ptr(bnpd), None, C.ptr(ws), nbytes, d, st)
     torch.cuda.synchronize()
     assert rel_err(dw, wr.grad) < 2e-5
     # last layer (64 -> 3, 4x4 s2)
@@ -497,3 +497,65 @@ def test_encoder_input_block_fused_backward(C, n, c, h, training):
     torch.cuda.synchronize()
     assert rel_err(wd.grad, wr.grad) < 5e-5
     assert rel_err(gd.grad, gr.grad) < 5e-5 and rel_err(bd.grad, br.grad) < 5e-5
+
+
+@pytest.mark.parametrize("n,hi,s,p,t,training", [(2, 13, 2, 0, 1, 1), (2, 27, 2, 0, 1, 1), (3, 20, 1, 1, 0, 1),
+                                                 (2, 13, 2, 0, 1, 0)])
+def test_fused_bn_backward_operand(C, n, hi, s, p, t, training):
+    """srlz_bn_bwd_operand: conv -> BatchNorm -> ReLU backward with d(loss)/dy rebuilt inside the data-gradient and
+    weight-gradient kernels' operand load, against fp64 autograd through conv + batch_norm + relu."""
+    g = torch.Generator().manual_seed(1000 + hi + s)
+    ho = out_size(hi, s, p, t)
+    x = torch.randn(n, 64, hi, hi, generator=g)
+    w, b = torch.randn(64, 64, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g) * 0.1
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    rm, rv = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
+    da = torch.randn(n, 64, ho, ho, generator=g)
+    xr, wr, br = (v.double().requires_grad_(True) for v in (x, w, b))
+    gr, ber = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    conv = F.conv_transpose2d if t else F.conv2d
+    yr = conv(xr, wr, br, stride=s, padding=p)
+    yr.retain_grad()
+    ar = F.relu(F.batch_norm(yr, rm.double().clone(), rv.double().clone(), gr, ber, bool(training), 0.1, 1e-5))
+    ar.backward(da.double())
+
+    st = C.stream()
+    d = C.Conv64Desc(n, hi, hi, ho, ho, 3, s, p, t)
+    xd, wd, bd, dad = nhwc(x).to(DEV), w.to(DEV), b.to(DEV), nhwc(da).to(DEV)
+    packs = torch.empty(2, C.conv64_packed_floats(), device=DEV)
+    C.conv64_pack_weights(C.ptr(wd), C.ptr(packs[0]), C.ptr(packs[1]), d, st)
+    y = torch.empty(n, ho, ho, 64, device=DEV)
+    stats = torch.empty(C.conv64_fwd_tiles(d), 128, device=DEV)
+    C.conv64_fwd(C.ptr(xd), C.ptr(packs[0]), C.ptr(bd), C.ptr(y), C.ptr(stats), None, d, st)
+    gd, bed, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    bnp = torch.empty(256, device=DEV)
+    nbn = C.bn_bwd_workspace(0)
+    bws = torch.empty(nbn, dtype=torch.uint8, device=DEV)
+    if training:
+        bstat = torch.empty(128, device=DEV)
+        C.bn_finalize(C.ptr(stats), stats.shape[0], n * ho * ho, C.ptr(gd), C.ptr(bed), 1e-5, 0.1, 1, C.ptr(rmd), C.ptr(rvd),
+                      C.ptr(bnp), C.ptr(bstat), C.ptr(bws), nbn, st)
+    else:
+        C.bn_eval_params(C.ptr(gd), C.ptr(bed), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(bnp), st)
+    sums, dgm, dbt = torch.empty(128, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    C.bn_relu_bwd_sums(C.ptr(y), C.ptr(bnp), C.ptr(dad), C.ptr(sums), C.ptr(dgm), C.ptr(dbt), C.ptr(bws), nbn, n * ho * ho, st)
+    dy_out = torch.full((n, ho, ho, 64), float("nan"), device=DEV)
+    op = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), n * ho * ho, training, dy_out.data_ptr())
+    dx = torch.full((n, hi, hi, 64), float("nan"), device=DEV)
+    C.conv64_bwd_data(C.ptr(dad), C.ptr(packs[1]), C.ptr(dx), op, d, st)
+    nbytes = C.conv64_bwd_weight_workspace(d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw, db = torch.full((64, 64, 3, 3), float("nan"), device=DEV), torch.full((64,), float("nan"), device=DEV)
+    op2 = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), n * ho * ho, training, None)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dad), C.ptr(dw), C.ptr(db), None, op2, C.ptr(ws), nbytes, d, st)
+    dw2 = torch.full((64, 64, 3, 3), float("nan"), device=DEV)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dy_out), C.ptr(dw2), None, None, None, C.ptr(ws), nbytes, d, st)
+    torch.cuda.synchronize()
+    assert rel_err(dgm, gr.grad) < 5e-5 and rel_err(dbt, ber.grad) < 5e-5
+    assert rel_err(nchw(dx), xr.grad) < 5e-5
+    assert rel_err(nchw(dy_out), yr.grad) < 5e-5  # by-product: d(loss)/dy, every element written exactly once
+    assert rel_err(dw, wr.grad) < 5e-5 and rel_err(dw2, wr.grad) < 5e-5
+    if training:  # the bias gradient of a convolution followed by train-mode BatchNorm is identically zero
+        assert db.abs().max().item() < 1e-3 * da.abs().sum().item() / 64
+    else:
+        assert rel_err(db, br.grad) < 5e-5

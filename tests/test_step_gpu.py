@@ -260,3 +260,48 @@ def test_no_cpu_fallback():
     model = build(["autoencoder"])
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 224, 224))
+
+
+@pytest.mark.parametrize("losses", [["autoencoder"], ["vae"]])
+def test_deferred_bn_backward_equals_materialised(losses):
+    """The product path defers the decoder's BatchNorm backward into the producing block's kernels (ops.BwdLink) and the
+    first block's into conv1's weight-gradient kernel (ops.EncInFn); both must give the gradients of the plain chain."""
+    import numpy as np
+    import torch
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModules
+    import losses.losses as L
+    from srlz import hotpath
+    import golden_util as gu
+
+    def grads(defer, fuse_enc):
+        old = hotpath._DEFER_BN_BWD, hotpath._FUSE_ENC_IN
+        hotpath._DEFER_BN_BWD, hotpath._FUSE_ENC_IN = defer, fuse_enc
+        try:
+            pre.N_CHANNELS = 3
+            np.random.seed(3)
+            torch.manual_seed(3)
+            model = SRLModules(state_dim=200, action_dim=6, cuda=True, model_type="custom_cnn", losses=losses).to("cuda:0")
+            model.train()
+            lm = L.LossManager(model, None)
+            obs, next_obs, _ = gu.golden_inputs(4, 3, 6, seed=99)
+            o, no = torch.from_numpy(obs).cuda(), torch.from_numpy(next_obs).cuda()
+            if "vae" in losses:
+                model.model.eps_fn = lambda mu: torch.full_like(mu, 0.25)
+                (dec, mu, logvar), (ndec, nmu, nlogvar) = model(o), model(no)
+                L.kullbackLeiblerLoss(mu, nmu, logvar, nlogvar, loss_manager=lm, beta=1.0)
+                L.generationLoss(dec, ndec, o, no, weight=0.5e-6, loss_manager=lm)
+            else:
+                (_, dec), (_, ndec) = model(o), model(no)
+                L.autoEncoderLoss(o, dec, no, ndec, weight=1.0, loss_manager=lm)
+            lm.computeTotalLoss().backward()
+            torch.cuda.synchronize()
+            return {k: v.grad.detach().cpu().double() for k, v in model.named_parameters() if v.grad is not None}
+        finally:
+            hotpath._DEFER_BN_BWD, hotpath._FUSE_ENC_IN = old
+
+    plain, fused = grads(False, False), grads(True, True)
+    assert plain.keys() == fused.keys() and len(plain) > 20
+    for k, ref in plain.items():
+        # (biases in front of a train-mode BatchNorm have an exactly-zero gradient: both sides hold rounding noise ~1e-9)
+        assert (fused[k] - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-7, k

@@ -71,9 +71,9 @@ def bench_conv64(sel):
         if sel("fwd"):
             report(label + " fwd", *timeit(lambda: C.conv64_fwd(C.ptr(x), C.ptr(packs[0]), None, C.ptr(y), C.ptr(stats), None, d, st)), flop=flop)
         if sel("dgrad"):
-            report(label + " dgrad", *timeit(lambda: C.conv64_bwd_data(C.ptr(dy), C.ptr(packs[1]), C.ptr(dx), d, st)), flop=flop)
+            report(label + " dgrad", *timeit(lambda: C.conv64_bwd_data(C.ptr(dy), C.ptr(packs[1]), C.ptr(dx), None, d, st)), flop=flop)
         if sel("wgrad"):
-            report(label + " wgrad(+reduce)", *timeit(lambda: C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), C.ptr(db), None, C.ptr(ws), nb, d, st)), flop=flop)
+            report(label + " wgrad(+reduce)", *timeit(lambda: C.conv64_bwd_weight(C.ptr(x), C.ptr(dy), C.ptr(dw), C.ptr(db), None, None, C.ptr(ws), nb, d, st)), flop=flop)
 
 
 def bench_skinny(sel):
