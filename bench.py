@@ -87,6 +87,30 @@ def cpu_baseline(losses, sample_b=64, steps=2):
                                                    torch.get_num_threads(), dt)}
 
 
+def conv64_algorithmic_bytes(layer_key, n):
+    """Input + output activations (fp32 NHWC, 64 channels) + the 9x64x64 weights of one launch; key = ops._conv64_key."""
+    import re
+    m = re.search(r"(\d+)x(\d+)->(\d+)x(\d+)", layer_key)
+    hi, wi, ho, wo = (int(g) for g in m.groups())
+    return 4.0 * 64 * n * (hi * wi + ho * wo) + 4.0 * 9 * 64 * 64
+
+
+def committed_pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest profiles/*_pmc_traffic.json (rocprofv3 PMC passes of this same
+    command, collected by tools/profile_round.sh and committed; counters cannot be read from inside the process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        rec = json.load(open(files[-1]))["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None, None
+    if not rec:
+        return None, None
+    return rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,11 +204,18 @@ def main():
                 if name.startswith("conv64_fwd_kernel<bn-bwd operand>/") and v["ms"] > 0:
                     fused[name.split("/", 1)[1]] = {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                                                     "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
+            alg_bytes = 0.0
+            for key, v in layers.items():
+                alg_bytes += v["launches"] * conv64_algorithmic_bytes(key, B)
+            alg_bytes /= max(1, k["launches"])
+            traffic, traffic_src = committed_pmc_traffic("conv64_fwd_kernel<4, false>")
             out["roofline"] = {"kernel": "conv64_fwd_kernel<4,false> (3x3 64->64 conv / convT forward and data-gradient, all "
                                          "layers; the <4,true> instantiation = data-gradient with the BatchNorm backward "
                                          "fused into its operand load is listed under fused_dgrad_layers)",
                                "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+                               "algorithmic_bytes_per_launch": round(alg_bytes),
                                "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),
                                "layers": layers, "fused_dgrad_layers": fused}
