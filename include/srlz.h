@@ -248,6 +248,22 @@ int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, int B, int 
  * ------------------------------------------------------------------------------------------------------------ */
 int srlz_normalize_u8(const uint8_t* img_nhwc, float* out_ncwh, int n, int h, int w, int c, srlz_stream_t stream);
 
+/* SRLModulesSplit.detachSplit (models/modules.py:191-236): the state rebuilt from zero blocks and ONE kept slice is a
+ * column mask: y[r][c] = x[r][c] for lo <= c < hi, else 0.  Its backward is the same call on the gradient. */
+int srlz_mask_columns(const float* x, float* y, int rows, int cols, int lo, int hi, srlz_stream_t stream);
+
+/* l1Loss / l2Loss (losses/losses.py:132-155) over the list of regularised parameters (LossManager.reg_params,
+ * losses.py:30-31).  ptrs[nseg] / lens[nseg]: DEVICE arrays with the device address and element count of each tensor.
+ * mode 0: norms[i] = sum |p_i|,  out = scale * sum_i norms[i]           (l1: scale = 1)
+ * mode 1: norms[i] = ||p_i||_2,  out = scale * sum_i norms[i]           (l2: scale = 1/nseg)
+ * fp64 accumulation, one workgroup per tensor, fixed order. */
+int srlz_param_norms(const float* const* ptrs, const long long* lens, int nseg, int mode, float scale, float* norms,
+                     float* out, srlz_stream_t stream);
+/* gradient of the above into gptrs[i] (same shapes): coef * sign(p) (mode 0) or coef * p / norms[i] (mode 1),
+ * coef = coef_dev[0] * scale (coef_dev may be NULL = 1). */
+int srlz_param_norms_grad(const float* const* ptrs, float* const* gptrs, const long long* lens, int nseg, int mode,
+                          const float* norms, const float* coef_dev, float scale, srlz_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Adam over one flat parameter buffer — th.optim.Adam(params, lr) models/learner.py:199,495 (torch defaults).
  * step is 1-based; grad_scale multiplies g first (1/world_size after the RCCL sum).

@@ -138,6 +138,68 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// y[r][c] = x[r][c] for lo <= c < hi, 0 elsewhere (SRLModulesSplit.detachSplit, models/modules.py:191-236: the state is
+// rebuilt from zero blocks and one kept slice, i.e. a column mask; its backward is the same mask on the gradient)
+__global__ void mask_columns_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols, int lo, int hi) {
+  const int total = rows * cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % cols;
+    y[i] = (c >= lo && c < hi) ? x[i] : 0.f;
+  }
+}
+
+// Regularisers over a LIST of parameter tensors (losses/losses.py:132-155): one workgroup per tensor, fp64 accumulation in
+// a fixed order.  mode 0: sum |p| ; mode 1: sqrt(sum p^2).  ptrs/lens are device arrays of nseg entries.
+__global__ __launch_bounds__(256) void param_norms_kernel(const float* const* __restrict__ ptrs, const long long* __restrict__ lens,
+                                                         int mode, float* __restrict__ norms) {
+  const float* p = ptrs[blockIdx.x];
+  const long long n = lens[blockIdx.x];
+  double acc = 0.0;
+  for (long long base = 0; base < n; base += 256 * 8) {
+    float local = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long i = base + j * 256 + threadIdx.x;
+      if (i < n) { const float v = p[i]; local += mode == 0 ? fabsf(v) : v * v; }
+    }
+    acc += (double)local;
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    norms[blockIdx.x] = (float)(mode == 0 ? t : sqrt(t));
+  }
+}
+
+// out = scale * sum_i norms[i]   (one wave; fp64)
+__global__ void param_norms_total(const float* __restrict__ norms, int nseg, float scale, float* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nseg; i += 64) s += (double)norms[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (float)(s * (double)scale);
+}
+
+// g_i = coef * sign(p_i)  (mode 0)   or   coef * p_i / ||p_i||  (mode 1), coef = coef_dev[0] * scale
+__global__ __launch_bounds__(256) void param_norms_grad_kernel(const float* const* __restrict__ ptrs,
+                                                              float* const* __restrict__ gptrs,
+                                                              const long long* __restrict__ lens, int mode,
+                                                              const float* __restrict__ norms,
+                                                              const float* __restrict__ coef_dev, float scale) {
+  const int seg = blockIdx.y;
+  const float* p = ptrs[seg];
+  float* g = gptrs[seg];
+  const long long n = lens[seg];
+  const float coef = (coef_dev ? coef_dev[0] : 1.f) * scale;
+  const float inv = mode == 1 ? 1.f / norms[seg] : 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = p[i];
+    g[i] = mode == 0 ? coef * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) : coef * (v * inv);
+  }
+}
+
 static int blocks_for(long long n, int cap) {
   long long b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -222,6 +284,39 @@ extern "C" int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, 
   SRLZ_REQUIRE(s && a && cat, SRLZ_ERR_NULL, "concat_onehot: null pointer");
   hipLaunchKernelGGL(concat_onehot_kernel, dim3(blocks_for((long long)B * (S + A), 1024)), dim3(256), 0, as_stream(stream), s, a,
                      cat, B, S, A);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_mask_columns(const float* x, float* y, int rows, int cols, int lo, int hi, srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && y, SRLZ_ERR_NULL, "mask_columns: null pointer");
+  SRLZ_REQUIRE(rows > 0 && cols > 0 && lo >= 0 && lo <= hi && hi <= cols, SRLZ_ERR_BAD_DESC,
+               "mask_columns: bad range [%d,%d) of %d columns", lo, hi, cols);
+  hipLaunchKernelGGL(mask_columns_kernel, dim3(blocks_for((long long)rows * cols, 1024)), dim3(256), 0, as_stream(stream), x, y,
+                     rows, cols, lo, hi);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_param_norms(const float* const* ptrs, const long long* lens, int nseg, int mode, float scale, float* norms,
+                                float* out, srlz_stream_t stream) {
+  SRLZ_REQUIRE(ptrs && lens && norms && out, SRLZ_ERR_NULL, "param_norms: null pointer");
+  SRLZ_REQUIRE(nseg > 0 && (mode == 0 || mode == 1), SRLZ_ERR_BAD_DESC, "param_norms: nseg=%d mode=%d", nseg, mode);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(param_norms_kernel, dim3(nseg), dim3(256), 0, st, ptrs, lens, mode, norms);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(param_norms_total, dim3(1), dim3(64), 0, st, (const float*)norms, nseg, scale, out);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_param_norms_grad(const float* const* ptrs, float* const* gptrs, const long long* lens, int nseg, int mode,
+                                     const float* norms, const float* coef_dev, float scale, srlz_stream_t stream) {
+  SRLZ_REQUIRE(ptrs && gptrs && lens && norms, SRLZ_ERR_NULL, "param_norms_grad: null pointer");
+  SRLZ_REQUIRE(nseg > 0 && nseg <= 65535 && (mode == 0 || mode == 1), SRLZ_ERR_BAD_DESC, "param_norms_grad: nseg=%d mode=%d",
+               nseg, mode);
+  hipLaunchKernelGGL(param_norms_grad_kernel, dim3(64, nseg), dim3(256), 0, as_stream(stream), ptrs, gptrs, lens, mode, norms,
+                     coef_dev, scale);
   SRLZ_LAUNCHED();
   return 0;
 }

@@ -1,7 +1,7 @@
-"""LossManager and the hot-path losses (reference losses/losses.py:19-59, 102-129, 172-214, 239-256).
+"""LossManager and the hot-path losses (reference losses/losses.py:19-59, 102-170, 172-214, 239-256).
 
 Same function names, argument order and return values as the reference; the reductions and their gradients run as
-fused HIP kernels (srlz/ops.py).  Losses of other SRL methods (priors, reward, triplet, perceptual, l1/l2, ...) are
+fused HIP kernels (srlz/ops.py).  Losses of other SRL methods (priors, triplet, perceptual, episode/reward priors) are
 outside the hot path and not provided.
 """
 from __future__ import print_function, division, absolute_import
@@ -52,6 +52,27 @@ class LossManager:
 
     def resetLosses(self):
         self.names, self.weights, self.losses = [], [], []
+
+
+def l1Loss(params, weight, loss_manager):
+    """L1 regularisation: sum over the parameter list of sum(|p|) (reference losses.py:132-142)."""
+    l1_loss = ops.ParamNormFn.apply(0, *params)
+    loss_manager.addToLosses('l1_loss', weight, l1_loss)
+    return weight * l1_loss
+
+
+def l2Loss(params, weight, loss_manager):
+    """L2 regularisation: mean over the parameter list of ||p||_2 (reference losses.py:145-155)."""
+    l2_loss = ops.ParamNormFn.apply(1, *params)
+    loss_manager.addToLosses('l2_loss', weight, l2_loss)
+    return weight * l2_loss
+
+
+def rewardModelLoss(rewards_pred, rewards_st, weight, loss_manager):
+    """cross-entropy between reward logits and the (categorical) reward (reference losses.py:158-170)."""
+    reward_loss = ops.CrossEntropyFn.apply(rewards_pred, rewards_st.view(-1))
+    loss_manager.addToLosses('reward_loss', weight, reward_loss)
+    return weight * reward_loss
 
 
 def reconstructionLoss(input_image, target_image):

@@ -69,8 +69,7 @@ class BaseRewardModel(BaseModelSRL):
         raise NotImplementedError()
 
     def rewardModel(self, state, next_state):
-        """reward logits from [state ; next_state] (head kept for checkpoint compatibility; reward loss is out of
-        the hot-path scope)."""
+        """reward logits from [state ; next_state] (reference forward_inverse.py:87-95)."""
         x = th.cat((state, next_state), dim=1)
         x = hotpath.linear(self.reward_net[0], x, relu=True)
         x = hotpath.linear(self.reward_net[2], x, relu=True)

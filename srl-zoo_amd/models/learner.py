@@ -21,12 +21,12 @@ import numpy as np
 import torch as th
 
 from losses.losses import LossManager, autoEncoderLoss, forwardModelLoss, inverseModelLoss, kullbackLeiblerLoss, \
-    generationLoss
+    generationLoss, rewardModelLoss, l1Loss, l2Loss
 from pipeline import NAN_ERROR
 from preprocessing.data_loader import DataLoader
 from utils import printRed, detachToNumpy, printYellow
 from srlz import optim
-from .modules import SRLModules
+from .modules import SRLModules, SRLModulesSplit
 
 MAX_BATCH_SIZE_GPU = 256  # minibatch size used when predicting states
 EPOCH_FLAG = 1            # print every epoch
@@ -41,7 +41,7 @@ BALANCED_SAMPLING = False
 # build-specific: ship decoded frames as uint8 and normalise on the GPU (bit-identical, 4x less PCIe traffic)
 RAW_UINT8_INPUT = True
 
-SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "random"}
+SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "reward", "random"}
 
 
 def _requireGpu(cuda):
@@ -112,8 +112,9 @@ class BaseLearner(object):
 class SRL4robotics(BaseLearner):
     """Trainer for the conv auto-encoder / VAE / forward-inverse family.
 
-    Arguments as in the reference (models/learner.py:121-148).  Accepted but unused because their code paths are
-    outside the hot path: l1_reg / l2_reg (must be 0), split_dimensions (must be -1), path_to_dae / state_dim_dae.
+    Arguments as in the reference (models/learner.py:121-148).  `split_dimensions` (OrderedDict with a positive sum)
+    selects SRLModulesSplit; `l1_reg` / `l2_reg` > 0 add the regularisers.  Accepted but unused because their code path
+    (perceptual loss) is outside the hot path: path_to_dae / state_dim_dae.
     """
 
     def __init__(self, state_dim, model_type="resnet", inverse_model_type="linear", log_folder="logs/default",
@@ -126,10 +127,6 @@ class SRL4robotics(BaseLearner):
         if unsupported:
             raise NotImplementedError("losses %s are outside the MI355X hot path of this build (supported: %s)"
                                       % (sorted(unsupported), sorted(SUPPORTED_LOSSES)))
-        if isinstance(split_dimensions, dict) and sum(split_dimensions.values()) > 0:
-            raise NotImplementedError("split state representation (SRLModulesSplit) is not part of this build yet")
-        if l1_reg > 0 or l2_reg > 0:
-            raise NotImplementedError("l1/l2 regularisation losses are outside the MI355X hot path of this build")
 
         self.multi_view = multi_view
         self.losses = losses
@@ -137,13 +134,20 @@ class SRL4robotics(BaseLearner):
         self.beta = beta
         self.use_forward_loss = "forward" in losses
         self.use_inverse_loss = "inverse" in losses
+        self.use_reward_loss = "reward" in losses
         self.use_autoencoder = "autoencoder" in losses
         self.use_vae = "vae" in losses
         self.use_dae = "dae" in losses
         self.use_triplets = False
 
-        self.model = SRLModules(state_dim=self.state_dim, action_dim=self.dim_action, model_type=model_type,
-                                cuda=cuda, losses=losses, inverse_model_type=inverse_model_type)
+        if isinstance(split_dimensions, OrderedDict) and sum(split_dimensions.values()) > 0:
+            printYellow("Using splitted representation")
+            self.model = SRLModulesSplit(state_dim=self.state_dim, action_dim=self.dim_action, model_type=model_type,
+                                         cuda=cuda, losses=losses, split_dimensions=split_dimensions,
+                                         inverse_model_type=inverse_model_type)
+        else:
+            self.model = SRLModules(state_dim=self.state_dim, action_dim=self.dim_action, model_type=model_type,
+                                    cuda=cuda, losses=losses, inverse_model_type=inverse_model_type)
         print("Using {} model".format(model_type))
 
         _requireGpu(cuda)
@@ -232,7 +236,7 @@ class SRL4robotics(BaseLearner):
         return outs[0], outs[1]
 
     def trainStep(self, obs, next_obs, actions_st, loss_manager, validation_mode=False, noisy_obs=None,
-                  next_noisy_obs=None):
+                  next_noisy_obs=None, rewards_st=None):
         """The minibatch-loop body of the reference (models/learner.py:362-497) on device tensors.
 
         Runs forward, losses, backward (also on validation minibatches, as the reference does), the gradient
@@ -258,12 +262,20 @@ class SRL4robotics(BaseLearner):
             states, next_states = self._forwardPair(obs, next_obs)
 
         w = self.losses_weights_dict
+        # same order as the reference's loop body (learner.py:420-449): regularisers, forward, inverse, reward, AE, VAE
+        if w['l1_reg'] > 0:
+            l1Loss(loss_manager.reg_params, w['l1_reg'], loss_manager)
+        if w['l2_reg'] > 0:
+            l2Loss(loss_manager.reg_params, w['l2_reg'], loss_manager)
         if self.use_forward_loss:
             next_states_pred = self.model.forwardModel(states, actions_st)
             forwardModelLoss(next_states_pred, next_states, weight=w['forward'], loss_manager=loss_manager)
         if self.use_inverse_loss:
             actions_pred = self.model.inverseModel(states, next_states)
             inverseModelLoss(actions_pred, actions_st, weight=w['inverse'], loss_manager=loss_manager)
+        if self.use_reward_loss:
+            rewards_pred = self.model.rewardModel(states, next_states)
+            rewardModelLoss(rewards_pred, rewards_st, weight=w['reward'], loss_manager=loss_manager)
         if self.use_autoencoder or self.use_dae:
             autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs,
                             weight=w["dae" if self.use_dae else "autoencoder"], loss_manager=loss_manager)
@@ -343,8 +355,14 @@ class SRL4robotics(BaseLearner):
                 obs, next_obs = self._toDevice(obs), self._toDevice(next_obs)
                 actions_st = th.from_numpy(actions[minibatchlist[minibatch_idx]]).view(-1, 1).to(self.device)
 
+                rewards_st = None
+                if self.use_reward_loss:
+                    rewards_st = rewards[minibatchlist[minibatch_idx]].copy()
+                    rewards_st[rewards_st == -1] = 0  # removing negative reward (reference learner.py:439-441)
+                    rewards_st = th.from_numpy(rewards_st).to(self.device).long()
+
                 loss = self.trainStep(obs, next_obs, actions_st, loss_manager, validation_mode, noisy_obs,
-                                      next_noisy_obs)
+                                      next_noisy_obs, rewards_st)
                 # one D2H copy for every scalar of this step
                 values = th.stack([l.detach().reshape(()) for l in loss_manager.losses] + [loss.detach()]).tolist()
                 loss_manager.updateLossHistory(values[:-1])

@@ -92,6 +92,9 @@ _PROTOS = {
     "srlz_cross_entropy": (c_int, [P, P, c_int, c_int, P, P, P]),
     "srlz_concat_onehot": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "srlz_normalize_u8": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srlz_mask_columns": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "srlz_param_norms": (c_int, [P, P, c_int, c_int, c_float, P, P, P]),
+    "srlz_param_norms_grad": (c_int, [P, P, P, c_int, c_int, P, P, c_float, P]),
     "srlz_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, P]),
 }
 

@@ -588,6 +588,75 @@ class LinearFn(Function):
         return dx, dw, db, None
 
 
+class MaskColumnsFn(Function):
+    """x with every column outside [lo, hi) zeroed — SRLModulesSplit.detachSplit (reference models/modules.py:191-236)
+    rebuilds the state from th.zeros_like blocks and one kept slice, i.e. applies this mask; gradient = same mask."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        x = _check(x, "split input")
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        C.mask_columns(ptr(x), ptr(y), rows, cols, lo, hi, stream())
+        ctx.range = (lo, hi)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _check(dy, "split grad")
+        rows, cols = dy.shape
+        dx = torch.empty_like(dy)
+        C.mask_columns(ptr(dy), ptr(dx), rows, cols, ctx.range[0], ctx.range[1], stream())
+        return dx, None, None
+
+
+_param_tables = {}
+
+
+def _param_table(params):
+    """Device arrays (addresses, lengths) of a parameter list, cached per list of storage addresses."""
+    key = tuple((p.data_ptr(), p.numel()) for p in params)
+    tab = _param_tables.get(key)
+    if tab is None:
+        dev = params[0].device
+        tab = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=dev),
+               torch.tensor([k[1] for k in key], dtype=torch.int64, device=dev))
+        _param_tables.clear()  # parameters are re-homed rarely (FlatParams): keep one table
+        _param_tables[key] = tab
+    return tab
+
+
+class ParamNormFn(Function):
+    """mode 0: sum_i sum|p_i| (l1Loss, reference losses.py:132-142); mode 1: (sum_i ||p_i||_2) / len(params) (l2Loss,
+    losses.py:145-155).  One launch over the whole parameter list (one workgroup per tensor, fp64 accumulation)."""
+
+    @staticmethod
+    def forward(ctx, mode, *params):
+        for p in params:
+            _check(p, "regularised parameter")
+        nseg = len(params)
+        ptrs, lens = _param_table(params)
+        dev = params[0].device
+        norms = torch.empty(nseg, dtype=torch.float32, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        scale = 1.0 if mode == 0 else 1.0 / nseg
+        C.param_norms(ptr(ptrs), ptr(lens), nseg, mode, scale, ptr(norms), ptr(out), stream())
+        ctx.save_for_backward(norms, ptrs, lens, *params)
+        ctx.mode, ctx.scale = mode, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        norms, ptrs, lens = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        dout = dout.contiguous()
+        grads = [torch.empty_like(p) for p in params]
+        gptrs = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64, device=norms.device)
+        C.param_norms_grad(ptr(ptrs), ptr(gptrs), ptr(lens), len(params), ctx.mode, ptr(norms), ptr(dout), ctx.scale,
+                           stream())
+        return (None,) + tuple(grads)
+
+
 class ToNHWCFn(Function):
     """[N,C,H,W] -> [N,H,W,C] (the decoder_fc -> view(N,64,6,6) seam, autoencoders.py:116-117)."""
 

@@ -34,6 +34,49 @@ def golden_inputs(B, C, A, seed=1234):
     return obs, next_obs, actions
 
 
+def golden_rewards(B, seed=1234):
+    """Rewards as the datasets store them (-1 / 0 / 1) and as the loop feeds them to the reward loss (-1 -> 0, int64;
+    reference models/learner.py:439-442)."""
+    raw = np.random.RandomState(seed + 33).randint(-1, 2, (B,)).astype(np.int64)
+    st = raw.copy()
+    st[st == -1] = 0
+    return raw, st
+
+
+def golden_noisy(obs, seed=1234):
+    """A deterministic occluded copy of a batch (what the DAE sees): one zeroed rectangle per image."""
+    rs = np.random.RandomState(seed + 55)
+    out = obs.copy()
+    for i in range(out.shape[0]):
+        h1, w1 = rs.randint(0, 112, 2)
+        h2, w2 = h1 + rs.randint(20, 112), w1 + rs.randint(20, 112)
+        out[i, :, h1:h2, w1:w2] = 0.0
+    return out
+
+
+def ext_cases():
+    """§8f-2/3 fixtures (tools/make_golden.py section 3b): name -> configuration of the step.  The first one is the
+    reference's own stacked-model test configuration (tests/test_modules.py:8-19) at B=4."""
+    from collections import OrderedDict as OD
+    stacked = OD([("dae", 20), ("reward", -1), ("forward", 60), ("inverse", 20)])
+    return {
+        "step_split_dae_rfi_b4": dict(losses=list(stacked.keys()), B=4, S=100, inverse="mlp", split=stacked, l2_reg=0.0001,
+                                      weights={"dae": 1.0, "reward": 1.0, "forward": 1.0, "inverse": 5.0}),
+        "step_split_vae_if_b2": dict(losses=["vae", "inverse", "forward"], B=2,
+                                     split=OD([("vae", 150), ("inverse", 50), ("forward", -1)])),
+        "step_split_ae_ri_b2": dict(losses=["autoencoder", "reward", "inverse"], B=2,
+                                    split=OD([("autoencoder", 120), ("reward", 80), ("inverse", -1)])),
+        "step_ae_reward_l1_b2": dict(losses=["autoencoder", "reward"], B=2, l1_reg=1e-5),
+        "step_dae_b2": dict(losses=["dae"], B=2),
+    }
+
+
+def ext_defaults(cfg):
+    out = dict(S=200, inverse="linear", split=None, l1_reg=0.0, l2_reg=0.0, weights=None)
+    out.update(cfg)
+    return out
+
+
 def tensor_digest(t):
     """sum, abs-sum, L2 norm (float64) and a strided flat subsample of a tensor/ndarray."""
     if hasattr(t, "detach"):

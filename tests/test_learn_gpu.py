@@ -64,3 +64,43 @@ def test_learn_end_to_end(workdir, losses, kind):
     with torch.no_grad():
         st2 = srl2.model.getStates(obs.cuda()).cpu().numpy()
     assert np.abs(st2 - states[:8]).max() <= 1e-5 * np.abs(states[:8]).max()
+
+
+def test_learn_stacked_split_model(workdir):
+    """The reference's stacked-model configuration (tests/test_modules.py:8-19: `dae:1:20 reward:1:-1 forward:1:60
+    inverse:5:20`, mlp inverse model, l2 regularisation, occlusion 0.3) through learn(), scaled to the tiny dataset."""
+    from collections import OrderedDict
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from models.learner import SRL4robotics
+    from models.modules import SRLModulesSplit
+    from oracle import torch_twin as T
+    name, paths, actions, rewards, starts = workdir
+    pre.N_CHANNELS = 3
+    learner.N_EPOCHS, learner.BATCH_SIZE, learner.VALIDATION_SIZE, learner.DISPLAY_PLOTS = 2, 8, 0.2, False
+    log = "logs/run_split"
+    os.makedirs(log, exist_ok=True)
+    split = OrderedDict([("dae", 4), ("reward", -1), ("forward", 6), ("inverse", 2)])
+    weights = OrderedDict([("dae", 1.0), ("reward", 1.0), ("forward", 1.0), ("inverse", 5.0)])
+    srl = SRL4robotics(12, model_type="custom_cnn", inverse_model_type="mlp", seed=3, learning_rate=1e-3, cuda=True,
+                       losses=list(split.keys()), losses_weights_dict=weights, n_actions=6, log_folder=log,
+                       split_dimensions=split, l2_reg=1e-4, occlusion_percentage=0.3)
+    assert isinstance(srl.model, SRLModulesSplit)
+    loss_history, states, pairs = srl.learn(paths, actions, rewards, starts)
+    assert states.shape == (len(paths), 12) and np.isfinite(states).all()
+    assert [n for n, _ in pairs] == ["l2_loss", "forward_loss", "inverse_loss", "reward_loss", "reconstruction_loss"]
+    assert dict(pairs)["inverse_loss"] == 5.0 and dict(pairs)["l2_loss"] == 1e-4
+    for k in ("train_loss", "val_loss", "reward_loss", "l2_loss"):
+        assert len(loss_history[k]) == 2 and np.isfinite(loss_history[k]).all(), k
+    sd = torch.load(log + "/srl_model.pth", map_location="cpu")
+    from preprocessing.data_loader import DataLoader
+    obs = torch.cat([DataLoader._makeBatchElement(p) for p in paths[:8]], 0)
+    ref = T.get_states(T.clone_state(sd, requires_grad=False), obs, "ae")
+    err = np.abs(states[:8] - ref.numpy()).max() / np.abs(ref.numpy()).max()
+    assert err < 1e-4, err
+    with open(log + "/exp_config.json", "w") as f:
+        json.dump(OrderedDict([("state-dim", 12), ("losses", list(split.keys())), ("n_actions", 6),
+                               ("model-type", "custom_cnn"), ("inverse-model-type", "mlp"),
+                               ("split-dimensions", split)]), f)
+    srl2, cfg = SRL4robotics.loadSavedModel(log + "/", ["dae", "reward", "inverse", "forward"], cuda=True)
+    assert isinstance(srl2.model, SRLModulesSplit)

@@ -13,12 +13,15 @@ from oracle import torch_twin as T
 RTOL = 2e-5
 
 
-def build(losses, C=3, S=200, A=6, seed=1, inverse="linear"):
+def build(losses, C=3, S=200, A=6, seed=1, inverse="linear", split=None):
     import preprocessing.preprocess as pre
-    from models.modules import SRLModules
+    from models.modules import SRLModules, SRLModulesSplit
     pre.N_CHANNELS = C
     np.random.seed(seed)
     torch.manual_seed(seed)
+    if split is not None:
+        return SRLModulesSplit(state_dim=S, action_dim=A, cuda=False, model_type="custom_cnn", losses=losses,
+                               split_dimensions=split, inverse_model_type=inverse)
     return SRLModules(state_dim=S, action_dim=A, cuda=False, model_type="custom_cnn", losses=losses,
                       inverse_model_type=inverse)
 
@@ -47,9 +50,9 @@ CASES = [("step_ae_b2", ["autoencoder"], 2, 3, "linear"),
          ("step_cnn_if_b2", ["inverse", "forward"], 2, 3, "linear")]
 
 
-def run_twin(losses, B, C, inverse, n_steps=1, lr=None):
+def run_twin(losses, B, C, inverse, n_steps=1, lr=None, S=200, split=None, weights=None, l1_reg=0.0, l2_reg=0.0):
     torch.set_num_threads(1)
-    model = build(losses, C=C, inverse=inverse)
+    model = build(losses, C=C, S=S, inverse=inverse, split=split)
     sd = T.clone_state(model.state_dict())
     opt = T.TwinAdam(sd, lr) if lr is not None else None
     outs = []
@@ -58,9 +61,15 @@ def run_twin(losses, B, C, inverse, n_steps=1, lr=None):
         eps = [None, None]
         if "vae" in losses:
             torch.manual_seed(99 + step)
-            eps = [torch.randn(B, 200), torch.randn(B, 200)]
+            eps = [torch.randn(B, S), torch.randn(B, S)]
+        noisy = (None, None)
+        if "dae" in losses:
+            noisy = (torch.from_numpy(gu.golden_noisy(obs, seed=1234 + step)),
+                     torch.from_numpy(gu.golden_noisy(next_obs, seed=4321 + step)))
+        rewards = torch.from_numpy(gu.golden_rewards(B, seed=1234 + step)[1]) if "reward" in losses else None
         out = T.train_step(sd, losses, torch.from_numpy(obs), torch.from_numpy(next_obs), torch.from_numpy(actions),
-                           eps=eps[0], next_eps=eps[1])
+                           eps=eps[0], next_eps=eps[1], weights=weights, split=split, rewards=rewards, l1_reg=l1_reg,
+                           l2_reg=l2_reg, noisy=noisy)
         outs.append(out)
         if opt is not None:
             opt.step(sd)
@@ -71,7 +80,61 @@ def run_twin(losses, B, C, inverse, n_steps=1, lr=None):
 def test_twin_step_matches_reference_golden(name, losses, B, C, inverse):
     g = gu.load(name)
     sd, outs = run_twin(losses, B, C, inverse)
-    out = outs[0]
+    check_step_against_golden(g, sd, outs[0], losses, B, C)
+
+
+@pytest.mark.parametrize("name", sorted(gu.ext_cases().keys()))
+def test_twin_split_reward_reg_steps_match_reference_golden(name):
+    """SRLModulesSplit / reward loss / l1-l2 regularisers / DAE inputs (SURVEY.md §8f-2,3) against the reference."""
+    cfg = gu.ext_defaults(gu.ext_cases()[name])
+    g = gu.load(name)
+    sd, outs = run_twin(cfg["losses"], cfg["B"], 3, cfg["inverse"], S=cfg["S"], split=cfg["split"], weights=cfg["weights"],
+                        l1_reg=cfg["l1_reg"], l2_reg=cfg["l2_reg"])
+    check_step_against_golden(g, sd, outs[0], cfg["losses"], cfg["B"], 3)
+
+
+def test_twin_split_adam_trace_matches_reference():
+    cfg = gu.ext_defaults(gu.ext_cases()["step_split_dae_rfi_b4"])
+    g = gu.load("trace_split_dae_rfi_b4")
+    sd, outs = run_twin(cfg["losses"], cfg["B"], 3, cfg["inverse"], S=cfg["S"], split=cfg["split"], weights=cfg["weights"],
+                        l1_reg=cfg["l1_reg"], l2_reg=cfg["l2_reg"], n_steps=3, lr=1e-4)
+    names = [str(n) for n in g["trace/names"]]
+    for step, out in enumerate(outs):
+        for j, nm in enumerate(names):
+            v = float(g["trace/values"][step, j])
+            got = out["total"] if nm == "total" else out["losses"][nm]
+            assert abs(got - v) <= 5e-4 * max(abs(v), 1e-6), (step, nm, got, v)
+
+
+def test_detach_split_kats():
+    """detachSplit's kept columns for six split configurations: the oracle's list-of-blocks restatement AND the
+    product's column range (SRLModulesSplit.splitRange) against the reference's masks."""
+    from collections import OrderedDict as OD
+    from models.modules import SRLModulesSplit
+    g = gu.load("detach_kats")
+
+    class Holder(object):
+        pass
+    checked = 0
+    for ci in range(int(g["n_configs"])):
+        cfg = OD((str(k), int(d)) for k, d in zip(g["cfg%d/keys" % ci], g["cfg%d/dims" % ci]))
+        S = sum(v for v in cfg.values() if v > 0)
+        h = Holder()
+        h.split_dimensions = cfg
+        for f in [f for f in g.files if f.startswith("cfg%d/mask/" % ci)]:
+            index = f.split("/")[-1]
+            ref = g[f].astype(np.float32)
+            got = T.detach_split(cfg, torch.ones(2, S), index)[0].numpy()
+            np.testing.assert_array_equal(got, ref)
+            lo, hi = SRLModulesSplit.splitRange(h, index)
+            rng = np.zeros(S, dtype=np.float32)
+            rng[lo:hi] = 1.0
+            np.testing.assert_array_equal(rng, ref)
+            checked += 1
+    assert checked >= 30
+
+
+def check_step_against_golden(g, sd, out, losses, B, C):
     for k in [f for f in g.files if f.startswith("loss/")]:
         nm = k[len("loss/"):]
         v = float(g[k])
@@ -95,7 +158,7 @@ def test_twin_step_matches_reference_golden(name, losses, B, C, inverse):
         ref = np.asarray(g[k], dtype=np.float64)
         got = sd[k[len("bn/"):]].double().numpy()
         np.testing.assert_allclose(got, ref, rtol=RTOL, atol=1e-7)
-    kind = "ae" if "autoencoder" in losses else ("vae" if "vae" in losses else "cnn")
+    kind = "ae" if ("autoencoder" in losses or "dae" in losses) else ("vae" if "vae" in losses else "cnn")
     obs, _, _ = gu.golden_inputs(B, C, 6, seed=1234)
     st = T.get_states(sd, torch.from_numpy(obs), kind)
     np.testing.assert_allclose(st.double().numpy(), g["eval_states/full"], rtol=1e-4, atol=1e-5)

@@ -25,20 +25,24 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-def build(losses, C=3, S=200, A=6, seed=1, inverse="linear"):
+def build(losses, C=3, S=200, A=6, seed=1, inverse="linear", split=None):
     import preprocessing.preprocess as pre
-    from models.modules import SRLModules
+    from models.modules import SRLModules, SRLModulesSplit
     pre.N_CHANNELS = C
     np.random.seed(seed)
     torch.manual_seed(seed)
+    if split is not None:
+        return SRLModulesSplit(state_dim=S, action_dim=A, cuda=True, model_type="custom_cnn", losses=losses,
+                               split_dimensions=split, inverse_model_type=inverse)
     return SRLModules(state_dim=S, action_dim=A, cuda=True, model_type="custom_cnn", losses=losses,
                       inverse_model_type=inverse)
 
 
-def hip_step(model, losses, obs, next_obs, actions, eps_list=None, beta=1.0, weights=None):
+def hip_step(model, losses, obs, next_obs, actions, eps_list=None, beta=1.0, weights=None, rewards=None, l1_reg=0.0,
+             l2_reg=0.0, noisy=None):
     """Loop body of the reference (models/learner.py:373-489) on the HIP classes."""
     import losses.losses as L
-    w = {"forward": 1.0, "inverse": 2.0, "autoencoder": 1.0, "vae": 0.5e-6}
+    w = {"forward": 1.0, "inverse": 2.0, "reward": 1.0, "autoencoder": 1.0, "dae": 1.0, "vae": 0.5e-6}
     if weights:
         w.update(weights)
     dev = torch.device("cuda")
@@ -58,8 +62,14 @@ def hip_step(model, losses, obs, next_obs, actions, eps_list=None, beta=1.0, wei
         taps.append(pins_from_taps(hotpath.TAPS))
         hotpath.TAPS = None
         return r
+    if l1_reg > 0:
+        L.l1Loss(lm.reg_params, l1_reg, lm)
+    if l2_reg > 0:
+        L.l2Loss(lm.reg_params, l2_reg, lm)
     if "autoencoder" in losses:
         (states, dec), (next_states, next_dec) = fwd(obs), fwd(next_obs)
+    elif "dae" in losses:
+        (states, dec), (next_states, next_dec) = fwd(noisy[0].to(dev)), fwd(noisy[1].to(dev))
     elif "vae" in losses:
         it = iter(eps_list)
         model.model.eps_fn = lambda mu: next(it).to(mu.device)
@@ -74,8 +84,11 @@ def hip_step(model, losses, obs, next_obs, actions, eps_list=None, beta=1.0, wei
         L.forwardModelLoss(model.forwardModel(states, act), next_states, weight=w["forward"], loss_manager=lm)
     if "inverse" in losses:
         L.inverseModelLoss(model.inverseModel(states, next_states), act, weight=w["inverse"], loss_manager=lm)
-    if "autoencoder" in losses:
-        L.autoEncoderLoss(obs, dec, next_obs, next_dec, weight=w["autoencoder"], loss_manager=lm)
+    if "reward" in losses:
+        L.rewardModelLoss(model.rewardModel(states, next_states), rewards.to(dev), weight=w["reward"], loss_manager=lm)
+    if "autoencoder" in losses or "dae" in losses:
+        L.autoEncoderLoss(obs, dec, next_obs, next_dec, weight=w["dae" if "dae" in losses else "autoencoder"],
+                          loss_manager=lm)
     if "vae" in losses:
         L.kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager=lm, beta=beta)
         L.generationLoss(dec, next_dec, obs, next_obs, weight=w["vae"], loss_manager=lm)
@@ -131,31 +144,54 @@ NOISE_GRADS = ("decoder_conv.0.bias", "decoder_conv.3.bias", "decoder_conv.6.bia
 
 @pytest.mark.parametrize("name,losses,B,C,inverse", CASES)
 def test_step_matches_oracle_and_golden(name, losses, B, C, inverse):
+    _check_case(name, gu.ext_defaults(dict(losses=losses, B=B, C=C, inverse=inverse)))
+
+
+@pytest.mark.parametrize("name", sorted(gu.ext_cases().keys()))
+def test_split_reward_reg_step_matches_oracle_and_golden(name):
+    """SRLModulesSplit (column-masked states), reward head + loss, l1/l2 regularisers, DAE inputs —
+    the first case is the reference's own stacked-model test configuration (tests/test_modules.py:8-19)."""
+    cfg = gu.ext_defaults(gu.ext_cases()[name])
+    cfg.setdefault("C", 3)
+    _check_case(name, cfg)
+
+
+def _check_case(name, cfg):
     from oracle import torch_twin as T
+    losses, B, C, inverse, S, split = cfg["losses"], cfg["B"], cfg["C"], cfg["inverse"], cfg["S"], cfg["split"]
     g = gu.load(name)
-    obs, next_obs, actions = gu.golden_inputs(B, C, 6, seed=1234)
-    obs, next_obs, actions = torch.from_numpy(obs), torch.from_numpy(next_obs), torch.from_numpy(actions)
-    model = build(losses, C=C, inverse=inverse)
+    obs_np, next_obs_np, actions = gu.golden_inputs(B, C, 6, seed=1234)
+    obs, next_obs, actions = torch.from_numpy(obs_np), torch.from_numpy(next_obs_np), torch.from_numpy(actions)
+    model = build(losses, C=C, S=S, inverse=inverse, split=split)
     init = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
     init64 = OrderedDict((k, v.double() if v.is_floating_point() else v.clone()) for k, v in init.items())
     sd0 = T.clone_state(init)
     eps = None
     if "vae" in losses:
         torch.manual_seed(99)
-        eps = [torch.randn(B, 200), torch.randn(B, 200)]  # same draws as std.new(...).normal_() in the reference
+        eps = [torch.randn(B, S), torch.randn(B, S)]  # same draws as std.new(...).normal_() in the reference
+    rewards = torch.from_numpy(gu.golden_rewards(B, seed=1234)[1]) if "reward" in losses else None
+    noisy = None
+    if "dae" in losses:
+        noisy = (torch.from_numpy(gu.golden_noisy(obs_np, seed=1234)), torch.from_numpy(gu.golden_noisy(next_obs_np, seed=4321)))
+    extra = dict(weights=cfg["weights"], split=split, rewards=rewards, l1_reg=cfg["l1_reg"], l2_reg=cfg["l2_reg"])
+
+    def dbl(pair):
+        return (None, None) if pair is None else (pair[0].double(), pair[1].double())
     ref = T.train_step(sd0, losses, obs, next_obs, actions, eps=None if eps is None else eps[0],
-                       next_eps=None if eps is None else eps[1])
+                       next_eps=None if eps is None else eps[1], noisy=noisy if noisy else (None, None), **extra)
     sd64 = T.clone_state(init64)
     ref64 = T.train_step(sd64, losses, obs.double(), next_obs.double(), actions,
                          eps=None if eps is None else eps[0].double(),
-                         next_eps=None if eps is None else eps[1].double())
+                         next_eps=None if eps is None else eps[1].double(), noisy=dbl(noisy), **extra)
     model = model.to("cuda")
-    got = hip_step(model, losses, obs, next_obs, actions, eps_list=eps)
+    got = hip_step(model, losses, obs, next_obs, actions, eps_list=eps, weights=cfg["weights"], rewards=rewards,
+                   l1_reg=cfg["l1_reg"], l2_reg=cfg["l2_reg"], noisy=noisy)
     # fp64 oracle at the HIP path's own ReLU / max-pool decisions
     sd64p = T.clone_state(init64)
     ref64p = T.train_step(sd64p, losses, obs.double(), next_obs.double(), actions,
                           eps=None if eps is None else eps[0].double(),
-                          next_eps=None if eps is None else eps[1].double(), pins=got["pins"])
+                          next_eps=None if eps is None else eps[1].double(), pins=got["pins"], noisy=dbl(noisy), **extra)
 
     # (a) against the oracle twin
     for k, v in ref["losses"].items():
@@ -213,10 +249,11 @@ def test_step_matches_oracle_and_golden(name, losses, B, C, inverse):
         assert np.linalg.norm(d["sub"] - sub) <= 5e-2 * max(np.linalg.norm(sub), 1e-30), k
 
     # the decisions themselves: HIP vs the fp64 oracle's own — differ only at near-ties, i.e. almost never
-    is_ae = "autoencoder" in losses
-    prefix = "model.encoder_conv" if ("autoencoder" in losses or "vae" in losses) else "model.conv_layers"
-    for x, pins in ((obs, got["pins"][0]), (next_obs, got["pins"][1])):
-        od = T.oracle_decisions(init64, x.double(), prefix=prefix, decoder=is_ae)
+    is_ae = "autoencoder" in losses or "dae" in losses
+    prefix = "model.encoder_conv" if (is_ae or "vae" in losses) else "model.conv_layers"
+    inputs = (obs, next_obs) if noisy is None else noisy
+    for x, pins in ((inputs[0], got["pins"][0]), (inputs[1], got["pins"][1])):
+        od = T.oracle_decisions(init64, x.double(), prefix=prefix, decoder=is_ae, split=split)
         total = flips = 0
         for name, v in od.items():
             if isinstance(v, tuple):

@@ -54,7 +54,7 @@ def import_reference():
     return th, ref_pre, SRLModules, ref_losses
 
 
-from golden_util import golden_inputs, tensor_digest, SUB  # noqa: E402
+from golden_util import golden_inputs, golden_rewards, golden_noisy, tensor_digest, SUB  # noqa: E402
 
 
 def digest_state_dict(sd):
@@ -69,10 +69,14 @@ def digest_state_dict(sd):
                 sums=np.array(sums), abss=np.array(abss))
 
 
-def build(th, ref_pre, SRLModules, losses, S=200, A=6, C=3, seed=1, inverse="linear"):
+def build(th, ref_pre, SRLModules, losses, S=200, A=6, C=3, seed=1, inverse="linear", split=None):
     ref_pre.N_CHANNELS = C
     np.random.seed(seed)
     th.manual_seed(seed)
+    if split is not None:
+        from models.modules import SRLModulesSplit  # the reference's
+        return SRLModulesSplit(state_dim=S, action_dim=A, cuda=False, model_type="custom_cnn", losses=losses,
+                               split_dimensions=split, inverse_model_type=inverse)
     return SRLModules(state_dim=S, action_dim=A, cuda=False, model_type="custom_cnn",
                       losses=losses, inverse_model_type=inverse)
 
@@ -93,10 +97,10 @@ def bn_digest(model, out, prefix="bn/"):
 
 
 def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1, lr=None,
-              eps_seed=99, beta=1.0, inverse="linear", weights=None):
+              eps_seed=99, beta=1.0, inverse="linear", weights=None, split=None, l1_reg=0.0, l2_reg=0.0):
     """One (or several) loop bodies of models/learner.py:373-497 driven on the reference classes."""
-    model = build(th, ref_pre, SRLModules, losses, S=S, A=A, C=C, inverse=inverse)
-    w = {"forward": 1.0, "inverse": 2.0, "autoencoder": 1.0, "vae": 0.5e-6}
+    model = build(th, ref_pre, SRLModules, losses, S=S, A=A, C=C, inverse=inverse, split=split)
+    w = {"forward": 1.0, "inverse": 2.0, "reward": 1.0, "autoencoder": 1.0, "dae": 1.0, "vae": 0.5e-6}
     if weights:
         w.update(weights)
     out = {}
@@ -115,8 +119,16 @@ def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1
             opt.zero_grad()
         lm.resetLosses()
         mu = logvar = None
+        if l1_reg > 0:
+            RL.l1Loss(lm.reg_params, l1_reg, lm)
+        if l2_reg > 0:
+            RL.l2Loss(lm.reg_params, l2_reg, lm)
         if "autoencoder" in losses:
             (states, dec), (next_states, next_dec) = model(obs), model(next_obs)
+        elif "dae" in losses:
+            noisy = th.from_numpy(golden_noisy(obs.numpy(), seed=1234 + step))
+            next_noisy = th.from_numpy(golden_noisy(next_obs.numpy(), seed=4321 + step))
+            (states, dec), (next_states, next_dec) = model(noisy), model(next_noisy)
         elif "vae" in losses:
             th.manual_seed(eps_seed + step)
             (dec, mu, logvar), (next_dec, next_mu, next_logvar) = model(obs), model(next_obs)
@@ -130,8 +142,13 @@ def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1
         if "inverse" in losses:
             logits = model.inverseModel(states, next_states)
             RL.inverseModelLoss(logits, act, weight=w["inverse"], loss_manager=lm)
-        if "autoencoder" in losses:
-            RL.autoEncoderLoss(obs, dec, next_obs, next_dec, weight=w["autoencoder"], loss_manager=lm)
+        if "reward" in losses:
+            _, rewards_st = golden_rewards(B, seed=1234 + step)
+            rewards_pred = model.rewardModel(states, next_states)
+            RL.rewardModelLoss(rewards_pred, th.from_numpy(rewards_st).long(), weight=w["reward"], loss_manager=lm)
+        if "autoencoder" in losses or "dae" in losses:
+            RL.autoEncoderLoss(obs, dec, next_obs, next_dec, weight=w["dae" if "dae" in losses else "autoencoder"],
+                               loss_manager=lm)
         if "vae" in losses:
             RL.kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager=lm, beta=beta)
             RL.generationLoss(dec, next_dec, obs, next_obs, weight=w["vae"], loss_manager=lm)
@@ -251,6 +268,38 @@ def head_kats(th, ref_pre, SRLModules):
     return out
 
 
+def detach_kats(th):
+    """SRLModulesSplit.detachSplit on an all-ones state for a list of split configurations: the kept-column mask per
+    (configuration, index).  Uses the reference's method unbound on a minimal stand-in object (it only reads
+    self.split_dimensions)."""
+    from collections import OrderedDict as OD
+    from models.modules import SRLModulesSplit
+    configs = [OD([("dae", 20), ("reward", -1), ("forward", 60), ("inverse", 20)]),
+               OD([("vae", 150), ("inverse", 50), ("forward", -1)]),
+               OD([("autoencoder", 120), ("reward", 80), ("inverse", -1)]),
+               OD([("autoencoder", 50), ("inverse", -1), ("forward", -1)]),
+               OD([("autoencoder", 30), ("inverse", -1), ("forward", -1), ("reward", 20)]),
+               OD([("inverse", 10), ("forward", 10), ("reward", 10)])]
+    out = {"n_configs": np.array(len(configs))}
+
+    class Holder(object):
+        pass
+    for ci, cfg in enumerate(configs):
+        S = sum(v for v in cfg.values() if v > 0)
+        h = Holder()
+        h.split_dimensions = cfg
+        out["cfg%d/keys" % ci] = np.array(list(cfg.keys()))
+        out["cfg%d/dims" % ci] = np.array(list(cfg.values()))
+        x = th.ones(2, S)
+        for index in list(cfg.keys()) + ["autoencoder", "vae", "absent"]:
+            try:
+                y = SRLModulesSplit.detachSplit(h, x, index)
+                out["cfg%d/mask/%s" % (ci, index)] = y[0].numpy().astype(np.int8)
+            except Exception as e:  # e.g. torch.cat of an empty list when nothing is kept and nothing is zeroed
+                out["cfg%d/error/%s" % (ci, index)] = np.array(type(e).__name__)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     th, ref_pre, SRLModules, RL = import_reference()
@@ -280,6 +329,22 @@ def main():
     save("trace_vae_b2", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, n_steps=3, lr=1e-4))
     save("trace_aeif_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2,
                                     n_steps=3, lr=1e-4))
+    # (3b) §8f-2/3: split representations (SRLModulesSplit), reward head + loss, l1/l2 regularisers, DAE inputs.
+    # The first case is the reference's own stacked-model test configuration (tests/test_modules.py:8-19) at B=4.
+    from collections import OrderedDict as OD
+    stacked = OD([("dae", 20), ("reward", -1), ("forward", 60), ("inverse", 20)])
+    stacked_w = {"dae": 1.0, "reward": 1.0, "forward": 1.0, "inverse": 5.0}
+    save("step_split_dae_rfi_b4", step_case(th, ref_pre, SRLModules, RL, list(stacked.keys()), B=4, S=100, inverse="mlp",
+                                            weights=stacked_w, split=stacked, l2_reg=0.0001))
+    save("trace_split_dae_rfi_b4", step_case(th, ref_pre, SRLModules, RL, list(stacked.keys()), B=4, S=100, inverse="mlp",
+                                             weights=stacked_w, split=stacked, l2_reg=0.0001, n_steps=3, lr=1e-4))
+    vsplit = OD([("vae", 150), ("inverse", 50), ("forward", -1)])
+    save("step_split_vae_if_b2", step_case(th, ref_pre, SRLModules, RL, list(vsplit.keys()), B=2, split=vsplit))
+    asplit = OD([("autoencoder", 120), ("reward", 80), ("inverse", -1)])
+    save("step_split_ae_ri_b2", step_case(th, ref_pre, SRLModules, RL, list(asplit.keys()), B=2, split=asplit))
+    save("step_ae_reward_l1_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "reward"], B=2, l1_reg=1e-5))
+    save("step_dae_b2", step_case(th, ref_pre, SRLModules, RL, ["dae"], B=2))
+    save("detach_kats", detach_kats(th))
     # (4) per-layer forward digests, loss KATs, head KATs
     save("layers_ae_b2", layer_trace(th, ref_pre, SRLModules))
     save("loss_kats", loss_kats(th, RL))
