@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void param_norms_grad_kernel(const float* cons
   float* g = gptrs[seg];
   const long long n = lens[seg];
   const float coef = (coef_dev ? coef_dev[0] : 1.f) * scale;
-  const float inv = mode == 1 ? 1.f / norms[seg] : 0.f;
+  const float inv = (mode == 1 && norms[seg] > 0.f) ? 1.f / norms[seg] : 0.f;  // torch: d||p||/dp = 0 at p = 0
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float v = p[i];
     g[i] = mode == 0 ? coef * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) : coef * (v * inv);

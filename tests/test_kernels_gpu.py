@@ -559,3 +559,39 @@ def test_fused_bn_backward_operand(C, n, hi, s, p, t, training):
         assert db.abs().max().item() < 1e-3 * da.abs().sum().item() / 64
     else:
         assert rel_err(db, br.grad) < 5e-5
+
+
+def test_mask_columns_and_param_norms(C):
+    """srlz_mask_columns (detachSplit) and srlz_param_norms / _grad (l1Loss, l2Loss) against torch, incl. edge cases:
+    empty kept range, full range, odd tensor lengths, an all-zero tensor under the 2-norm."""
+    from srlz import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(7, 100, generator=g)
+    for lo, hi in ((0, 0), (0, 100), (20, 80), (99, 100)):
+        xd = x.to(DEV).requires_grad_(True)
+        y = ops.MaskColumnsFn.apply(xd, lo, hi)
+        ref = torch.zeros_like(x)
+        ref[:, lo:hi] = x[:, lo:hi]
+        assert torch.equal(y.cpu(), ref)
+        y.backward(torch.ones_like(y))
+        gref = torch.zeros_like(x)
+        gref[:, lo:hi] = 1.0
+        assert torch.equal(xd.grad.cpu(), gref)
+    shapes = [(64, 3, 7, 7), (64,), (200, 2304), (1,), (13, 5), (33,)]
+    params = [torch.randn(*s, generator=g) for s in shapes]
+    params[3].zero_()
+    for mode in (0, 1):
+        pr = [p.double().requires_grad_(True) for p in params]
+        ref = sum(p.abs().sum() for p in pr) if mode == 0 else sum(p.norm(2) for p in pr) / len(pr)
+        (ref * 0.37).backward()
+        pd = [p.to(DEV).requires_grad_(True) for p in params]
+        out = ops.ParamNormFn.apply(mode, *pd)
+        (out * 0.37).backward()
+        torch.cuda.synchronize()
+        assert rel_err(out, ref) < 1e-6
+        for a, b in zip(pd, pr):
+            assert torch.isfinite(a.grad).all()
+            if b.grad.abs().max() == 0:
+                assert a.grad.abs().max().item() == 0.0
+            else:
+                assert rel_err(a.grad, b.grad) < 1e-6
