@@ -279,6 +279,9 @@ int srlz_adam_step(float* p, const float* g, float* m, float* v, long long n, fl
 int srlz_conv64_debug_program(const srlz_conv64_desc* d, int backward_data, int* out, int cap);
 /* Back-to-back fp32 MFMA on random operands (no memory traffic): the matrix rate the chip sustains under load. */
 int srlz_debug_mfma_peak(float* out, int blocks, int iters, srlz_stream_t stream);
+/* Debug: out[4*b..] = {XCC id, HW_ID register, start clock, end clock} of workgroup b of a launch whose workgroups each
+ * hold lds_bytes of LDS and spin for `spin` ticks (how the dispatcher places / replaces co-resident workgroups). */
+int srlz_debug_placement(unsigned* out, int blocks, int lds_bytes, int spin, srlz_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -56,3 +56,32 @@ extern "C" int srlz_debug_mfma_peak(float* out, int blocks, int iters, srlz_stre
   if (e != hipSuccess) return srlz_hip_fail(e, "mfma_peak launch");
   return 0;
 }
+
+// ---- placement probe: which XCD / SE / CU does workgroup b land on, and when?  (tools/placement.py) ----
+// out[b] = {xcc_id, hw_id, start clock (s_memtime low 32 bits), end clock}; every workgroup holds `lds_bytes` of LDS and
+// spins for `spin` clock ticks so that later workgroups must wait for a free slot.
+__global__ __launch_bounds__(256) void placement_kernel(unsigned* out, int spin) {
+  extern __shared__ unsigned char smem[];
+  if (threadIdx.x == 0) {
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while ((long long)(__builtin_readcyclecounter() - t0) < spin) { smem[0] = (unsigned char)spin; }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[4 * blockIdx.x + 0] = xcc;
+    out[4 * blockIdx.x + 1] = hwid;
+    out[4 * blockIdx.x + 2] = (unsigned)t0;
+    out[4 * blockIdx.x + 3] = (unsigned)t1;
+  }
+}
+
+extern "C" int srlz_debug_placement(unsigned* out, int blocks, int lds_bytes, int spin, srlz_stream_t stream) {
+  if (!out || blocks <= 0) { srlz_set_error("placement: bad arguments"); return SRLZ_ERR_BAD_DESC; }
+  hipError_t e = hipFuncSetAttribute((const void*)placement_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return srlz_hip_fail(e, "placement attribute");
+  hipLaunchKernelGGL(placement_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, out, spin);
+  e = hipGetLastError();
+  if (e != hipSuccess) return srlz_hip_fail(e, "placement launch");
+  return 0;
+}

@@ -56,6 +56,7 @@ _PROTOS = {
     "srlz_conv64_bwd_weight_workspace": (c_size_t, [_C64]),
     "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, _BO, P, c_size_t, _C64, P]),
     "srlz_conv64_debug_program": (c_int, [_C64, c_int, POINTER(c_int), c_int]),
+    "srlz_debug_placement": (c_int, [P, c_int, c_int, c_int, P]),
     "srlz_debug_mfma_peak": (c_int, [P, c_int, c_int, P]),
     "srlz_skinny_tiles": (c_int, [_SK]),
     "srlz_conv1_fwd": (c_int, [P, P, P, P, _SK, P]),

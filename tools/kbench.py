@@ -17,7 +17,7 @@ DEV = "cuda"
 N = int(os.environ.get("KB_N", "256"))
 
 
-def timeit(fn, reps=12, warm=3):
+def timeit(fn, reps=12, warm=25):  # long warm-up: the clock governor needs ~10 ms of load to settle
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

@@ -3,7 +3,7 @@
 tag=$1; shift
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-env "$@" rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_$tag -o p -- python tools/kbench.py "conv64 fwd" > gpurun_out/pmc_${tag}_kbench.txt 2>&1
+env "$@" rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_$tag -o p -- ${PMC_CMD:-python tools/kbench.py "conv64 fwd"} > gpurun_out/pmc_${tag}_cmd.txt 2>&1
 python - /tmp/pmc_$tag > gpurun_out/pmc_${tag}.txt <<'PY'
 import csv, glob, sys, collections
 cf = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
