@@ -134,9 +134,13 @@ int srlz_conv1_bwd_weight_fused(const float* x_nchw, const float* y_nhwc, const 
 int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
                        const float* x_bnp /* may be NULL, see srlz_conv64_fwd */, const srlz_skinny_desc* d,
                        srlz_stream_t stream);
-/* kind 1 data gradient: dx_nhwc [N,hf,wf,64] from dy_nchw. */
-int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc,
-                            const srlz_skinny_desc* d, srlz_stream_t stream);
+/* kind 1 data gradient: dx_nhwc [N,hf,wf,64] from dy_nchw.
+ * x_raw / x_bnp / bn_bwd_partial (all three or none): the layer input was relu(batchnorm(x_raw)) (models/models.py:79-81),
+ * so dx is dA of that BatchNorm+ReLU; the epilogue then also reads x_raw and writes, per 16x16 tile, the partial
+ * BatchNorm-backward sums  bn_bwd_partial[tile][0..64) = sum dA*[bn(x)>0],  [64..128) = sum dA*[bn(x)>0]*xhat
+ * (srlz_skinny_tiles(d) rows) for srlz_bn_bwd_finalize_partials — no separate pass over (dA, x_raw). */
+int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,
+                            const float* x_bnp, float* bn_bwd_partial, const srlz_skinny_desc* d, srlz_stream_t stream);
 /* kind 1 weight gradient: dw_ref [64,C,4,4], dbias [C]. */
 int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias,
                               const float* x_bnp, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
@@ -185,6 +189,10 @@ int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argma
                           srlz_stream_t stream);
 /* a = relu(y*scale+shift) over `pixels` x 64 */
 int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long long pixels, srlz_stream_t stream);
+/* Second stage for the per-tile partials of a data-gradient epilogue (srlz_convT_out_bwd_data, srlz_conv64_bwd_data):
+ * partial[n_partials][128] -> sums[128], dgamma[64], dbeta[64]; fp64 across tiles, fixed order. */
+int srlz_bn_bwd_finalize_partials(const float* partial, int n_partials, float* sums, float* dgamma, float* dbeta, void* ws,
+                                  size_t ws_bytes, srlz_stream_t stream);
 /* First half of srlz_bn_relu_bwd: sums[128] = {sum dz[64], sum dz*xhat[64]} (= dbeta, dgamma), for srlz_bn_bwd_operand. */
 int srlz_bn_relu_bwd_sums(const float* y, const float* bnp, const float* da, float* sums, float* dgamma, float* dbeta,
                           void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream);

@@ -540,6 +540,23 @@ static int bn_relu_bwd_sums_launch(const float* y, const float* bnp, const float
   return 0;
 }
 
+// Second stage for per-tile partials emitted by a data-gradient kernel's epilogue (srlz_convT_out_bwd_data with x_raw):
+// partial[n_partials][128] (fp32: sum dz, sum dz*xhat per tile) -> sums / dgamma / dbeta, fp64 across tiles.
+extern "C" int srlz_bn_bwd_finalize_partials(const float* partial, int n_partials, float* sums, float* dgamma, float* dbeta,
+                                             void* ws, size_t ws_bytes, srlz_stream_t stream) {
+  SRLZ_REQUIRE(partial && sums && ws, SRLZ_ERR_NULL, "bn_bwd_finalize_partials: null pointer");
+  SRLZ_REQUIRE(n_partials > 0, SRLZ_ERR_BAD_DESC, "bn_bwd_finalize_partials: empty reduction");
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_bwd_finalize_partials: workspace too small");
+  hipStream_t st = as_stream(stream);
+  double* staged = (double*)ws;
+  const int g = stage_blocks(n_partials);
+  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g), dim3(256), 0, st, partial, n_partials, staged);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, g, sums, dgamma, dbeta);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
 extern "C" int srlz_bn_relu_bwd_sums(const float* y, const float* bnp, const float* da, float* sums, float* dgamma,
                                      float* dbeta, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream) {
   SRLZ_REQUIRE(y && bnp && da && sums && ws, SRLZ_ERR_NULL, "bn_relu_bwd_sums: null pointer");

@@ -81,12 +81,17 @@ __device__ __forceinline__ void stage_image(float* __restrict__ T, const float* 
 // 256 threads, tile = 16x16 output pixels; wave w owns tile rows 4w..4w+3 (two 32-pixel M-tiles) x 64 channels.
 // Persistent over tiles; for C == 3 the 64 x KT weight matrix is staged in LDS once per workgroup.
 // ------------------------------------------------------------------------------------------------------------------
-template <int K, int PAD>
+template <int K, int PAD, bool BNBWD = false>
 __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __restrict__ img,
                                                             const float* __restrict__ w_ref,
                                                             float* __restrict__ feat,
                                                             float* __restrict__ stats_partial, int N, int C, int H,
-                                                            int W, int HF, int WF, int tiles_y, int tiles_x) {
+                                                            int W, int HF, int WF, int tiles_y, int tiles_x,
+                                                            const float* __restrict__ y_raw,
+                                                            const float* __restrict__ y_bnp) {
+  // BNBWD (data-gradient use, kind 1; y_raw != NULL): `feat` is dA = d(loss)/d(relu(bn(y_raw))) and the per-tile partials become
+  // the two BatchNorm-backward sums  sum dz  and  sum dz*xhat  (dz = dA*[bn(y)>0]) instead of  sum v  and  sum v^2 —
+  // the separate pass that re-reads dA and y (srlz_bn_relu_bwd_sums) disappears.
   constexpr int KT = Geo<K>::KT, KS = Geo<K>::KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* T = (float*)smem;                      // image window
@@ -125,6 +130,23 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // BNBWD: this lane's 2 x 32 values of y_raw are requested now and consumed in the epilogue, behind the tile's MFMAs
+    float yv[BNBWD ? 2 : 1][BNBWD ? 2 : 1][16];
+    if (BNBWD) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int oy = oy0 + wave * 4 + mt * 2 + (i >> 4), ox = ox0 + (i & 15);
+          float a0 = 0.f, a1 = 0.f;
+          if (oy < HF && ox < WF) {
+            const float* yp = y_raw + ((size_t)(n * HF + oy) * WF + ox) * 64 + l31;
+            a0 = yp[0]; a1 = yp[32];
+          }
+          yv[BNBWD ? mt : 0][0][r] = a0; yv[BNBWD ? mt : 0][BNBWD ? 1 : 0][r] = a1;
+        }
+    }
 
     for (int cg = 0; cg < ncg; ++cg) {
       __syncthreads();
@@ -143,6 +165,11 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
       }
     }
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    float mean0 = 0.f, mean1 = 0.f, inv0 = 0.f, inv1 = 0.f, sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f;
+    if (BNBWD) {
+      mean0 = y_bnp[l31]; mean1 = y_bnp[32 + l31]; inv0 = y_bnp[64 + l31]; inv1 = y_bnp[96 + l31];
+      sc0 = y_bnp[128 + l31]; sc1 = y_bnp[160 + l31]; sh0 = y_bnp[192 + l31]; sh1 = y_bnp[224 + l31];
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -153,7 +180,13 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
           const float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
           float* o = feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + l31;
           o[0] = v0; o[32] = v1;
-          s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1;
+          if (BNBWD) {
+            const float y0 = yv[BNBWD ? mt : 0][0][r], y1 = yv[BNBWD ? mt : 0][BNBWD ? 1 : 0][r];
+            if (y0 * sc0 + sh0 > 0.f) { s0 += v0; q0 += v0 * ((y0 - mean0) * inv0); }
+            if (y1 * sc1 + sh1 > 0.f) { s1 += v1; q1 += v1 * ((y1 - mean1) * inv1); }
+          } else {
+            s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1;
+          }
         }
       }
     if (stats_partial) {
@@ -521,13 +554,23 @@ static int persistent_grid(int ntiles) {
 }
 
 template <int K, int PAD>
-static int launch_conv(const float* img, const float* w, float* feat, float* stats, const srlz_skinny_desc* d, hipStream_t st) {
+static int launch_conv(const float* img, const float* w, float* feat, float* stats, const srlz_skinny_desc* d, hipStream_t st,
+                       const float* y_raw = nullptr, const float* y_bnp = nullptr) {
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
   const size_t lds = conv_lds<K>();
-  SRLZ_HIP(hipFuncSetAttribute((const void*)skinny_conv_kernel<K, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((skinny_conv_kernel<K, PAD>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
-                     d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx);
+  if constexpr (K == 4) if (y_raw) {
+    SRLZ_HIP(hipFuncSetAttribute((const void*)skinny_conv_kernel<K, PAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, true>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
+                       d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp);
+    SRLZ_LAUNCHED();
+    return 0;
+  }
+  {
+    SRLZ_HIP(hipFuncSetAttribute((const void*)skinny_conv_kernel<K, PAD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, false>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
+                       d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp);
+  }
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -621,13 +664,16 @@ extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const
   return 0;
 }
 
-extern "C" int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const srlz_skinny_desc* d,
+extern "C" int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,
+                                       const float* x_bnp, float* bn_bwd_partial, const srlz_skinny_desc* d,
                                        srlz_stream_t stream) {
   if (int rc = check_skinny(d)) return rc;
   SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_bwd_data: descriptor kind must be 1");
   SRLZ_REQUIRE(dy_nchw && w_ref && dx_nhwc, SRLZ_ERR_NULL, "convT_out_bwd_data: null pointer");
+  SRLZ_REQUIRE((x_raw != nullptr) == (x_bnp != nullptr) && (x_raw != nullptr) == (bn_bwd_partial != nullptr), SRLZ_ERR_NULL,
+               "convT_out_bwd_data: x_raw, x_bnp and bn_bwd_partial go together");
   // dx[n,iy,ix,ci] = sum_{co,ky,kx} dy[n,co,2iy+ky,2ix+kx] * w_ref[ci,co,ky,kx]  == a 4x4 s2 p0 "conv" of dy
-  return launch_conv<4, 0>(dy_nchw, w_ref, dx_nhwc, nullptr, d, as_stream(stream));
+  return launch_conv<4, 0>(dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, d, as_stream(stream), x_raw, x_bnp);
 }
 
 extern "C" int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias,

@@ -65,7 +65,8 @@ _PROTOS = {
     "srlz_conv1_bwd_weight_fused": (c_int, [P, P, P, P, P, P, c_int, P, P, c_size_t, _SK, _PD, P]),
     "srlz_bn_relu_pool_bwd_sums": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, _PD, P]),
     "srlz_convT_out_fwd": (c_int, [P, P, P, P, P, _SK, P]),
-    "srlz_convT_out_bwd_data": (c_int, [P, P, P, _SK, P]),
+    "srlz_convT_out_bwd_data": (c_int, [P, P, P, P, P, P, _SK, P]),
+    "srlz_bn_bwd_finalize_partials": (c_int, [P, c_int, P, P, P, P, c_size_t, P]),
     "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _SK, P]),
     "srlz_bn_finalize": (c_int, [P, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),

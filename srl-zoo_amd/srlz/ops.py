@@ -434,13 +434,28 @@ def _bn_relu_backward_sums(y, bnp, da):
     return sums, dgamma, dbeta
 
 
-def _bn_backward_for_producer(link, y_prev, bnp, da, training):
-    """BatchNorm+ReLU backward of the block input: deferred to the producer through `link`, or materialised."""
+def _bn_backward_for_producer(link, y_prev, bnp, da, training, partial=None):
+    """BatchNorm+ReLU backward of the block input: deferred to the producer through `link`, or materialised.
+    `partial`: per-tile partial sums already written by the epilogue of the kernel that produced `da`."""
     if link is not None:
-        sums, dgamma, dbeta = _bn_relu_backward_sums(y_prev, bnp, da)
+        if partial is not None:
+            sums, dgamma, dbeta = _bn_backward_sums_from_partials(partial)
+        else:
+            sums, dgamma, dbeta = _bn_relu_backward_sums(y_prev, bnp, da)
         link.put(y_prev, bnp, sums, training)
         return da, dgamma, dbeta
     return _bn_relu_backward(y_prev, bnp, da, training)
+
+
+def _bn_backward_sums_from_partials(partial):
+    dev = partial.device
+    sums = torch.empty(128, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(64, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(64, dtype=torch.float32, device=dev)
+    nbytes = C.bn_bwd_workspace(0)
+    ws = _ws(nbytes, dev)
+    C.bn_bwd_finalize_partials(ptr(partial), partial.shape[0], ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream())
+    return sums, dgamma, dbeta
 
 
 def _operand_from(link):
@@ -536,8 +551,13 @@ class DecOutFn(Function):
         with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
             C.convT_out_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream())
         da = torch.empty_like(y_prev)
-        C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), d, stream())
-        dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training)
+        # with the BatchNorm backward deferred (in_link), its two sums come out of this kernel's epilogue
+        partial = None
+        if ctx.in_link is not None:
+            partial = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=dy.device)
+        C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), ptr(y_prev) if partial is not None else None,
+                             ptr(bnp) if partial is not None else None, ptr(partial), d, stream())
+        dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial)
         side.join()
         return dy_prev, None, dgamma, dbeta, None, None, None, dw, db, None
 

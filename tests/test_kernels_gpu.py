@@ -160,7 +160,7 @@ def test_convT_out(C, n, c, hf):
     torch.cuda.synchronize()
     assert rel_err(y, yr) < 2e-5
     dx = torch.full((n, hf, hf, 64), float("nan"), device=DEV)
-    C.convT_out_bwd_data(C.ptr(dyd), C.ptr(wd), C.ptr(dx), d, st)
+    C.convT_out_bwd_data(C.ptr(dyd), C.ptr(wd), C.ptr(dx), None, None, None, d, st)
     torch.cuda.synchronize()
     assert rel_err(nchw(dx), xr.grad) < 2e-5
     nbytes = C.skinny_bwd_weight_workspace(d)
@@ -595,3 +595,35 @@ def test_mask_columns_and_param_norms(C):
                 assert a.grad.abs().max().item() == 0.0
             else:
                 assert rel_err(a.grad, b.grad) < 1e-6
+
+
+@pytest.mark.parametrize("n,c,hf", [(2, 3, 111), (1, 6, 37)])
+def test_convT_out_bwd_data_emits_bn_backward_sums(C, n, c, hf):
+    """The data-gradient epilogue's per-tile partials (x_raw given) reduce to the same BatchNorm-backward sums, dgamma and
+    dbeta as the stand-alone pass srlz_bn_relu_bwd_sums over (x_raw, dA)."""
+    g = torch.Generator().manual_seed(31 + hf)
+    himg = (hf - 1) * 2 + 4
+    x_raw = (torch.randn(n, hf, hf, 64, generator=g) * 1.3 + 0.2).to(DEV)
+    w = (torch.randn(64, c, 4, 4, generator=g) * 0.1).to(DEV)
+    dimg = torch.randn(n, c, himg, himg, generator=g).to(DEV)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    mean, var = x_raw.double().mean((0, 1, 2)).cpu(), x_raw.double().var((0, 1, 2), unbiased=False).cpu()
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    bnp = torch.cat((mean, invstd, gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd)).float().to(DEV)
+    d = C.SkinnyDesc(n, c, himg, himg, hf, hf, 1)
+    st = C.stream()
+    da0, da1 = torch.empty(n, hf, hf, 64, device=DEV), torch.empty(n, hf, hf, 64, device=DEV)
+    C.convT_out_bwd_data(C.ptr(dimg), C.ptr(w), C.ptr(da0), None, None, None, d, st)
+    partial = torch.full((C.skinny_tiles(d), 128), float("nan"), device=DEV)
+    C.convT_out_bwd_data(C.ptr(dimg), C.ptr(w), C.ptr(da1), C.ptr(x_raw), C.ptr(bnp), C.ptr(partial), d, st)
+    nb = C.bn_bwd_workspace(0)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    out = [[torch.empty(k, device=DEV) for k in (128, 64, 64)] for _ in range(2)]
+    C.bn_relu_bwd_sums(C.ptr(x_raw), C.ptr(bnp), C.ptr(da0), C.ptr(out[0][0]), C.ptr(out[0][1]), C.ptr(out[0][2]), C.ptr(ws), nb,
+                       n * hf * hf, st)
+    C.bn_bwd_finalize_partials(C.ptr(partial), partial.shape[0], C.ptr(out[1][0]), C.ptr(out[1][1]), C.ptr(out[1][2]), C.ptr(ws),
+                               nb, st)
+    torch.cuda.synchronize()
+    assert torch.equal(da0, da1)
+    for a, b in zip(out[0], out[1]):
+        assert rel_err(b, a) < 2e-5

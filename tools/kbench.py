@@ -99,7 +99,7 @@ def bench_skinny(sel):
                bytes_=4.0 * N * (111 * 111 * 64 + 3 * 224 * 224))
     dxf = torch.empty(N, 111, 111, 64, device=DEV)
     if sel("convT5 dgrad"):
-        report("convT5 4x4 s2 dgrad", *timeit(lambda: C.convT_out_bwd_data(C.ptr(dimg), C.ptr(wt), C.ptr(dxf), d1, st)), flop=flop1,
+        report("convT5 4x4 s2 dgrad", *timeit(lambda: C.convT_out_bwd_data(C.ptr(dimg), C.ptr(wt), C.ptr(dxf), None, None, None, d1, st)), flop=flop1,
                bytes_=4.0 * N * (111 * 111 * 64 + 3 * 224 * 224))
     nb1 = C.skinny_bwd_weight_workspace(d1)
     ws1 = torch.empty(nb1, dtype=torch.uint8, device=DEV)
