@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int BR = 16;
+constexpr int BR = 32;
 constexpr int LD = 68;  // 64 + 4 padding floats
 
 // blockIdx.z = split of the reduction range [z*rchunk, min(R, (z+1)*rchunk)); with gridDim.z > 1 the kernel writes
@@ -20,8 +20,10 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
                                                           const float* __restrict__ B, long long sbr, long long sbj,
                                                           const float* __restrict__ bias, float* __restrict__ C, int I,
                                                           int J, int R, int relu, int rchunk) {
-  __shared__ float As[BR][LD];
-  __shared__ float Bs[BR][LD];
+  // Double-buffered LDS tiles; the next r-step's global loads are issued before the current step's MFMAs and land in the
+  // other buffer after them: one barrier per step and the load latency sits behind the matrix work.
+  __shared__ float As[2][BR][LD];
+  __shared__ float Bs[2][BR][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int wi = wave & 1, wj = wave >> 1;
@@ -33,29 +35,50 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
   const int rbeg = blockIdx.z * rchunk;
   const int rend = (rbeg + rchunk < R) ? rbeg + rchunk : R;
   C += (size_t)blockIdx.z * I * J;
-  for (int r0 = rbeg; r0 < rend; r0 += BR) {
-    __syncthreads();
+  constexpr int U = BR * 64 / 256;  // elements of a 64 x BR tile per thread
+  float va[U], vb[U];
+  auto fetch = [&](int r0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + 256 * u;  // 1024 elements of a 64 x 16 tile
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + 256 * u;
       int i, r;
-      if (sar == 1) { i = e >> 4; r = e & 15; } else { r = e >> 6; i = e & 63; }
-      float v = 0.f;
-      if (i0 + i < I && r0 + r < rend) v = A[(long long)(i0 + i) * sai + (long long)(r0 + r) * sar];
-      As[r][i] = v;
+      if (sar == 1) { i = e / BR; r = e % BR; } else { r = e >> 6; i = e & 63; }
+      va[u] = 0.f;
+      if (i0 + i < I && r0 + r < rend) va[u] = A[(long long)(i0 + i) * sai + (long long)(r0 + r) * sar];
       int j, rb;
-      if (sbr == 1) { j = e >> 4; rb = e & 15; } else { rb = e >> 6; j = e & 63; }
-      float w = 0.f;
-      if (j0 + j < J && r0 + rb < rend) w = B[(long long)(r0 + rb) * sbr + (long long)(j0 + j) * sbj];
-      Bs[rb][j] = w;
+      if (sbr == 1) { j = e / BR; rb = e % BR; } else { rb = e >> 6; j = e & 63; }
+      vb[u] = 0.f;
+      if (j0 + j < J && r0 + rb < rend) vb[u] = B[(long long)(r0 + rb) * sbr + (long long)(j0 + j) * sbj];
     }
-    __syncthreads();
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + 256 * u;
+      int i, r;
+      if (sar == 1) { i = e / BR; r = e % BR; } else { r = e >> 6; i = e & 63; }
+      As[buf][r][i] = va[u];
+      int j, rb;
+      if (sbr == 1) { j = e / BR; rb = e % BR; } else { rb = e >> 6; j = e & 63; }
+      Bs[buf][rb][j] = vb[u];
+    }
+  };
+  fetch(rbeg);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rbeg; r0 < rend; r0 += BR) {
+    const bool more = r0 + BR < rend;
+    if (more) fetch(r0 + BR);
 #pragma unroll
     for (int s = 0; s < BR / 2; ++s) {
-      const float a = As[2 * s + h][wi * 32 + l31];
-      const float b = Bs[2 * s + h][wj * 32 + l31];
+      const float a = As[buf][2 * s + h][wi * 32 + l31];
+      const float b = Bs[buf][2 * s + h][wj * 32 + l31];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    if (more) stash(buf ^ 1);  // nobody reads buf^1 during this step (the barrier below closed the previous one)
+    __syncthreads();
+    buf ^= 1;
   }
   const int j = j0 + wj * 32 + l31;
   const float bj = (bias && j < J) ? bias[j] : 0.f;
@@ -82,13 +105,26 @@ __global__ void splitk_combine_kernel(const float* __restrict__ partial, int nsp
   C[e] = s;
 }
 
-// db[n] = sum_m dy[m][n]
-__global__ void colsum_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int m = 0; m < M; ++m) s += dy[(long long)m * N + n];
-  db[n] = s;
+// db[n] = sum_m dy[m][n]: block = 64 columns x 4 row slices, 4 independent accumulators per thread, fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int per = (M + 3) / 4;
+  const int m0 = part * per, m1 = (m0 + per < M) ? m0 + per : M;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int m = m0;
+    for (; m + 3 < m1; m += 4) {
+      s0 += dy[(long long)m * N + n];
+      s1 += dy[(long long)(m + 1) * N + n];
+      s2 += dy[(long long)(m + 2) * N + n];
+      s3 += dy[(long long)(m + 3) * N + n];
+    }
+    for (; m < m1; ++m) s0 += dy[(long long)m * N + n];
+  }
+  __shared__ float sm[4][64];
+  sm[part][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part == 0 && n < N) db[n] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 __global__ void relu_bwd_kernel(const float* __restrict__ y, float* __restrict__ dy, long long n) {
@@ -157,7 +193,7 @@ extern "C" int srlz_linear_bwd_weight(const float* dy, const float* x, float* dw
   SRLZ_REQUIRE(dy && x && dw, SRLZ_ERR_NULL, "linear_bwd_weight: null pointer");
   if (int rc = launch(dy, 1, N, x, K, 1, nullptr, dw, N, K, M, 0, ws, ws_bytes, as_stream(stream))) return rc;
   if (db) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), dy, db, M, N);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, as_stream(stream), dy, db, M, N);
     SRLZ_LAUNCHED();
   }
   return 0;
