@@ -272,6 +272,12 @@ int srlz_param_norms(const float* const* ptrs, const long long* lens, int nseg, 
 int srlz_param_norms_grad(const float* const* ptrs, float* const* gptrs, const long long* lens, int nseg, int mode,
                           const float* norms, const float* coef_dev, float scale, srlz_stream_t stream);
 
+/* Gradient delivery.  The weight-gradient kernels write each parameter's k-th contribution of a backward pass into
+ * stage k (stages = nstage copies of the flat bucket, each n floats); this call folds them into the bucket,
+ * grad[i] = ((grad[i] + stage0[i]) + stage1[i]) ..., and clears the stages.  One launch replaces autograd's per-parameter,
+ * per-contribution `grad += new` kernels (AccumulateGrad behind loss.backward(), models/learner.py:487-489). */
+int srlz_fold_grads(float* grad, float* stages, long long n, int nstage, srlz_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Adam over one flat parameter buffer — th.optim.Adam(params, lr) models/learner.py:199,495 (torch defaults).
  * step is 1-based; grad_scale multiplies g first (1/world_size after the RCCL sum).

@@ -200,6 +200,25 @@ __global__ __launch_bounds__(256) void param_norms_grad_kernel(const float* cons
   }
 }
 
+// g[i] = ((g[i] + s[0][i]) + s[1][i]) + ... ; s[k][i] = 0      (k < nstage, stage k at s + k*n)
+// The per-parameter gradient contributions of one backward pass are written by the weight-gradient kernels straight into
+// staging copies of the flat bucket (first contribution of a parameter -> stage 0, second -> stage 1, ...); this one
+// launch folds them into the bucket and clears the stages, replacing autograd's per-parameter `grad += new` kernels.
+__global__ __launch_bounds__(256) void fold_grads_kernel(float* __restrict__ g, float* __restrict__ s, long long n, int nstage) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = *(f32x4*)(g + 4 * i);
+    for (int k = 0; k < nstage; ++k) {
+      f32x4* p = (f32x4*)(s + (size_t)k * n + 4 * i);
+      const f32x4 t = *p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += t[e];
+      *p = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    *(f32x4*)(g + 4 * i) = v;
+  }
+}
+
 static int blocks_for(long long n, int cap) {
   long long b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -317,6 +336,15 @@ extern "C" int srlz_param_norms_grad(const float* const* ptrs, float* const* gpt
                nseg, mode);
   hipLaunchKernelGGL(param_norms_grad_kernel, dim3(64, nseg), dim3(256), 0, as_stream(stream), ptrs, gptrs, lens, mode, norms,
                      coef_dev, scale);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_fold_grads(float* grad, float* stages, long long n, int nstage, srlz_stream_t stream) {
+  SRLZ_REQUIRE(grad && stages, SRLZ_ERR_NULL, "fold_grads: null pointer");
+  SRLZ_REQUIRE(n > 0 && (n & 3) == 0 && nstage >= 1 && nstage <= 8, SRLZ_ERR_BAD_DESC,
+               "fold_grads: n=%lld (must be a multiple of 4) nstage=%d", n, nstage);
+  hipLaunchKernelGGL(fold_grads_kernel, dim3(blocks_for(n / 4, 2048)), dim3(256), 0, as_stream(stream), grad, stages, n, nstage);
   SRLZ_LAUNCHED();
   return 0;
 }

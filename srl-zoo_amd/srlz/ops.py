@@ -53,6 +53,34 @@ def timers_report():
     return rep
 
 
+# Direct gradient delivery (srlz.optim.FlatParams.grad_buffer / deliver): a parameter re-homed into the flat bucket
+# carries `_srlz_flat`; its weight-gradient kernel writes straight into a staging copy of the bucket and autograd gets
+# None, which removes one tiny `grad += new` launch per parameter and contribution.  SRLZ_DIRECT_GRADS=0 restores the
+# classic path (A/B, tests).
+_DIRECT_GRADS = __import__("os").environ.get("SRLZ_DIRECT_GRADS", "1") != "0"
+
+
+def _gbuf(param, shape=None, device=None):
+    """Output buffer for the gradient of `param` (a staging view when the parameter lives in a FlatParams bucket)."""
+    if param is not None and _DIRECT_GRADS:
+        home = getattr(param, "_srlz_flat", None)
+        if home is not None:
+            buf = home[0].grad_buffer(home[1])
+            if buf is not None:
+                buf._srlz_staged = True
+                return buf
+    if param is not None:
+        return torch.empty_like(param)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _give(param, grad):
+    """What a backward function returns to autograd for `param`: None when `grad` was written into a staging bucket."""
+    if grad is not None and getattr(grad, "_srlz_staged", False):
+        return None
+    return grad
+
+
 def _conv64_flop(d):
     # algorithmic FLOP (2 x MAC) of the layer: 9 taps x 64 x 64 per position of the low-resolution side
     pos = d.n * (d.hi * d.wi if d.transposed else d.ho * d.wo)
@@ -168,11 +196,11 @@ class Conv1Fn(Function):
         x, w = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "conv1 dy")
-        dw = torch.empty_like(w)
+        dw = _gbuf(w)
         nbytes = C.skinny_bwd_weight_workspace(d)
         ws = _ws(nbytes, x.device)
         C.conv1_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, d, stream())
-        return None, dw, None
+        return None, _give(w, dw), None
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -204,6 +232,7 @@ class Conv64Fn(Function):
         ctx.desc = d
         ctx.has_bias = bias is not None
         ctx.needs_dx = ctx.needs_input_grad[0]
+        ctx.params = (w, bias)
         if stats is None:
             stats = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(stats)
@@ -214,8 +243,8 @@ class Conv64Fn(Function):
         x, packs = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "conv64 dy")
-        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=x.device)
-        db = torch.empty(64, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        dw = _gbuf(ctx.params[0])
+        db = _gbuf(ctx.params[1]) if ctx.has_bias else None
         nbytes = C.conv64_bwd_weight_workspace(d)
         ws = _ws(nbytes, x.device, slot=1)
         with _OnSide(x.device, x, dy, dw, db, ws) as side:
@@ -228,7 +257,7 @@ class Conv64Fn(Function):
                     lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), None, d, stream()))
         ctx_side = side
         ctx_side.join()
-        return dx, dw, db, None, None, None, None
+        return dx, _give(ctx.params[0], dw), _give(ctx.params[1], db), None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -291,6 +320,7 @@ class BNReLUPoolFn(Function):
         if need_bwd:
             ctx.save_for_backward(y, bnp, argmax, pooled)
         ctx.desc, ctx.training = d, training
+        ctx.params = (gamma, beta)
         return pooled
 
     @staticmethod
@@ -298,13 +328,13 @@ class BNReLUPoolFn(Function):
         y, bnp, argmax, pooled = ctx.saved_tensors
         dpooled = _check(dpooled, "pool grad")
         dy = torch.empty_like(y)
-        dgamma = torch.empty(64, dtype=torch.float32, device=y.device)
-        dbeta = torch.empty(64, dtype=torch.float32, device=y.device)
+        dgamma = _gbuf(ctx.params[0])
+        dbeta = _gbuf(ctx.params[1])
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, y.device)
         C.bn_relu_pool_bwd(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(dy), ptr(dgamma), ptr(dbeta),
                            1 if ctx.training else 0, ptr(ws), nbytes, ctx.desc, stream())
-        return dy, None, dgamma, dbeta, None, None, None, None, None, None
+        return dy, None, _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None, None
 
 
 class EncInFn(Function):
@@ -333,6 +363,7 @@ class EncInFn(Function):
         if need_bwd:
             ctx.save_for_backward(y, bnp, argmax, pooled, x, w)
         ctx.desc, ctx.pdesc, ctx.training = d, pd, training
+        ctx.params = (gamma, beta)
         ctx.mark_non_differentiable(y)
         ctx.set_materialize_grads(False)  # no 0.8 GB zero tensor for the (non-differentiable) second output
         return pooled, y
@@ -342,19 +373,19 @@ class EncInFn(Function):
         y, bnp, argmax, pooled, x, w = ctx.saved_tensors
         dpooled = _check(dpooled, "pool grad")
         dev = y.device
-        dgamma = torch.empty(64, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(64, dtype=torch.float32, device=dev)
+        dgamma = _gbuf(ctx.params[0])
+        dbeta = _gbuf(ctx.params[1])
         sums = torch.empty(128, dtype=torch.float32, device=dev)
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, dev)
         C.bn_relu_pool_bwd_sums(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(sums), ptr(dgamma), ptr(dbeta),
                                 ptr(ws), nbytes, ctx.pdesc, stream())
-        dw = torch.empty_like(w)
+        dw = _gbuf(w)
         nbytes = C.skinny_bwd_weight_workspace(ctx.desc)
         ws = _ws(nbytes, dev)
         C.conv1_bwd_weight_fused(ptr(x), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums), 1 if ctx.training else 0,
                                  ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc, stream())
-        return None, dw, dgamma, dbeta, None, None, None, None, None
+        return None, _give(w, dw), _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None
 
 
 class BNReLUFn(Function):
@@ -376,8 +407,8 @@ class BNReLUFn(Function):
         y, bnp = ctx.saved_tensors
         da = _check(da, "bn grad")
         dy = torch.empty_like(y)
-        dgamma = torch.empty(64, dtype=torch.float32, device=y.device)
-        dbeta = torch.empty(64, dtype=torch.float32, device=y.device)
+        dgamma = _gbuf(None, 64, y.device)
+        dbeta = _gbuf(None, 64, y.device)
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, y.device)
         C.bn_relu_bwd(ptr(y), ptr(bnp), ptr(da), ptr(dy), ptr(dgamma), ptr(dbeta), 1 if ctx.training else 0, ptr(ws),
@@ -390,10 +421,10 @@ class BNReLUFn(Function):
 # (models/models.py:67-82: BatchNorm2d -> ReLU -> ConvTranspose2d).  Input = RAW output of the previous transposed
 # convolution + its BatchNorm statistics; the activated tensor relu(bn(y)) is never written to memory.
 # ----------------------------------------------------------------------------------------------------------------
-def _bn_relu_backward(y, bnp, da, training):
+def _bn_relu_backward(y, bnp, da, training, gb=(None, None)):
     dy = torch.empty_like(y)
-    dgamma = torch.empty(64, dtype=torch.float32, device=y.device)
-    dbeta = torch.empty(64, dtype=torch.float32, device=y.device)
+    dgamma = _gbuf(gb[0], 64, y.device)
+    dbeta = _gbuf(gb[1], 64, y.device)
     nbytes = C.bn_bwd_workspace(0)
     ws = _ws(nbytes, y.device)
     C.bn_relu_bwd(ptr(y), ptr(bnp), ptr(da), ptr(dy), ptr(dgamma), ptr(dbeta), 1 if training else 0, ptr(ws), nbytes,
@@ -422,11 +453,11 @@ class BwdLink:
         return rec
 
 
-def _bn_relu_backward_sums(y, bnp, da):
+def _bn_relu_backward_sums(y, bnp, da, gb=(None, None)):
     dev = y.device
     sums = torch.empty(128, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(64, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(64, dtype=torch.float32, device=dev)
+    dgamma = _gbuf(gb[0], 64, dev)
+    dbeta = _gbuf(gb[1], 64, dev)
     nbytes = C.bn_bwd_workspace(0)
     ws = _ws(nbytes, dev)
     C.bn_relu_bwd_sums(ptr(y), ptr(bnp), ptr(da), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, y.numel() // 64,
@@ -434,24 +465,24 @@ def _bn_relu_backward_sums(y, bnp, da):
     return sums, dgamma, dbeta
 
 
-def _bn_backward_for_producer(link, y_prev, bnp, da, training, partial=None):
+def _bn_backward_for_producer(link, y_prev, bnp, da, training, partial=None, gb=(None, None)):
     """BatchNorm+ReLU backward of the block input: deferred to the producer through `link`, or materialised.
     `partial`: per-tile partial sums already written by the epilogue of the kernel that produced `da`."""
     if link is not None:
         if partial is not None:
-            sums, dgamma, dbeta = _bn_backward_sums_from_partials(partial)
+            sums, dgamma, dbeta = _bn_backward_sums_from_partials(partial, gb)
         else:
-            sums, dgamma, dbeta = _bn_relu_backward_sums(y_prev, bnp, da)
+            sums, dgamma, dbeta = _bn_relu_backward_sums(y_prev, bnp, da, gb)
         link.put(y_prev, bnp, sums, training)
         return da, dgamma, dbeta
-    return _bn_relu_backward(y_prev, bnp, da, training)
+    return _bn_relu_backward(y_prev, bnp, da, training, gb)
 
 
-def _bn_backward_sums_from_partials(partial):
+def _bn_backward_sums_from_partials(partial, gb=(None, None)):
     dev = partial.device
     sums = torch.empty(128, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(64, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(64, dtype=torch.float32, device=dev)
+    dgamma = _gbuf(gb[0], 64, dev)
+    dbeta = _gbuf(gb[1], 64, dev)
     nbytes = C.bn_bwd_workspace(0)
     ws = _ws(nbytes, dev)
     C.bn_bwd_finalize_partials(ptr(partial), partial.shape[0], ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream())
@@ -491,6 +522,7 @@ class DecBlockFn(Function):
         ctx.save_for_backward(y_prev, bnp, packs)
         ctx.desc, ctx.training = d, training
         ctx.in_link, ctx.out_link = in_link, out_link
+        ctx.params = (gamma, beta, w, bias)
         if stats is None:
             stats = torch.empty(0, device=y_prev.device)
         ctx.mark_non_differentiable(stats)
@@ -510,17 +542,18 @@ class DecBlockFn(Function):
                 _conv64_flop(d), lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(da), dy_bn, d, stream()))
         if dy_true is not None:
             dy = dy_true
-        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=dy.device)
-        db = torch.empty(64, dtype=torch.float32, device=dy.device)
+        dw = _gbuf(ctx.params[2])
+        db = _gbuf(ctx.params[3], 64, dy.device)
         nbytes = C.conv64_bwd_weight_workspace(d)
         ws = _ws(nbytes, dy.device, slot=1)
         with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
             _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
                     lambda: C.conv64_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), None, ptr(ws), nbytes, d,
                                                 stream()))
-        dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training)
+        dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, gb=ctx.params[:2])
         side.join()
-        return dy_prev, None, dgamma, dbeta, None, None, None, dw, db, None, None, None
+        gp, bp, wp, cp = ctx.params
+        return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(wp, dw), _give(cp, db), None, None, None
 
 
 class DecOutFn(Function):
@@ -537,6 +570,7 @@ class DecOutFn(Function):
         C.convT_out_fwd(ptr(y_prev), ptr(w), ptr(bias), ptr(y), ptr(bnp), d, stream())
         ctx.save_for_backward(y_prev, bnp, w)
         ctx.desc, ctx.training, ctx.in_link = d, training, in_link
+        ctx.params = (gamma, beta, bias)
         return y
 
     @staticmethod
@@ -544,8 +578,8 @@ class DecOutFn(Function):
         y_prev, bnp, w = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "decoder output dy")
-        dw = torch.empty_like(w)
-        db = torch.empty(d.c, dtype=torch.float32, device=dy.device)
+        dw = _gbuf(w)
+        db = _gbuf(ctx.params[2], d.c, dy.device)
         nbytes = C.skinny_bwd_weight_workspace(d)
         ws = _ws(nbytes, dy.device, slot=1)
         with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
@@ -557,9 +591,10 @@ class DecOutFn(Function):
             partial = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=dy.device)
         C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), ptr(y_prev) if partial is not None else None,
                              ptr(bnp) if partial is not None else None, ptr(partial), d, stream())
-        dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial)
+        dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial, gb=ctx.params[:2])
         side.join()
-        return dy_prev, None, dgamma, dbeta, None, None, None, dw, db, None
+        gp, bp, cp = ctx.params
+        return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(w, dw), _give(cp, db), None
 
 
 def bn_relu_materialise(y, bnp_source):
@@ -585,6 +620,7 @@ class LinearFn(Function):
         C.linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), m, n, k, 1 if relu else 0, ptr(ws), nbytes, stream())
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.relu, ctx.has_bias, ctx.needs_dx = relu, b is not None, ctx.needs_input_grad[0]
+        ctx.params = (b,)
         return y
 
     @staticmethod
@@ -602,10 +638,10 @@ class LinearFn(Function):
         if ctx.needs_dx:
             dx = torch.empty_like(x)
             C.linear_bwd_data(ptr(dy), ptr(w), ptr(dx), m, n, k, ptr(ws), nbytes, stream())
-        dw = torch.empty_like(w)
-        db = torch.empty(n, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        dw = _gbuf(w)
+        db = _gbuf(ctx.params[0]) if ctx.has_bias else None
         C.linear_bwd_weight(ptr(dy), ptr(x), ptr(dw), ptr(db), m, n, k, ptr(ws), nbytes, stream())
-        return dx, dw, db, None
+        return dx, _give(w, dw), _give(ctx.params[0], db), None
 
 
 class MaskColumnsFn(Function):
@@ -819,6 +855,10 @@ def normalize_u8(frames):
     out = torch.empty((n, c, w, h), dtype=torch.float32, device=frames.device)
     C.normalize_u8(ptr(frames), ptr(out), n, h, w, c, stream())
     return out
+
+
+def fold_grads(grad, stages):
+    C.fold_grads(ptr(grad), ptr(stages), grad.numel(), stages.shape[0], stream())
 
 
 def adam_step(p, g, m, v, lr, step, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):

@@ -29,14 +29,46 @@ class FlatParams(object):
         self.grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.params, self.offsets = params, offsets
         with torch.no_grad():
-            for p, off in zip(params, offsets):
+            for i, (p, off) in enumerate(zip(params, offsets)):
                 n = p.numel()
                 self.flat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
+                p._srlz_flat = (self, i)  # lets srlz.ops write gradient contributions into the staging buckets
+        # -- direct gradient delivery -------------------------------------------------------------------------------
+        # autograd would run one `grad += new` kernel per parameter and contribution (two frames -> ~70 tiny launches
+        # per step).  Instead the ops' backward functions ask grad_buffer() where to let their kernels write a
+        # parameter's gradient (k-th request of a pass -> stage k, a copy of the bucket at a FIXED address), return None
+        # to autograd, and deliver() folds the stages into the bucket with one launch that also clears them.
+        self.stage = torch.zeros((self.NSTAGE, total), dtype=torch.float32, device=device)
+        self._served = [0] * len(params)
+        self._dirty = False
+
+    NSTAGE = 2
+
+    def grad_buffer(self, index):
+        """Where the next gradient contribution of parameter `index` should be written, or None (all stages used in this
+        pass: the caller allocates and returns the gradient to autograd as usual)."""
+        k = self._served[index]
+        if k >= self.NSTAGE:
+            return None
+        self._served[index] = k + 1
+        self._dirty = True
+        p, off = self.params[index], self.offsets[index]
+        return self.stage[k, off:off + p.numel()].view(p.shape)
+
+    def deliver(self):
+        """Fold the staged contributions into the flat gradient (idempotent; call after backward)."""
+        if self._dirty:
+            ops.fold_grads(self.grad, self.stage)
+            self._dirty = False
 
     def zero_grad(self):
         self.grad.zero_()
+        if self._dirty:  # a backward pass whose gradients were never delivered (validation minibatch)
+            self.stage.zero_()
+            self._dirty = False
+        self._served = [0] * len(self.params)
         # autograd accumulates in place into an existing .grad, so the views persist; re-attach if someone dropped them
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
@@ -61,6 +93,7 @@ class FusedAdam(object):
         self.fp.zero_grad()
 
     def step(self, grad_scale=1.0):
+        self.fp.deliver()
         self.t += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.t, grad_scale, self.betas, self.eps)
 
@@ -73,6 +106,7 @@ def world():
 
 def allreduce_gradients(flat_params):
     """One all-reduce (sum) of the whole gradient bucket; returns the scale Adam must apply (1/world_size)."""
+    flat_params.deliver()
     rank, size = world()
     if size == 1:
         return 1.0

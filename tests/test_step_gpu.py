@@ -342,3 +342,52 @@ def test_deferred_bn_backward_equals_materialised(losses):
     for k, ref in plain.items():
         # (biases in front of a train-mode BatchNorm have an exactly-zero gradient: both sides hold rounding noise ~1e-9)
         assert (fused[k] - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-7, k
+
+
+def test_direct_gradient_delivery_is_bitwise_identical():
+    """FlatParams.grad_buffer/deliver (gradients written into staging buckets, folded by one launch) must give
+    exactly the bucket autograd's per-parameter `grad += new` kernels build: same values, same summation order."""
+    import numpy as np
+    import torch
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModules
+    import losses.losses as L
+    from srlz import ops, optim
+    import golden_util as gu
+    losses = ["autoencoder", "inverse", "forward", "reward"]
+
+    def bucket(direct):
+        old = ops._DIRECT_GRADS
+        ops._DIRECT_GRADS = direct
+        try:
+            pre.N_CHANNELS = 3
+            np.random.seed(5)
+            torch.manual_seed(5)
+            model = SRLModules(state_dim=200, action_dim=6, cuda=True, model_type="custom_cnn", losses=losses).to("cuda:0")
+            flat = optim.FlatParams(model)
+            model.train()
+            lm = L.LossManager(model, None)
+            obs, next_obs, actions = gu.golden_inputs(4, 3, 6, seed=77)
+            o, no = torch.from_numpy(obs).cuda(), torch.from_numpy(next_obs).cuda()
+            act = torch.from_numpy(actions).view(-1, 1).cuda()
+            rew = torch.from_numpy(gu.golden_rewards(4, seed=77)[1]).cuda()
+            flat.zero_grad()
+            (s, dec), (ns, ndec) = model(o), model(no)
+            L.l2Loss(lm.reg_params, 1e-4, lm)
+            L.forwardModelLoss(model.forwardModel(s, act), ns, weight=1.0, loss_manager=lm)
+            L.inverseModelLoss(model.inverseModel(s, ns), act, weight=2.0, loss_manager=lm)
+            L.rewardModelLoss(model.rewardModel(s, ns), rew, weight=1.0, loss_manager=lm)
+            L.autoEncoderLoss(o, dec, no, ndec, weight=1.0, loss_manager=lm)
+            lm.computeTotalLoss().backward()
+            pending = sum(flat._served)
+            flat.deliver()
+            torch.cuda.synchronize()
+            return flat.grad.clone(), pending
+        finally:
+            ops._DIRECT_GRADS = old
+
+    classic, n0 = bucket(False)
+    direct, n1 = bucket(True)
+    assert n0 == 0 and n1 > 60  # every conv / BN / linear parameter of both frames was written into a staging bucket
+    assert classic.abs().max().item() > 0
+    assert torch.equal(classic, direct)
