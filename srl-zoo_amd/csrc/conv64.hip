@@ -481,6 +481,169 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-gradient kernel, ring version (programs with ONE source class: stride-1 conv, transposed conv).
+// Same GEMM as above, but
+//  * a workgroup walks a CONTIGUOUS range of chunks and keeps the source rows in a 256-row LDS ring: consecutive
+//    chunks share TK+span-64 of their TK+span rows (span = 116 for conv2), so each chunk only fetches 64 new source rows
+//    instead of 180 (121 -> 64 for the transposed convolutions);
+//  * the new source rows and the next gradient rows are requested into registers BEFORE the chunk's MFMA loop and
+//    written to LDS after it: their latency sits behind the matrix work (two barriers per group remain).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RING = 256;  // rows; >= TK + span + (prefetched TK rows are written only after the readers' barrier)
+
+// rows [qstart, qstart+64) of class `cls`: 4 rows per thread (16 apart) into registers; okmask bit j = row j in bounds
+__device__ __forceinline__ void rows64_load(f32x4 (&v)[4], unsigned& okmask, const float* __restrict__ src, int H, int W,
+                                            int stride, int cls, int PW, int PH, int total_q, int qstart) {
+  const int t = threadIdx.x, slot = t & 15;
+  const int cy = cls >> 1, cx = cls & 1;
+  const int PHW = PH * PW;
+  const int sa = 16 / PW, sb = 16 - sa * PW;
+  const int qq = qstart + (t >> 4) + PHW;  // shifted by one image: non-negative for the first rows of the first chunk
+  int n1 = qq / PHW;
+  int rem = qq - n1 * PHW;
+  int a = rem / PW;
+  int b = rem - a * PW;
+  const int N1max = total_q / PHW;
+  okmask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int y = a * stride + cy, x = b * stride + cx;
+    const bool ok = n1 >= 1 && n1 <= N1max && y < H && x < W;
+    okmask |= (ok ? 1u : 0u) << j;
+    if (ok) v[j] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
+    b += sb; a += sa;
+    if (b >= PW) { b -= PW; ++a; }
+    if (a >= PH) { a -= PH; ++n1; }
+  }
+}
+
+// registers -> LDS rows (row index of this thread's j-th row = rbase + 16*j, masked with `mask` for the ring);
+// bnp != NULL: relu(batchnorm(.)) applied to in-bounds rows on the way (OpFuse forward fusion)
+__device__ __forceinline__ void rows64_store(float* __restrict__ lds, int rbase, int mask, f32x4 (&v)[4], unsigned okmask,
+                                             const float* __restrict__ bnp) {
+  const int t = threadIdx.x, slot = t & 15;
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (bnp && ((okmask >> j) & 1u)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = z > 0.f ? z : 0.f; }
+    }
+    const int R = (rbase + (t >> 4) + 16 * j) & mask;
+    *(f32x4*)(lds + R * 64 + slot * 4) = v[j];
+  }
+}
+
+template <bool S2>
+__global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ g,
+                                                                  float* __restrict__ partial, const ConvProg P,
+                                                                  int nchunks, int chunks_per_wg,
+                                                                  const float* __restrict__ x_bnp) {
+  constexpr int TK = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Ss = (float*)smem;        // ring: source row q lives at slot (q & 255)
+  float* Gs = Ss + RING * 64;      // TK x 64: gradient rows of the current (chunk, destination class)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mi = wave & 1, nj = wave >> 1;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  constexpr int NG = S2 ? 4 : 1;
+  constexpr int GSTART[5] = {0, S2 ? 4 : 9, 6, 8, 9};
+  const int cs = P.tsrc[0];  // the single source class
+
+  const int c_begin = blockIdx.x * chunks_per_wg;
+  const int c_end = (c_begin + chunks_per_wg < nchunks) ? c_begin + chunks_per_wg : nchunks;
+  if (c_begin < c_end) {
+    // prologue: source rows [q0+min_off, q0+min_off+TK+span) of the first chunk, gradient rows of its first class
+    const int q0 = c_begin * TK;
+    f32x4 v[4];
+    unsigned ok;
+    for (int r0 = 0; r0 < TK + P.span; r0 += 64) {
+      rows64_load(v, ok, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0);
+      rows64_store(Ss, q0 + P.min_off + r0, RING - 1, v, ok, x_bnp);
+    }
+    rows64_load(v, ok, g, P.Hd, P.Wd, P.ds, P.tdst[0], P.PW, P.PH, P.total_q, q0);
+    rows64_store(Gs, 0, 0xffff, v, ok, nullptr);
+  }
+  __syncthreads();
+
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const int q0 = chunk * TK;
+    const bool last_chunk = chunk + 1 >= c_end;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int t0 = GSTART[gi], t1 = GSTART[gi + 1];
+      const bool last_group = gi == NG - 1;
+      // ---- requests for what the NEXT step needs: the next class's gradient rows; at the last group of a chunk also the
+      //      64 new source rows of the next chunk (they overwrite ring slots nobody reads after this chunk)
+      f32x4 pg[4], ps[4];
+      unsigned okg = 0, oks = 0;
+      const bool want_g = !(last_group && last_chunk);
+      const bool want_s = last_group && !last_chunk;
+      if (want_g) {
+        const int nq0 = last_group ? q0 + TK : q0;
+        const int ncls = last_group ? P.tdst[0] : P.tdst[GSTART[gi + 1]];
+        rows64_load(pg, okg, g, P.Hd, P.Wd, P.ds, ncls, P.PW, P.PH, P.total_q, nq0);
+      }
+      if (want_s) rows64_load(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span);
+      // ---- this group's work
+      {
+        const int col = tid & 63, part = tid >> 6;
+#pragma unroll
+        for (int r = 0; r < TK / 4; ++r) bsum += Gs[(part * (TK / 4) + r) * 64 + col];
+      }
+      const float* gcol = Gs + nj * 32 + l31;
+      const float* scol = Ss + mi * 32 + l31;
+#pragma unroll 4
+      for (int ks = 0; ks < TK / 2; ++ks) {
+        const int row = 2 * ks + h;
+        const float bfrag = gcol[row * 64];
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {
+          const float afrag = scol[((q0 + row + P.toff[t]) & (RING - 1)) * 64];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[t], 0, 0, 0);
+        }
+      }
+      // ---- land the prefetched rows
+      __syncthreads();
+      if (want_g) rows64_store(Gs, 0, 0xffff, pg, okg, nullptr);
+      if (want_s) rows64_store(Ss, q0 + P.min_off + TK + P.span, RING - 1, ps, oks, x_bnp);
+      __syncthreads();
+    }
+  }
+  // partial[wg][9 (reference tap index)][64 ci][64 co] + [wg][64] bias sums after all workgroups' tap blocks
+  float* out = partial + (size_t)blockIdx.x * (NTAPS * 4096);
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t) {
+    float* o = out + (size_t)P.tw[t] * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      o[row * 64 + nj * 32 + l31] = acc[t][r];
+    }
+  }
+  float* red = Ss;
+  red[tid] = bsum;
+  __syncthreads();
+  if (tid < 64) {
+    float* bout = partial + (size_t)gridDim.x * (NTAPS * 4096) + (size_t)blockIdx.x * 64;
+    bout[tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+  }
+}
+
 // dw_ref[...] = sum over workgroups (fixed order); layout: conv [co][ci][3][3], convT [ci][co][3][3].
 // 1024 threads per block: 256 outputs x 4 slices of the workgroup range, 4 loads in flight per thread, fp64 combine.
 __global__ __launch_bounds__(1024) void conv64_wgrad_reduce(const float* __restrict__ partial, int nwg,
@@ -675,21 +838,39 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
                "conv64_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
   const int tk = wgrad_tk(P);
   const int nchunks = (P.total_q + tk - 1) / tk;
-  const size_t lds = wgrad_lds_bytes(P, tk);
-  SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64 wgrad: chunk needs %zu bytes of LDS", lds);
   hipStream_t st = as_stream(stream);
   float* partial = (float*)ws;
+  bool single_src = true;
+  for (int t = 1; t < NTAPS; ++t) single_src = single_src && P.tsrc[t] == P.tsrc[0];
+  static const int use_ring = [] { const char* e = getenv("SRLZ_WGRAD_RING"); return e ? atoi(e) : 1; }();
+  int launched_grid = grid;
+  if (use_ring && single_src && gf.y == nullptr && tk + P.span <= RING - 64 + 64 && tk == 64) {
+    // contiguous chunk ranges per workgroup (ring re-use of the source rows)
+    const int cpw = (nchunks + grid - 1) / grid;
+    launched_grid = (nchunks + cpw - 1) / cpw;
+    const size_t lds = (size_t)(RING + 64) * 256;
+    if (P.s2) {
+      SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<true>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, x_bnp);
+    } else {
+      SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<false>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, x_bnp);
+    }
+  } else {
+    const size_t lds = wgrad_lds_bytes(P, tk);
+    SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64 wgrad: chunk needs %zu bytes of LDS", lds);
 #define SRLZ_WGRAD_LAUNCH(S2V, TKV)                                                                                        \
   do {                                                                                                                     \
     SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<S2V, TKV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)lds));                                                                               \
     hipLaunchKernelGGL((conv64_wgrad_kernel<S2V, TKV>), dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, xf, gf); \
   } while (0)
-  if (P.s2) SRLZ_WGRAD_LAUNCH(true, 64);
-  else SRLZ_WGRAD_LAUNCH(false, 64);
+    if (P.s2) SRLZ_WGRAD_LAUNCH(true, 64);
+    else SRLZ_WGRAD_LAUNCH(false, 64);
 #undef SRLZ_WGRAD_LAUNCH
+  }
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(1024), 0, st, partial, grid,
+  hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(1024), 0, st, partial, launched_grid,
                      dw_ref, dbias, d->transposed);
   SRLZ_LAUNCHED();
   return 0;
