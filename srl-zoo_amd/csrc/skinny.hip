@@ -443,25 +443,32 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
     const int trem = tile - n * (tiles_y * tiles_x);
     const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
     __syncthreads();  // previous tile's gather is done with Tt
-    auto load_a = [&](int mtile, f32x4 (&a)[4]) {
+    // loads only: the BatchNorm+ReLU of a fused operand is applied when the fragment is CONSUMED (activate), otherwise the
+    // affine would wait for the load right here and nothing would stay in flight behind the MFMAs
+    auto load_a = [&](int mtile, f32x4 (&a)[4]) -> bool {
       const int p = mtile * 16 + li;
       const int ia = p / 17, ib = p - ia * 17;
       const int fy = a0 - 1 + ia, fx = b0 - 1 + ib;
       const bool ok = (mtile < 19) && (p < 289) && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
       const float* src = feat + ((size_t)(n * HF + (ok ? fy : 0)) * WF + (ok ? fx : 0)) * 64 + 4 * kq;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a[c] = ok ? *(const f32x4*)(src + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (feat_bnp && ok) {
+      for (int c = 0; c < 4; ++c) a[c] = ok ? *(const f32x4*)(src + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      return ok;
+    };
+    auto activate = [&](f32x4 (&a)[4], bool ok) {
+      if (feat_bnp && ok) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const float z = a[c][e] * fsc[c][e] + fsh[c][e]; a[c][e] = z > 0.f ? z : 0.f; }
-        }
       }
     };
-    f32x4 a[4], an[4];
-    load_a(wave, a);
+    f32x4 a[4], an[4], an2[4];
+    bool oka = load_a(wave, a);
+    bool okn = load_a(wave + 4, an);
     for (int mtile = wave; mtile < 19; mtile += 4) {
-      load_a(mtile + 4, an);  // next M-tile's fragments travel while this one's MFMAs run
+      const bool okn2 = load_a(mtile + 8, an2);  // fragments travel two M-tiles ahead of the MFMAs that consume them
+      activate(a, oka);
       f32x4 acc[3];
 #pragma unroll
       for (int co = 0; co < 3; ++co) {
@@ -478,7 +485,8 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) Tt[(mtile * 16 + kq * 4 + r) * TP + co * 16 + li] = acc[co][r];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a[c] = an[c];
+      for (int c = 0; c < 4; ++c) { a[c] = an[c]; an[c] = an2[c]; }
+      oka = okn; okn = okn2;
     }
     __syncthreads();
     const int oxl = tid & 31, rg = tid >> 5;

@@ -97,6 +97,10 @@ def bench_skinny(sel):
     if sel("convT5 fwd"):
         report("convT5 4x4 s2 fwd", *timeit(lambda: C.convT_out_fwd(C.ptr(xf), C.ptr(wt), C.ptr(b), C.ptr(img), None, d1, st)), flop=flop1,
                bytes_=4.0 * N * (111 * 111 * 64 + 3 * 224 * 224))
+    bnp1 = torch.cat((torch.zeros(64), torch.ones(64), torch.ones(64), torch.zeros(64))).to(DEV)
+    if sel("convT5 fwd"):
+        report("convT5 4x4 s2 fwd (+BN/ReLU on load)", *timeit(lambda: C.convT_out_fwd(C.ptr(xf), C.ptr(wt), C.ptr(b), C.ptr(img), C.ptr(bnp1), d1, st)), flop=flop1,
+               bytes_=4.0 * N * (111 * 111 * 64 + 3 * 224 * 224))
     dxf = torch.empty(N, 111, 111, 64, device=DEV)
     if sel("convT5 dgrad"):
         report("convT5 4x4 s2 dgrad", *timeit(lambda: C.convT_out_bwd_data(C.ptr(dimg), C.ptr(wt), C.ptr(dxf), None, None, None, d1, st)), flop=flop1,
