@@ -76,6 +76,45 @@ __device__ __forceinline__ void stage_image(float* __restrict__ T, const float* 
   }
 }
 
+// The same staging split in two (request into registers / land in LDS) for software-pipelined callers.
+template <int K>
+struct ImgRegs {
+  static constexpr int TOT = 3 * Geo<K>::ROWS * Geo<K>::COLS;
+  static constexpr int PER = (TOT + 255) / 256;
+  float v[PER];
+};
+
+template <int K, int PAD>
+__device__ __forceinline__ void image_request(ImgRegs<K>& r, const float* __restrict__ img, int n, int C, int cg, int H,
+                                              int W, int oy0, int ox0, bool valid) {
+  constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS, TOT = ImgRegs<K>::TOT;
+  const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
+#pragma unroll
+  for (int j = 0; j < ImgRegs<K>::PER; ++j) {
+    const int idx = threadIdx.x + 256 * j;
+    const int c = idx / (ROWS * COLS);
+    const int rem = idx - c * (ROWS * COLS);
+    const int row = rem / COLS, xl = rem - row * COLS;
+    const int iy = iy0 + row, ix = ix0 + xl;
+    r.v[j] = 0.f;
+    if (valid && idx < TOT && iy >= 0 && iy < H && ix >= 0 && ix < W)
+      r.v[j] = img[((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix];
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K>& r) {
+  constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS, TOT = ImgRegs<K>::TOT;
+#pragma unroll
+  for (int j = 0; j < ImgRegs<K>::PER; ++j) {
+    const int idx = threadIdx.x + 256 * j;
+    const int c = idx / (ROWS * COLS);
+    const int rem = idx - c * (ROWS * COLS);
+    const int row = rem / COLS, xl = rem - row * COLS;
+    if (idx < TOT) T[(c * 2 + (xl & 1)) * Geo<K>::PP + row * XP + (xl >> 1)] = r.v[j];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // feat[n,oy,ox,:] = sum_{c,ky,kx} img[n,c,2oy-PAD+ky,2ox-PAD+kx] * w_ref[:,c,ky,kx]      (w_ref: [64][C][K][K])
 // 256 threads, tile = 16x16 output pixels; wave w owns tile rows 4w..4w+3 (two 32-pixel M-tiles) x 64 channels.
@@ -246,6 +285,36 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   // feat_bnp != NULL: `feat` is a raw convolution output and the operand is relu(batchnorm(feat)) (fused, see conv64.hip)
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   if (feat_bnp) { sc4 = *(const f32x4*)(feat_bnp + 128 + slot * 4); sh4 = *(const f32x4*)(feat_bnp + 192 + slot * 4); }
+  // Plain (non pool-fused) feature staging is software-pipelined: the 8 rows a thread contributes to the NEXT half tile are
+  // requested before the current half's MFMA loop and written to LDS after it (pv / pmask carry them across).
+  // (K = 4 only: the 7x7 kernel's 160 accumulator registers leave no room for the 32 in-flight registers)
+  constexpr bool piped = (K == 4);
+  f32x4 pv[8];
+  unsigned pmask = 0;
+  auto f_request = [&](int tile_, int half_) {
+    const int n_ = tile_ / (tiles_y * tiles_x);
+    const int trem_ = tile_ - n_ * (tiles_y * tiles_x);
+    const int oy0_ = (trem_ / tiles_x) * 16, ox0_ = (trem_ % tiles_x) * 16;
+    pmask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // pixel p = 16*j + prow of the half: tile row 8*half + j, column prow
+      const int oy = oy0_ + 8 * half_ + j, ox = ox0_ + prow;
+      pv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tile_ < ntiles && oy < HF && ox < WF) {
+        pv[j] = *(const f32x4*)(feat + ((size_t)(n_ * HF + oy) * WF + ox) * 64 + slot * 4);
+        pmask |= 1u << j;
+      }
+    }
+  };
+  ImgRegs<piped ? K : 1> ir;  // K = 4: the image window of the next tile, requested during the second half of this one
+  auto i_request = [&](int tile_) {
+    if constexpr (piped) {
+      const int n_ = tile_ / (tiles_y * tiles_x);
+      const int trem_ = tile_ - n_ * (tiles_y * tiles_x);
+      image_request<K, PAD>(ir, img, n_, C, cg, H, W, (trem_ / tiles_x) * 16, (trem_ % tiles_x) * 16, tile_ < ntiles);
+    }
+  };
+  if (piped && (int)blockIdx.x < ntiles) { f_request(blockIdx.x, 0); i_request(blockIdx.x); }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_y * tiles_x);
     const int trem = tile - n * (tiles_y * tiles_x);
@@ -253,7 +322,10 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       __syncthreads();
-      if (half == 0) stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
+      if (half == 0) {
+        if constexpr (piped) image_land<K>(T, ir);
+        else stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
+      }
       if (K == 7 && pf.y) {
         // Fused BatchNorm + ReLU + MaxPool(3,2,pad=1) backward for this lane's column of 8 output rows (oy0 + 8*half + j,
         // ox) x 4 channels.  oy0 is a multiple of 8, so the pooling windows that can have picked one of these rows are
@@ -320,25 +392,25 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
           *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = o;
         }
       } else {
-        f32x4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {  // pixel p = 16*j + prow of the half: tile row 8*half + j, column prow
-          const int oy = oy0 + 8 * half + j, ox = ox0 + prow;
-          v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (oy < HF && ox < WF) v[j] = *(const f32x4*)(feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + slot * 4);
-        }
+        // K = 4: the rows were requested one half tile ago (f_request); K = 7: request them here.
+        // A fused BatchNorm+ReLU is applied now, at consumption.
+        if (!piped) f_request(tile, half);
         if (feat_bnp) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const bool ok = (oy0 + 8 * half + j < HF) && (ox0 + prow < WF);
+            const bool ok = (pmask >> j) & 1u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = (ok && z > 0.f) ? z : 0.f; }
+            for (int e = 0; e < 4; ++e) { const float z = pv[j][e] * sc4[e] + sh4[e]; pv[j][e] = (ok && z > 0.f) ? z : 0.f; }
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = v[j];
+        for (int j = 0; j < 8; ++j) *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = pv[j];
       }
       __syncthreads();
+      if (piped) {
+        if (half == 0) f_request(tile, 1);
+        else { f_request(tile + gridDim.x, 0); i_request(tile + gridDim.x); }
+      }
       // 32 k-steps per wave: step s covers pixels (row 4*sub + (s>>3) of the half, column 2*(s&7) + h)
       const float* fcol = F + mt * 32 + l31;
 #pragma unroll 4
