@@ -153,6 +153,9 @@ def main():
         sys.stdout = stdout
     loss_manager = LossManager(srl.model, None)
     obs, next_obs, actions = synthetic_batch(B, 3, 1234 + rank, device)
+    rewards = None
+    if "reward" in args.losses:
+        rewards = torch.from_numpy(np.random.RandomState(99 + rank).randint(0, 2, (B,)).astype(np.int64)).to(device)
 
     def sync():
         if world > 1:
@@ -161,13 +164,13 @@ def main():
 
     totals = []
     for _ in range(args.warmup):
-        srl.trainStep(obs, next_obs, actions, loss_manager)
+        srl.trainStep(obs, next_obs, actions, loss_manager, rewards_st=rewards)
     sync()
     if not args.no_kernel_timers:
         ops.timers_enable(True)
     t0 = time.time()
     for _ in range(args.steps):
-        totals.append(srl.trainStep(obs, next_obs, actions, loss_manager).detach())
+        totals.append(srl.trainStep(obs, next_obs, actions, loss_manager, rewards_st=rewards).detach())
     sync()
     dt = time.time() - t0
     ops.timers_enable(False)
