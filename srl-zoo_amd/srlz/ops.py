@@ -388,34 +388,6 @@ class EncInFn(Function):
         return None, _give(w, dw), _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None
 
 
-class BNReLUFn(Function):
-    @staticmethod
-    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, training, stat_sink):
-        y = _check(y, "bn input")
-        pixels = y.numel() // 64
-        bnp, batch_stat = _bn_params(stats, pixels, gamma, beta, running_mean, running_var, training, y.device)
-        if stat_sink is not None and batch_stat is not None:
-            stat_sink.append(batch_stat)
-        a = torch.empty_like(y)
-        C.bn_relu_fwd(ptr(y), ptr(bnp), ptr(a), pixels, stream())
-        ctx.save_for_backward(y, bnp)
-        ctx.training = training
-        return a
-
-    @staticmethod
-    def backward(ctx, da):
-        y, bnp = ctx.saved_tensors
-        da = _check(da, "bn grad")
-        dy = torch.empty_like(y)
-        dgamma = _gbuf(None, 64, y.device)
-        dbeta = _gbuf(None, 64, y.device)
-        nbytes = C.bn_bwd_workspace(0)
-        ws = _ws(nbytes, y.device)
-        C.bn_relu_bwd(ptr(y), ptr(bnp), ptr(da), ptr(dy), ptr(dgamma), ptr(dbeta), 1 if ctx.training else 0, ptr(ws),
-                      nbytes, y.numel() // 64, stream())
-        return dy, None, dgamma, dbeta, None, None, None, None
-
-
 # ----------------------------------------------------------------------------------------------------------------
 # Decoder blocks with the BatchNorm-apply + ReLU fused into the NEXT layer's operand load
 # (models/models.py:67-82: BatchNorm2d -> ReLU -> ConvTranspose2d).  Input = RAW output of the previous transposed

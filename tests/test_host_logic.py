@@ -138,3 +138,53 @@ def test_state_dict_keys_and_flat_params():
     flat.zero_grad()
     idx = [i for i, q in enumerate(flat.params) if q is p][0]
     assert float(flat.grad.abs().sum()) == 0.0 and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offsets[idx]
+
+
+def test_flat_params_staging_bookkeeping():
+    """grad_buffer(): k-th request of a pass -> a view of stage k at the parameter's offset (fixed addresses), None when
+    all stages are used; zero_grad() starts a new pass.  (deliver() itself is a HIP kernel: tests/test_step_gpu.py.)"""
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModules
+    from srlz import optim, ops
+    pre.N_CHANNELS = 3
+    m = SRLModules(state_dim=10, action_dim=4, model_type="custom_cnn", losses=["autoencoder"])
+    flat = optim.FlatParams(m)
+    p = dict(m.named_parameters())["model.encoder_conv.4.weight"]
+    home, idx = p._srlz_flat
+    assert home is flat and flat.params[idx] is p
+    off = flat.offsets[idx]
+    views = [flat.grad_buffer(idx) for _ in range(flat.NSTAGE + 1)]
+    assert views[-1] is None and flat._dirty
+    for k, v in enumerate(views[:-1]):
+        assert v.shape == p.shape and v.data_ptr() == flat.stage.data_ptr() + 4 * (k * flat.stage.shape[1] + off)
+    # the ops-side helpers: a staged buffer is recognised and withheld from autograd; anything else is passed through
+    flat.zero_grad()
+    assert not flat._dirty and flat._served[idx] == 0
+    buf = ops._gbuf(p)
+    assert ops._give(p, buf) is None and buf.data_ptr() == flat.stage.data_ptr() + 4 * off
+    other = torch.zeros_like(p)
+    assert ops._give(p, other) is other and ops._give(None, None) is None
+    q = torch.nn.Parameter(torch.zeros(3))  # not part of a bucket: plain allocation, returned to autograd
+    assert ops._give(q, ops._gbuf(q)) is not None
+
+
+def test_split_model_host_logic():
+    """SRLModulesSplit construction checks (reference models/modules.py:120-129) and the kept column ranges."""
+    from collections import OrderedDict
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModulesSplit
+    pre.N_CHANNELS = 3
+    split = OrderedDict([("autoencoder", 6), ("reward", -1), ("forward", 3), ("inverse", 1)])
+    m = SRLModulesSplit(state_dim=10, action_dim=4, model_type="custom_cnn", losses=list(split.keys()), split_dimensions=split)
+    assert [m.splitRange(k) for k in ("autoencoder", "reward", "forward", "inverse", "vae")] == \
+        [(0, 6), (0, 6), (6, 9), (9, 10), (0, 0)]
+    with pytest.raises(AssertionError):
+        SRLModulesSplit(state_dim=11, action_dim=4, losses=list(split.keys()), split_dimensions=split)
+    with pytest.raises(AssertionError):
+        SRLModulesSplit(state_dim=10, action_dim=4, losses=["autoencoder"], split_dimensions=split)
+    with pytest.raises(ValueError):
+        SRLModulesSplit(state_dim=10, action_dim=4, model_type="resnet", losses=list(split.keys()), split_dimensions=split)
+    bad = OrderedDict([("reward", -1), ("autoencoder", 10)])
+    m2 = SRLModulesSplit(state_dim=10, action_dim=4, losses=list(bad.keys()), split_dimensions=bad)
+    with pytest.raises(ValueError):
+        m2.splitRange("reward")
