@@ -136,6 +136,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend="nccl")  # RCCL over xGMI
+        # communicator set-up (seconds) must never land in the timed region, whatever --warmup says
+        warm = torch.zeros(1 << 20, device=device)
+        torch.distributed.all_reduce(warm)
+        torch.cuda.synchronize()
 
     import models.learner as learner
     from models.learner import SRL4robotics

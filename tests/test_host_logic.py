@@ -188,3 +188,29 @@ def test_split_model_host_logic():
     m2 = SRLModulesSplit(state_dim=10, action_dim=4, losses=list(bad.keys()), split_dimensions=bad)
     with pytest.raises(ValueError):
         m2.splitRange("reward")
+
+
+def test_bench_line_contract_on_committed_profile():
+    """The newest committed bench line (profiles/*_bench_ae_bs256.json, written by bench.py on an MI355X) carries every
+    field of the driver's contract, and its roofline numbers are self-consistent."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "*_bench_ae_bs256.json")))
+    assert files
+    line = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
+    images = 2 * line["config"]["global_batch"] * line["steps"]
+    assert abs(line["value"] - images / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-3 * line["value"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e-3) < 0.01 * r["achieved"]
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
