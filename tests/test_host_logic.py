@@ -211,6 +211,6 @@ def test_bench_line_contract_on_committed_profile():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e-3) < 0.01 * r["achieved"]
+    assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e3) < 0.01 * r["achieved"]
     c = line["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
