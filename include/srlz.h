@@ -119,6 +119,11 @@ int srlz_skinny_tiles(const srlz_skinny_desc* d); /* BN partial records written 
 int srlz_conv1_fwd(const float* x_nchw, const float* w_ref, float* y_nhwc, float* stats_partial,
                    const srlz_skinny_desc* d, srlz_stream_t stream);
 size_t srlz_skinny_bwd_weight_workspace(const srlz_skinny_desc* d);
+/* kind 0 data gradient: dx_nchw [N,C,himg,wimg] = d(loss)/d(image) from dy_nhwc [N,hf,wf,64].  The training path never
+ * needs it (conv1 is the first layer); it exists for the perceptual loss (losses/losses.py:217-236), whose frozen
+ * denoiser encodes a DECODED image that carries a gradient (models/learner.py:404-412). */
+int srlz_conv1_bwd_data(const float* dy_nhwc, const float* w_ref, float* dx_nchw, const srlz_skinny_desc* d,
+                        srlz_stream_t stream);
 /* kind 0 weight gradient: dw_ref [64,C,7,7] from x_nchw and dy_nhwc. */
 int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, float* dw_ref, void* ws, size_t ws_bytes,
                           const srlz_skinny_desc* d, srlz_stream_t stream);

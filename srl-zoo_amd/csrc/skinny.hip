@@ -242,6 +242,106 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// conv1 DATA gradient (only needed when the image itself carries a gradient: the frozen denoiser of the perceptual loss,
+// /root/reference/losses/losses.py:217-236, reads a decoded image):
+//   dx[n,c,iy,ix] = sum_{f,ky,kx} dy[n,oy,ox,f] * w_ref[f,c,ky,kx],   iy = 2*oy - 3 + ky,  ix = 2*ox - 3 + kx
+// Same two-phase scheme as convT_out_kernel: per 16x16 IMAGE tile the 11x11 feature pixels that reach it are multiplied
+// with W[64][3*49] (v_mfma_f32_16x16x4_f32, N padded to 160) into LDS, then each image pixel gathers its <= 4x4
+// products.  Wave w owns the N-tiles {w, w+4, w+8} for all eight M-tiles, so its 48 B-fragment registers are loaded once.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int DG_NF = 11;                 // feature rows / columns reaching a 16x16 image tile (1 below, 2 above)
+constexpr int DG_NPROD = 147;             // 3 channels x 49 taps
+constexpr int DG_TP = 149;                // LDS pitch (floats) of one feature pixel's products
+
+__global__ __launch_bounds__(256, 2) void conv1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w_ref,
+                                                            float* __restrict__ dx, int N, int C, int H, int W, int HF,
+                                                            int WF, int tiles_y, int tiles_x) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Tt = (float*)smem;  // [128][DG_TP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int cg = blockIdx.y;
+  const int ntiles = N * tiles_y * tiles_x;
+
+  // B fragments of this wave's N-tiles: column n = (wave + 4j)*16 + li = (co, tap); breg[j][c][r] = W[f = 16c+4kq+r][n]
+  f32x4 breg[3][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int ncol = (wave + 4 * j) * 16 + li;
+    const bool valid = (wave + 4 * j) < 10 && ncol < DG_NPROD;
+    const int co = valid ? ncol / 49 : 0, tap = valid ? ncol % 49 : 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        breg[j][c][r] = valid ? w_ref[((size_t)(16 * c + 4 * kq + r) * C + cg * 3 + co) * 49 + tap] : 0.f;
+  }
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tiles_y * tiles_x);
+    const int trem = tile - n * (tiles_y * tiles_x);
+    const int ty = trem / tiles_x, tx = trem % tiles_x;
+    const int fy0 = 8 * ty - 1, fx0 = 8 * tx - 1;
+    __syncthreads();  // previous tile's gather is done with Tt
+    auto load_a = [&](int mtile, f32x4 (&a)[4]) {
+      const int p = mtile * 16 + li;
+      const int ia = p / DG_NF, ib = p - ia * DG_NF;
+      const int fy = fy0 + ia, fx = fx0 + ib;
+      const bool ok = mtile < 8 && p < DG_NF * DG_NF && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
+      const float* src = dy + ((size_t)(n * HF + (ok ? fy : 0)) * WF + (ok ? fx : 0)) * 64 + 4 * kq;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[c] = ok ? *(const f32x4*)(src + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 a[4], an[4];
+    load_a(0, a);
+#pragma unroll 1
+    for (int mtile = 0; mtile < 8; ++mtile) {
+      load_a(mtile + 1, an);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (wave + 4 * j < 10) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][r], breg[j][c][r], acc, 0, 0, 0);
+          // D layout: column = lane & 15, row (pixel) = (lane >> 4) * 4 + reg
+          const int ncol = (wave + 4 * j) * 16 + li;
+          if (ncol < DG_NPROD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tt[(mtile * 16 + kq * 4 + r) * DG_TP + ncol] = acc[r];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[c] = an[c];
+    }
+    __syncthreads();
+    // gather: thread = image pixel (oyl, oxl) of the tile; ky = py + 2*dyk with py = (oyl + 1) & 1 (iy + 3 - ky must be even)
+    const int oxl = tid & 15, oyl = tid >> 4;
+    const int iy = 16 * ty + oyl, ix = 16 * tx + oxl;
+    const int py = (oyl + 1) & 1, px = (oxl + 1) & 1;
+    const int ay = (oyl + 3 - py) / 2 + 1, ax = (oxl + 3 - px) / 2 + 1;  // local feature index for dyk = 0 / dxk = 0
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+      float v = 0.f;
+#pragma unroll
+      for (int dyk = 0; dyk < 4; ++dyk) {
+        const int ky = py + 2 * dyk;
+        if (ky > 6) continue;
+#pragma unroll
+        for (int dxk = 0; dxk < 4; ++dxk) {
+          const int kx = px + 2 * dxk;
+          if (kx > 6) continue;
+          v += Tt[((ay - dyk) * DG_NF + (ax - dxk)) * DG_TP + co * 49 + ky * 7 + kx];
+        }
+      }
+      if (iy < H && ix < W) dx[((size_t)(n * C + cg * 3 + co) * H + iy) * W + ix] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // dW[ch][k] = sum_{n,pix} feat[n,pix,ch] * im2col(img)[n,pix,k]     ch in [0,64), k = (c,ky,kx) of channel group cg.
 // GEMM view: M = 64 feature channels (2 M-tiles), N = KT taps (NT tiles of 32), K = pixels.
 // Per 16x16-pixel tile the image window is staged in LDS (T) and the 64-channel feature rows are staged in two halves
@@ -703,6 +803,21 @@ extern "C" int srlz_conv1_fwd(const float* x_nchw, const float* w_ref, float* y_
 extern "C" size_t srlz_skinny_bwd_weight_workspace(const srlz_skinny_desc* d) {
   if (check_skinny(d)) return 0;
   return d->kind == 0 ? wgrad_ws<7>(d) : wgrad_ws<4>(d);
+}
+
+extern "C" int srlz_conv1_bwd_data(const float* dy_nhwc, const float* w_ref, float* dx_nchw, const srlz_skinny_desc* d,
+                                   srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 0, SRLZ_ERR_BAD_DESC, "conv1_bwd_data: descriptor kind must be 0");
+  SRLZ_REQUIRE(dy_nhwc && w_ref && dx_nchw, SRLZ_ERR_NULL, "conv1_bwd_data: null pointer");
+  const int ty = (d->himg + 15) / 16, tx = (d->wimg + 15) / 16;
+  const int ntiles = d->n * ty * tx;
+  const size_t lds = (size_t)128 * DG_TP * sizeof(float);
+  SRLZ_HIP(hipFuncSetAttribute((const void*)conv1_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(conv1_dgrad_kernel, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), dy_nhwc,
+                     w_ref, dx_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx);
+  SRLZ_LAUNCHED();
+  return 0;
 }
 
 extern "C" int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, float* dw_ref, void* ws, size_t ws_bytes,

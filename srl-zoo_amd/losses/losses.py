@@ -1,8 +1,8 @@
 """LossManager and the hot-path losses (reference losses/losses.py:19-59, 102-170, 172-214, 239-256).
 
 Same function names, argument order and return values as the reference; the reductions and their gradients run as
-fused HIP kernels (srlz/ops.py).  Losses of other SRL methods (priors, triplet, perceptual, episode/reward priors) are
-outside the hot path and not provided.
+fused HIP kernels (srlz/ops.py).  Losses of other SRL methods (priors, triplet, episode/reward priors) are outside the
+hot path and not provided.
 """
 from __future__ import print_function, division, absolute_import
 
@@ -106,6 +106,16 @@ def generationLoss(decoded, next_decoded, obs, next_obs, weight, loss_manager):
     generation_loss = ops.SqDiffSumFn.apply(decoded, obs) + ops.SqDiffSumFn.apply(next_decoded, next_obs)
     loss_manager.addToLosses('generation_loss', weight, generation_loss)
     return weight * generation_loss
+
+
+def perceptualSimilarityLoss(encoded_real, encoded_prediction, next_encoded_real, next_encoded_prediction,
+                             weight, loss_manager):
+    """DARLA's perceptual similarity: summed squared distance between the frozen denoiser's encodings of the real frames
+    and of the VAE's reconstructions, both frames (reference losses.py:217-236)."""
+    pretrained_dae_encoding_loss = ops.SqDiffSumFn.apply(encoded_real, encoded_prediction) + \
+        ops.SqDiffSumFn.apply(next_encoded_real, next_encoded_prediction)
+    loss_manager.addToLosses("denoising perceptual similarity", weight, pretrained_dae_encoding_loss)
+    return weight * pretrained_dae_encoding_loss
 
 
 def kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager, beta=1):

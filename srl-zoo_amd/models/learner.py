@@ -21,7 +21,7 @@ import numpy as np
 import torch as th
 
 from losses.losses import LossManager, autoEncoderLoss, forwardModelLoss, inverseModelLoss, kullbackLeiblerLoss, \
-    generationLoss, rewardModelLoss, l1Loss, l2Loss
+    generationLoss, rewardModelLoss, l1Loss, l2Loss, perceptualSimilarityLoss
 from pipeline import NAN_ERROR
 from preprocessing.data_loader import DataLoader
 from utils import printRed, detachToNumpy, printYellow
@@ -41,7 +41,7 @@ BALANCED_SAMPLING = False
 # build-specific: ship decoded frames as uint8 and normalise on the GPU (bit-identical, 4x less PCIe traffic)
 RAW_UINT8_INPUT = True
 
-SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "reward", "random"}
+SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "reward", "perceptual", "random"}
 
 
 def _requireGpu(cuda):
@@ -113,8 +113,8 @@ class SRL4robotics(BaseLearner):
     """Trainer for the conv auto-encoder / VAE / forward-inverse family.
 
     Arguments as in the reference (models/learner.py:121-148).  `split_dimensions` (OrderedDict with a positive sum)
-    selects SRLModulesSplit; `l1_reg` / `l2_reg` > 0 add the regularisers.  Accepted but unused because their code path
-    (perceptual loss) is outside the hot path: path_to_dae / state_dim_dae.
+    selects SRLModulesSplit; `l1_reg` / `l2_reg` > 0 add the regularisers; `path_to_dae` / `state_dim_dae` name the
+    pre-trained denoiser of the perceptual loss (`--losses vae perceptual`).
     """
 
     def __init__(self, state_dim, model_type="resnet", inverse_model_type="linear", log_folder="logs/default",
@@ -139,6 +139,9 @@ class SRL4robotics(BaseLearner):
         self.use_vae = "vae" in losses
         self.use_dae = "dae" in losses
         self.use_triplets = False
+        self.perceptual_similarity_loss = "perceptual" in losses
+        self.path_to_dae = path_to_dae
+        self.denoiser = None
 
         if isinstance(split_dimensions, OrderedDict) and sum(split_dimensions.values()) > 0:
             printYellow("Using splitted representation")
@@ -210,6 +213,17 @@ class SRL4robotics(BaseLearner):
         return srl_model, exp_config
 
     # ---------------------------------------------------------------------------------------------------------
+    def loadDenoiser(self, state_dict):
+        """The pre-trained, frozen DAE of the perceptual loss (reference learner.py:317-326): eval mode, no gradients to
+        its parameters — only to the images it encodes."""
+        self.denoiser = SRLModules(state_dim=self.state_dim_dae, action_dim=self.dim_action, model_type="custom_cnn",
+                                   cuda=self.cuda, losses=["dae"])
+        self.denoiser.load_state_dict(state_dict)
+        self.denoiser.eval()
+        self.denoiser = self.denoiser.to(self.device)
+        for param in self.denoiser.parameters():
+            param.requires_grad = False
+
     def saveModel(self, path):
         """th.save(state_dict) with the reference's keys and NCHW shapes (CPU tensors, loadable anywhere)."""
         th.save(OrderedDict((k, v.detach().cpu().clone()) for k, v in self.model.state_dict().items()), path)
@@ -258,6 +272,13 @@ class SRL4robotics(BaseLearner):
         elif self.use_vae:
             (decoded_obs, mu, logvar), (decoded_next_obs, next_mu, next_logvar) = self._forwardPair(obs, next_obs)
             states, next_states = self.model.getStates(obs), self.model.getStates(next_obs)
+            if self.perceptual_similarity_loss:
+                # the frozen denoiser's encodings of the real frames and of the reconstructions (reference
+                # learner.py:404-412; only the states of its (states, decoded) pairs are used, so its decoder is skipped)
+                states_denoiser = self.denoiser.getStates(obs)
+                next_states_denoiser = self.denoiser.getStates(next_obs)
+                states_denoiser_predicted = self.denoiser.getStates(decoded_obs)
+                next_states_denoiser_predicted = self.denoiser.getStates(decoded_next_obs)
         else:
             states, next_states = self._forwardPair(obs, next_obs)
 
@@ -281,7 +302,12 @@ class SRL4robotics(BaseLearner):
                             weight=w["dae" if self.use_dae else "autoencoder"], loss_manager=loss_manager)
         if self.use_vae:
             kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager=loss_manager, beta=self.beta)
-            generationLoss(decoded_obs, decoded_next_obs, obs, next_obs, weight=w['vae'], loss_manager=loss_manager)
+            if self.perceptual_similarity_loss:
+                perceptualSimilarityLoss(states_denoiser, states_denoiser_predicted, next_states_denoiser,
+                                         next_states_denoiser_predicted, weight=w['perceptual'],
+                                         loss_manager=loss_manager)
+            else:
+                generationLoss(decoded_obs, decoded_next_obs, obs, next_obs, weight=w['vae'], loss_manager=loss_manager)
 
         loss = loss_manager.computeTotalLoss()
         loss.backward()  # the reference backpropagates on validation minibatches too (learner.py:487-489)
@@ -322,6 +348,9 @@ class SRL4robotics(BaseLearner):
         print("{} unique actions / {} actions".format(len(set(actions)), n_actions))
         print("Number of observations per action")
         print(np.array([np.sum(actions == i) for i in range(n_actions)], dtype=np.int64))
+
+        if self.use_vae and self.perceptual_similarity_loss and self.path_to_dae is not None:
+            self.loadDenoiser(th.load(self.path_to_dae, map_location=self.device))
 
         data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
                                  use_triplets=False, is_training=True, apply_occlusion=self.use_dae,

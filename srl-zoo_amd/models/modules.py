@@ -12,7 +12,7 @@ from .forward_inverse import BaseForwardModel, BaseInverseModel, BaseRewardModel
 from .models import *  # noqa: F401,F403  (BaseModelSRL, CustomCNN, encodeOneHot, ... as in the reference)
 
 OUT_OF_SCOPE = "model_type '{}' / losses {} are outside the MI355X hot path of this build (custom_cnn with " \
-               "autoencoder | vae | dae | inverse | forward | reward); use the reference implementation for them"
+               "autoencoder | vae | dae | inverse | forward | reward | perceptual); use the reference implementation for them"
 
 
 class SRLModules(BaseForwardModel, BaseInverseModel, BaseRewardModel):

@@ -62,6 +62,7 @@ _PROTOS = {
     "srlz_conv1_fwd": (c_int, [P, P, P, P, _SK, P]),
     "srlz_skinny_bwd_weight_workspace": (c_size_t, [_SK]),
     "srlz_conv1_bwd_weight": (c_int, [P, P, P, P, c_size_t, _SK, P]),
+    "srlz_conv1_bwd_data": (c_int, [P, P, P, _SK, P]),
     "srlz_conv1_bwd_weight_fused": (c_int, [P, P, P, P, P, P, c_int, P, P, c_size_t, _SK, _PD, P]),
     "srlz_bn_relu_pool_bwd_sums": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, _PD, P]),
     "srlz_convT_out_fwd": (c_int, [P, P, P, P, P, _SK, P]),

@@ -45,7 +45,7 @@ def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
     """models/models.py:47-63.  x: [N,C,H,W] (reference layout) -> [N,64,6,6] (NCHW, ready for .view(N,-1))."""
     conv1, bn1, conv2, bn2, conv3, bn3 = seq[0], seq[1], seq[4], seq[5], seq[8], seq[9]
     _tick(bn1, training)
-    if _FUSE_ENC_IN:
+    if _FUSE_ENC_IN and not x.requires_grad:  # (an image that carries a gradient needs conv1's data gradient: plain chain)
         p, y = ops.EncInFn.apply(x, conv1.weight, *_bn_args(bn1), training, 1, stat_sink)
         _tap(name, 0, y)
         _tap(name, 3, p)

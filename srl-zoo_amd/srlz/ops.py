@@ -152,7 +152,7 @@ class _OnSide(object):
         return False
 
     def join(self):
-        if self.side is not None:
+        if self.side is not None and getattr(self, "done", None) is not None:
             torch.cuda.current_stream(self.device).wait_event(self.done)
 
 
@@ -196,11 +196,17 @@ class Conv1Fn(Function):
         x, w = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "conv1 dy")
-        dw = _gbuf(w)
-        nbytes = C.skinny_bwd_weight_workspace(d)
-        ws = _ws(nbytes, x.device)
-        C.conv1_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, d, stream())
-        return None, _give(w, dw), None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = _gbuf(w)
+            nbytes = C.skinny_bwd_weight_workspace(d)
+            ws = _ws(nbytes, x.device)
+            C.conv1_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, d, stream())
+        dx = None
+        if ctx.needs_input_grad[0]:  # only when the image carries a gradient (frozen denoiser of the perceptual loss)
+            dx = torch.empty_like(x)
+            C.conv1_bwd_data(ptr(dy), ptr(w), ptr(dx), d, stream())
+        return dx, _give(w, dw), None
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -243,13 +249,17 @@ class Conv64Fn(Function):
         x, packs = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "conv64 dy")
-        dw = _gbuf(ctx.params[0])
-        db = _gbuf(ctx.params[1]) if ctx.has_bias else None
-        nbytes = C.conv64_bwd_weight_workspace(d)
-        ws = _ws(nbytes, x.device, slot=1)
-        with _OnSide(x.device, x, dy, dw, db, ws) as side:
-            _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
-                    lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, None, ptr(ws), nbytes, d, stream()))
+        dw = db = None
+        side = _OnSide(x.device)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):  # (a frozen layer needs neither)
+            dw = _gbuf(ctx.params[0])
+            db = _gbuf(ctx.params[1]) if ctx.has_bias else None
+            nbytes = C.conv64_bwd_weight_workspace(d)
+            ws = _ws(nbytes, x.device, slot=1)
+            with _OnSide(x.device, x, dy, dw, db, ws) as side:
+                _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                        lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, None, ptr(ws), nbytes, d,
+                                                    stream()))
         dx = None
         if ctx.needs_dx:
             dx = torch.empty_like(x)

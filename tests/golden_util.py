@@ -68,11 +68,14 @@ def ext_cases():
                                     split=OD([("autoencoder", 120), ("reward", 80), ("inverse", -1)])),
         "step_ae_reward_l1_b2": dict(losses=["autoencoder", "reward"], B=2, l1_reg=1e-5),
         "step_dae_b2": dict(losses=["dae"], B=2),
+        # VAE trained through a frozen denoiser (DARLA's perceptual similarity); the denoiser is the
+        # seed-7 initialisation of SRLModules(losses=["dae"]) in eval mode
+        "step_vae_perceptual_b2": dict(losses=["vae", "perceptual"], B=2, weights={"perceptual": 1.0}, dae_seed=7),
     }
 
 
 def ext_defaults(cfg):
-    out = dict(S=200, inverse="linear", split=None, l1_reg=0.0, l2_reg=0.0, weights=None)
+    out = dict(S=200, inverse="linear", split=None, l1_reg=0.0, l2_reg=0.0, weights=None, dae_seed=None)
     out.update(cfg)
     return out
 

@@ -627,3 +627,21 @@ def test_convT_out_bwd_data_emits_bn_backward_sums(C, n, c, hf):
     assert torch.equal(da0, da1)
     for a, b in zip(out[0], out[1]):
         assert rel_err(b, a) < 2e-5
+
+
+@pytest.mark.parametrize("n,c,h", [(2, 3, 224), (1, 6, 64), (2, 3, 50)])
+def test_conv1_bwd_data(C, n, c, h):
+    """srlz_conv1_bwd_data: d(loss)/d(image) of Conv2d(C,64,7,2,3) (two-phase pixel-GEMM + gather) against fp64 autograd."""
+    g = torch.Generator().manual_seed(900 + h + c)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(64, c, 7, 7, generator=g) * 0.1
+    hf = (h + 6 - 7) // 2 + 1
+    dy = torch.randn(n, 64, hf, hf, generator=g)
+    xr = x.double().requires_grad_(True)
+    F.conv2d(xr, w.double(), None, stride=2, padding=3).backward(dy.double())
+    d = C.SkinnyDesc(n, c, h, h, hf, hf, 0)
+    dx = torch.full((n, c, h, h), float("nan"), device=DEV)
+    wd, dyd = w.to(DEV), nhwc(dy).to(DEV)
+    C.conv1_bwd_data(C.ptr(dyd), C.ptr(wd), C.ptr(dx), d, C.stream())
+    torch.cuda.synchronize()
+    assert rel_err(dx, xr.grad) < 2e-5

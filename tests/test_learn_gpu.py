@@ -104,3 +104,31 @@ def test_learn_stacked_split_model(workdir):
                                ("split-dimensions", split)]), f)
     srl2, cfg = SRL4robotics.loadSavedModel(log + "/", ["dae", "reward", "inverse", "forward"], cuda=True)
     assert isinstance(srl2.model, SRLModulesSplit)
+
+
+def test_learn_vae_with_perceptual_loss(workdir):
+    """`--losses vae perceptual --path-to-dae <srl_model.pth of a DAE run>` (reference train.py:120-125, learner.py:317-326):
+    a DAE is trained first, then a VAE whose decoder is trained through the frozen denoiser's encoder."""
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from models.learner import SRL4robotics
+    name, paths, actions, rewards, starts = workdir
+    pre.N_CHANNELS = 3
+    learner.N_EPOCHS, learner.BATCH_SIZE, learner.VALIDATION_SIZE, learner.DISPLAY_PLOTS = 1, 8, 0.2, False
+    os.makedirs("logs/run_dae", exist_ok=True)
+    os.makedirs("logs/run_percep", exist_ok=True)
+    dae = SRL4robotics(12, model_type="custom_cnn", seed=4, learning_rate=1e-3, cuda=True, losses=["dae"], n_actions=6,
+                       log_folder="logs/run_dae", occlusion_percentage=0.3)
+    dae.learn(paths, actions, rewards, starts)
+    srl = SRL4robotics(10, model_type="custom_cnn", seed=5, learning_rate=1e-3, cuda=True, losses=["vae", "perceptual"],
+                       n_actions=6, log_folder="logs/run_percep", path_to_dae="logs/run_dae/srl_model.pth", state_dim_dae=12,
+                       losses_weights_dict={"vae": 0.5e-6, "perceptual": 1e-3})
+    before = [p.detach().clone() for p in srl.model.model.decoder_conv.parameters()]
+    loss_history, states, pairs = srl.learn(paths, actions, rewards, starts)
+    assert [n for n, _ in pairs] == ["kl_loss", "denoising perceptual similarity"]
+    assert states.shape == (len(paths), 10) and np.isfinite(states).all()
+    assert np.isfinite(loss_history["denoising perceptual similarity"]).all()
+    assert all(not p.requires_grad for p in srl.denoiser.parameters()) and not srl.denoiser.training
+    # the decoder only receives gradient through the denoiser: it must have moved
+    after = list(srl.model.model.decoder_conv.parameters())
+    assert any((a.detach() - b).abs().max().item() > 0 for a, b in zip(after, before))

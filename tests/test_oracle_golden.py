@@ -50,10 +50,14 @@ CASES = [("step_ae_b2", ["autoencoder"], 2, 3, "linear"),
          ("step_cnn_if_b2", ["inverse", "forward"], 2, 3, "linear")]
 
 
-def run_twin(losses, B, C, inverse, n_steps=1, lr=None, S=200, split=None, weights=None, l1_reg=0.0, l2_reg=0.0):
+def run_twin(losses, B, C, inverse, n_steps=1, lr=None, S=200, split=None, weights=None, l1_reg=0.0, l2_reg=0.0,
+             dae_seed=None):
     torch.set_num_threads(1)
     model = build(losses, C=C, S=S, inverse=inverse, split=split)
     sd = T.clone_state(model.state_dict())
+    dae_sd = None
+    if dae_seed is not None:
+        dae_sd = T.clone_state(build(["dae"], C=C, S=S, seed=dae_seed).state_dict(), requires_grad=False)
     opt = T.TwinAdam(sd, lr) if lr is not None else None
     outs = []
     for step in range(n_steps):
@@ -69,7 +73,7 @@ def run_twin(losses, B, C, inverse, n_steps=1, lr=None, S=200, split=None, weigh
         rewards = torch.from_numpy(gu.golden_rewards(B, seed=1234 + step)[1]) if "reward" in losses else None
         out = T.train_step(sd, losses, torch.from_numpy(obs), torch.from_numpy(next_obs), torch.from_numpy(actions),
                            eps=eps[0], next_eps=eps[1], weights=weights, split=split, rewards=rewards, l1_reg=l1_reg,
-                           l2_reg=l2_reg, noisy=noisy)
+                           l2_reg=l2_reg, noisy=noisy, dae_sd=dae_sd)
         outs.append(out)
         if opt is not None:
             opt.step(sd)
@@ -89,7 +93,7 @@ def test_twin_split_reward_reg_steps_match_reference_golden(name):
     cfg = gu.ext_defaults(gu.ext_cases()[name])
     g = gu.load(name)
     sd, outs = run_twin(cfg["losses"], cfg["B"], 3, cfg["inverse"], S=cfg["S"], split=cfg["split"], weights=cfg["weights"],
-                        l1_reg=cfg["l1_reg"], l2_reg=cfg["l2_reg"])
+                        l1_reg=cfg["l1_reg"], l2_reg=cfg["l2_reg"], dae_seed=cfg["dae_seed"])
     check_step_against_golden(g, sd, outs[0], cfg["losses"], cfg["B"], 3)
 
 

@@ -99,8 +99,15 @@ def bn_digest(model, out, prefix="bn/"):
 def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1, lr=None,
               eps_seed=99, beta=1.0, inverse="linear", weights=None, split=None, l1_reg=0.0, l2_reg=0.0):
     """One (or several) loop bodies of models/learner.py:373-497 driven on the reference classes."""
-    model = build(th, ref_pre, SRLModules, losses, S=S, A=A, C=C, inverse=inverse, split=split)
-    w = {"forward": 1.0, "inverse": 2.0, "reward": 1.0, "autoencoder": 1.0, "dae": 1.0, "vae": 0.5e-6}
+    model = build(th, ref_pre, SRLModules, [l for l in losses if l != "perceptual"] if split is None else losses, S=S, A=A,
+                  C=C, inverse=inverse, split=split)
+    denoiser = None
+    if "perceptual" in losses:  # the frozen, eval-mode DAE of learner.py:317-326 (seed 7 stands in for "pre-trained")
+        denoiser = build(th, ref_pre, SRLModules, ["dae"], S=S, A=A, C=C, seed=7)
+        denoiser.eval()
+        for param in denoiser.parameters():
+            param.requires_grad = False
+    w = {"forward": 1.0, "inverse": 2.0, "reward": 1.0, "autoencoder": 1.0, "dae": 1.0, "vae": 0.5e-6, "perceptual": 1e-6}
     if weights:
         w.update(weights)
     out = {}
@@ -151,7 +158,12 @@ def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1
                                loss_manager=lm)
         if "vae" in losses:
             RL.kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager=lm, beta=beta)
-            RL.generationLoss(dec, next_dec, obs, next_obs, weight=w["vae"], loss_manager=lm)
+            if denoiser is not None:
+                (sd_real, _), (nsd_real, _) = denoiser(obs), denoiser(next_obs)
+                (sd_pred, _), (nsd_pred, _) = denoiser(dec), denoiser(next_dec)
+                RL.perceptualSimilarityLoss(sd_real, sd_pred, nsd_real, nsd_pred, weight=w["perceptual"], loss_manager=lm)
+            else:
+                RL.generationLoss(dec, next_dec, obs, next_obs, weight=w["vae"], loss_manager=lm)
         loss = lm.computeTotalLoss()
         loss.backward()
         rec = {n: float(l.item()) for n, l in zip(lm.names, lm.losses)}
@@ -344,6 +356,8 @@ def main():
     save("step_split_ae_ri_b2", step_case(th, ref_pre, SRLModules, RL, list(asplit.keys()), B=2, split=asplit))
     save("step_ae_reward_l1_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "reward"], B=2, l1_reg=1e-5))
     save("step_dae_b2", step_case(th, ref_pre, SRLModules, RL, ["dae"], B=2))
+    save("step_vae_perceptual_b2", step_case(th, ref_pre, SRLModules, RL, ["vae", "perceptual"], B=2,
+                                             weights={"perceptual": 1.0}))
     save("detach_kats", detach_kats(th))
     # (4) per-layer forward digests, loss KATs, head KATs
     save("layers_ae_b2", layer_trace(th, ref_pre, SRLModules))
