@@ -51,6 +51,51 @@ def _requireGpu(cuda):
                            % (cuda, th.cuda.is_available()))
 
 
+class _DeviceFeed(object):
+    """One-minibatch look-ahead between the loader process and the GPU: the H2D copy of minibatch i+1 is issued on a copy
+    stream right after step i has been enqueued (advance()), i.e. BEFORE the host blocks on step i's loss scalars, so it
+    travels while step i computes.  Iteration order and contents are the loader's."""
+
+    def __init__(self, loader, device):
+        self.it, self.device = iter(loader), device
+        self.copy = th.cuda.Stream(device=device)
+        self.ahead = None
+        self.exhausted = False  # the loader's end-of-epoch marker was seen: never pull from it again (the loader process
+        self.advance()          # is already producing the NEXT epoch, which belongs to the next _DeviceFeed)
+
+    def _load(self):
+        try:
+            item = next(self.it)
+        except StopIteration:
+            self.exhausted = True
+            return None
+        with th.cuda.stream(self.copy):
+            moved = tuple(t.to(self.device, non_blocking=True) if th.is_tensor(t) else t for t in item)
+        done = th.cuda.Event()
+        done.record(self.copy)
+        return moved, done
+
+    def advance(self):
+        """Start moving the next minibatch (no-op if one is already on its way or the epoch is over)."""
+        if self.ahead is None and not self.exhausted:
+            self.ahead = self._load()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        self.advance()
+        if self.ahead is None:
+            raise StopIteration
+        (item, done), self.ahead = self.ahead, None
+        cur = th.cuda.current_stream(self.device)
+        cur.wait_event(done)
+        for t in item:
+            if th.is_tensor(t):
+                t.record_stream(cur)
+        return item
+
+
 class BaseLearner(object):
     """Base class of a state-representation learner.
 
@@ -377,7 +422,8 @@ class SRL4robotics(BaseLearner):
         val_set = set(int(i) for i in val_indices)
         for epoch in range(n_epochs):
             epoch_loss, epoch_batches, val_loss, val_batches = 0.0, 0, 0.0, 0
-            for minibatch_num, (minibatch_idx, obs, next_obs, noisy_obs, next_noisy_obs) in enumerate(data_loader):
+            feed = _DeviceFeed(data_loader, self.device)
+            for minibatch_num, (minibatch_idx, obs, next_obs, noisy_obs, next_noisy_obs) in enumerate(feed):
                 validation_mode = int(minibatch_idx) in val_set
                 if self.use_dae:
                     noisy_obs, next_noisy_obs = self._toDevice(noisy_obs), self._toDevice(next_noisy_obs)
@@ -392,6 +438,7 @@ class SRL4robotics(BaseLearner):
 
                 loss = self.trainStep(obs, next_obs, actions_st, loss_manager, validation_mode, noisy_obs,
                                       next_noisy_obs, rewards_st)
+                feed.advance()  # next minibatch's H2D copy overlaps this step (issued before the host waits below)
                 # one D2H copy for every scalar of this step
                 values = th.stack([l.detach().reshape(()) for l in loss_manager.losses] + [loss.detach()]).tolist()
                 loss_manager.updateLossHistory(values[:-1])

@@ -214,3 +214,61 @@ def test_bench_line_contract_on_committed_profile():
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e3) < 0.01 * r["achieved"]
     c = line["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_device_feed_protocol(monkeypatch):
+    """_DeviceFeed (copy-stream look-ahead of the learner) yields exactly one epoch of the loader, in order, and never pulls
+    from the loader again after its end-of-epoch marker — the loader process is already producing the next epoch."""
+    import models.learner as learner
+
+    class FakeStream(object):
+        def __init__(self, device=None):
+            pass
+
+        def wait_event(self, ev):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    class FakeEvent(object):
+        def record(self, stream):
+            pass
+
+    monkeypatch.setattr(learner.th.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(learner.th.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(learner.th.cuda, "stream", lambda s: s)
+    monkeypatch.setattr(learner.th.cuda, "current_stream", lambda device=None: FakeStream())
+    monkeypatch.setattr(torch.Tensor, "record_stream", lambda self, s: None, raising=False)
+
+    class EpochLoader(object):
+        """Like preprocessing.data_loader.DataLoader(infinite_loop=True): StopIteration once per epoch, then goes on."""
+
+        def __init__(self, per_epoch):
+            self.per_epoch, self.count, self.pulls = per_epoch, 0, 0
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            self.pulls += 1
+            if self.count == self.per_epoch:
+                self.count = 0
+                raise StopIteration
+            self.count += 1
+            return (self.count, torch.full((2,), float(self.count)), None)
+
+    loader = EpochLoader(3)
+    for epoch in range(2):
+        feed = learner._DeviceFeed(loader, "cpu")
+        seen = []
+        for idx, t, none in feed:
+            seen.append((idx, float(t[0])))
+            feed.advance()
+            feed.advance()  # idempotent
+        assert seen == [(1, 1.0), (2, 2.0), (3, 3.0)]
+        assert feed.exhausted
+    assert loader.pulls == 2 * 4  # three minibatches + one end marker per epoch, nothing beyond
