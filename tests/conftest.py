@@ -18,3 +18,13 @@ def pytest_configure(config):
 def cabi():
     from srlz import _cabi
     return _cabi
+
+
+def pytest_collection_modifyitems(config, items):
+    """Every test gets a wall-clock limit (pytest-timeout, when installed): a hung loader process or kernel must fail the
+    test, not stall the run."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(420))
