@@ -1,6 +1,6 @@
 """Diagnostic: per-parameter gradient error of the HIP step vs the fp64 oracle (and the fp32 oracle's own noise)."""
 import sys, os
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(REPO, "srl-zoo_amd"), REPO, os.path.join(REPO, "tests")]
 from collections import OrderedDict
 import numpy as np, torch

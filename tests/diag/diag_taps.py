@@ -1,6 +1,6 @@
 """Diagnostic: activation-gradient error per layer, HIP vs fp64 oracle (and fp32 oracle vs fp64)."""
 import sys, os
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(REPO, "srl-zoo_amd"), REPO, os.path.join(REPO, "tests")]
 from collections import OrderedDict
 import numpy as np, torch

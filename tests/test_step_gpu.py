@@ -7,7 +7,7 @@ BatchNorm running statistics.
 Parameter GRADIENTS need care.  The network has ~2.4 M ReLU / max-pool decisions per image; a pre-activation that
 is within fp32 rounding of zero (or two pool candidates within rounding of a tie) is decided differently by two
 correct fp32 implementations, and at B=2 a single flipped decision moves a weight gradient by 1e-3 .. 1e-1 in max-norm
-(the reference's own fp32 result is that far from its fp64 evaluation, see tools/diag_taps.py).  So gradients are
+(the reference's own fp32 result is that far from its fp64 evaluation, see tests/diag/diag_taps.py).  So gradients are
 checked in the rigorous way: the fp64 oracle is run with the discrete decisions PINNED to the ones the HIP forward
 took (ReLU masks, pool argmax — exported through srlz.hotpath.TAPS); its gradient is then the exact linearisation of
 the same piecewise-linear function and must match to 1e-4.  Separately the decisions themselves are compared with the
