@@ -113,3 +113,34 @@ def test_program_tap_grouping(cabi, hi, s, p, t):
         else:
             assert len(set(key)) == 1
         assert sorted(w for (_, _, _, w) in P["taps"]) == list(range(9))
+
+
+@pytest.mark.parametrize("hi,s,p,t", [(56, 1, 1, 0), (6, 2, 0, 1), (13, 2, 0, 1), (27, 2, 0, 1), (55, 2, 0, 1), (9, 1, 1, 0)])
+def test_wgrad_ring_schedule_never_aliases(cabi, hi, s, p, t):
+    """conv64_wgrad_ring_kernel keeps source row q in LDS slot q & 255 and, per 64-position chunk, lands only the 64 new
+    rows of the NEXT chunk after the current chunk's last MFMA.  Replay that schedule for the forward program of every
+    single-source-class layer: whenever a tap reads slot (q0 + row + off) & 255 it must still hold row q0 + row + off."""
+    P = get_program(cabi, 2, hi, s, p, t, 0)
+    assert len(set(c for (c, _, _, _) in P["taps"])) == 1, "ring kernel is only used for single-source-class programs"
+    RING, TK = 256, 64
+    span, min_off = P["span"], P["min_off"]
+    assert TK + span <= RING
+    total = P["N"] * P["PH"] * P["PW"]
+    nchunks = (total + TK - 1) // TK
+    offs = sorted(set(off for (_, _, off, _) in P["taps"]))
+    assert offs[0] == min_off and offs[-1] - offs[0] == span
+    for (c_begin, c_end) in ((0, nchunks), (3, min(nchunks, 9))):  # a workgroup's contiguous chunk range
+        slot = {}
+        q0 = c_begin * TK
+        for r in range(0, TK + span, 64):  # prologue: passes of 64 rows, may run past TK + span
+            for q in range(q0 + min_off + r, q0 + min_off + r + 64):
+                slot[q & (RING - 1)] = q
+        for chunk in range(c_begin, c_end):
+            q0 = chunk * TK
+            for row in range(TK):
+                for off in offs:
+                    q = q0 + row + off
+                    assert slot.get(q & (RING - 1)) == q, (chunk, row, off)
+            if chunk + 1 < c_end:  # landed after the barrier that follows this chunk's MFMA loop
+                for q in range(q0 + min_off + TK + span, q0 + min_off + TK + span + 64):
+                    slot[q & (RING - 1)] = q
