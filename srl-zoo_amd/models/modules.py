@@ -3,9 +3,7 @@
 Only the conv family (`custom_cnn`) is on the MI355X hot path."""
 from __future__ import print_function, division, absolute_import
 
-import torch as th
-
-from srlz import hotpath, ops
+from srlz import ops
 from .autoencoders import CNNAutoEncoder
 from .vae import CNNVAE
 from .forward_inverse import BaseForwardModel, BaseInverseModel, BaseRewardModel

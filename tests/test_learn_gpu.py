@@ -30,7 +30,6 @@ def test_learn_end_to_end(workdir, losses, kind):
     import preprocessing.preprocess as pre
     from models.learner import SRL4robotics
     from oracle import torch_twin as T
-    import golden_util as gu
     name, paths, actions, rewards, starts = workdir
     pre.N_CHANNELS = 3
     learner.N_EPOCHS, learner.BATCH_SIZE, learner.VALIDATION_SIZE, learner.DISPLAY_PLOTS = 3, 8, 0.2, False

@@ -54,7 +54,7 @@ def import_reference():
     return th, ref_pre, SRLModules, ref_losses
 
 
-from golden_util import golden_inputs, golden_rewards, golden_noisy, tensor_digest, SUB  # noqa: E402
+from golden_util import golden_inputs, golden_rewards, golden_noisy, tensor_digest  # noqa: E402
 
 
 def digest_state_dict(sd):
