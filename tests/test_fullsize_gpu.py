@@ -1,0 +1,95 @@
+"""The bench workload at its FULL size (BASELINE.json configs[1]: bs = 256, 224x224x3, --losses autoencoder, state-dim 200)
+on the product classes, checked through properties that do not need a full-size oracle backward:
+  * the oracle's train-mode FORWARD at bs = 256 (a few seconds of CPU): losses, a sample of states / reconstructions and the
+    BatchNorm running statistics — i.e. the per-tile statistics path reduced over 256 x 112 x 112 positions;
+  * run-to-run determinism of the whole step (loss and the 2.4 M-element gradient bucket, bit for bit);
+  * batch-size independence in eval mode: the 256-image launch equals four 64-image launches;
+  * the eval-mode oracle on a few images of the batch.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+B = 256
+
+
+def _model():
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModules
+    pre.N_CHANNELS = 3
+    np.random.seed(11)
+    torch.manual_seed(11)
+    return SRLModules(state_dim=200, action_dim=6, cuda=True, model_type="custom_cnn", losses=["autoencoder"])
+
+
+def _step(model, obs, next_obs):
+    import losses.losses as L
+    from srlz import optim
+    flat = optim.FlatParams(model)
+    model.train()
+    flat.zero_grad()
+    lm = L.LossManager(model, None)
+    (s, dec), (ns, ndec) = model(obs), model(next_obs)
+    L.autoEncoderLoss(obs, dec, next_obs, ndec, weight=1.0, loss_manager=lm)
+    loss = lm.computeTotalLoss()
+    loss.backward()
+    flat.deliver()
+    torch.cuda.synchronize()
+    return loss.detach().clone(), flat.grad.clone(), s.detach(), dec.detach()
+
+
+def test_full_size_step():
+    from oracle import torch_twin as T
+    obs_np, next_np, _ = gu.golden_inputs(B, 3, 6, seed=4242)
+    obs, nxt = torch.from_numpy(obs_np), torch.from_numpy(next_np)
+    model = _model()
+    init = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+
+    # ---- oracle: train-mode forward at the full batch (no backward: seconds on the host cores)
+    sd = T.clone_state(init, requires_grad=False)
+    with torch.no_grad():
+        ref_s, ref_dec = T.ae_forward(sd, obs, True)
+        _, ref_ndec = T.ae_forward(sd, nxt, True)
+        ref_loss = T.reconstruction_loss(obs, ref_dec) + T.reconstruction_loss(nxt, ref_ndec)
+
+    model = model.to("cuda")
+    o, no = obs.cuda(), nxt.cuda()
+    loss1, grad1, s1, dec1 = _step(model, o, no)
+    assert abs(loss1.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item())
+    pick = torch.arange(0, B, 37)
+    err_s = (s1.cpu()[pick] - ref_s[pick]).abs().max().item() / ref_s.abs().max().item()
+    err_d = (dec1.cpu()[pick] - ref_dec[pick]).abs().max().item() / ref_dec.abs().max().item()
+    assert err_s < 1e-4 and err_d < 1e-4, (err_s, err_d)
+    got_sd = model.state_dict()
+    for k in sd:
+        if "running_" in k:  # statistics of 256 x H x W positions, two momentum updates
+            ref_v, got_v = sd[k].double(), got_sd[k].double().cpu()
+            assert (got_v - ref_v).abs().max().item() <= 1e-4 * ref_v.abs().max().item(), k
+
+    # ---- determinism: the same step from the same initial state, bit for bit
+    model.load_state_dict(init)
+    loss2, grad2, _, _ = _step(model, o, no)
+    model.load_state_dict(init)
+    loss3, grad3, _, _ = _step(model, o, no)
+    assert torch.equal(loss2, loss3) and torch.equal(grad2, grad3)
+    assert torch.isfinite(grad2).all() and grad2.abs().max().item() > 0
+
+    # ---- eval mode: one 256-image launch == four 64-image launches; a few images against the eval-mode oracle
+    model.eval()
+    with torch.no_grad():
+        s_all, dec_all = model(o)
+        parts = [model(o[i:i + 64]) for i in range(0, B, 64)]
+        s_parts, dec_parts = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    assert (s_all - s_parts).abs().max().item() <= 1e-6 * s_all.abs().max().item()
+    assert (dec_all - dec_parts).abs().max().item() <= 1e-6 * dec_all.abs().max().item()
+    sd_eval = T.clone_state(OrderedDict((k, v.detach().cpu()) for k, v in model.state_dict().items()), requires_grad=False)
+    sel = torch.tensor([0, 101, 255])
+    with torch.no_grad():
+        ref_es, ref_edec = T.ae_forward(sd_eval, obs[sel], False)
+    assert (s_all.cpu()[sel] - ref_es).abs().max().item() <= 1e-4 * ref_es.abs().max().item()
+    assert (dec_all.cpu()[sel] - ref_edec).abs().max().item() <= 1e-4 * ref_edec.abs().max().item()
