@@ -18,6 +18,18 @@ int srlz_hip_fail(hipError_t e, const char* what);
     if (_e != hipSuccess) return srlz_hip_fail(_e, #expr); \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit once (per call site / template instantiation), not on every launch: the call is
+// host overhead on a launch-bound path, and it is not a stream operation, so it must not happen while the stream is being
+// captured into a hipGraph (srlz/graph.py) — after the warm-up launches every limit is already in place.
+#define SRLZ_MAX_LDS(fn, bytes)                                                                                         \
+  do {                                                                                                                  \
+    static int srlz_lds_set_ = -1;                                                                                      \
+    if ((int)(bytes) > srlz_lds_set_) {                                                                                 \
+      SRLZ_HIP(hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));      \
+      srlz_lds_set_ = (int)(bytes);                                                                                     \
+    }                                                                                                                   \
+  } while (0)
+
 #define SRLZ_REQUIRE(cond, code, ...) \
   do {                                \
     if (!(cond)) {                    \

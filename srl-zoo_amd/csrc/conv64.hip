@@ -737,8 +737,7 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
   static const int nw = [] { const char* e = getenv("SRLZ_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
 #define SRLZ_FWD_LAUNCH(NWV, BWDV)                                                                                          \
   do {                                                                                                                     \
-    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_fwd_kernel<NWV, BWDV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                 (int)lds));                                                                               \
+    SRLZ_MAX_LDS((conv64_fwd_kernel<NWV, BWDV>), lds);                                                                      \
     hipLaunchKernelGGL((conv64_fwd_kernel<NWV, BWDV>), dim3(ntiles), dim3(NWV * 64), lds, st, src, wpack, bias, dst, stats, \
                        P, ntiles, src_fuse);                                                                               \
   } while (0)
@@ -850,10 +849,10 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
     launched_grid = (nchunks + cpw - 1) / cpw;
     const size_t lds = (size_t)(RING + 64) * 256;
     if (P.s2) {
-      SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SRLZ_MAX_LDS(conv64_wgrad_ring_kernel<true>, lds);
       hipLaunchKernelGGL((conv64_wgrad_ring_kernel<true>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, x_bnp);
     } else {
-      SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SRLZ_MAX_LDS(conv64_wgrad_ring_kernel<false>, lds);
       hipLaunchKernelGGL((conv64_wgrad_ring_kernel<false>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, x_bnp);
     }
   } else {
@@ -861,8 +860,7 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
     SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64 wgrad: chunk needs %zu bytes of LDS", lds);
 #define SRLZ_WGRAD_LAUNCH(S2V, TKV)                                                                                        \
   do {                                                                                                                     \
-    SRLZ_HIP(hipFuncSetAttribute((const void*)conv64_wgrad_kernel<S2V, TKV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 (int)lds));                                                                               \
+    SRLZ_MAX_LDS((conv64_wgrad_kernel<S2V, TKV>), lds);                                                                     \
     hipLaunchKernelGGL((conv64_wgrad_kernel<S2V, TKV>), dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, xf, gf); \
   } while (0)
     if (P.s2) SRLZ_WGRAD_LAUNCH(true, 64);

@@ -22,11 +22,15 @@ extern "C" int srlz_version(void) { return 100; }
 extern "C" const char* srlz_last_error(void) { return g_err; }
 
 extern "C" int srlz_device_cus(void) {
+  // queried once per process (one process drives one GPU): this sits on every persistent kernel's launch path
+  static int cached = 0;
+  if (cached > 0) return cached;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 256;
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
-  return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  cached = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  return cached;
 }
 
 // ---- calibration micro-benchmark: back-to-back v_mfma_f32_32x32x2_f32 on random operands, no memory traffic ----

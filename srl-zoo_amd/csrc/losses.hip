@@ -219,6 +219,30 @@ __global__ __launch_bounds__(256) void fold_grads_kernel(float* __restrict__ g, 
   }
 }
 
+// Device-side step counter for hipGraph replays (a captured kernel argument cannot change from step to step):
+// step_dev[0] += 1, then the two bias corrections of torch.optim.Adam for that step -> bc[0] = 1 - b1^t, bc[1] = sqrt(1 - b2^t)
+__global__ void adam_tick_kernel(int* __restrict__ step_dev, float* __restrict__ bc, float b1, float b2) {
+  const int t = step_dev[0] + 1;
+  step_dev[0] = t;
+  bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+  bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, long long n, float lr, float b1, float b2,
+                                                      float eps, const float* __restrict__ bc, float grad_scale) {
+  const float step_size = lr / bc[0];
+  const float bc2_sqrt = bc[1];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+
 static int blocks_for(long long n, int cap) {
   long long b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -357,6 +381,18 @@ extern "C" int srlz_adam_step(float* p, const float* g, float* m, float* v, long
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2,
                      eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                                  float eps, int* step_dev, float* bc_dev, float grad_scale, srlz_stream_t stream) {
+  SRLZ_REQUIRE(p && g && m && v && step_dev && bc_dev, SRLZ_ERR_NULL, "adam_step_dev: null pointer");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_dev, bc_dev, beta1, beta2);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps,
+                     (const float*)bc_dev, grad_scale);
   SRLZ_LAUNCHED();
   return 0;
 }

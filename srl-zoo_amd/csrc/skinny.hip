@@ -740,14 +740,14 @@ static int launch_conv(const float* img, const float* w, float* feat, float* sta
   const int ntiles = d->n * ty * tx;
   const size_t lds = conv_lds<K>();
   if constexpr (K == 4) if (y_raw) {
-    SRLZ_HIP(hipFuncSetAttribute((const void*)skinny_conv_kernel<K, PAD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, true>), lds);
     hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, true>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
                        d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp);
     SRLZ_LAUNCHED();
     return 0;
   }
   {
-    SRLZ_HIP(hipFuncSetAttribute((const void*)skinny_conv_kernel<K, PAD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, false>), lds);
     hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, false>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
                        d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp);
   }
@@ -813,7 +813,7 @@ extern "C" int srlz_conv1_bwd_data(const float* dy_nhwc, const float* w_ref, flo
   const int ty = (d->himg + 15) / 16, tx = (d->wimg + 15) / 16;
   const int ntiles = d->n * ty * tx;
   const size_t lds = (size_t)128 * DG_TP * sizeof(float);
-  SRLZ_HIP(hipFuncSetAttribute((const void*)conv1_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SRLZ_MAX_LDS(conv1_dgrad_kernel, lds);
   hipLaunchKernelGGL(conv1_dgrad_kernel, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), dy_nhwc,
                      w_ref, dx_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx);
   SRLZ_LAUNCHED();

@@ -208,6 +208,11 @@ class SRL4robotics(BaseLearner):
         # HIP streams so one frame's kernel tails, small layers and HBM-bound passes overlap the other's (autograd runs
         # each frame's backward on its forward stream).  Opt-in (SRLZ_TWO_STREAMS=1): measured +1 % on MI355X because the big
         # kernels already fill the chip; the default runs the frames back to back.
+        # hipGraph replay of the step body (see _graphStep), opt-in with SRLZ_GRAPH=1.  Measured on MI355X: 3 % at bs = 32
+        # (3.94 vs 4.06 ms), nothing at bs >= 64 — the ~300 small kernels of a step cost ~10 us each ON THE GPU whether
+        # they are enqueued one by one or replayed from a graph, so the cure for small minibatches is fewer kernels.
+        self._use_graph = os.environ.get("SRLZ_GRAPH", "0") == "1"
+        self._graphs = {}
         self._frame_streams = None
         if os.environ.get("SRLZ_TWO_STREAMS", "0") != "0":
             self._frame_streams = (th.cuda.Stream(device=self.device), th.cuda.Stream(device=self.device))
@@ -300,8 +305,74 @@ class SRL4robotics(BaseLearner):
 
         Runs forward, losses, backward (also on validation minibatches, as the reference does), the gradient
         all-reduce and the Adam step.  Returns the total loss as a 0-dim device tensor; per-loss tensors stay in
-        `loss_manager`.
+        `loss_manager`.  With hipGraph mode on (SRLZ_GRAPH, see _graphStep) the same body is replayed from a captured
+        graph: one launch per step instead of ~300.
         """
+        if self._use_graph and self.world_size == 1:
+            return self._graphStep(loss_manager, validation_mode, dict(obs=obs, next_obs=next_obs, actions_st=actions_st,
+                                                                       noisy_obs=noisy_obs, next_noisy_obs=next_noisy_obs,
+                                                                       rewards_st=rewards_st))
+        return self._eagerStep(obs, next_obs, actions_st, loss_manager, validation_mode, noisy_obs, next_noisy_obs,
+                               rewards_st)
+
+    # -- hipGraph mode ----------------------------------------------------------------------------------------------
+    # The step body can be captured ONCE per variant (training / validation) into a HIP graph
+    # — forward, losses, backward, gradient delivery, Adam with a device-side step counter — and replayed on static input
+    # buffers.  Capturing needs warm-up executions of the body (allocator, lazy initialisation); the parameters, Adam
+    # moments, BatchNorm buffers and the RNG state they disturb are snapshotted and restored, so a graphed run follows the
+    # eager one step for step.  Single GPU only (the RCCL all-reduce stays outside graphs in this build).
+    def _stateTensors(self):
+        tensors = [self.flat_params.flat, self.optimizer.m, self.optimizer.v, self.optimizer.t_dev]
+        tensors += [b for b in self.model.buffers()]
+        return tensors
+
+    def _graphStep(self, loss_manager, validation_mode, inputs):
+        entry = self._graphs.get(validation_mode)
+        if entry is None:
+            self.optimizer.use_device_step()
+            static = {k: (th.empty_like(v) if v is not None else None) for k, v in inputs.items()}
+            for k, v in inputs.items():
+                if v is not None:
+                    static[k].copy_(v)
+            snapshot = [t.clone() for t in self._stateTensors()]
+            rng = th.cuda.get_rng_state(self.device)
+            host_t = self.optimizer.t
+            warm_lm = LossManager(self.model, None)
+            cur = th.cuda.current_stream(self.device)
+            side = th.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with th.cuda.stream(side):
+                for _ in range(2):
+                    self._eagerStep(loss_manager=warm_lm, validation_mode=validation_mode, **static)
+            cur.wait_stream(side)
+            th.cuda.synchronize(self.device)
+            for t, saved in zip(self._stateTensors(), snapshot):
+                t.copy_(saved)
+            th.cuda.set_rng_state(rng, self.device)
+            self.optimizer.t = host_t
+            cap_lm = LossManager(self.model, None)
+            graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(graph):
+                loss = self._eagerStep(loss_manager=cap_lm, validation_mode=validation_mode, **static)
+            self.optimizer.t = host_t
+            entry = dict(graph=graph, static=static, loss=loss, lm=cap_lm)
+            self._graphs[validation_mode] = entry
+        for k, v in inputs.items():
+            if v is not None:
+                entry["static"][k].copy_(v)
+        if validation_mode:
+            self.model.eval()
+        else:
+            self.model.train()
+            self.optimizer.t += 1
+        entry["graph"].replay()
+        loss_manager.names, loss_manager.weights = list(entry["lm"].names), list(entry["lm"].weights)
+        loss_manager.losses = list(entry["lm"].losses)
+        self._last_obs = inputs["obs"]
+        return entry["loss"]
+
+    def _eagerStep(self, obs, next_obs, actions_st, loss_manager, validation_mode=False, noisy_obs=None,
+                   next_noisy_obs=None, rewards_st=None):
         if validation_mode:
             self.model.eval()
         else:
@@ -359,6 +430,8 @@ class SRL4robotics(BaseLearner):
         if not validation_mode:
             grad_scale = optim.allreduce_gradients(self.flat_params)
             self.optimizer.step(grad_scale)
+        else:
+            self.flat_params.discard()
         self._last_obs = obs
         return loss
 

@@ -100,6 +100,7 @@ _PROTOS = {
     "srlz_param_norms_grad": (c_int, [P, P, P, c_int, c_int, P, P, c_float, P]),
     "srlz_fold_grads": (c_int, [P, P, c_longlong, c_int, P]),
     "srlz_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    "srlz_adam_step_dev": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, P, P, c_float, P]),
 }
 
 # entry points whose int return value is data, not a status

@@ -688,11 +688,19 @@ class ParamNormFn(Function):
         norms, ptrs, lens = ctx.saved_tensors[:3]
         params = ctx.saved_tensors[3:]
         dout = dout.contiguous()
-        grads = [torch.empty_like(p) for p in params]
-        gptrs = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64, device=norms.device)
+        grads = [_gbuf(p) for p in params]  # staging views for bucketed parameters: fixed addresses, table cached
+        key = tuple(g.data_ptr() for g in grads)
+        gptrs = _grad_tables.get(key)
+        if gptrs is None:
+            gptrs = torch.tensor(key, dtype=torch.int64, device=norms.device)
+            _grad_tables.clear()
+            _grad_tables[key] = gptrs
         C.param_norms_grad(ptr(ptrs), ptr(gptrs), ptr(lens), len(params), ctx.mode, ptr(norms), ptr(dout), ctx.scale,
                            stream())
-        return (None,) + tuple(grads)
+        return (None,) + tuple(_give(p, g) for p, g in zip(params, grads))
+
+
+_grad_tables = {}
 
 
 class ToNHWCFn(Function):
@@ -845,6 +853,11 @@ def fold_grads(grad, stages):
 
 def adam_step(p, g, m, v, lr, step, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
     C.adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, step, grad_scale, stream())
+
+
+def adam_step_dev(p, g, m, v, lr, step_dev, bc_dev, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    C.adam_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, ptr(step_dev), ptr(bc_dev),
+                    grad_scale, stream())
 
 
 def bn_replay(batch_stat, running_mean, running_var):

@@ -44,7 +44,7 @@ class FlatParams(object):
         self._served = [0] * len(params)
         self._dirty = False
 
-    NSTAGE = 2
+    NSTAGE = 3  # two frames + one regulariser contribution per parameter
 
     def grad_buffer(self, index):
         """Where the next gradient contribution of parameter `index` should be written, or None (all stages used in this
@@ -63,9 +63,15 @@ class FlatParams(object):
             ops.fold_grads(self.grad, self.stage)
             self._dirty = False
 
+    def discard(self):
+        """Drop the staged contributions of a backward pass whose gradients are not used (validation minibatch)."""
+        if self._dirty:
+            self.stage.zero_()
+            self._dirty = False
+
     def zero_grad(self):
         self.grad.zero_()
-        if self._dirty:  # a backward pass whose gradients were never delivered (validation minibatch)
+        if self._dirty:  # a backward pass whose gradients were neither delivered nor discarded
             self.stage.zero_()
             self._dirty = False
         self._served = [0] * len(self.params)
@@ -88,14 +94,32 @@ class FusedAdam(object):
         self.m = torch.zeros_like(flat_params.flat)
         self.v = torch.zeros_like(flat_params.flat)
         self.t = 0
+        # device-side step counter (+ 2 floats of bias corrections): the form a captured hipGraph can replay
+        self.device_step = False
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=flat_params.flat.device)
+        self.bc_dev = torch.zeros(2, dtype=torch.float32, device=flat_params.flat.device)
 
     def zero_grad(self):
         self.fp.zero_grad()
 
+    def use_device_step(self):
+        """Switch to the device-side step counter (continuing from the current step)."""
+        if not self.device_step:
+            self.t_dev.fill_(self.t)
+            self.device_step = True
+
     def step(self, grad_scale=1.0):
         self.fp.deliver()
-        self.t += 1
-        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.t, grad_scale, self.betas, self.eps)
+        self.t += 1  # (host mirror; in device_step mode a graph replay advances only t_dev — see steps())
+        if self.device_step:
+            ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.t_dev, self.bc_dev, grad_scale,
+                              self.betas, self.eps)
+        else:
+            ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr, self.t, grad_scale, self.betas, self.eps)
+
+    def steps(self):
+        """Number of updates applied so far."""
+        return int(self.t_dev.item()) if self.device_step else self.t
 
 
 def world():

@@ -131,3 +131,43 @@ def test_learn_vae_with_perceptual_loss(workdir):
     # the decoder only receives gradient through the denoiser: it must have moved
     after = list(srl.model.model.decoder_conv.parameters())
     assert any((a.detach() - b).abs().max().item() > 0 for a, b in zip(after, before))
+
+
+@pytest.mark.parametrize("losses", [["autoencoder", "inverse", "forward", "reward"], ["vae"]])
+def test_graph_mode_follows_eager(losses):
+    """hipGraph replay of the step body (SRL4robotics._graphStep: forward + losses + backward + gradient delivery + Adam with
+    a device-side step counter, captured once per variant) against the eager step, minibatch by minibatch — including a
+    validation minibatch in the middle and, for the VAE, the noise drawn inside the graph."""
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from models.learner import SRL4robotics
+    from losses.losses import LossManager
+    import golden_util as gu
+    pre.N_CHANNELS = 3
+    B = 4
+    learner.BATCH_SIZE = B
+
+    def run(use_graph):
+        srl = SRL4robotics(16, model_type="custom_cnn", seed=9, learning_rate=1e-3, cuda=True, losses=losses, n_actions=6,
+                           log_folder="/tmp", l2_reg=1e-4 if "vae" not in losses else 0.0)
+        srl._use_graph = use_graph
+        lm = LossManager(srl.model, None)
+        torch.manual_seed(123)
+        trace = []
+        for step in range(6):
+            obs, nxt, act = gu.golden_inputs(B, 3, 6, seed=500 + step)
+            rew = torch.from_numpy(gu.golden_rewards(B, seed=500 + step)[1]).cuda()
+            loss = srl.trainStep(torch.from_numpy(obs).cuda(), torch.from_numpy(nxt).cuda(),
+                                 torch.from_numpy(act).view(-1, 1).cuda(), lm, validation_mode=(step == 3), rewards_st=rew)
+            trace.append([float(loss)] + [float(l) for l in lm.losses])
+            assert len(lm.names) == len(lm.losses) == len(lm.weights)
+        torch.cuda.synchronize()
+        return np.array(trace), srl.flat_params.flat.clone(), [b.clone() for b in srl.model.buffers()], srl.optimizer.steps()
+
+    eager, p0, b0, t0 = run(False)
+    graph, p1, b1, t1 = run(True)
+    assert t0 == t1 == 5
+    np.testing.assert_allclose(graph, eager, rtol=2e-5, atol=1e-7)
+    assert (p1 - p0).abs().max().item() <= 2e-5 * p0.abs().max().item()
+    for x, y in zip(b0, b1):
+        assert (x.double() - y.double()).abs().max().item() <= 2e-5 * max(1.0, x.double().abs().max().item())
