@@ -8,6 +8,21 @@ from .models import BaseModelSRL
 from srlz import hotpath, ops
 
 
+def _three_layer_head(n_in, n_hidden, n_out):
+    """Linear - ReLU - Linear - ReLU - Linear, indices 0 / 2 / 4 as in the reference's state_dict."""
+    return nn.Sequential(nn.Linear(n_in, n_hidden), nn.ReLU(), nn.Linear(n_hidden, n_hidden), nn.ReLU(),
+                         nn.Linear(n_hidden, n_out))
+
+
+def _run_head(net, x):
+    """A head through the HIP linear kernels (ReLU fused into the first two layers of a 3-layer head)."""
+    if isinstance(net, nn.Linear):
+        return hotpath.linear(net, x)
+    x = hotpath.linear(net[0], x, relu=True)
+    x = hotpath.linear(net[2], x, relu=True)
+    return hotpath.linear(net[4], x)
+
+
 class BaseForwardModel(BaseModelSRL):
     def __init__(self):
         self.action_dim = None
@@ -33,26 +48,18 @@ class BaseInverseModel(BaseModelSRL):
         super(BaseInverseModel, self).__init__()
 
     def initInverseNet(self, state_dim, action_dim, n_hidden=128, model_type="linear"):
-        if model_type == "linear":
-            self.inverse_net = nn.Linear(state_dim * 2, action_dim)
-        elif model_type == "mlp":
-            self.inverse_net = nn.Sequential(nn.Linear(state_dim * 2, n_hidden), nn.ReLU(),
-                                             nn.Linear(n_hidden, n_hidden), nn.ReLU(),
-                                             nn.Linear(n_hidden, action_dim))
-        else:
+        if model_type not in ("linear", "mlp"):
             raise ValueError("Unknown model_type for inverse model: {}".format(model_type))
+        # one Linear, or the 3-layer perceptron; layer creation order = the reference's (same RNG stream, same keys)
+        self.inverse_net = nn.Linear(2 * state_dim, action_dim) if model_type == "linear" \
+            else _three_layer_head(2 * state_dim, n_hidden, action_dim)
 
     def forward(self, x):
         raise NotImplementedError()
 
     def inverseModel(self, state, next_state):
         """action logits from [state ; next_state]."""
-        x = th.cat((state, next_state), dim=1)
-        if isinstance(self.inverse_net, nn.Linear):
-            return hotpath.linear(self.inverse_net, x)
-        x = hotpath.linear(self.inverse_net[0], x, relu=True)
-        x = hotpath.linear(self.inverse_net[2], x, relu=True)
-        return hotpath.linear(self.inverse_net[4], x)
+        return _run_head(self.inverse_net, th.cat((state, next_state), dim=1))
 
 
 class BaseRewardModel(BaseModelSRL):
@@ -61,16 +68,11 @@ class BaseRewardModel(BaseModelSRL):
         super(BaseRewardModel, self).__init__()
 
     def initRewardNet(self, state_dim, n_rewards=2, n_hidden=16):
-        self.reward_net = nn.Sequential(nn.Linear(2 * state_dim, n_hidden), nn.ReLU(),
-                                        nn.Linear(n_hidden, n_hidden), nn.ReLU(),
-                                        nn.Linear(n_hidden, n_rewards))
+        self.reward_net = _three_layer_head(2 * state_dim, n_hidden, n_rewards)
 
     def forward(self, x):
         raise NotImplementedError()
 
     def rewardModel(self, state, next_state):
         """reward logits from [state ; next_state] (reference forward_inverse.py:87-95)."""
-        x = th.cat((state, next_state), dim=1)
-        x = hotpath.linear(self.reward_net[0], x, relu=True)
-        x = hotpath.linear(self.reward_net[2], x, relu=True)
-        return hotpath.linear(self.reward_net[4], x)
+        return _run_head(self.reward_net, th.cat((state, next_state), dim=1))

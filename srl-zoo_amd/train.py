@@ -4,7 +4,7 @@ driving the MI355X-native SRL4robotics.  Multi-GPU: launch one process per GPU w
 environment; backend "nccl" is RCCL on ROCm).
 
 Out of scope of this build (rejected with a clear message): --model-type other than custom_cnn, the losses of other
-SRL methods (priors, reward, triplet, perceptual, episode-prior, reward-prior), split dimensions, plots.
+SRL methods (priors, triplet, episode-prior, reward-prior), plots.
 """
 from __future__ import print_function, division, absolute_import
 
@@ -26,43 +26,45 @@ LOSS_CHOICES = ["forward", "inverse", "reward", "priors", "episode-prior", "rewa
                 "autoencoder", "vae", "perceptual", "dae", "random"]
 
 
+# The reference's command line (train.py:25-61): identical flags, short forms, types and defaults; one row per flag.
+_INT, _FLOAT, _STR, _FLAG = int, float, str, "flag"
+_CLI = [
+    (("--epochs",), _INT, 30, "training epochs"),
+    (("--seed",), _INT, 1, "seed of numpy / torch"),
+    (("--state-dim",), _INT, 2, "dimension of the learned state"),
+    (("-bs", "--batch-size"), _INT, 32, "samples per minibatch (per GPU)"),
+    (("--val-size",), _FLOAT, 0.2, "fraction of the minibatches held out for validation"),
+    (("--training-set-size",), _INT, -1, "use only the first N samples (-1: all)"),
+    (("-lr", "--learning-rate"), _FLOAT, 0.005, "Adam learning rate"),
+    (("--l1-reg",), _FLOAT, 0.0, "weight of the L1 regulariser"),
+    (("--l2-reg",), _FLOAT, 0.0, "weight of the L2 regulariser"),
+    (("--no-cuda",), _FLAG, False, "accepted for compatibility; this build has no CPU path"),
+    (("--no-display-plots",), _FLAG, False, "accepted for compatibility; plotting is not part of this build"),
+    (("--data-folder",), _STR, "", "dataset folder under data/ (required)"),
+    (("--log-folder",), _STR, "", "output folder (default: logs/<dataset>/<timestamp>_<model>_ST_DIM<n>_<losses>)"),
+    (("--multi-view",), _FLAG, False, "two stacked camera views (6 input channels)"),
+    (("--balanced-sampling",), _FLAG, False, "accepted for compatibility (episode prior only)"),
+    (("--beta",), _FLOAT, 1.0, "weight of the KL term (beta-VAE)"),
+    (("--path-to-dae",), _STR, "", "srl_model.pth of a trained DAE (perceptual loss)"),
+    (("--state-dim-dae",), _INT, 200, "state dimension of that DAE"),
+    (("--occlusion-percentage",), _FLOAT, 0.5, "largest occluded fraction per side (DAE)"),
+]
+
+
 def buildParser():
     parser = argparse.ArgumentParser(description='State Representation Learning on MI355X (srl-zoo hot path)')
-    parser.add_argument('--epochs', type=int, default=30, metavar='N', help='number of epochs to train (default: 30)')
-    parser.add_argument('--seed', type=int, default=1, metavar='S', help='random seed (default: 1)')
-    parser.add_argument('--state-dim', type=int, default=2, help='state dimension (default: 2)')
-    parser.add_argument('-bs', '--batch-size', type=int, default=32, help='batch_size (default: 32)')
-    parser.add_argument('--val-size', type=float, default=0.2, help='Validation set size in percentage (default: 0.2)')
-    parser.add_argument('--training-set-size', type=int, default=-1,
-                        help='Limit size (number of samples) of the training set (default: -1)')
-    parser.add_argument('-lr', '--learning-rate', type=float, default=0.005, help='learning rate (default: 0.005)')
-    parser.add_argument('--l1-reg', type=float, default=0.0, help='L1 regularization coeff (default: 0.0)')
-    parser.add_argument('--l2-reg', type=float, default=0.0, help='L2 regularization coeff (default: 0.0)')
-    parser.add_argument('--no-cuda', action='store_true', default=False, help='disables CUDA training')
-    parser.add_argument('--no-display-plots', action='store_true', default=False,
-                        help='disables live plots of the representation learned')
+    for names, kind, default, text in _CLI:
+        if kind == _FLAG:
+            parser.add_argument(*names, action='store_true', default=default, help=text)
+        else:
+            parser.add_argument(*names, type=kind, default=default, help="%s (default: %r)" % (text, default),
+                                required=(names[0] == "--data-folder"))
     parser.add_argument('--model-type', type=str, default="custom_cnn", choices=['custom_cnn', 'resnet', 'mlp', 'linear'],
-                        help='Model architecture (default: "custom_cnn")')
+                        help='encoder family; only custom_cnn runs here')
     parser.add_argument('--inverse-model-type', type=str, default="linear", choices=['mlp', 'linear'],
-                        help='Inverse model s architecture (default: "linear")')
-    parser.add_argument('--data-folder', type=str, default="", help='Dataset folder', required=True)
-    parser.add_argument('--log-folder', type=str, default="",
-                        help='Folder where the experiment model and plots will be saved. By default '
-                             'logs/DatasetName/YY-MM-DD_HHhMM_SS_ModelType_ST_DIMN_LOSSES')
-    parser.add_argument('--multi-view', action='store_true', default=False, help='Enable use of multiple camera')
-    parser.add_argument('--balanced-sampling', action='store_true', default=False,
-                        help='Force balanced sampling for episode independent prior instead of uniform')
+                        help='architecture of the inverse model')
     parser.add_argument('--losses', nargs='+', default=["inverse"], **parseLossArguments(
-        choices=LOSS_CHOICES,
-        help='The wanted losses. One may also want to specify a weight and dimension '
-             'that apply as follows: "<name>:<weight>:<dimension>".'))
-    parser.add_argument('--beta', type=float, default=1.0,
-                        help='(For beta-VAE only) Factor on the KL divergence, higher value means more disentangling.')
-    parser.add_argument('--path-to-dae', type=str, default="",
-                        help='Path to a pre-trained dae model when using the perceptual loss with VAE')
-    parser.add_argument('--state-dim-dae', type=int, default=200, help='state dimension of the pre-trained dae (default: 200)')
-    parser.add_argument('--occlusion-percentage', type=float, default=0.5,
-                        help='Max percentage of input occlusion for masks when using DAE')
+        choices=LOSS_CHOICES, help='losses to combine, as <name> or <name>:<weight>[:<dimension>]'))
     return parser
 
 
