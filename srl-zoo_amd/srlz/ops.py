@@ -189,6 +189,7 @@ class Conv1Fn(Function):
         if stats is None:
             stats = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)  # no zero tensor for the statistics output in backward
         return y, stats
 
     @staticmethod
@@ -242,6 +243,7 @@ class Conv64Fn(Function):
         if stats is None:
             stats = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)  # no zero tensor for the statistics output in backward
         return y, stats
 
     @staticmethod
@@ -508,6 +510,7 @@ class DecBlockFn(Function):
         if stats is None:
             stats = torch.empty(0, device=y_prev.device)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)  # no zero tensor for the statistics output in backward
         return y, stats
 
     @staticmethod
