@@ -144,3 +144,54 @@ def test_wgrad_ring_schedule_never_aliases(cabi, hi, s, p, t):
             if chunk + 1 < c_end:  # landed after the barrier that follows this chunk's MFMA loop
                 for q in range(q0 + min_off + TK + span, q0 + min_off + TK + span + 64):
                     slot[q & (RING - 1)] = q
+
+
+def test_programs_for_random_shapes(cabi):
+    """Beyond the network's own layers: random sizes (odd / even, rectangular inputs are square here by ABI), both strides,
+    padded and unpadded, plain and transposed — forward and data-gradient programs against torch, plus the structural
+    invariants the kernels rely on (a zero row/column behind every negative offset, span within the LDS ring)."""
+    rs = np.random.RandomState(2024)
+    checked, declined = 0, []
+    for _ in range(60):
+        t = int(rs.randint(0, 2))
+        s = int(rs.randint(1, 3))
+        p = int(rs.randint(0, 2))
+        hi = int(rs.randint(3, 20))
+        if not t and hi + 2 * p < 3:
+            continue
+        ho = out_size(hi, s, p, t)
+        if ho < 1:
+            continue
+        d = cabi.Conv64Desc(2, hi, hi, ho, ho, 3, s, p, t)
+        buf = (ctypes.c_int * 64)()
+        if cabi._lib.srlz_conv64_debug_program(ctypes.byref(d), 0, buf, 64) != 48 or \
+                cabi._lib.srlz_conv64_debug_program(ctypes.byref(d), 1, buf, 64) != 48:
+            # a geometry one of the two programs cannot express (e.g. the data gradient of an unpadded stride-1 conv needs
+            # offsets of -2 rows): the C ABI rejects the descriptor loudly instead of computing something else
+            declined.append((hi, s, p, t))
+            continue
+        N, C = 2, 2
+        x = rs.randn(N, hi, hi, C)
+        Wg = rs.randn(9, C, C)
+        P = get_program(cabi, N, hi, s, p, t, 0)
+        got = interpret(P, x, Wg)
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2).requires_grad_(True)
+        if t:
+            w = torch.from_numpy(Wg.reshape(3, 3, C, C)).permute(2, 3, 0, 1).contiguous()
+            y = F.conv_transpose2d(xt, w, stride=s, padding=p)
+        else:
+            w = torch.from_numpy(Wg.reshape(3, 3, C, C)).permute(3, 2, 0, 1).contiguous()
+            y = F.conv2d(xt, w, stride=s, padding=p)
+        np.testing.assert_allclose(got, y.detach().permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-10)
+        dy = rs.randn(N, ho, ho, C)
+        y.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+        Pb = get_program(cabi, N, hi, s, p, t, 1)
+        gotb = interpret(Pb, dy, Wg.transpose(0, 2, 1))
+        np.testing.assert_allclose(gotb, xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-10)
+        for prog in (P, Pb):
+            assert prog["span"] + 64 <= 256 or len(set(c for (c, _, _, _) in prog["taps"])) > 1 or prog["PW"] > 95
+            assert prog["min_off"] <= 0 <= prog["min_off"] + prog["span"]
+        checked += 1
+    assert checked >= 20, (checked, declined)
+    assert all(not (s == 1 and p == 1 and not t) and not (s == 2 and p == 0 and t) and not (s == 2 and p == 1 and not t)
+               for (_, s, p, t) in declined), "a geometry of the network's own layers was declined: %r" % declined
