@@ -171,3 +171,27 @@ def test_graph_mode_follows_eager(losses):
     assert (p1 - p0).abs().max().item() <= 2e-5 * p0.abs().max().item()
     for x, y in zip(b0, b1):
         assert (x.double() - y.double()).abs().max().item() <= 2e-5 * max(1.0, x.double().abs().max().item())
+
+
+def test_train_cli_end_to_end(workdir):
+    """The command line itself, the way the reference's own tests drive it (tests/test_modules.py, test_pipeline.py: run
+    `python train.py ...`, expect exit code 0 and the output files): the reference's stacked-model flags on the tiny dataset."""
+    import subprocess
+    import sys
+    name = workdir[0]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = os.path.join(os.getcwd(), "logs", "cli_run")
+    args = ["--no-display-plots", "--data-folder", name, "--epochs", "1", "--seed", "0", "--val-size", "0.2",
+            "--state-dim", "10", "--model-type", "custom_cnn", "-bs", "8", "--log-folder", log,
+            "--losses", "dae:1:2", "reward:1:-1", "forward:1:6", "inverse:5:2", "--inverse-model-type", "mlp",
+            "--occlusion-percentage", "0.3", "--l2-reg", "0.0001"]
+    env = dict(os.environ)
+    proc = subprocess.run([sys.executable, os.path.join(repo, "srl-zoo_amd", "train.py")] + args, cwd=os.getcwd(), env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert proc.returncode == 0, proc.stdout.decode("utf-8", "replace")[-3000:]
+    for f in ("srl_model.pth", "exp_config.json", "states_rewards.npz", "image_to_state.json"):
+        assert os.path.exists(os.path.join(log, f)), f
+    cfg = json.load(open(os.path.join(log, "exp_config.json")))
+    assert cfg["losses"] == ["dae", "reward", "forward", "inverse"] and cfg["split-dimensions"]["forward"] == 6
+    z = np.load(os.path.join(log, "states_rewards.npz"))
+    assert z["states"].shape[1] == 10 and np.isfinite(z["states"]).all()
