@@ -195,3 +195,23 @@ def test_train_cli_end_to_end(workdir):
     assert cfg["losses"] == ["dae", "reward", "forward", "inverse"] and cfg["split-dimensions"]["forward"] == 6
     z = np.load(os.path.join(log, "states_rewards.npz"))
     assert z["states"].shape[1] == 10 and np.isfinite(z["states"]).all()
+
+
+def test_train_cli_multi_view_vae(tmp_path):
+    """`--multi-view --losses vae`: two stacked camera views -> 6-channel CNNVAE (the reference-valid half of BASELINE.json
+    configs[4]; the reference itself crashes on `vae triplet`)."""
+    import subprocess
+    import sys
+    make_dataset(str(tmp_path), name="tiny_mv", n_episodes=3, ep_len=14, multi_view=True)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = str(tmp_path / "logs" / "mv")
+    args = ["--no-display-plots", "--data-folder", "tiny_mv", "--epochs", "1", "--state-dim", "6", "-bs", "4", "--multi-view",
+            "--losses", "vae", "--log-folder", log]
+    proc = subprocess.run([sys.executable, os.path.join(repo, "srl-zoo_amd", "train.py")] + args, cwd=str(tmp_path),
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert proc.returncode == 0, proc.stdout.decode("utf-8", "replace")[-3000:]
+    sd = torch.load(os.path.join(log, "srl_model.pth"), map_location="cpu")
+    assert tuple(sd["model.encoder_conv.0.weight"].shape) == (64, 6, 7, 7)
+    assert tuple(sd["model.decoder_conv.12.weight"].shape) == (64, 6, 4, 4)
+    z = np.load(os.path.join(log, "states_rewards.npz"))
+    assert z["states"].shape[1] == 6 and np.isfinite(z["states"]).all()
