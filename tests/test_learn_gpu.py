@@ -159,7 +159,7 @@ def test_graph_mode_follows_eager(losses):
             rew = torch.from_numpy(gu.golden_rewards(B, seed=500 + step)[1]).cuda()
             loss = srl.trainStep(torch.from_numpy(obs).cuda(), torch.from_numpy(nxt).cuda(),
                                  torch.from_numpy(act).view(-1, 1).cuda(), lm, validation_mode=(step == 3), rewards_st=rew)
-            trace.append([float(loss)] + [float(l) for l in lm.losses])
+            trace.append([float(loss.detach())] + [float(l.detach()) for l in lm.losses])
             assert len(lm.names) == len(lm.losses) == len(lm.weights)
         torch.cuda.synchronize()
         return np.array(trace), srl.flat_params.flat.clone(), [b.clone() for b in srl.model.buffers()], srl.optimizer.steps()
