@@ -409,3 +409,26 @@ def test_direct_gradient_delivery_is_bitwise_identical():
     assert n0 == 0 and n1 > 60  # every conv / BN / linear parameter of both frames was written into a staging bucket
     assert classic.abs().max().item() > 0
     assert torch.equal(classic, direct)
+
+
+@pytest.mark.parametrize("B,losses", [(1, ["autoencoder", "inverse", "forward"]), (3, ["vae"]), (7, ["autoencoder"])])
+def test_odd_batch_sizes(B, losses):
+    """Ragged ends of every tiling (a single image, odd counts): losses, states and the last layer's gradient against the
+    oracle on the same parameters and inputs."""
+    from oracle import torch_twin as T
+    model = build(losses, seed=2)
+    sd = T.clone_state(model.state_dict())
+    obs, nxt, act = gu.golden_inputs(B, 3, 6, seed=31 + B)
+    obs, nxt, act = torch.from_numpy(obs), torch.from_numpy(nxt), torch.from_numpy(act)
+    eps = None
+    if "vae" in losses:
+        torch.manual_seed(5)
+        eps = [torch.randn(B, 200), torch.randn(B, 200)]
+    ref = T.train_step(sd, losses, obs, nxt, act, eps=None if eps is None else eps[0],
+                       next_eps=None if eps is None else eps[1])
+    model = model.to("cuda")
+    got = hip_step(model, losses, obs, nxt, act, eps_list=eps)
+    assert abs(got["total"] - ref["total"]) <= RTOL * abs(ref["total"])
+    assert rel(got["states"], ref["states"]) < RTOL and rel(got["next_states"], ref["next_states"]) < RTOL
+    g = dict(model.named_parameters())["model.decoder_conv.12.weight"].grad
+    assert rel(g, ref["grads"]["model.decoder_conv.12.weight"]) < RTOL
