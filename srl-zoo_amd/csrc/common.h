@@ -20,7 +20,8 @@ int srlz_hip_fail(hipError_t e, const char* what);
 
 // Raise a kernel's dynamic-LDS limit once (per call site / template instantiation), not on every launch: the call is
 // host overhead on a launch-bound path, and it is not a stream operation, so it must not happen while the stream is being
-// captured into a hipGraph (srlz/graph.py) — after the warm-up launches every limit is already in place.
+// captured into a hipGraph (models/learner.py::_graphStep) — after the warm-up launches every limit is already in place.
+// (One host thread drives one GPU per process, so the per-site static needs no lock.)
 #define SRLZ_MAX_LDS(fn, bytes)                                                                                         \
   do {                                                                                                                  \
     static int srlz_lds_set_ = -1;                                                                                      \

@@ -267,8 +267,7 @@ class Conv64Fn(Function):
             dx = torch.empty_like(x)
             _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
                     lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), None, d, stream()))
-        ctx_side = side
-        ctx_side.join()
+        side.join()
         return dx, _give(ctx.params[0], dw), _give(ctx.params[1], db), None, None, None, None
 
 
