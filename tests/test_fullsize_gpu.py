@@ -93,3 +93,89 @@ def test_full_size_step():
         ref_es, ref_edec = T.ae_forward(sd_eval, obs[sel], False)
     assert (s_all.cpu()[sel] - ref_es).abs().max().item() <= 1e-4 * ref_es.abs().max().item()
     assert (dec_all.cpu()[sel] - ref_edec).abs().max().item() <= 1e-4 * ref_edec.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] (--losses vae, beta 1) and configs[3]'s per-GPU workload (--losses autoencoder inverse forward)
+# at bs = 256, through the product's own loop body (SRL4robotics.trainStep), against the oracle's train-mode forward:
+# every loss term (the KL and the sum-reduced generation loss are 1e6..1e9 at this size), a sample of the states /
+# reconstructions, the BatchNorm running statistics after the step (for the VAE: four momentum updates, learner.py:402),
+# and bit-for-bit determinism of the step (loss terms + the flat gradient bucket).
+# ---------------------------------------------------------------------------------------------------------------------
+def _learner(losses):
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    pre.N_CHANNELS = 3
+    learner.BATCH_SIZE = B
+    return learner.SRL4robotics(200, model_type="custom_cnn", seed=11, learning_rate=1e-4, cuda=True, losses=losses,
+                                n_actions=6, log_folder="/tmp")
+
+
+@pytest.mark.parametrize("losses", [["vae"], ["autoencoder", "inverse", "forward"]], ids=["vae", "aeif"])
+def test_full_size_loop_body(losses):
+    import torch.nn.functional as F
+    from losses.losses import LossManager
+    from oracle import torch_twin as T
+    obs_np, next_np, act_np = gu.golden_inputs(B, 3, 6, seed=777)
+    obs, nxt, act = torch.from_numpy(obs_np), torch.from_numpy(next_np), torch.from_numpy(act_np)
+    torch.manual_seed(5)
+    eps, next_eps = torch.randn(B, 200), torch.randn(B, 200)
+
+    def run():
+        srl = _learner(losses)
+        init = OrderedDict((k, v.detach().cpu().clone()) for k, v in srl.model.state_dict().items())
+        if "vae" in losses:
+            it = iter((eps, next_eps))
+            srl.model.model.eps_fn = lambda mu: next(it).to(mu.device)
+        lm = LossManager(srl.model, None)
+        taken = {}
+        orig_step = srl.optimizer.step
+
+        def step_spy(grad_scale=1.0):  # the gradient bucket as Adam sees it
+            srl.flat_params.deliver()
+            taken["grad"] = srl.flat_params.grad.clone()
+            return orig_step(grad_scale)
+        srl.optimizer.step = step_spy
+        total = srl.trainStep(obs.cuda(), nxt.cuda(), act.view(-1, 1).cuda(), lm)
+        vals = dict(zip(lm.names, lm.lossValues()))
+        torch.cuda.synchronize()
+        return srl, init, vals, float(total.detach()), taken["grad"]
+
+    srl, init, vals, total, grad = run()
+
+    # ---- oracle: the same loop body, forward only (learner.py:392-402, 432-468), on the host cores
+    sd = T.clone_state(init, requires_grad=False)
+    ref = {}
+    with torch.no_grad():
+        if "vae" in losses:
+            dec, mu, logvar = T.vae_forward(sd, obs, True, eps)
+            ndec, nmu, nlogvar = T.vae_forward(sd, nxt, True, next_eps)
+            states, _ = T.vae_encode(sd, obs, True)       # the getStates quirk: two more train-mode encoder passes
+            next_states, _ = T.vae_encode(sd, nxt, True)
+            ref["kl_loss"] = float(T.kl_loss(mu, logvar) + T.kl_loss(nmu, nlogvar))
+            ref["generation_loss"] = float(F.mse_loss(dec, obs, reduction="sum") + F.mse_loss(ndec, nxt, reduction="sum"))
+            ref_total = 1.0 * ref["kl_loss"] + 0.5e-6 * ref["generation_loss"]
+        else:
+            states, dec = T.ae_forward(sd, obs, True)
+            next_states, ndec = T.ae_forward(sd, nxt, True)
+            ref["forward_loss"] = float(T.reconstruction_loss(T.forward_model(sd, states, act, 6), next_states))
+            ref["inverse_loss"] = float(F.cross_entropy(T.inverse_model(sd, states, next_states), act))
+            ref["reconstruction_loss"] = float(T.reconstruction_loss(obs, dec) + T.reconstruction_loss(nxt, ndec))
+            ref_total = ref["forward_loss"] + 2.0 * ref["inverse_loss"] + ref["reconstruction_loss"]
+    assert sorted(vals) == sorted(ref)
+    for k in ref:
+        assert abs(vals[k] - ref[k]) <= 1e-4 * abs(ref[k]), (k, vals[k], ref[k])
+    assert abs(total - ref_total) <= 1e-4 * abs(ref_total)
+    got_sd = srl.model.state_dict()
+    for k in sd:
+        if "running_" in k:
+            ref_v, got_v = sd[k].double(), got_sd[k].double().cpu()
+            assert (got_v - ref_v).abs().max().item() <= 1e-4 * ref_v.abs().max().item(), k
+        if "num_batches_tracked" in k:
+            assert int(got_sd[k]) == int(sd[k]), k
+
+    # ---- determinism: a second learner from the same seed takes the bit-identical step
+    srl2, _, vals2, total2, grad2 = run()
+    assert vals2 == vals and total2 == total
+    assert torch.equal(grad, grad2) and torch.isfinite(grad).all() and grad.abs().max().item() > 0
+    assert torch.equal(srl.flat_params.flat, srl2.flat_params.flat)

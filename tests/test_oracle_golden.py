@@ -51,7 +51,7 @@ CASES = [("step_ae_b2", ["autoencoder"], 2, 3, "linear"),
 
 
 def run_twin(losses, B, C, inverse, n_steps=1, lr=None, S=200, split=None, weights=None, l1_reg=0.0, l2_reg=0.0,
-             dae_seed=None):
+             dae_seed=None, val_steps=()):
     torch.set_num_threads(1)
     model = build(losses, C=C, S=S, inverse=inverse, split=split)
     sd = T.clone_state(model.state_dict())
@@ -73,9 +73,9 @@ def run_twin(losses, B, C, inverse, n_steps=1, lr=None, S=200, split=None, weigh
         rewards = torch.from_numpy(gu.golden_rewards(B, seed=1234 + step)[1]) if "reward" in losses else None
         out = T.train_step(sd, losses, torch.from_numpy(obs), torch.from_numpy(next_obs), torch.from_numpy(actions),
                            eps=eps[0], next_eps=eps[1], weights=weights, split=split, rewards=rewards, l1_reg=l1_reg,
-                           l2_reg=l2_reg, noisy=noisy, dae_sd=dae_sd)
+                           l2_reg=l2_reg, noisy=noisy, dae_sd=dae_sd, training=step not in val_steps)
         outs.append(out)
-        if opt is not None:
+        if opt is not None and step not in val_steps:  # a validation minibatch: backward, no update (learner.py:487-497)
             opt.step(sd)
     return sd, outs
 
@@ -168,12 +168,21 @@ def check_step_against_golden(g, sd, out, losses, B, C):
     np.testing.assert_allclose(st.double().numpy(), g["eval_states/full"], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name,losses", [("trace_ae_b2", ["autoencoder"]), ("trace_vae_b2", ["vae"]),
-                                         ("trace_aeif_b2", ["autoencoder", "inverse", "forward"])])
-def test_twin_adam_trace_matches_reference(name, losses):
-    """Three optimisation steps (Adam, lr 1e-4): per-step losses follow the reference."""
+TRACES = [("trace_ae_b2", ["autoencoder"], {}), ("trace_vae_b2", ["vae"], {}),
+          ("trace_aeif_b2", ["autoencoder", "inverse", "forward"], {}),
+          ("trace10_ae_b2", ["autoencoder"], {}), ("trace10_vae_b2", ["vae"], {}),
+          ("trace_val_aeif_b2", ["autoencoder", "inverse", "forward"], dict(val_steps=(1,))),
+          ("trace_val_vae_b2", ["vae"], dict(val_steps=(2,))),
+          ("trace_ae_l1l2_b2", ["autoencoder"], dict(l1_reg=1e-5, l2_reg=1e-4))]
+
+
+@pytest.mark.parametrize("name,losses,extra", TRACES)
+def test_twin_adam_trace_matches_reference(name, losses, extra):
+    """3 / 4 / 10 optimisation steps (Adam, lr 1e-4), with validation minibatches in the middle for the trace_val_*
+    fixtures: per-step losses follow the reference."""
     g = gu.load(name)
-    sd, outs = run_twin(losses, 2, 3, "linear", n_steps=3, lr=1e-4)
+    n_steps = int(g["trace/values"].shape[0])
+    sd, outs = run_twin(losses, 2, 3, "linear", n_steps=n_steps, lr=1e-4, **extra)
     names = [str(n) for n in g["trace/names"]]
     for step, out in enumerate(outs):
         for j, nm in enumerate(names):

@@ -97,8 +97,10 @@ def bn_digest(model, out, prefix="bn/"):
 
 
 def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1, lr=None,
-              eps_seed=99, beta=1.0, inverse="linear", weights=None, split=None, l1_reg=0.0, l2_reg=0.0):
-    """One (or several) loop bodies of models/learner.py:373-497 driven on the reference classes."""
+              eps_seed=99, beta=1.0, inverse="linear", weights=None, split=None, l1_reg=0.0, l2_reg=0.0, val_steps=()):
+    """One (or several) loop bodies of models/learner.py:373-497 driven on the reference classes.
+    `val_steps`: steps run as validation minibatches (learner.py:362-364,487-497: eval mode, forward + backward, no
+    optimizer step)."""
     model = build(th, ref_pre, SRLModules, [l for l in losses if l != "perceptual"] if split is None else losses, S=S, A=A,
                   C=C, inverse=inverse, split=split)
     denoiser = None
@@ -121,7 +123,10 @@ def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1
         obs, next_obs, actions = golden_inputs(B, C, A, seed=1234 + step)
         obs, next_obs = th.from_numpy(obs), th.from_numpy(next_obs)
         act = th.from_numpy(actions).view(-1, 1)
-        model.train()
+        if step in val_steps:
+            model.eval()
+        else:
+            model.train()
         if opt is not None:
             opt.zero_grad()
         lm.resetLosses()
@@ -188,7 +193,7 @@ def step_case(th, ref_pre, SRLModules, RL, losses, B, C=3, S=200, A=6, n_steps=1
                     out["next_logvar/" + k] = v
             grads_digest(model, out)
             bn_digest(model, out)
-        if opt is not None:
+        if opt is not None and step not in val_steps:
             opt.step()
     if n_steps > 1 or opt is not None:
         names = sorted(trace[0].keys())
@@ -312,11 +317,95 @@ def detach_kats(th):
     return out
 
 
+def _install_cv2_shim():
+    """PIL-backed stand-in for the five cv2 symbols the reference loader touches (data_loader.py:48-51,212,238,247):
+    imread -> BGR ndarray or None, resize (identity for 224x224 sources, the only case used), cvtColor(BGR2RGB),
+    INTER_AREA, COLOR_BGR2RGB.  Everything downstream of the decoded uint8 frame is the reference's own code."""
+    from PIL import Image
+    cv2 = sys.modules["cv2"]
+
+    def imread(path):
+        try:
+            with Image.open(path) as f:
+                return np.ascontiguousarray(np.asarray(f.convert("RGB"))[..., ::-1])
+        except (IOError, OSError):
+            return None
+
+    def resize(im, size, interpolation=None):
+        assert (im.shape[1], im.shape[0]) == tuple(size), "shim: only already-sized frames"
+        return im
+
+    cv2.imread, cv2.resize = imread, resize
+    cv2.cvtColor = lambda im, code: np.ascontiguousarray(im[..., ::-1])
+    cv2.INTER_AREA, cv2.COLOR_BGR2RGB = 3, 4
+
+
+def loop_case(th, losses, n_epochs=2, bs=8, S=12, seed=3, lr=1e-4, n_episodes=4, ep_len=26, **ctor):
+    """The UNMODIFIED SRL4robotics.learn() (models/learner.py:259-579: forked loader process, queue, train/validation
+    split, best-model checkpoint, state prediction) on the tiny generated dataset of tests/dataset_util.py."""
+    import tempfile
+    import shutil
+    from dataset_util import make_dataset
+    _install_cv2_shim()
+    import models.learner as RLn
+    tmp = tempfile.mkdtemp(prefix="srlz_loop_")
+    cwd = os.getcwd()
+    try:
+        name, paths, actions, rewards, starts = make_dataset(tmp, n_episodes=n_episodes, ep_len=ep_len)
+        os.chdir(tmp)
+        os.makedirs("logs/run", exist_ok=True)
+        RLn.DISPLAY_PLOTS, RLn.N_EPOCHS, RLn.BATCH_SIZE, RLn.VALIDATION_SIZE = False, n_epochs, bs, 0.2
+        srl = RLn.SRL4robotics(S, model_type="custom_cnn", seed=seed, learning_rate=lr, cuda=False, losses=losses,
+                               n_actions=6, log_folder="logs/run", **ctor)
+        loss_history, states, pairs = srl.learn(paths, actions, rewards, starts)
+        out = {"states/full": np.asarray(states, dtype=np.float64),
+               "pairs/names": np.array([p[0] for p in pairs]), "pairs/weights": np.array([float(p[1]) for p in pairs]),
+               "history/names": np.array(sorted(loss_history.keys())),
+               "history/values": np.array([loss_history[k] for k in sorted(loss_history.keys())], dtype=np.float64)}
+        sd = digest_state_dict(th.load("logs/run/srl_model.pth"))
+        out["final/names"], out["final/sums"], out["final/abss"] = sd["names"], sd["sums"], sd["abss"]
+        out["config"] = np.array(json.dumps(dict(losses=losses, n_epochs=n_epochs, bs=bs, S=S, seed=seed, lr=lr,
+                                                 n_episodes=n_episodes, ep_len=ep_len)))
+        return out
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# whole-loop cases run in a FRESH interpreter each: learn() forks its loader processes, and a child forked from a parent
+# that has already run OpenMP-parallel torch code dead-locks in its first parallel region
+LOOP_CASES = {"loop_aeif": dict(losses=["autoencoder", "inverse", "forward"]),
+              "loop_ae_reward": dict(losses=["autoencoder", "reward"], n_epochs=1, seed=5, l2_reg=1e-4)}
+
+
+def run_loop_child(name):
+    import subprocess
+    import tempfile
+    tmp = tempfile.mktemp(suffix=".npz")
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "--loop-child", name, tmp], timeout=1500)
+    with np.load(tmp, allow_pickle=False) as z:
+        d = {k: z[k] for k in z.files}
+    os.remove(tmp)
+    return d
+
+
+def loop_child(name, path):
+    _stub_modules()
+    sys.path.insert(0, REF)
+    import torch as th
+    np.savez_compressed(path, **loop_case(th, **LOOP_CASES[name]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     th, ref_pre, SRLModules, RL = import_reference()
 
-    def save(name, d):
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+
+    def save(name, fn):
+        if only and not any(name.startswith(o) for o in only):
+            return
+        d = fn()
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **d)
         print("wrote %-28s %6.1f KB  (%d arrays)" % (name + ".npz", os.path.getsize(path) / 1024.0, len(d)))
@@ -324,46 +413,60 @@ def main():
     # (1) init KATs: same seed + same constructor order => identical parameters
     for tag, losses, C in (("ae_c3", ["autoencoder"], 3), ("vae_c3", ["vae"], 3), ("ae_c6", ["autoencoder"], 6),
                            ("cnn_c3", ["inverse"], 3)):
-        save("init_" + tag, digest_state_dict(build(th, ref_pre, SRLModules, losses, C=C).state_dict()))
+        save("init_" + tag, lambda: digest_state_dict(build(th, ref_pre, SRLModules, losses, C=C).state_dict()))
     # (2) single train-mode steps
-    save("step_ae_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2))
-    save("step_ae_b4", step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=4))
-    save("step_vae_b2", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2))
-    save("step_vae_b4", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=4))
-    save("step_aeif_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2))
-    save("step_aeif_mlp_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2,
+    save("step_ae_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2))
+    save("step_ae_b4", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=4))
+    save("step_vae_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2))
+    save("step_vae_b4", lambda: step_case(th, ref_pre, SRLModules, RL, ["vae"], B=4))
+    save("step_aeif_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2))
+    save("step_aeif_mlp_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2,
                                        inverse="mlp"))
-    save("step_ae_c6_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, C=6))
-    save("step_vae_c6_b2", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, C=6))
-    save("step_cnn_if_b2", step_case(th, ref_pre, SRLModules, RL, ["inverse", "forward"], B=2))
+    save("step_ae_c6_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, C=6))
+    save("step_vae_c6_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, C=6))
+    save("step_cnn_if_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["inverse", "forward"], B=2))
     # (3) short optimisation traces (Adam, lr 1e-4)
-    save("trace_ae_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, n_steps=3, lr=1e-4))
-    save("trace_vae_b2", step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, n_steps=3, lr=1e-4))
-    save("trace_aeif_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2,
+    save("trace_ae_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, n_steps=3, lr=1e-4))
+    save("trace_vae_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, n_steps=3, lr=1e-4))
+    save("trace_aeif_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2,
                                     n_steps=3, lr=1e-4))
     # (3b) §8f-2/3: split representations (SRLModulesSplit), reward head + loss, l1/l2 regularisers, DAE inputs.
     # The first case is the reference's own stacked-model test configuration (tests/test_modules.py:8-19) at B=4.
     from collections import OrderedDict as OD
     stacked = OD([("dae", 20), ("reward", -1), ("forward", 60), ("inverse", 20)])
     stacked_w = {"dae": 1.0, "reward": 1.0, "forward": 1.0, "inverse": 5.0}
-    save("step_split_dae_rfi_b4", step_case(th, ref_pre, SRLModules, RL, list(stacked.keys()), B=4, S=100, inverse="mlp",
+    save("step_split_dae_rfi_b4", lambda: step_case(th, ref_pre, SRLModules, RL, list(stacked.keys()), B=4, S=100, inverse="mlp",
                                             weights=stacked_w, split=stacked, l2_reg=0.0001))
-    save("trace_split_dae_rfi_b4", step_case(th, ref_pre, SRLModules, RL, list(stacked.keys()), B=4, S=100, inverse="mlp",
+    save("trace_split_dae_rfi_b4", lambda: step_case(th, ref_pre, SRLModules, RL, list(stacked.keys()), B=4, S=100, inverse="mlp",
                                              weights=stacked_w, split=stacked, l2_reg=0.0001, n_steps=3, lr=1e-4))
     vsplit = OD([("vae", 150), ("inverse", 50), ("forward", -1)])
-    save("step_split_vae_if_b2", step_case(th, ref_pre, SRLModules, RL, list(vsplit.keys()), B=2, split=vsplit))
+    save("step_split_vae_if_b2", lambda: step_case(th, ref_pre, SRLModules, RL, list(vsplit.keys()), B=2, split=vsplit))
     asplit = OD([("autoencoder", 120), ("reward", 80), ("inverse", -1)])
-    save("step_split_ae_ri_b2", step_case(th, ref_pre, SRLModules, RL, list(asplit.keys()), B=2, split=asplit))
-    save("step_ae_reward_l1_b2", step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "reward"], B=2, l1_reg=1e-5))
-    save("step_dae_b2", step_case(th, ref_pre, SRLModules, RL, ["dae"], B=2))
-    save("step_vae_perceptual_b2", step_case(th, ref_pre, SRLModules, RL, ["vae", "perceptual"], B=2,
+    save("step_split_ae_ri_b2", lambda: step_case(th, ref_pre, SRLModules, RL, list(asplit.keys()), B=2, split=asplit))
+    save("step_ae_reward_l1_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "reward"], B=2, l1_reg=1e-5))
+    save("step_dae_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["dae"], B=2))
+    save("step_vae_perceptual_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["vae", "perceptual"], B=2,
                                              weights={"perceptual": 1.0}))
-    save("detach_kats", detach_kats(th))
+    save("detach_kats", lambda: detach_kats(th))
     # (4) per-layer forward digests, loss KATs, head KATs
-    save("layers_ae_b2", layer_trace(th, ref_pre, SRLModules))
-    save("loss_kats", loss_kats(th, RL))
-    save("head_kats", head_kats(th, ref_pre, SRLModules))
+    save("layers_ae_b2", lambda: layer_trace(th, ref_pre, SRLModules))
+    save("loss_kats", lambda: loss_kats(th, RL))
+    save("head_kats", lambda: head_kats(th, ref_pre, SRLModules))
+    # (5) round 2: longer trajectories, a validation minibatch inside a trajectory, the whole learn() loop
+    save("trace10_ae_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, n_steps=10, lr=1e-4))
+    save("trace10_vae_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, n_steps=10, lr=1e-4))
+    save("trace_val_aeif_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder", "inverse", "forward"], B=2,
+                                                n_steps=4, lr=1e-4, val_steps=(1,)))
+    save("trace_val_vae_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["vae"], B=2, n_steps=4, lr=1e-4,
+                                               val_steps=(2,)))
+    save("trace_ae_l1l2_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, n_steps=3, lr=1e-4,
+                                               l1_reg=1e-5, l2_reg=1e-4))
+    for lname in LOOP_CASES:
+        save(lname, lambda: run_loop_child(lname))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 4 and sys.argv[1] == "--loop-child":
+        loop_child(sys.argv[2], sys.argv[3])
+    else:
+        main()
