@@ -285,14 +285,15 @@ int srlz_fold_grads(float* grad, float* stages, long long n, int nstage, srlz_st
 
 /* ------------------------------------------------------------------------------------------------------------
  * Adam over one flat parameter buffer — th.optim.Adam(params, lr) models/learner.py:199,495 (torch defaults).
- * step is 1-based; grad_scale multiplies g first (1/world_size after the RCCL sum).
+ * step is 1-based; grad_scale multiplies g first (1/world_size after the RCCL sum).  The hyper-parameters are doubles, as
+ * torch holds them: lr / (1 - beta1^step), sqrt(1 - beta2^step) and (1 - beta) are evaluated in double and rounded once.
  * ------------------------------------------------------------------------------------------------------------ */
-int srlz_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                   float eps, int step, float grad_scale, srlz_stream_t stream);
+int srlz_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                   double eps, int step, float grad_scale, srlz_stream_t stream);
 /* The same update with the step count kept ON THE DEVICE (step_dev[0] is incremented first; bc_dev = 2 floats of scratch):
  * the form a captured hipGraph can replay, since a kernel argument frozen at capture time cannot advance. */
-int srlz_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                       float eps, int* step_dev, float* bc_dev, float grad_scale, srlz_stream_t stream);
+int srlz_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                       double eps, int* step_dev, float* bc_dev, float grad_scale, srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Debug / calibration hooks (not on the product path).

@@ -123,15 +123,16 @@ __global__ void concat_onehot_kernel(const float* __restrict__ s, const int64_t*
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                  float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                  float bc1, float bc2_sqrt, float grad_scale) {
+                                                  float* __restrict__ v, long long n, float step_size, float b1, float b2,
+                                                  float eps, float omb1, float omb2, float bc2_sqrt, float grad_scale) {
   // torch.optim.Adam (no amsgrad, no weight decay): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
   // p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
-  const float step_size = lr / bc1;
+  // Every scalar is evaluated in DOUBLE on the host and rounded once, as torch does with its Python floats
+  // (step_size = lr / (1 - b1^t), omb = 1 - beta): 1.f - 0.999f would be 0.00099998713, 1.3e-5 away from torch's 0.001f.
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * grad_scale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * gi * gi;
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= step_size * (mi / denom);
@@ -220,23 +221,24 @@ __global__ __launch_bounds__(256) void fold_grads_kernel(float* __restrict__ g, 
 }
 
 // Device-side step counter for hipGraph replays (a captured kernel argument cannot change from step to step):
-// step_dev[0] += 1, then the two bias corrections of torch.optim.Adam for that step -> bc[0] = 1 - b1^t, bc[1] = sqrt(1 - b2^t)
-__global__ void adam_tick_kernel(int* __restrict__ step_dev, float* __restrict__ bc, float b1, float b2) {
+// step_dev[0] += 1, then the two step scalars of torch.optim.Adam for that step -> bc[0] = lr / (1 - b1^t), bc[1] = sqrt(1 - b2^t)
+__global__ void adam_tick_kernel(int* __restrict__ step_dev, float* __restrict__ bc, double lr, double b1, double b2) {
   const int t = step_dev[0] + 1;
   step_dev[0] = t;
-  bc[0] = (float)(1.0 - pow((double)b1, (double)t));
-  bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+  bc[0] = (float)(lr / (1.0 - pow(b1, (double)t)));  // step_size
+  bc[1] = (float)sqrt(1.0 - pow(b2, (double)t));
 }
 
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                      float* __restrict__ v, long long n, float lr, float b1, float b2,
-                                                      float eps, const float* __restrict__ bc, float grad_scale) {
-  const float step_size = lr / bc[0];
+                                                      float* __restrict__ v, long long n, float b1, float b2,
+                                                      float eps, float omb1, float omb2, const float* __restrict__ bc,
+                                                      float grad_scale) {
+  const float step_size = bc[0];
   const float bc2_sqrt = bc[1];
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * grad_scale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * gi * gi;
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= step_size * (mi / denom);
@@ -373,26 +375,28 @@ extern "C" int srlz_fold_grads(float* grad, float* stages, long long n, int nsta
   return 0;
 }
 
-extern "C" int srlz_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                              float eps, int step, float grad_scale, srlz_stream_t stream) {
+extern "C" int srlz_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                              double eps, int step, float grad_scale, srlz_stream_t stream) {
   SRLZ_REQUIRE(p && g && m && v, SRLZ_ERR_NULL, "adam_step: null pointer");
   SRLZ_REQUIRE(step >= 1, SRLZ_ERR_BAD_DESC, "adam_step: step is 1-based");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2,
-                     eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, (float)(lr / bc1),
+                     (float)beta1, (float)beta2, (float)eps, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)sqrt(bc2),
+                     grad_scale);
   SRLZ_LAUNCHED();
   return 0;
 }
 
-extern "C" int srlz_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                                  float eps, int* step_dev, float* bc_dev, float grad_scale, srlz_stream_t stream) {
+extern "C" int srlz_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,
+                                  double beta2, double eps, int* step_dev, float* bc_dev, float grad_scale,
+                                  srlz_stream_t stream) {
   SRLZ_REQUIRE(p && g && m && v && step_dev && bc_dev, SRLZ_ERR_NULL, "adam_step_dev: null pointer");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_dev, bc_dev, beta1, beta2);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_dev, bc_dev, lr, beta1, beta2);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps,
-                     (const float*)bc_dev, grad_scale);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, st, p, g, m, v, n, (float)beta1, (float)beta2,
+                     (float)eps, (float)(1.0 - beta1), (float)(1.0 - beta2), (const float*)bc_dev, grad_scale);
   SRLZ_LAUNCHED();
   return 0;
 }

@@ -6,7 +6,7 @@ There is NO fallback: if the library is missing the import fails loudly, and eve
 """
 import ctypes
 import os
-from ctypes import c_int, c_longlong, c_float, c_void_p, c_size_t, c_char_p, POINTER, Structure
+from ctypes import c_int, c_longlong, c_float, c_double, c_void_p, c_size_t, c_char_p, POINTER, Structure
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrlz_hip.so")
@@ -99,8 +99,8 @@ _PROTOS = {
     "srlz_param_norms": (c_int, [P, P, c_int, c_int, c_float, P, P, P]),
     "srlz_param_norms_grad": (c_int, [P, P, P, c_int, c_int, P, P, c_float, P]),
     "srlz_fold_grads": (c_int, [P, P, c_longlong, c_int, P]),
-    "srlz_adam_step": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, P]),
-    "srlz_adam_step_dev": (c_int, [P, P, P, P, c_longlong, c_float, c_float, c_float, c_float, P, P, c_float, P]),
+    "srlz_adam_step": (c_int, [P, P, P, P, c_longlong, c_double, c_double, c_double, c_double, c_int, c_float, P]),
+    "srlz_adam_step_dev": (c_int, [P, P, P, P, c_longlong, c_double, c_double, c_double, c_double, P, P, c_float, P]),
 }
 
 # entry points whose int return value is data, not a status

@@ -113,3 +113,31 @@ def check_digest(t, g, prefix, rtol=1e-4, atol_scale=1e-5):
     assert err_l2 <= rtol, "%s: l2 rel err %.3e" % (prefix, err_l2)
     assert err_sum <= rtol, "%s: sum err (rel. to abs-sum) %.3e" % (prefix, err_sum)
     return worst
+
+
+NOISE_BIASES = tuple("model.decoder_conv.%d.bias" % i for i in (0, 3, 6, 9))
+
+
+def endpoint_errors(sd, g, lr, n_steps, eval_states):
+    """Errors of a trajectory END POINT (`sd`: name -> tensor after the last step, `eval_states`: eval-mode states of that
+    model on the fixture's first batch) against a trace fixture `g` -> {"param", "noise_bias", "bn", "eval_states"} plus the
+    per-tensor table.  Parameters are measured as max(|sum - ref|, |abs-sum - ref|) / (abs-sum + lr*n_steps*numel): the
+    second term is the distance Adam can travel in n_steps, which is the natural scale for parameters that start at
+    zero (BatchNorm biases).  Counters (num_batches_tracked) must match exactly and are asserted here."""
+    import numpy as _np
+    worst = {"param": 0.0, "noise_bias": 0.0, "bn": 0.0}
+    table = {}
+    for k, ref_sum, ref_abs in zip(g["final/names"], g["final/sums"], g["final/abss"]):
+        k = str(k)
+        v = sd[k].detach().double().cpu()
+        if "num_batches_tracked" in k:
+            assert int(v) == int(ref_sum), (k, int(v), int(ref_sum))
+            continue
+        err = max(abs(float(v.sum()) - ref_sum), abs(float(v.abs().sum()) - ref_abs))
+        err /= (ref_abs + lr * n_steps * v.numel())
+        kind = "noise_bias" if k in NOISE_BIASES else ("bn" if "running_" in k else "param")
+        worst[kind] = max(worst[kind], err)
+        table[k] = err
+    ref = g["eval_states/full"]
+    worst["eval_states"] = float(_np.abs(_np.asarray(eval_states, dtype=_np.float64) - ref).max() / _np.abs(ref).max())
+    return worst, table

@@ -401,6 +401,9 @@ def test_adam(C):
         g_d = (gr * 4).to(DEV)
         C.adam_step(C.ptr(pd), C.ptr(g_d), C.ptr(m), C.ptr(v), n, 5e-3, 0.9, 0.999, 1e-8, step, 0.25, C.stream())
     assert rel_err(pd, pr) < 1e-6
+    # the moments too: (1 - beta) must be torch's double-evaluated scalar (1.f - 0.999f is 1.3e-5 off)
+    st = opt.state[pr]
+    assert rel_err(m, st["exp_avg"]) < 5e-7 and rel_err(v, st["exp_avg_sq"]) < 5e-7
 
 
 def test_fused_bn_relu_operand(C):

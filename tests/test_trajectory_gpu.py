@@ -11,12 +11,27 @@ including validation minibatches in the middle of a trajectory (eval mode, backw
 reference learner.py:362-364,487-497) and the l1+l2 case that overflows the gradient staging buckets (4 contributions per
 encoder weight, srlz/optim.py NSTAGE=3).
 
-Checked per case: every per-step loss (5e-4, the tolerance the CPU twin is held to), every parameter's sum / abs-sum after
-the last step, the BatchNorm running statistics and counters, and the eval-mode states of the updated model.
+Two tests per fixture, because an Adam trajectory at B = 2 is CHAOTIC in fp32: Adam divides every gradient element by its
+own magnitude, so an element whose gradient is rounding noise (or sits next to a ReLU / max-pool tie) takes +-lr steps of
+arbitrary sign.  The reference run with 8 instead of 1 MKLDNN threads ends 0.6 % (3 steps) / 4 % (10 steps) away from
+itself in eval-mode states (tools/measure_spread.py -> tests/golden/trajectory_spread.json).
+
+ 1. test_train_step_trajectory_follows_reference — free running against the fixture: every per-step loss to 5e-4 (the
+    tolerance the CPU twin is held to), optimiser-step and num_batches_tracked counters exactly, and the END POINT
+    (parameter sums, BatchNorm running statistics, eval-mode states) within SPREAD_FACTOR x the reference's own rounding
+    spread, taken as the largest one over the fixtures with as many steps (whether a particular fixture's handful of
+    noisy elements flips in a particular run is luck; the amplitude when they do is the property) — a gross-divergence
+    bound, no more.
+ 2. test_train_step_rides_along_the_oracle — the tight one, by induction over the steps: before every step the CPU oracle
+    is re-seeded with the product's CURRENT parameters / buffers, so nothing accumulates.  Per step: every loss 1e-5;
+    BatchNorm buffers after the step 1e-5; the gradient bucket Adam consumed against the oracle's gradient (norm 5e-3,
+    direction 3e-2 — set by the handful of near-tie ReLU / max-pool decisions per step, cf. tests/test_step_gpu.py;
+    measured on MI355X: losses 8e-7, buffers 5e-7, norms 7e-4, directions 1e-2, update 6e-8); the parameter update
+    against Adam's formula evaluated in fp64 on that very bucket (3e-7 absolute); a validation step leaves parameters,
+    moments, step count and running statistics bit-identical.
 
 Pre-BatchNorm ConvTranspose biases (decoder_conv.{0,3,6,9}.bias) have an analytically ZERO gradient; what either
-implementation feeds Adam there is summation noise, which Adam's normalisation turns into +-lr steps of random sign.  They
-cannot agree and do not matter (BatchNorm removes a per-channel constant): bounded by lr * steps per element instead.
+implementation feeds Adam there is summation noise.  They are reported separately and bounded by Adam's travel only.
 """
 import json
 import os
@@ -30,10 +45,9 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 LR = 1e-4
 LOSS_RTOL = 5e-4
-PARAM_RTOL = 2e-4   # |sum - ref| and |abs-sum - ref| relative to the reference abs-sum
-BN_RTOL = 1e-4
-STATE_RTOL = 5e-4
-NOISE_BIASES = tuple("model.decoder_conv.%d.bias" % i for i in (0, 3, 6, 9))
+SPREAD_FACTOR = 5.0
+ENDPOINT_FLOOR = {"param": 2e-4, "bn": 2e-4, "eval_states": 5e-4, "noise_bias": 1.0}
+NOISE_BIASES = gu.NOISE_BIASES
 
 _split = gu.ext_defaults(gu.ext_cases()["step_split_dae_rfi_b4"])
 CASES = {
@@ -50,97 +64,62 @@ CASES = {
 }
 
 
-def drive_product(losses, n_steps, B=2, S=200, inverse="linear", split=None, weights=None, l1_reg=0.0, l2_reg=0.0,
-                  val_steps=()):
-    """n_steps calls of SRL4robotics.trainStep on the fixture inputs; returns (learner, [per-step {name: value}])."""
+def make_learner(losses, B=2, S=200, inverse="linear", split=None, weights=None, l1_reg=0.0, l2_reg=0.0, **_):
     import models.learner as learner
     import preprocessing.preprocess as pre
-    from losses.losses import LossManager
     pre.N_CHANNELS = 3
     learner.BATCH_SIZE = B
-    srl = learner.SRL4robotics(S, model_type="custom_cnn", inverse_model_type=inverse, seed=1, learning_rate=LR, cuda=True,
-                               losses=losses, losses_weights_dict=weights, n_actions=6, log_folder="/tmp",
-                               split_dimensions=split if split is not None else -1, l1_reg=l1_reg, l2_reg=l2_reg)
-    dev = srl.device
-    if "vae" in losses:  # the reference draws eps from the CPU generator (models/models.py:161); same draws, same order
-        srl.model.model.eps_fn = lambda mu: torch.empty(mu.shape).normal_().to(mu.device)
-    lm = LossManager(srl.model, None)
-    trace = []
-    for step in range(n_steps):
-        obs, nxt, act = gu.golden_inputs(B, 3, 6, seed=1234 + step)
-        noisy = next_noisy = rew = None
-        if "dae" in losses:
-            noisy = torch.from_numpy(gu.golden_noisy(obs, seed=1234 + step)).to(dev)
-            next_noisy = torch.from_numpy(gu.golden_noisy(nxt, seed=4321 + step)).to(dev)
-        if "reward" in losses:
-            rew = torch.from_numpy(gu.golden_rewards(B, seed=1234 + step)[1]).to(dev)
+    return learner.SRL4robotics(S, model_type="custom_cnn", inverse_model_type=inverse, seed=1, learning_rate=LR, cuda=True,
+                                losses=losses, losses_weights_dict=weights, n_actions=6, log_folder="/tmp",
+                                split_dimensions=split if split is not None else -1, l1_reg=l1_reg, l2_reg=l2_reg)
+
+
+def step_inputs(losses, step, B, S):
+    """The fixture's inputs of one step as CPU tensors (tools/make_golden.py::step_case)."""
+    obs, nxt, act = gu.golden_inputs(B, 3, 6, seed=1234 + step)
+    d = dict(obs=torch.from_numpy(obs), next_obs=torch.from_numpy(nxt), actions=torch.from_numpy(act), noisy=(None, None),
+             rewards=None, eps=(None, None))
+    if "dae" in losses:
+        d["noisy"] = (torch.from_numpy(gu.golden_noisy(obs, seed=1234 + step)),
+                      torch.from_numpy(gu.golden_noisy(nxt, seed=4321 + step)))
+    if "reward" in losses:
+        d["rewards"] = torch.from_numpy(gu.golden_rewards(B, seed=1234 + step)[1])
+    if "vae" in losses:  # the reference draws eps from the CPU generator right before the forwards (models/models.py:161)
         torch.manual_seed(99 + step)
-        loss = srl.trainStep(torch.from_numpy(obs).to(dev), torch.from_numpy(nxt).to(dev),
-                             torch.from_numpy(act).view(-1, 1).to(dev), lm, validation_mode=step in val_steps,
-                             noisy_obs=noisy, next_noisy_obs=next_noisy, rewards_st=rew)
-        rec = dict(zip(lm.names, lm.lossValues()))
-        rec["total"] = float(loss.detach())
-        trace.append(rec)
+        d["eps"] = (torch.empty(B, S).normal_(), torch.empty(B, S).normal_())
+    return d
+
+
+def product_step(srl, lm, losses, inp, validation):
+    dev = srl.device
+    if "vae" in losses:
+        it = iter(inp["eps"])
+        srl.model.model.eps_fn = lambda mu: next(it).to(mu.device)
+    to = lambda t: None if t is None else t.to(dev)
+    loss = srl.trainStep(to(inp["obs"]), to(inp["next_obs"]), inp["actions"].view(-1, 1).to(dev), lm,
+                         validation_mode=validation, noisy_obs=to(inp["noisy"][0]), next_noisy_obs=to(inp["noisy"][1]),
+                         rewards_st=to(inp["rewards"]))
+    rec = dict(zip(lm.names, lm.lossValues()))
+    rec["total"] = float(loss.detach())
+    return rec
+
+
+def drive_product(losses, n_steps, val_steps=(), **cfg):
+    """n_steps calls of SRL4robotics.trainStep on the fixture inputs; returns (learner, [per-step {name: value}])."""
+    from losses.losses import LossManager
+    srl = make_learner(losses, **cfg)
+    lm = LossManager(srl.model, None)
+    trace = [product_step(srl, lm, losses, step_inputs(losses, step, cfg.get("B", 2), cfg.get("S", 200)), step in val_steps)
+             for step in range(n_steps)]
     torch.cuda.synchronize()
     return srl, trace
 
 
-def compare_with_fixture(name, srl, trace, n_steps):
-    """-> (list of failure strings, dict of worst errors)."""
-    g = gu.load(name)
-    fails, worst = [], {}
-
-    def note(kind, err, tol, what):
-        worst[kind] = max(worst.get(kind, 0.0), err)
-        if not err <= tol:
-            fails.append("%s: %s err %.3e > %.1e" % (kind, what, err, tol))
-
-    names = [str(n) for n in g["trace/names"]]
-    assert g["trace/values"].shape == (n_steps, len(names))
-    for step, rec in enumerate(trace):
-        assert sorted(rec.keys()) == sorted(names), (sorted(rec.keys()), names)
-        for j, nm in enumerate(names):
-            v = float(g["trace/values"][step, j])
-            note("loss", abs(rec[nm] - v) / max(abs(v), 1e-6), LOSS_RTOL, "step %d %s (%.6g vs %.6g)" % (step, nm, rec[nm], v))
-
-    sd = srl.model.state_dict()
-    assert [str(k) for k in g["final/names"]] == list(sd.keys())
-    for k, ref_sum, ref_abs in zip(g["final/names"], g["final/sums"], g["final/abss"]):
-        k = str(k)
-        v = sd[k].detach().double().cpu()
-        if "num_batches_tracked" in k:
-            assert int(v) == int(ref_sum), (k, int(v), int(ref_sum))
-            continue
-        e_sum = abs(float(v.sum()) - ref_sum)
-        e_abs = abs(float(v.abs().sum()) - ref_abs)
-        if k in NOISE_BIASES:  # +-lr per step and element at most (see the module docstring)
-            bound = 2.0 * LR * n_steps * v.numel()
-            note("noise_bias", max(e_sum, e_abs) / bound, 1.0, k)
-        else:
-            note("param", max(e_sum, e_abs) / max(ref_abs, 1e-30), PARAM_RTOL, k)
-    for k in [f for f in g.files if f.startswith("final_bn/")]:
-        key = k[len("final_bn/"):]
-        ref = g[k]
-        v = sd[key].detach().double().cpu().numpy()
-        if "num_batches" in key:
-            assert int(v) == int(ref), (key, int(v), int(ref))
-        else:
-            note("bn", float(np.abs(v - ref).max()) / max(float(np.abs(ref).max()), 1e-30), BN_RTOL, key)
-
-    srl.model.eval()
-    obs, _, _ = gu.golden_inputs(int(g["eval_states/full"].shape[0]), 3, 6, seed=1234)
-    with torch.no_grad():
-        st = srl.model.getStates(torch.from_numpy(obs).to(srl.device)).double().cpu().numpy()
-    ref = g["eval_states/full"]
-    note("eval_states", float(np.abs(st - ref).max()) / float(np.abs(ref).max()), STATE_RTOL, "eval-mode states")
-    return fails, worst
-
-
-def _report(name, worst):
+def _report(test, name, worst):
     try:
         os.makedirs("gpurun_out", exist_ok=True)
         with open(os.path.join("gpurun_out", "trajectory_report.jsonl"), "a") as f:
-            f.write(json.dumps({"case": name, "worst": worst}, sort_keys=True) + "\n")
+            f.write(json.dumps({"test": test, "case": name, "worst": worst}, sort_keys=True) + "\n")
     except OSError:
         pass
 
@@ -148,18 +127,148 @@ def _report(name, worst):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_train_step_trajectory_follows_reference(name):
     cfg = dict(CASES[name])
+    n_steps = cfg["n_steps"]
     srl, trace = drive_product(**cfg)
     # an optimiser step was taken for every training minibatch and none for a validation one
-    assert srl.optimizer.steps() == cfg["n_steps"] - len(cfg.get("val_steps", ()))
-    fails, worst = compare_with_fixture(name, srl, trace, cfg["n_steps"])
-    _report(name, worst)
+    assert srl.optimizer.steps() == n_steps - len(cfg.get("val_steps", ()))
+    g = gu.load(name)
+    fails = []
+    names = [str(n) for n in g["trace/names"]]
+    assert g["trace/values"].shape == (n_steps, len(names))
+    worst_loss = 0.0
+    for step, rec in enumerate(trace):
+        assert sorted(rec.keys()) == sorted(names), (sorted(rec.keys()), names)
+        for j, nm in enumerate(names):
+            v = float(g["trace/values"][step, j])
+            err = abs(rec[nm] - v) / max(abs(v), 1e-6)
+            worst_loss = max(worst_loss, err)
+            if not err <= LOSS_RTOL:
+                fails.append("loss step %d %s: %.6g vs %.6g" % (step, nm, rec[nm], v))
+    # end point (counters are asserted exactly inside endpoint_errors)
+    sd = srl.model.state_dict()
+    assert [str(k) for k in g["final/names"]] == list(sd.keys())
+    srl.model.eval()
+    obs, _, _ = gu.golden_inputs(int(g["eval_states/full"].shape[0]), 3, 6, seed=1234)
+    with torch.no_grad():
+        st = srl.model.getStates(torch.from_numpy(obs).to(srl.device)).double().cpu().numpy()
+    worst, table = gu.endpoint_errors(sd, g, LR, n_steps, st)
+    with open(os.path.join(gu.GOLDEN_DIR, "trajectory_spread.json")) as f:
+        spreads = json.load(f)["cases"]
+    peers = [c for c in spreads if (CASES[c]["n_steps"] > 4) == (n_steps > 4)]
+    spread = {kind: max(spreads[c][kind] for c in peers) for kind in worst}
+    for kind, err in worst.items():
+        tol = max(ENDPOINT_FLOOR[kind], SPREAD_FACTOR * spread[kind])
+        if not err <= tol:
+            fails.append("end point %s: %.3e > %.3e (reference self-spread %.3e)" % (kind, err, tol, spread[kind]))
+    worst["loss"] = worst_loss
+    worst["worst_params"] = dict(sorted(table.items(), key=lambda kv: -kv[1])[:4])
+    _report("free", name, worst)
+    assert not fails, "\n".join(fails)
+
+
+RIDE_CASES = ["trace_ae_b2", "trace_vae_b2", "trace_aeif_b2", "trace_split_dae_rfi_b4", "trace_val_aeif_b2", "trace_val_vae_b2",
+              "trace_ae_l1l2_b2", "trace10_vae_b2"]
+
+
+@pytest.mark.parametrize("name", RIDE_CASES)
+def test_train_step_rides_along_the_oracle(name):
+    """Per-step parity with the CPU oracle re-seeded from the product's state (see the module docstring, test 2)."""
+    from collections import OrderedDict
+    from losses.losses import LossManager
+    from oracle import torch_twin as T
+    cfg = dict(CASES[name])
+    losses, n_steps, val_steps = cfg["losses"], cfg["n_steps"], cfg.get("val_steps", ())
+    B, S = cfg.get("B", 2), cfg.get("S", 200)
+    srl = make_learner(**cfg)
+    lm = LossManager(srl.model, None)
+    fp, opt = srl.flat_params, srl.optimizer
+    pname = {id(p): n for n, p in srl.model.named_parameters()}
+    slices = [(pname[id(p)], off, p.numel(), tuple(p.shape)) for p, off in zip(fp.params, fp.offsets)]
+    taken = {}
+    real_step = opt.step
+
+    def step_spy(grad_scale=1.0):  # the gradient bucket exactly as Adam consumes it
+        fp.deliver()
+        taken["grad"] = fp.grad.detach().clone()
+        return real_step(grad_scale)
+    opt.step = step_spy
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    worst = {"loss": 0.0, "bn": 0.0, "grad_norm": 0.0, "grad_dir": 0.0, "adam": 0.0}
+    fails = []
+
+    def note(kind, err, tol, what):
+        worst[kind] = max(worst[kind], err)
+        if not err <= tol:
+            fails.append("%s: %s err %.3e > %.1e" % (kind, what, err, tol))
+
+    for step in range(n_steps):
+        validation = step in val_steps
+        inp = step_inputs(losses, step, B, S)
+        before = OrderedDict((k, v.detach().cpu().clone()) for k, v in srl.model.state_dict().items())
+        flat0, m0, v0, t0 = fp.flat.clone(), opt.m.clone(), opt.v.clone(), opt.steps()
+        taken.clear()
+        rec = product_step(srl, lm, losses, inp, validation)
+        torch.cuda.synchronize()
+
+        # ---- the oracle takes the same step from the same state
+        sd = T.clone_state(before)
+        ref = T.train_step(sd, losses, inp["obs"], inp["next_obs"], inp["actions"], eps=inp["eps"][0], next_eps=inp["eps"][1],
+                           weights=cfg.get("weights"), split=cfg.get("split"), rewards=inp["rewards"],
+                           l1_reg=cfg.get("l1_reg", 0.0), l2_reg=cfg.get("l2_reg", 0.0), noisy=inp["noisy"],
+                           training=not validation)
+        assert sorted(rec) == sorted(list(ref["losses"]) + ["total"])
+        for nm, v in list(ref["losses"].items()) + [("total", ref["total"])]:
+            note("loss", abs(rec[nm] - v) / max(abs(v), 1e-6), 1e-5, "step %d %s (%.7g vs %.7g)" % (step, nm, rec[nm], v))
+        after = srl.model.state_dict()
+        for k in before:
+            if "running_" in k:
+                r, got = sd[k].double(), after[k].double().cpu()
+                note("bn", float((got - r).abs().max() / r.abs().max()), 1e-5, "step %d %s" % (step, k))
+            elif "num_batches_tracked" in k:
+                assert int(after[k]) == int(sd[k]), (step, k, int(after[k]), int(sd[k]))
+
+        if validation:  # backward ran and was discarded: nothing that defines the trajectory may have moved
+            assert "grad" not in taken and opt.steps() == t0
+            assert torch.equal(fp.flat, flat0) and torch.equal(opt.m, m0) and torch.equal(opt.v, v0)
+            for k in before:
+                if "running_" in k:
+                    assert torch.equal(after[k].cpu(), before[k]), (step, k)
+            continue
+
+        # ---- the gradient bucket Adam consumed vs the oracle's gradient
+        assert opt.steps() == t0 + 1
+        grad = taken["grad"].double().cpu()
+        for nm, off, n, shape in slices:
+            gref = ref["grads"].get(nm)
+            g_got = grad[off:off + n]
+            if gref is None:  # a head without a loss: torch skips it (grad None); the bucket must hold zeros
+                assert float(g_got.abs().max()) == 0.0, (step, nm)
+                continue
+            gref = gref.double().reshape(-1)
+            if nm in NOISE_BIASES:  # analytically zero: compare absolutely, on the scale of the layer's weight gradient
+                scale = float(ref["grads"][nm.replace(".bias", ".weight")].abs().max())
+                note("grad_dir", float((g_got - gref).abs().max()) / scale * 5e-2 / 1e-4, 5e-2, "step %d %s (noise bias)" % (step, nm))
+                continue
+            nr = float(gref.norm())
+            note("grad_norm", abs(float(g_got.norm()) - nr) / max(nr, 1e-30), 5e-3, "step %d %s" % (step, nm))
+            note("grad_dir", float((g_got - gref).norm()) / max(nr, 1e-30), 3e-2, "step %d %s" % (step, nm))
+
+        # ---- Adam's update on THAT bucket, evaluated in fp64 (torch.optim.Adam defaults, models/learner.py:199)
+        t = t0 + 1
+        g64 = taken["grad"].double()
+        m1 = 0.9 * m0.double() + 0.1 * g64
+        v1 = 0.999 * v0.double() + 0.001 * g64 * g64
+        expect = flat0.double() - (LR / (1 - 0.9 ** t)) * m1 / ((v1 / (1 - 0.999 ** t)).sqrt() + 1e-8)
+        note("adam", float((fp.flat.double() - expect).abs().max()), 3e-7, "step %d parameter update" % step)
+        assert float((opt.m.double() - m1).abs().max()) <= 1e-6 * max(float(m1.abs().max()), 1e-30)
+        assert float((opt.v.double() - v1).abs().max()) <= 1e-6 * max(float(v1.abs().max()), 1e-30)
+    _report("ride", name, worst)
     assert not fails, "\n".join(fails)
 
 
 def test_staging_overflow_is_exercised():
     """l1 + l2 + two frames = four gradient contributions per regularised weight: the fourth finds no staging bucket
     (FlatParams.grad_buffer -> None) and must travel through autograd's own accumulation."""
-    import models.learner as learner
     from srlz import optim
     calls = {"none": 0}
     orig = optim.FlatParams.grad_buffer

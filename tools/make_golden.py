@@ -365,7 +365,7 @@ def loop_case(th, losses, n_epochs=2, bs=8, S=12, seed=3, lr=1e-4, n_episodes=4,
         sd = digest_state_dict(th.load("logs/run/srl_model.pth"))
         out["final/names"], out["final/sums"], out["final/abss"] = sd["names"], sd["sums"], sd["abss"]
         out["config"] = np.array(json.dumps(dict(losses=losses, n_epochs=n_epochs, bs=bs, S=S, seed=seed, lr=lr,
-                                                 n_episodes=n_episodes, ep_len=ep_len)))
+                                                 n_episodes=n_episodes, ep_len=ep_len, ctor=ctor)))
         return out
     finally:
         os.chdir(cwd)
@@ -393,6 +393,7 @@ def loop_child(name, path):
     _stub_modules()
     sys.path.insert(0, REF)
     import torch as th
+    th.set_num_threads(1)  # before anything runs: deterministic summation order, and nothing for a forked child to trip over
     np.savez_compressed(path, **loop_case(th, **LOOP_CASES[name]))
 
 
