@@ -38,8 +38,9 @@ def synthetic_batch(B, C, seed, device):
     from golden_util import synthetic_obs
     obs, next_obs = synthetic_obs(B, C, seed)
     actions = np.random.RandomState(seed + 77).randint(0, 6, (B,)).astype(np.int64)
-    return (torch.from_numpy(obs).to(device), torch.from_numpy(next_obs).to(device),
-            torch.from_numpy(actions).view(-1, 1).to(device))
+    # the two frames are the halves of ONE device buffer, as the learner's feed delivers them (SRL4robotics._toDevicePair)
+    both = torch.from_numpy(np.concatenate((obs, next_obs), 0)).to(device)
+    return both[:B], both[B:], torch.from_numpy(actions).view(-1, 1).to(device)
 
 
 def host_cores():
@@ -87,11 +88,12 @@ def cpu_baseline(losses, sample_b=64, steps=2):
                                                    torch.get_num_threads(), dt)}
 
 
-def conv64_algorithmic_bytes(layer_key, n):
-    """Input + output activations (fp32 NHWC, 64 channels) + the 9x64x64 weights of one launch; key = ops._conv64_key."""
+def conv64_algorithmic_bytes(layer_key):
+    """Input + output activations (fp32 NHWC, 64 channels) + the 9x64x64 weights of one launch; key = ops._conv64_key
+    (n = images per launch: 2 x bs when the two frames of a step are batched)."""
     import re
-    m = re.search(r"(\d+)x(\d+)->(\d+)x(\d+)", layer_key)
-    hi, wi, ho, wo = (int(g) for g in m.groups())
+    m = re.search(r" n(\d+) (\d+)x(\d+)->(\d+)x(\d+)", layer_key)
+    n, hi, wi, ho, wo = (int(g) for g in m.groups())
     return 4.0 * 64 * n * (hi * wi + ho * wo) + 4.0 * 9 * 64 * 64
 
 
@@ -172,7 +174,7 @@ def main():
     def step():
         if host_frames is None:
             return srl.trainStep(obs, next_obs, actions, loss_manager, rewards_st=rewards)
-        o, no = srl._toDevice(host_frames[0]), srl._toDevice(host_frames[1])  # H2D (uint8) + normalise on the GPU
+        o, no = srl._toDevicePair(host_frames[0], host_frames[1])  # H2D (uint8) + normalise on the GPU
         return srl.trainStep(o, no, actions, loss_manager, rewards_st=rewards)
 
     def sync():
@@ -228,7 +230,7 @@ def main():
                                                     "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
             alg_bytes = 0.0
             for key, v in layers.items():
-                alg_bytes += v["launches"] * conv64_algorithmic_bytes(key, B)
+                alg_bytes += v["launches"] * conv64_algorithmic_bytes(key)
             alg_bytes /= max(1, k["launches"])
             traffic, traffic_src = committed_pmc_traffic("conv64_fwd_kernel<4, false>")
             out["roofline"] = {"kernel": "conv64_fwd_kernel<4,false> (3x3 64->64 conv / convT forward and data-gradient, all "

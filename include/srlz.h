@@ -58,6 +58,11 @@ typedef struct {
   int stride;     /* 1 or 2 */
   int pad;        /* conv: zero padding; convT: `padding` argument */
   int transposed; /* 0 = nn.Conv2d, 1 = nn.ConvTranspose2d */
+  int groups;     /* BatchNorm groups batched along n (0 / 1 = one): images [g*n/groups, (g+1)*n/groups) are group g, i.e. the
+                     launch is the union of `groups` independent model calls — `obs || next_obs` of one training step,
+                     models/learner.py:392-393.  Every BatchNorm record argument (x_bnp, bnp, sums) then holds `groups`
+                     consecutive records, statistics partials come group after group (tiles never straddle two groups),
+                     weight gradients are summed over all groups. */
 } srlz_conv64_desc;
 
 /* floats needed for one packed weight copy (9 taps x 64 x 64) */
@@ -86,10 +91,10 @@ typedef struct {
   const float* y;
   const float* bnp;
   const float* sums;
-  long long count;
+  long long count;   /* N*H*W of y PER GROUP */
   int training;
   float* dy_out;
-} srlz_bn_bwd_operand;
+} srlz_bn_bwd_operand; /* with srlz_conv64_desc.groups > 1: bnp / sums hold one record per group */
 /* dx = d(loss)/d(x) from dy (dy_bn may be NULL: dy is then the plain gradient). */
 int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx, const srlz_bn_bwd_operand* dy_bn,
                          const srlz_conv64_desc* d, srlz_stream_t stream);
@@ -112,6 +117,7 @@ typedef struct {
   int himg, wimg; /* image-side spatial size (224 x 224) */
   int hf, wf;  /* 64-channel feature-map spatial size (112x112 for kind 0, 111x111 for kind 1) */
   int kind;    /* 0 = conv1 7x7 s2 p3 ; 1 = convT 4x4 s2 p0 */
+  int groups;  /* BatchNorm groups along n (0 / 1 = one), as in srlz_conv64_desc */
 } srlz_skinny_desc;
 
 int srlz_skinny_tiles(const srlz_skinny_desc* d); /* BN partial records written by conv1 forward */
@@ -159,8 +165,12 @@ int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* 
 /* Training-mode statistics from the convolution's per-tile partials: fills bnp and applies `repeat` momentum
  * updates of running_mean / running_var (momentum, unbiased variance — torch defaults eps 1e-5, momentum 0.1).
  * batch_stat[2][64] (may be NULL) receives {mean, unbiased var} so the update can be replayed (VAE getStates quirk,
- * models/learner.py:402).  ws: srlz_bn_bwd_workspace(0) bytes of scratch (two-stage fp64 reduction of the partials). */
-int srlz_bn_finalize(const float* stats_partial, int n_partials, long long count, const float* gamma,
+ * models/learner.py:402).  ws: srlz_bn_bwd_workspace(0) bytes of scratch (two-stage fp64 reduction of the partials).
+ * groups > 1: `groups` independent BatchNorm calls batched along n (the conv descriptors' `groups`): stats_partial holds
+ * n_partials / groups records per group, group after group; count is PER GROUP; bnp receives `groups` records of 256
+ * floats, batch_stat `groups` x 128; the running statistics take the groups' momentum updates in order (obs, then
+ * next_obs, models/learner.py:392-393).  Per group the arithmetic is exactly that of a single-group call. */
+int srlz_bn_finalize(const float* stats_partial, int n_partials, int groups, long long count, const float* gamma,
                      const float* beta, float eps, float momentum, int repeat, float* running_mean,
                      float* running_var, float* bnp, float* batch_stat, void* ws, size_t ws_bytes,
                      srlz_stream_t stream);
@@ -176,6 +186,7 @@ typedef struct srlz_pool_desc_s {
   int hp, wp;       /* pooled [N,hp,wp,64] */
   int pool_pad;     /* 0 or 1 (kernel 3, stride 2) */
   int out_nchw;     /* 1: write the pooled map as [N,64,hp,wp] (feeds Linear(2304,S), autoencoders.py:107-108) */
+  int groups;       /* BatchNorm groups along n (0 / 1 = one), as in srlz_conv64_desc: bnp / sums hold one record per group */
 } srlz_pool_desc;
 
 /* pooled = maxpool3x3s2(relu(y*scale+shift)); argmax (uint8 per output, window index 0..8) may be NULL (eval). */
@@ -196,13 +207,14 @@ int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argma
 int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long long pixels, srlz_stream_t stream);
 /* Second stage for the per-tile partials of a data-gradient epilogue (srlz_convT_out_bwd_data, srlz_conv64_bwd_data):
  * partial[n_partials][128] -> sums[128], dgamma[64], dbeta[64]; fp64 across tiles, fixed order. */
-int srlz_bn_bwd_finalize_partials(const float* partial, int n_partials, float* sums, float* dgamma, float* dbeta, void* ws,
-                                  size_t ws_bytes, srlz_stream_t stream);
+int srlz_bn_bwd_finalize_partials(const float* partial, int n_partials, int groups, float* sums, float* dgamma, float* dbeta,
+                                  void* ws, size_t ws_bytes, srlz_stream_t stream);
 /* First half of srlz_bn_relu_bwd: sums[128] = {sum dz[64], sum dz*xhat[64]} (= dbeta, dgamma), for srlz_bn_bwd_operand. */
+/* (groups > 1: bnp / sums hold one record per group, `pixels` counts all groups; dgamma / dbeta are the groups' totals) */
 int srlz_bn_relu_bwd_sums(const float* y, const float* bnp, const float* da, float* sums, float* dgamma, float* dbeta,
-                          void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream);
+                          void* ws, size_t ws_bytes, long long pixels, int groups, srlz_stream_t stream);
 int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* da, float* dy, float* dgamma, float* dbeta,
-                     int training, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream);
+                     int training, void* ws, size_t ws_bytes, long long pixels, int groups, srlz_stream_t stream);
 /* [N,C,H,W] <-> [N,H,W,C] for the two 6x6x64 seams around the FC layers (autoencoders.py:107-108,116-117). */
 int srlz_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, srlz_stream_t stream);
 int srlz_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, srlz_stream_t stream);
@@ -232,9 +244,18 @@ size_t srlz_reduce_workspace(long long n);
 /* out[0] = sum((a-b)^2)            reconstructionLoss 172-181 (caller divides by numel) / F.mse_loss(sum) 210-211 */
 int srlz_sqdiff_sum(const float* a, const float* b, long long n, float* out, void* ws, size_t ws_bytes,
                     srlz_stream_t stream);
+/* The same for `groups` consecutive slices of n_per_group elements (the two frames of a step batched along n): out[g] is
+ * group g's sum, each exactly as a single call on that slice would compute it. */
+int srlz_sqdiff_sum_groups(const float* a, const float* b, long long n_per_group, int groups, float* out, void* ws,
+                           size_t ws_bytes, srlz_stream_t stream);
 /* da[i] = coef_dev[0] * coef * (a[i]-b[i])   (gradient of the above w.r.t. a; coef_dev may be NULL = 1) */
 int srlz_sqdiff_grad(const float* a, const float* b, const float* coef_dev, float coef, float* da, long long n,
                      srlz_stream_t stream);
+/* grouped form: slice g is scaled by coef_dev[g] * coef */
+int srlz_sqdiff_grad_groups(const float* a, const float* b, const float* coef_dev, float coef, float* da,
+                            long long n_per_group, int groups, srlz_stream_t stream);
+/* out = [a ; b] (n_each floats each) — joins the halves of a batched pair (th.cat of learner.py's obs / next_obs) */
+int srlz_join2(const float* a, const float* b, float* out, long long n_each, srlz_stream_t stream);
 /* out[0] = -0.5*sum(1 + logvar - mu^2 - exp(logvar))      kullbackLeiblerLoss 239-256 */
 int srlz_kl_sum(const float* mu, const float* logvar, long long n, float* out, void* ws, size_t ws_bytes,
                 srlz_stream_t stream);

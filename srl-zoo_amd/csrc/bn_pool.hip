@@ -10,8 +10,11 @@ constexpr int STAGE_ROWS = 128;  // rows of the intermediate [STAGE_ROWS][128] f
 
 // Stage A of every per-channel reduction: rows[nrows][128] (fp32 or fp64) -> out[gridDim.x][128] fp64.
 // Block b sums rows b*2+half, stepping 2*gridDim.x; fixed assignment -> deterministic.
+// blockIdx.y = BatchNorm group: its rows are rows[g*nrows .. (g+1)*nrows), its output out[g*gridDim.x .. ][128].
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const T* __restrict__ rows, int nrows, double* __restrict__ out) {
+  rows += (size_t)blockIdx.y * nrows * 128;
+  out += (size_t)blockIdx.y * gridDim.x * 128;
   const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const int step = 2 * gridDim.x;
@@ -37,42 +40,50 @@ static int stage_blocks(int nrows) {
 }
 
 // bnp record: [0,64) mean, [64,128) invstd, [128,192) scale, [192,256) shift
+// `groups` independent BatchNorm calls (one per group of images) are finalised one after the other by the same block:
+// group g's staged partials are partial[g*n_partials ..], its records bnp[g*256 ..] / batch_stat[g*128 ..], and the running
+// statistics receive the groups' momentum updates IN ORDER (obs, then next_obs — models/learner.py:392-393).
 __global__ void bn_finalize_kernel(const double* __restrict__ partial, int n_partials, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, int repeat, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ bnp,
-                                   float* __restrict__ batch_stat) {
+                                   float* __restrict__ batch_stat, int groups) {
   // one block of 256 threads: thread (c = tid & 63, part = tid >> 6) sums a strided quarter of the partial records
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-  double s = 0.0, q = 0.0;
-  for (int i = part; i < n_partials; i += 4) {
-    s += partial[(size_t)i * 128 + c];
-    q += partial[(size_t)i * 128 + 64 + c];
-  }
   __shared__ double sm[2][4][64];
-  sm[0][part][c] = s; sm[1][part][c] = q;
-  __syncthreads();
-  if (part == 0) {
-    s = sm[0][0][c] + sm[0][1][c] + sm[0][2][c] + sm[0][3][c];
-    q = sm[1][0][c] + sm[1][1][c] + sm[1][2][c] + sm[1][3][c];
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma[c], b = beta[c];
-    const float scale = g * invstd;
-    bnp[c] = (float)mean; bnp[64 + c] = invstd; bnp[128 + c] = scale; bnp[192 + c] = b - (float)mean * scale;
-    const double unbiased = (count > 1.0) ? var * count / (count - 1.0) : var;
-    if (batch_stat) { batch_stat[c] = (float)mean; batch_stat[64 + c] = (float)unbiased; }
-    if (running_mean && running_var) {
-      float rm = running_mean[c], rv = running_var[c];
+  float rm = 0.f, rv = 0.f;
+  const bool upd = running_mean && running_var;
+  if (part == 0 && upd) { rm = running_mean[c]; rv = running_var[c]; }
+  for (int g = 0; g < groups; ++g) {
+    const double* pg = partial + (size_t)g * n_partials * 128;
+    double s = 0.0, q = 0.0;
+    for (int i = part; i < n_partials; i += 4) {
+      s += pg[(size_t)i * 128 + c];
+      q += pg[(size_t)i * 128 + 64 + c];
+    }
+    __syncthreads();  // (the previous group's readers are done with sm)
+    sm[0][part][c] = s; sm[1][part][c] = q;
+    __syncthreads();
+    if (part == 0) {
+      s = sm[0][0][c] + sm[0][1][c] + sm[0][2][c] + sm[0][3][c];
+      q = sm[1][0][c] + sm[1][1][c] + sm[1][2][c] + sm[1][3][c];
+      const double mean = s / count;
+      double var = q / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float ga = gamma[c], be = beta[c];
+      const float scale = ga * invstd;
+      float* rec = bnp + g * 256;
+      rec[c] = (float)mean; rec[64 + c] = invstd; rec[128 + c] = scale; rec[192 + c] = be - (float)mean * scale;
+      const double unbiased = (count > 1.0) ? var * count / (count - 1.0) : var;
+      if (batch_stat) { batch_stat[g * 128 + c] = (float)mean; batch_stat[g * 128 + 64 + c] = (float)unbiased; }
       for (int r = 0; r < repeat; ++r) {
         rm = (1.f - momentum) * rm + momentum * (float)mean;
         rv = (1.f - momentum) * rv + momentum * (float)unbiased;
       }
-      running_mean[c] = rm; running_var[c] = rv;
     }
   }
+  if (part == 0 && upd) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
 __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -93,13 +104,16 @@ __global__ void bn_replay_kernel(const float* batch_stat, float momentum, float*
 // Element (pooled pixel, 4 channels) per thread.  argmax = window index ky*3+kx of the first maximum.
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                               float* __restrict__ pooled, uint8_t* __restrict__ argmax,
-                                                              int N, int H, int W, int HP, int WP, int pad, int out_nchw) {
+                                                              int N, int H, int W, int HP, int WP, int pad, int out_nchw,
+                                                              int npg) {
   // grid: x covers (px, c4) of one pooled row, y = n*HP + py  -> no per-thread integer division
+  // npg = images per BatchNorm group: image n uses record bnp[(n / npg) * 256 ..]
   {
     const int c4 = threadIdx.x & 15;
     const int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (px >= WP) return;
     const int n = blockIdx.y / HP, py = blockIdx.y - n * HP;
+    bnp += (n / npg) * 256;
     const long long pix = ((long long)n * HP + py) * WP + px;
     const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
     const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
@@ -150,7 +164,7 @@ __device__ __forceinline__ void block_reduce_store(const double (&s1)[4], const 
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += sm[r][threadIdx.x];
-    partial[(size_t)blockIdx.x * 128 + threadIdx.x] = s;
+    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 + threadIdx.x] = s;  // (blockIdx.y = BatchNorm group)
   }
 }
 
@@ -161,6 +175,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
                                                               const float* __restrict__ dpooled,
                                                               const float* __restrict__ pooled, double* __restrict__ partial,
                                                               int N, int H, int W, int HP, int WP, int pad, int dp_nchw) {
+  // N = images per BatchNorm group; blockIdx.y = group (its images start at blockIdx.y * N)
+  bnp += blockIdx.y * 256;
+  const int n0 = blockIdx.y * N;
   // dz is non-zero only at a window's argmax and only if the pooled value is positive.  The pooled value IS
   // z = scale*v + shift at that position, so xhat = ((z - shift)/scale - mean)*invstd needs no access to y — unless
   // `pooled` is not supplied or scale == 0, where v is gathered from y (one scattered 4-byte read per element).
@@ -171,7 +188,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
   const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
   double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
   // block b walks pooled rows b, b + gridDim.x, ... (row = n*HP + py); 16 pixel-lanes x 16 channel-quads per block
-  for (int row = blockIdx.x; row < N * HP; row += gridDim.x) {
+  for (int lrow = blockIdx.x; lrow < N * HP; lrow += gridDim.x) {
+    const int row = n0 * HP + lrow;
     const int n = row / HP, py = row - n * HP;
     for (int px = threadIdx.x >> 4; px < WP; px += 16) {
       const long long pix = (long long)row * WP + px;
@@ -214,20 +232,30 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
   block_reduce_store(s1, s2, partial);
 }
 
-// sums[0..64) = sum dz (= dbeta), sums[64..128) = sum dz*xhat (= dgamma); also written to dgamma/dbeta.
+// Per group g: sums[g*128 + 0..64) = sum dz, sums[g*128 + 64..128) = sum dz*xhat; dbeta / dgamma = their totals over the groups
+// (the layer's parameters are shared by the batched calls).  partial: [groups][nblocks][128] fp64.
 // 1024 threads: 8 row slices x 128 columns, combined through LDS in a fixed order.
 __global__ __launch_bounds__(1024) void bn_bwd_finalize(const double* __restrict__ partial, int nblocks, float* __restrict__ sums,
-                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int groups) {
   const int c = threadIdx.x & 127, part = threadIdx.x >> 7;
-  double s = 0.0;
-  for (int i = part; i < nblocks; i += 8) s += partial[(size_t)i * 128 + c];
   __shared__ double sm[8][128];
-  sm[part][c] = s;
-  __syncthreads();
+  double total = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    const double* pg = partial + (size_t)g * nblocks * 128;
+    double s = 0.0;
+    for (int i = part; i < nblocks; i += 8) s += pg[(size_t)i * 128 + c];
+    __syncthreads();
+    sm[part][c] = s;
+    __syncthreads();
+    if (part == 0) {
+      s = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) + ((sm[4][c] + sm[5][c]) + (sm[6][c] + sm[7][c]));
+      sums[g * 128 + c] = (float)s;
+      total = (g == 0) ? s : total + s;
+    }
+  }
   if (part == 0) {
-    s = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c])) + ((sm[4][c] + sm[5][c]) + (sm[6][c] + sm[7][c]));
-    sums[c] = (float)s;
-    if (c < 64) { if (dbeta) dbeta[c] = (float)s; } else { if (dgamma) dgamma[c - 64] = (float)s; }
+    // one group: (float)s exactly as before; several: the fp64 total, rounded once
+    if (c < 64) { if (dbeta) dbeta[c] = (float)total; } else { if (dgamma) dgamma[c - 64] = (float)total; }
   }
 }
 
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply(const float* __res
                                                              const uint8_t* __restrict__ argmax,
                                                              const float* __restrict__ dpooled, const float* __restrict__ sums,
                                                              float* __restrict__ dy, int N, int H, int W, int HP, int WP,
-                                                             int pad, int dp_nchw, int training, float inv_count) {
+                                                             int pad, int dp_nchw, int training, float inv_count, int npg) {
   // block grid over (by, bx): iy = 2*by - pad .. +1, ix = 2*bx - pad .. +1 ; by in [0, HB), bx in [0, WB)
   const int HB = (H + pad + 1) / 2, WB = (W + pad + 1) / 2;
   // grid: x covers (bx, c4) of one block-row, y = n*HB + by
@@ -249,6 +277,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply(const float* __res
     const int bx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (bx >= WB) return;
     const int n = blockIdx.y / HB, by = blockIdx.y - n * HB;
+    bnp += (n / npg) * 256;   // this image's BatchNorm group (npg images per group)
+    sums += (n / npg) * 128;
     const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
     const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
     const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
@@ -335,6 +365,10 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce(const float* __restrict__ y, const float* __restrict__ bnp,
                                                          const float* __restrict__ da, double* __restrict__ partial,
                                                          long long pixels) {
+  // pixels = positions of ONE BatchNorm group; blockIdx.y = group
+  bnp += blockIdx.y * 256;
+  y += (size_t)blockIdx.y * pixels * 64;
+  da += (size_t)blockIdx.y * pixels * 64;
   const int c4 = threadIdx.x & 15;
   const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
   const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
@@ -357,6 +391,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply(const float* __restrict
                                                         const float* __restrict__ da, const float* __restrict__ sums,
                                                         float* __restrict__ dy, long long pixels, int training,
                                                         float inv_count) {
+  // pixels = positions of ONE BatchNorm group; blockIdx.y = group
+  bnp += blockIdx.y * 256;
+  sums += blockIdx.y * 128;
+  y += (size_t)blockIdx.y * pixels * 64;
+  da += (size_t)blockIdx.y * pixels * 64;
+  dy += (size_t)blockIdx.y * pixels * 64;
   const long long total = pixels * 16;
   for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(id & 15);
@@ -411,10 +451,14 @@ static int grid_for(long long work_items, int per_block) {
 }
 
 constexpr int RED_BLOCKS = 1024;
+constexpr int MAX_GROUPS = 8;  // (RED_BLOCKS + STAGE_ROWS) rows of scratch hold MAX_GROUPS x STAGE_ROWS staged rows
+static int norm_groups(int groups) { return groups > 1 ? groups : 1; }
 
 static int check_pool(const srlz_pool_desc* d) {
   SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "pool: null descriptor");
   SRLZ_REQUIRE(d->n > 0 && (d->pool_pad == 0 || d->pool_pad == 1), SRLZ_ERR_BAD_DESC, "pool: bad descriptor");
+  SRLZ_REQUIRE(d->groups >= 0 && d->groups <= 8 && (d->groups <= 1 || d->n % d->groups == 0), SRLZ_ERR_BAD_DESC,
+               "pool: n = %d is not a multiple of groups = %d", d->n, d->groups);
   SRLZ_REQUIRE(d->hp == (d->h + 2 * d->pool_pad - 3) / 2 + 1 && d->wp == (d->w + 2 * d->pool_pad - 3) / 2 + 1,
                SRLZ_ERR_BAD_DESC, "pool: pooled size %dx%d inconsistent with %dx%d pad %d", d->hp, d->wp, d->h, d->w, d->pool_pad);
   return 0;
@@ -422,19 +466,22 @@ static int check_pool(const srlz_pool_desc* d) {
 
 }  // namespace
 
-extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, long long count, const float* gamma,
+extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, int groups, long long count, const float* gamma,
                                 const float* beta, float eps, float momentum, int repeat, float* running_mean,
                                 float* running_var, float* bnp, float* batch_stat, void* ws, size_t ws_bytes,
                                 srlz_stream_t stream) {
   SRLZ_REQUIRE(stats_partial && gamma && beta && bnp && ws, SRLZ_ERR_NULL, "bn_finalize: null pointer");
-  SRLZ_REQUIRE(n_partials > 0 && count > 0, SRLZ_ERR_BAD_DESC, "bn_finalize: empty reduction");
+  const int G = norm_groups(groups);
+  SRLZ_REQUIRE(n_partials > 0 && count > 0 && G <= MAX_GROUPS && n_partials % G == 0, SRLZ_ERR_BAD_DESC,
+               "bn_finalize: %d partial records do not split into %d groups", n_partials, G);
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_finalize: workspace too small");
   double* staged = (double*)ws;
-  const int g = stage_blocks(n_partials);
-  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g), dim3(256), 0, as_stream(stream), stats_partial, n_partials, staged);
+  const int per = n_partials / G;
+  const int g = stage_blocks(per);  // per group exactly what a single-group call uses: results are bit-identical to G calls
+  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, G), dim3(256), 0, as_stream(stream), stats_partial, per, staged);
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double*)staged, g, (double)count,
-                     gamma, beta, eps, momentum, repeat, running_mean, running_var, bnp, batch_stat);
+                     gamma, beta, eps, momentum, repeat, running_mean, running_var, bnp, batch_stat, G);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -462,14 +509,14 @@ extern "C" int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* po
   SRLZ_REQUIRE(y && bnp && pooled, SRLZ_ERR_NULL, "bn_relu_pool_fwd: null pointer");
   SRLZ_REQUIRE((long long)d->n * d->hp <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*hp too large for one launch");
   hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((d->wp * 16 + 255) / 256, d->n * d->hp), dim3(256), 0, as_stream(stream), y, bnp, pooled,
-                     argmax, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw);
+                     argmax, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, d->n / norm_groups(d->groups));
   SRLZ_LAUNCHED();
   return 0;
 }
 
 extern "C" size_t srlz_bn_bwd_workspace(long long elems) {
   (void)elems;
-  return (size_t)(RED_BLOCKS + STAGE_ROWS) * 128 * sizeof(double) + 128 * sizeof(float);
+  return (size_t)(RED_BLOCKS + STAGE_ROWS) * 128 * sizeof(double) + MAX_GROUPS * 128 * sizeof(float);
 }
 
 // stage 1 of the pooled-block backward: sums[0..64) = sum dz, sums[64..128) = sum dz*xhat (also dbeta / dgamma)
@@ -477,15 +524,17 @@ static int pool_bwd_sums(const float* y, const float* bnp, const uint8_t* argmax
                          float* sums, float* dgamma, float* dbeta, void* ws, const srlz_pool_desc* d, hipStream_t st) {
   double* partial = (double*)ws;
   double* staged = partial + RED_BLOCKS * 128;
-  int nb = d->n * d->hp;
-  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-  hipLaunchKernelGGL(bn_relu_pool_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, argmax, dpooled, pooled, partial, d->n, d->h, d->w,
+  const int G = norm_groups(d->groups), npg = d->n / G;
+  int nb = npg * d->hp;
+  if (nb > RED_BLOCKS / G) nb = RED_BLOCKS / G;
+  hipLaunchKernelGGL(bn_relu_pool_bwd_reduce, dim3(nb, G), dim3(256), 0, st, y, bnp, argmax, dpooled, pooled, partial, npg, d->h, d->w,
                      d->hp, d->wp, d->pool_pad, d->out_nchw);
   SRLZ_LAUNCHED();
-  const int sg = stage_blocks(nb);
-  hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(sg), dim3(256), 0, st, (const double*)partial, nb, staged);
+  int sg = stage_blocks(nb);
+  if (sg > STAGE_ROWS / G) sg = STAGE_ROWS / G;
+  hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(sg, G), dim3(256), 0, st, (const double*)partial, nb, staged);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, sg, sums, dgamma, dbeta, G);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -506,13 +555,14 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   SRLZ_REQUIRE(y && bnp && argmax && dpooled && dy && ws, SRLZ_ERR_NULL, "bn_relu_pool_bwd: null pointer");
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_pool_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
-  float* sums = (float*)((double*)ws + (RED_BLOCKS + STAGE_ROWS) * 128);
+  float* sums = (float*)((double*)ws + (RED_BLOCKS + STAGE_ROWS) * 128);  // [groups][128]
   if (int rc = pool_bwd_sums(y, bnp, argmax, dpooled, pooled, sums, dgamma, dbeta, ws, d, st)) return rc;
   const int HB = (d->h + d->pool_pad + 1) / 2, WB = (d->w + d->pool_pad + 1) / 2;
   SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
-  const float inv_count = 1.0f / (float)((double)d->n * d->h * d->w);
+  const int npg = d->n / norm_groups(d->groups);
+  const float inv_count = 1.0f / (float)((double)npg * d->h * d->w);
   hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3((WB * 16 + 255) / 256, d->n * HB), dim3(256), 0, st, y, bnp, argmax, dpooled, sums, dy,
-                     d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count);
+                     d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count, npg);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -524,55 +574,66 @@ extern "C" int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long
   return 0;
 }
 
+// pixels = positions of ALL groups together (a multiple of G)
 static int bn_relu_bwd_sums_launch(const float* y, const float* bnp, const float* da, float* sums, float* dgamma, float* dbeta,
-                                   void* ws, long long pixels, hipStream_t st) {
+                                   void* ws, long long pixels, int G, hipStream_t st) {
+  SRLZ_REQUIRE(G >= 1 && G <= MAX_GROUPS && pixels % G == 0, SRLZ_ERR_BAD_DESC, "bn_relu_bwd: %lld positions do not split into %d groups",
+               pixels, G);
   double* partial = (double*)ws;
   double* staged = partial + RED_BLOCKS * 128;
-  int nb = (int)((pixels + 15) / 16);
-  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-  hipLaunchKernelGGL(bn_relu_bwd_reduce, dim3(nb), dim3(256), 0, st, y, bnp, da, partial, pixels);
+  const long long ppg = pixels / G;
+  int nb = (int)((ppg + 15) / 16);
+  if (nb > RED_BLOCKS / G) nb = RED_BLOCKS / G;
+  hipLaunchKernelGGL(bn_relu_bwd_reduce, dim3(nb, G), dim3(256), 0, st, y, bnp, da, partial, ppg);
   SRLZ_LAUNCHED();
-  const int sg = stage_blocks(nb);
-  hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(sg), dim3(256), 0, st, (const double*)partial, nb, staged);
+  int sg = stage_blocks(nb);
+  if (sg > STAGE_ROWS / G) sg = STAGE_ROWS / G;
+  hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(sg, G), dim3(256), 0, st, (const double*)partial, nb, staged);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, sg, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, sg, sums, dgamma, dbeta, G);
   SRLZ_LAUNCHED();
   return 0;
 }
 
 // Second stage for per-tile partials emitted by a data-gradient kernel's epilogue (srlz_convT_out_bwd_data with x_raw):
 // partial[n_partials][128] (fp32: sum dz, sum dz*xhat per tile) -> sums / dgamma / dbeta, fp64 across tiles.
-extern "C" int srlz_bn_bwd_finalize_partials(const float* partial, int n_partials, float* sums, float* dgamma, float* dbeta,
-                                             void* ws, size_t ws_bytes, srlz_stream_t stream) {
+extern "C" int srlz_bn_bwd_finalize_partials(const float* partial, int n_partials, int groups, float* sums, float* dgamma,
+                                             float* dbeta, void* ws, size_t ws_bytes, srlz_stream_t stream) {
   SRLZ_REQUIRE(partial && sums && ws, SRLZ_ERR_NULL, "bn_bwd_finalize_partials: null pointer");
-  SRLZ_REQUIRE(n_partials > 0, SRLZ_ERR_BAD_DESC, "bn_bwd_finalize_partials: empty reduction");
+  const int G = norm_groups(groups);
+  SRLZ_REQUIRE(n_partials > 0 && G <= MAX_GROUPS && n_partials % G == 0, SRLZ_ERR_BAD_DESC,
+               "bn_bwd_finalize_partials: %d records do not split into %d groups", n_partials, G);
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_bwd_finalize_partials: workspace too small");
   hipStream_t st = as_stream(stream);
   double* staged = (double*)ws;
-  const int g = stage_blocks(n_partials);
-  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g), dim3(256), 0, st, partial, n_partials, staged);
+  const int per = n_partials / G;
+  const int g = stage_blocks(per);
+  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, G), dim3(256), 0, st, partial, per, staged);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, g, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(1), dim3(1024), 0, st, (const double*)staged, g, sums, dgamma, dbeta, G);
   SRLZ_LAUNCHED();
   return 0;
 }
 
 extern "C" int srlz_bn_relu_bwd_sums(const float* y, const float* bnp, const float* da, float* sums, float* dgamma,
-                                     float* dbeta, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream) {
+                                     float* dbeta, void* ws, size_t ws_bytes, long long pixels, int groups,
+                                     srlz_stream_t stream) {
   SRLZ_REQUIRE(y && bnp && da && sums && ws, SRLZ_ERR_NULL, "bn_relu_bwd_sums: null pointer");
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_bwd_sums: workspace too small");
-  return bn_relu_bwd_sums_launch(y, bnp, da, sums, dgamma, dbeta, ws, pixels, as_stream(stream));
+  return bn_relu_bwd_sums_launch(y, bnp, da, sums, dgamma, dbeta, ws, pixels, norm_groups(groups), as_stream(stream));
 }
 
 extern "C" int srlz_bn_relu_bwd(const float* y, const float* bnp, const float* da, float* dy, float* dgamma, float* dbeta,
-                                int training, void* ws, size_t ws_bytes, long long pixels, srlz_stream_t stream) {
+                                int training, void* ws, size_t ws_bytes, long long pixels, int groups, srlz_stream_t stream) {
   SRLZ_REQUIRE(y && bnp && da && dy && ws, SRLZ_ERR_NULL, "bn_relu_bwd: null pointer");
   SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_relu_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
-  float* sums = (float*)((double*)ws + (RED_BLOCKS + STAGE_ROWS) * 128);
-  if (int rc = bn_relu_bwd_sums_launch(y, bnp, da, sums, dgamma, dbeta, ws, pixels, st)) return rc;
-  const float inv_count = 1.0f / (float)(double)pixels;
-  hipLaunchKernelGGL(bn_relu_bwd_apply, dim3(grid_for(pixels * 16, 256)), dim3(256), 0, st, y, bnp, da, sums, dy, pixels,
+  const int G = norm_groups(groups);
+  float* sums = (float*)((double*)ws + (RED_BLOCKS + STAGE_ROWS) * 128);  // [G][128]
+  if (int rc = bn_relu_bwd_sums_launch(y, bnp, da, sums, dgamma, dbeta, ws, pixels, G, st)) return rc;
+  const long long ppg = pixels / G;
+  const float inv_count = 1.0f / (float)(double)ppg;
+  hipLaunchKernelGGL(bn_relu_bwd_apply, dim3(grid_for(ppg * 16, 256), G), dim3(256), 0, st, y, bnp, da, sums, dy, ppg,
                      training, inv_count);
   SRLZ_LAUNCHED();
   return 0;

@@ -30,7 +30,9 @@ constexpr int TM = 128;       // grid positions per forward tile
 constexpr int NTAPS = 9;
 
 struct ConvProg {
-  int N, PH, PW, PHW, total_q;
+  int N, PH, PW, PHW, total_q;  // N / total_q: images / grid positions of ONE BatchNorm group
+  int G, tpg;                   // groups batched along the image axis (images [g*N, (g+1)*N)); forward tiles per group
+  long long src_gstride, dst_gstride;  // floats between two groups' images in src / dst
   int ss, Hs, Ws;  // source: stride, image dims
   int ds, Hd, Wd;  // dest
   int tsrc[NTAPS], tdst[NTAPS], toff[NTAPS], tw[NTAPS];
@@ -47,9 +49,14 @@ struct Axis {
 static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 // Build the program.  gather != 0: conv-like (dst is the low-res / same-res side); else convT-like.
-static int build_program(ConvProg* P, int gather, int stride, int pad, int N, int Hs, int Ws, int Hd, int Wd) {
+static int build_program(ConvProg* P, int gather, int stride, int pad, int N, int Hs, int Ws, int Hd, int Wd, int G = 1) {
   if (stride != 1 && stride != 2) return -1;
+  if (G < 1 || N % G != 0) return -1;
+  N /= G;  // the virtual grid covers ONE group; a tile / chunk never straddles two groups (see conv64_fwd_kernel)
   P->N = N; P->Hs = Hs; P->Ws = Ws; P->Hd = Hd; P->Wd = Wd;
+  P->G = G;
+  P->src_gstride = (long long)N * Hs * Ws * 64;
+  P->dst_gstride = (long long)N * Hd * Wd * 64;
   int kcls[3], kd[3];  // identical for both axes (square kernel, same stride/pad)
   if (gather) {
     P->ss = stride; P->ds = 1;
@@ -90,6 +97,7 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
   long long tq = (long long)N * P->PHW;
   if (tq > 0x7fffff00LL) return -1;
   P->total_q = (int)tq;
+  P->tpg = (P->total_q + TM - 1) / TM;
   // taps, grouped by class, groups in descending size (4,2,2,1 for stride 2)
   int nclass = stride * stride;
   int order[4] = {0, 1, 2, 3}, cnt[4] = {0, 0, 0, 0};
@@ -143,6 +151,16 @@ struct OpFuse {
   float* dy_out;
 };
 #define SRLZ_NO_FUSE OpFuse{nullptr, nullptr, nullptr, 0.f, 0, nullptr}
+
+// The records of BatchNorm group `grp` (bnp: 256 floats per group, sums: 128) and the group's slice of the tensors that are
+// indexed like the staged source (y, dy_out): `goff` floats further.
+__device__ __forceinline__ OpFuse fuse_for_group(OpFuse f, int grp, long long goff) {
+  if (f.bnp) f.bnp += grp * 256;
+  if (f.sums) f.sums += grp * 128;
+  if (f.y) f.y += goff;
+  if (f.dy_out) f.dy_out += goff;
+  return f;
+}
 
 template <bool SWZ, int BATCH = 8, int NTHREADS = 256, bool BWD = false>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ dst,
                                                                     float* __restrict__ stats_partial,
-                                                                    const ConvProg P, int ntiles, const OpFuse src_fuse) {
+                                                                    const ConvProg P, int ntiles, const OpFuse src_fuse_all) {
   constexpr int NT = NW * 64;      // threads
   constexpr int NACC = 8 / NW;     // 32-column tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -246,8 +264,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
   const int lane = tid & 63, wave = tid >> 6;
   const int wrow = wave & 3, wcol = wave >> 2;  // row group (32 rows), first column tile
   const int h = lane >> 5, l31 = lane & 31;
+  // BatchNorm groups (P.G > 1: `obs || next_obs` of one training step batched along n): tiles [g*tpg, (g+1)*tpg) cover group g's
+  // own virtual grid, so a tile never mixes two groups — its statistics partial belongs to one group, its fused operand
+  // uses one group's BatchNorm record — and the launch is exactly the union of the G per-group launches.
   const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int q0 = tile * TM;
+  const int grp = (P.G > 1) ? tile / P.tpg : 0;
+  const int q0 = (tile - grp * P.tpg) * TM;
+  src += grp * P.src_gstride;
+  dst += grp * P.dst_gstride;
+  const OpFuse src_fuse = fuse_for_group(src_fuse_all, grp, grp * P.src_gstride);
 
   if (tid < TM) {
     const int q = q0 + tid;
@@ -422,8 +447,15 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
   constexpr int NG = S2 ? 4 : 1;
   constexpr int GSTART[5] = {0, S2 ? 4 : 9, 6, 8, 9};
 
+  // nchunks = P.G * cpg: chunk -> (BatchNorm group, chunk of that group's grid); a chunk never straddles two groups
+  const int cpg = nchunks / P.G;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int q0 = chunk * TK;
+    const int grp = (P.G > 1) ? chunk / cpg : 0;
+    const int q0 = (chunk - grp * cpg) * TK;
+    const float* __restrict__ xg = x + grp * P.src_gstride;
+    const float* __restrict__ gg = g + grp * P.dst_gstride;
+    const OpFuse xf = fuse_for_group(x_fuse, grp, grp * P.src_gstride);
+    const OpFuse gf = fuse_for_group(g_fuse, grp, grp * P.dst_gstride);
     int cur_s = -1, cur_g = -1;
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -431,13 +463,13 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
       const int cs = P.tsrc[t0], cd = P.tdst[t0];
       __syncthreads();
       if (cs != cur_s) {
-        stage_rows<false, 4>(Ss, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span, x_fuse);
+        stage_rows<false, 4>(Ss, xg, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off, TK + P.span, xf);
         cur_s = cs;
       }
       const bool newg = (cd != cur_g);
       if (newg) {
-        if (g_fuse.y) stage_rows<false, 2, 256, true>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK, g_fuse);
-        else stage_rows<false, 4>(Gs, g, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK);
+        if (g_fuse.y) stage_rows<false, 2, 256, true>(Gs, gg, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK, gf);
+        else stage_rows<false, 4>(Gs, gg, P.Hd, P.Wd, P.ds, cd, P.PW, P.PH, P.total_q, q0, TK);
         cur_g = cd;
       }
       __syncthreads();
@@ -541,8 +573,9 @@ template <bool S2>
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ g,
                                                                   float* __restrict__ partial, const ConvProg P,
-                                                                  int nchunks, int chunks_per_wg,
+                                                                  int nchunks, int chunks_per_wg, int wgs_per_group,
                                                                   const float* __restrict__ x_bnp) {
+  // nchunks / chunks_per_wg describe ONE BatchNorm group; workgroups [g*wgs_per_group, (g+1)*wgs_per_group) walk group g
   constexpr int TK = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Ss = (float*)smem;        // ring: source row q lives at slot (q & 255)
@@ -564,7 +597,11 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   constexpr int GSTART[5] = {0, S2 ? 4 : 9, 6, 8, 9};
   const int cs = P.tsrc[0];  // the single source class
 
-  const int c_begin = blockIdx.x * chunks_per_wg;
+  const int grp = (P.G > 1) ? blockIdx.x / wgs_per_group : 0;
+  x += grp * P.src_gstride;
+  g += grp * P.dst_gstride;
+  if (x_bnp) x_bnp += grp * 256;
+  const int c_begin = (blockIdx.x - grp * wgs_per_group) * chunks_per_wg;
   const int c_end = (c_begin + chunks_per_wg < nchunks) ? c_begin + chunks_per_wg : nchunks;
   if (c_begin < c_end) {
     // prologue: source rows [q0+min_off, q0+min_off+TK+span) of the first chunk, gradient rows of its first class
@@ -700,6 +737,8 @@ static int check_desc(const srlz_conv64_desc* d) {
   SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "conv64: null descriptor");
   SRLZ_REQUIRE(d->ksize == 3 && (d->stride == 1 || d->stride == 2) && d->n > 0, SRLZ_ERR_BAD_DESC,
                "conv64: only 3x3 stride 1/2 supported (k=%d s=%d)", d->ksize, d->stride);
+  SRLZ_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->n % d->groups == 0), SRLZ_ERR_BAD_DESC,
+               "conv64: n = %d is not a multiple of groups = %d", d->n, d->groups);
   int eho, ewo;
   if (!d->transposed) {
     eho = (d->hi + 2 * d->pad - 3) / d->stride + 1;
@@ -715,10 +754,11 @@ static int check_desc(const srlz_conv64_desc* d) {
 
 static int program_for(ConvProg* P, const srlz_conv64_desc* d, int backward_data) {
   int rc;
+  const int G = d->groups > 1 ? d->groups : 1;
   if (!backward_data)
-    rc = build_program(P, !d->transposed, d->stride, d->pad, d->n, d->hi, d->wi, d->ho, d->wo);
+    rc = build_program(P, !d->transposed, d->stride, d->pad, d->n, d->hi, d->wi, d->ho, d->wo, G);
   else
-    rc = build_program(P, d->transposed, d->stride, d->pad, d->n, d->ho, d->wo, d->hi, d->wi);
+    rc = build_program(P, d->transposed, d->stride, d->pad, d->n, d->ho, d->wo, d->hi, d->wi, G);
   SRLZ_REQUIRE(rc == 0, SRLZ_ERR_BAD_DESC, "conv64: cannot build a grid program for this descriptor");
   return 0;
 }
@@ -729,7 +769,7 @@ static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried
 
 static int launch_fwd(const float* src, const float* wpack, const float* bias, float* dst, float* stats,
                       const ConvProg& P, hipStream_t st, const OpFuse src_fuse = SRLZ_NO_FUSE) {
-  const int ntiles = (P.total_q + TM - 1) / TM;
+  const int ntiles = P.G * P.tpg;
   const size_t lds = fwd_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64: tile needs %zu bytes of LDS", lds);
   // 4 waves (32x64 per wave) is the default; SRLZ_NW=8 selects 8 waves of 32x32 (measured within +-3 %: the kernel is
@@ -764,12 +804,14 @@ static int make_bwd_fuse(OpFuse* f, const srlz_bn_bwd_operand* o, const char* wh
   return 0;
 }
 
+// workgroups of the weight-gradient kernels (all groups together); a multiple of P.G
 static int wgrad_grid(const ConvProg& P) {
   const int tk = wgrad_tk(P);
-  const int nchunks = (P.total_q + tk - 1) / tk;
-  int g = 2 * srlz_device_cus();
+  const int nchunks = (P.total_q + tk - 1) / tk;  // per group
+  int g = 2 * srlz_device_cus() / P.G;            // per group
   if (g > nchunks) g = nchunks;
-  return g < 1 ? 1 : g;
+  if (g < 1) g = 1;
+  return g * P.G;
 }
 
 }  // namespace
@@ -790,7 +832,7 @@ extern "C" int srlz_conv64_fwd_tiles(const srlz_conv64_desc* d) {
   if (check_desc(d)) return -1;
   ConvProg P;
   if (program_for(&P, d, 0)) return -1;
-  return (P.total_q + TM - 1) / TM;
+  return P.G * P.tpg;
 }
 
 extern "C" int srlz_conv64_fwd(const float* x, const float* wpack_fwd, const float* bias, float* y,
@@ -836,7 +878,7 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   SRLZ_REQUIRE(ws_bytes >= (size_t)grid * (NTAPS * 4096 + 64) * sizeof(float), SRLZ_ERR_WORKSPACE,
                "conv64_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
   const int tk = wgrad_tk(P);
-  const int nchunks = (P.total_q + tk - 1) / tk;
+  const int nchunks = (P.total_q + tk - 1) / tk;  // per BatchNorm group
   hipStream_t st = as_stream(stream);
   float* partial = (float*)ws;
   bool single_src = true;
@@ -844,16 +886,18 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   static const int use_ring = [] { const char* e = getenv("SRLZ_WGRAD_RING"); return e ? atoi(e) : 1; }();
   int launched_grid = grid;
   if (use_ring && single_src && gf.y == nullptr && tk + P.span <= RING - 64 + 64 && tk == 64) {
-    // contiguous chunk ranges per workgroup (ring re-use of the source rows)
-    const int cpw = (nchunks + grid - 1) / grid;
-    launched_grid = (nchunks + cpw - 1) / cpw;
+    // contiguous chunk ranges per workgroup (ring re-use of the source rows), group by group
+    const int gpg = grid / P.G;
+    const int cpw = (nchunks + gpg - 1) / gpg;
+    const int wpg = (nchunks + cpw - 1) / cpw;
+    launched_grid = wpg * P.G;
     const size_t lds = (size_t)(RING + 64) * 256;
     if (P.s2) {
       SRLZ_MAX_LDS(conv64_wgrad_ring_kernel<true>, lds);
-      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<true>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, x_bnp);
+      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<true>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, wpg, x_bnp);
     } else {
       SRLZ_MAX_LDS(conv64_wgrad_ring_kernel<false>, lds);
-      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<false>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, x_bnp);
+      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<false>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, wpg, x_bnp);
     }
   } else {
     const size_t lds = wgrad_lds_bytes(P, tk);
@@ -861,7 +905,7 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
 #define SRLZ_WGRAD_LAUNCH(S2V, TKV)                                                                                        \
   do {                                                                                                                     \
     SRLZ_MAX_LDS((conv64_wgrad_kernel<S2V, TKV>), lds);                                                                     \
-    hipLaunchKernelGGL((conv64_wgrad_kernel<S2V, TKV>), dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks, xf, gf); \
+    hipLaunchKernelGGL((conv64_wgrad_kernel<S2V, TKV>), dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks * P.G, xf, gf); \
   } while (0)
     if (P.s2) SRLZ_WGRAD_LAUNCH(true, 64);
     else SRLZ_WGRAD_LAUNCH(false, 64);

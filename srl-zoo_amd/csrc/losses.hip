@@ -12,6 +12,10 @@ constexpr int RED_BLOCKS = 1024;
 template <int OP>  // 0: (a-b)^2 ; 1: -0.5*(1 + b - a^2 - exp(b))  (a = mu, b = logvar)
 __global__ __launch_bounds__(256) void reduce_partial(const float* __restrict__ a, const float* __restrict__ b, long long n,
                                                      double* __restrict__ partial) {
+  // blockIdx.y = group (independent reductions over consecutive slices of n elements, e.g. the two frames of a step)
+  a += (size_t)blockIdx.y * n;
+  b += (size_t)blockIdx.y * n;
+  partial += (size_t)blockIdx.y * gridDim.x;
   double acc = 0.0;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -41,17 +45,20 @@ __global__ __launch_bounds__(256) void reduce_partial(const float* __restrict__ 
 }
 
 __global__ void reduce_final(const double* __restrict__ partial, int nb, float* __restrict__ out) {
-  // one wave
+  // one wave per group (blockIdx.x)
+  partial += (size_t)blockIdx.x * nb;
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
   s = wave_sum_d(s);
-  if (threadIdx.x == 0) out[0] = (float)s;
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void sqdiff_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ coef_dev, float coef,
                                                          float* __restrict__ da, long long n) {
-  const float g = (coef_dev ? coef_dev[0] : 1.f) * coef;
+  // blockIdx.y = group: its slice of n elements and its own upstream coefficient coef_dev[group]
+  a += (size_t)blockIdx.y * n; b += (size_t)blockIdx.y * n; da += (size_t)blockIdx.y * n;
+  const float g = (coef_dev ? coef_dev[blockIdx.y] : 1.f) * coef;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -251,29 +258,52 @@ static int blocks_for(long long n, int cap) {
   return b < 1 ? 1 : (int)b;
 }
 
+constexpr int MAX_GROUPS = 8;
+
+// `groups` independent reductions over consecutive slices of n elements each -> out[groups]; per group exactly the launch
+// geometry and summation order of a single-group call (bit-identical results).
 template <int OP>
-static int reduce_launch(const float* a, const float* b, long long n, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+static int reduce_launch(const float* a, const float* b, long long n, int groups, float* out, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
   SRLZ_REQUIRE(a && b && out && ws, SRLZ_ERR_NULL, "reduce: null pointer");
-  SRLZ_REQUIRE(ws_bytes >= RED_BLOCKS * sizeof(double), SRLZ_ERR_WORKSPACE, "reduce: workspace too small");
-  SRLZ_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, SRLZ_ERR_BAD_DESC, "reduce: inputs must be 16-byte aligned");
+  SRLZ_REQUIRE(groups >= 1 && groups <= MAX_GROUPS, SRLZ_ERR_BAD_DESC, "reduce: groups = %d", groups);
+  SRLZ_REQUIRE(ws_bytes >= (size_t)groups * RED_BLOCKS * sizeof(double), SRLZ_ERR_WORKSPACE, "reduce: workspace too small");
+  SRLZ_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && (groups == 1 || (n & 3) == 0), SRLZ_ERR_BAD_DESC,
+               "reduce: inputs (and every group's slice) must be 16-byte aligned");
   const int nb = blocks_for((n + 3) / 4, RED_BLOCKS);
-  hipLaunchKernelGGL(reduce_partial<OP>, dim3(nb), dim3(256), 0, st, a, b, n, (double*)ws);
+  hipLaunchKernelGGL(reduce_partial<OP>, dim3(nb, groups), dim3(256), 0, st, a, b, n, (double*)ws);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(reduce_final, dim3(1), dim3(64), 0, st, (const double*)ws, nb, out);
+  hipLaunchKernelGGL(reduce_final, dim3(groups), dim3(64), 0, st, (const double*)ws, nb, out);
   SRLZ_LAUNCHED();
   return 0;
+}
+
+// out = [a ; b] (n floats each): joins the two halves of a batched pair when they do not already sit next to each other
+__global__ __launch_bounds__(256) void join2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float* __restrict__ out, long long n) {
+  const float* __restrict__ src = blockIdx.y ? b : a;
+  float* __restrict__ dst = out + (size_t)blockIdx.y * n;
+  const long long n4 = n >> 2, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    *(f32x4*)(dst + i * 4) = *(const f32x4*)(src + i * 4);
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
 }  // namespace
 
 extern "C" size_t srlz_reduce_workspace(long long n) {
   (void)n;
-  return RED_BLOCKS * sizeof(double);
+  return (size_t)MAX_GROUPS * RED_BLOCKS * sizeof(double);
 }
 
 extern "C" int srlz_sqdiff_sum(const float* a, const float* b, long long n, float* out, void* ws, size_t ws_bytes,
                                srlz_stream_t stream) {
-  return reduce_launch<0>(a, b, n, out, ws, ws_bytes, as_stream(stream));
+  return reduce_launch<0>(a, b, n, 1, out, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int srlz_sqdiff_sum_groups(const float* a, const float* b, long long n_per_group, int groups, float* out, void* ws,
+                                      size_t ws_bytes, srlz_stream_t stream) {
+  return reduce_launch<0>(a, b, n_per_group, groups, out, ws, ws_bytes, as_stream(stream));
 }
 
 extern "C" int srlz_sqdiff_grad(const float* a, const float* b, const float* coef_dev, float coef, float* da, long long n,
@@ -285,9 +315,29 @@ extern "C" int srlz_sqdiff_grad(const float* a, const float* b, const float* coe
   return 0;
 }
 
+extern "C" int srlz_sqdiff_grad_groups(const float* a, const float* b, const float* coef_dev, float coef, float* da,
+                                       long long n_per_group, int groups, srlz_stream_t stream) {
+  SRLZ_REQUIRE(a && b && da && coef_dev, SRLZ_ERR_NULL, "sqdiff_grad_groups: null pointer");
+  SRLZ_REQUIRE(groups >= 1 && groups <= MAX_GROUPS && (groups == 1 || (n_per_group & 3) == 0), SRLZ_ERR_BAD_DESC,
+               "sqdiff_grad_groups: groups = %d, %lld elements each", groups, n_per_group);
+  hipLaunchKernelGGL(sqdiff_grad_kernel, dim3(blocks_for((n_per_group + 3) / 4, 8192 / groups), groups), dim3(256), 0,
+                     as_stream(stream), a, b, coef_dev, coef, da, n_per_group);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_join2(const float* a, const float* b, float* out, long long n_each, srlz_stream_t stream) {
+  SRLZ_REQUIRE(a && b && out, SRLZ_ERR_NULL, "join2: null pointer");
+  SRLZ_REQUIRE(n_each > 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0 && (n_each & 3) == 0, SRLZ_ERR_BAD_DESC,
+               "join2: halves must be 16-byte aligned multiples of 4 floats (%lld)", n_each);
+  hipLaunchKernelGGL(join2_kernel, dim3(blocks_for((n_each + 3) / 4, 4096), 2), dim3(256), 0, as_stream(stream), a, b, out, n_each);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
 extern "C" int srlz_kl_sum(const float* mu, const float* logvar, long long n, float* out, void* ws, size_t ws_bytes,
                            srlz_stream_t stream) {
-  return reduce_launch<1>(mu, logvar, n, out, ws, ws_bytes, as_stream(stream));
+  return reduce_launch<1>(mu, logvar, n, 1, out, ws, ws_bytes, as_stream(stream));
 }
 
 extern "C" int srlz_kl_grad(const float* mu, const float* logvar, const float* coef_dev, float coef, float* dmu,

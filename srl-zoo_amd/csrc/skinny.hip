@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
                                                             float* __restrict__ stats_partial, int N, int C, int H,
                                                             int W, int HF, int WF, int tiles_y, int tiles_x,
                                                             const float* __restrict__ y_raw,
-                                                            const float* __restrict__ y_bnp) {
+                                                            const float* __restrict__ y_bnp, int npg) {
+  // npg = images per BatchNorm group (N when there is one group): image n uses the record y_bnp[(n / npg) * 256 ..]
   // BNBWD (data-gradient use, kind 1; y_raw != NULL): `feat` is dA = d(loss)/d(relu(bn(y_raw))) and the per-tile partials become
   // the two BatchNorm-backward sums  sum dz  and  sum dz*xhat  (dz = dA*[bn(y)>0]) instead of  sum v  and  sum v^2 —
   // the separate pass that re-reads dA and y (srlz_bn_relu_bwd_sums) disappears.
@@ -206,8 +207,9 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
     float mean0 = 0.f, mean1 = 0.f, inv0 = 0.f, inv1 = 0.f, sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f;
     if (BNBWD) {
-      mean0 = y_bnp[l31]; mean1 = y_bnp[32 + l31]; inv0 = y_bnp[64 + l31]; inv1 = y_bnp[96 + l31];
-      sc0 = y_bnp[128 + l31]; sc1 = y_bnp[160 + l31]; sh0 = y_bnp[192 + l31]; sh1 = y_bnp[224 + l31];
+      const float* __restrict__ yb = y_bnp + (n / npg) * 256;
+      mean0 = yb[l31]; mean1 = yb[32 + l31]; inv0 = yb[64 + l31]; inv1 = yb[96 + l31];
+      sc0 = yb[128 + l31]; sc1 = yb[160 + l31]; sh0 = yb[192 + l31]; sh1 = yb[224 + l31];
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -354,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
                                                              const float* __restrict__ feat,
                                                              float* __restrict__ partial, int N, int C, int H, int W,
                                                              int HF, int WF, int tiles_y, int tiles_x,
-                                                             const float* __restrict__ feat_bnp, const PoolFuse pf) {
+                                                             const float* __restrict__ feat_bnp, const PoolFuse pf, int npg) {
+  // npg = images per BatchNorm group: image n uses the records feat_bnp / pf.bnp [(n / npg) * 256 ..], pf.sums [(n / npg) * 128 ..]
   constexpr int KT = Geo<K>::KT;
   constexpr int NT = (KT + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   const int slot = tid & 15, prow = tid >> 4;  // feature staging: 16 lanes per pixel row (256 B), 16 pixels per pass
   // feat_bnp != NULL: `feat` is a raw convolution output and the operand is relu(batchnorm(feat)) (fused, see conv64.hip)
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-  if (feat_bnp) { sc4 = *(const f32x4*)(feat_bnp + 128 + slot * 4); sh4 = *(const f32x4*)(feat_bnp + 192 + slot * 4); }
+  int cur_grp = -1;  // group whose scale / shift sit in sc4 / sh4
   // Plain (non pool-fused) feature staging is software-pipelined: the 8 rows a thread contributes to the NEXT half tile are
   // requested before the current half's MFMA loop and written to LDS after it (pv / pmask carry them across).
   // (K = 4 only: the 7x7 kernel's 160 accumulator registers leave no room for the 32 in-flight registers)
@@ -419,6 +422,14 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
     const int n = tile / (tiles_y * tiles_x);
     const int trem = tile - n * (tiles_y * tiles_x);
     const int oy0 = (trem / tiles_x) * 16, ox0 = (trem % tiles_x) * 16;
+    const int grp = n / npg;
+    if constexpr (K == 4) {  // (the 7x7 kernel has no registers to spare and never takes a fused forward operand)
+      if (feat_bnp && grp != cur_grp) {
+        sc4 = *(const f32x4*)(feat_bnp + grp * 256 + 128 + slot * 4);
+        sh4 = *(const f32x4*)(feat_bnp + grp * 256 + 192 + slot * 4);
+        cur_grp = grp;
+      }
+    }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       __syncthreads();
@@ -432,9 +443,11 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
         // the 5 window rows pb..pb+4 (pb = first_row/2): an even row r is only the centre (ky=1) of window r/2, an odd
         // row is ky=0 of window (r+1)/2 and ky=2 of window (r-1)/2; same along x with the parity of ox.  All <=10
         // windows are loaded up front (independent loads), then the 8 rows are resolved from registers.
-        const f32x4 mean = *(const f32x4*)(pf.bnp + slot * 4), invstd = *(const f32x4*)(pf.bnp + 64 + slot * 4);
-        const f32x4 sc = *(const f32x4*)(pf.bnp + 128 + slot * 4), sh = *(const f32x4*)(pf.bnp + 192 + slot * 4);
-        f32x4 m1 = *(const f32x4*)(pf.sums + slot * 4), m2 = *(const f32x4*)(pf.sums + 64 + slot * 4);
+        const float* __restrict__ pbnp = pf.bnp + grp * 256;
+        const float* __restrict__ psums = pf.sums + grp * 128;
+        const f32x4 mean = *(const f32x4*)(pbnp + slot * 4), invstd = *(const f32x4*)(pbnp + 64 + slot * 4);
+        const f32x4 sc = *(const f32x4*)(pbnp + 128 + slot * 4), sh = *(const f32x4*)(pbnp + 192 + slot * 4);
+        f32x4 m1 = *(const f32x4*)(psums + slot * 4), m2 = *(const f32x4*)(psums + 64 + slot * 4);
         if (!pf.training) m1 = m2 = f32x4{0.f, 0.f, 0.f, 0.f};
         const int oyb = oy0 + 8 * half, ox = ox0 + prow, pb = oyb >> 1;
         const bool xodd = ox & 1, xin = ox < WF;
@@ -495,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
         // K = 4: the rows were requested one half tile ago (f_request); K = 7: request them here.
         // A fused BatchNorm+ReLU is applied now, at consumption.
         if (!piped) f_request(tile, half);
-        if (feat_bnp) {
+        if (K == 4 && feat_bnp) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const bool ok = (pmask >> j) & 1u;
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
                                                           const float* __restrict__ w_ref,
                                                           const float* __restrict__ bias, float* __restrict__ img,
                                                           int N, int C, int H, int W, int HF, int WF, int tiles_y,
-                                                          int tiles_x, const float* __restrict__ feat_bnp) {
+                                                          int tiles_x, const float* __restrict__ feat_bnp, int npg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Tt = (float*)smem;  // [304][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -602,16 +615,21 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
   float bs[3];
 #pragma unroll
   for (int co = 0; co < 3; ++co) bs[co] = bias ? bias[cg * 3 + co] : 0.f;
-  // feat_bnp != NULL: the operand is relu(batchnorm(feat)); this lane's channels are 16c + 4kq + r
+  // feat_bnp != NULL: the operand is relu(batchnorm(feat)); this lane's channels are 16c + 4kq + r.  The record is the one
+  // of the image's BatchNorm group (npg images per group), re-read when a workgroup's tile sequence crosses into the next group
   f32x4 fsc[4], fsh[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    fsc[c] = f32x4{1.f, 1.f, 1.f, 1.f}; fsh[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (feat_bnp) { fsc[c] = *(const f32x4*)(feat_bnp + 128 + 16 * c + 4 * kq); fsh[c] = *(const f32x4*)(feat_bnp + 192 + 16 * c + 4 * kq); }
-  }
+  for (int c = 0; c < 4; ++c) { fsc[c] = f32x4{1.f, 1.f, 1.f, 1.f}; fsh[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  int cur_grp = -1;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_y * tiles_x);
+    if (feat_bnp && n / npg != cur_grp) {
+      cur_grp = n / npg;
+      const float* __restrict__ rec = feat_bnp + cur_grp * 256;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { fsc[c] = *(const f32x4*)(rec + 128 + 16 * c + 4 * kq); fsh[c] = *(const f32x4*)(rec + 192 + 16 * c + 4 * kq); }
+    }
     const int trem = tile - n * (tiles_y * tiles_x);
     const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
     __syncthreads();  // previous tile's gather is done with Tt
@@ -713,6 +731,8 @@ __global__ void nchw_chan_sum_final(const double* __restrict__ partial, int N, f
 static int check_skinny(const srlz_skinny_desc* d) {
   SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "skinny: null descriptor");
   SRLZ_REQUIRE(d->n > 0 && d->c > 0 && d->c % 3 == 0 && d->c <= 9, SRLZ_ERR_BAD_DESC, "skinny: C must be 3, 6 or 9 (got %d)", d->c);
+  SRLZ_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->n % d->groups == 0), SRLZ_ERR_BAD_DESC,
+               "skinny: n = %d is not a multiple of groups = %d", d->n, d->groups);
   if (d->kind == 0) {
     SRLZ_REQUIRE(d->hf == (d->himg + 6 - 7) / 2 + 1 && d->wf == (d->wimg + 6 - 7) / 2 + 1, SRLZ_ERR_BAD_DESC,
                  "conv1: feature map %dx%d inconsistent with image %dx%d", d->hf, d->wf, d->himg, d->wimg);
@@ -728,6 +748,8 @@ static int check_skinny(const srlz_skinny_desc* d) {
 template <int K>
 static size_t conv_lds() { return (size_t)(Geo<K>::TILE_FLOATS + Geo<K>::KS * 128 + 512) * 4; }
 
+static int images_per_group(const srlz_skinny_desc* d) { return d->n / (d->groups > 1 ? d->groups : 1); }
+
 static int persistent_grid(int ntiles) {
   int g = 2 * srlz_device_cus();
   return g > ntiles ? ntiles : g;
@@ -742,14 +764,14 @@ static int launch_conv(const float* img, const float* w, float* feat, float* sta
   if constexpr (K == 4) if (y_raw) {
     SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, true>), lds);
     hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, true>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
-                       d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp);
+                       d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp, images_per_group(d));
     SRLZ_LAUNCHED();
     return 0;
   }
   {
     SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, false>), lds);
     hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, false>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
-                       d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp);
+                       d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp, images_per_group(d));
   }
   SRLZ_LAUNCHED();
   return 0;
@@ -771,12 +793,13 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
   const int ntiles = d->n * ty * tx;
   const int g = persistent_grid(ntiles);
   SRLZ_REQUIRE(ws_bytes >= wgrad_ws<K>(d), SRLZ_ERR_WORKSPACE, "skinny wgrad: workspace too small (%zu)", ws_bytes);
+  SRLZ_REQUIRE(K == 4 || feat_bnp == nullptr, SRLZ_ERR_BAD_DESC, "skinny wgrad: a fused forward operand exists for the 4x4 layer only");
   const size_t lds = (size_t)(Geo<K>::TILE_FLOATS + 128 * 64) * 4;
   float* partial = (float*)ws;
   PoolFuse pf = {};
   if (pfuse) pf = *pfuse;
   hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                     d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf);
+                     d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d));
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
@@ -836,12 +859,13 @@ extern "C" int srlz_conv1_bwd_weight_fused(const float* x_nchw, const float* y_n
   SRLZ_REQUIRE(d->kind == 0 && pd, SRLZ_ERR_BAD_DESC, "conv1_bwd_weight_fused: descriptor kind must be 0");
   SRLZ_REQUIRE(x_nchw && y_nhwc && bnp && argmax && dpooled && sums && dw_ref && ws, SRLZ_ERR_NULL,
                "conv1_bwd_weight_fused: null pointer");
-  SRLZ_REQUIRE(pd->n == d->n && pd->h == d->hf && pd->w == d->wf && !pd->out_nchw && pd->pool_pad == 1, SRLZ_ERR_BAD_DESC,
+  SRLZ_REQUIRE(pd->n == d->n && pd->h == d->hf && pd->w == d->wf && !pd->out_nchw && pd->pool_pad == 1 &&
+               (pd->groups > 1 ? pd->groups : 1) == (d->groups > 1 ? d->groups : 1), SRLZ_ERR_BAD_DESC,
                "conv1_bwd_weight_fused: pooling descriptor does not match conv1's output");
   PoolFuse pf;
   pf.y = y_nhwc; pf.argmax = argmax; pf.dpooled = dpooled; pf.bnp = bnp; pf.sums = sums;
   pf.HP = pd->hp; pf.WP = pd->wp; pf.pad = pd->pool_pad; pf.training = training;
-  pf.inv_count = 1.0f / (float)((double)d->n * d->hf * d->wf);
+  pf.inv_count = 1.0f / (float)((double)images_per_group(d) * d->hf * d->wf);  // BatchNorm count of ONE group
   return launch_wgrad<7, 3>(x_nchw, y_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream), nullptr, &pf);
 }
 
@@ -854,7 +878,7 @@ extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const
   const int ntiles = d->n * ty * tx;
   const size_t lds = (size_t)304 * TP * 4;
   hipLaunchKernelGGL(convT_out_kernel, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
-                     w_ref, bias, y_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp);
+                     w_ref, bias, y_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp, images_per_group(d));
   SRLZ_LAUNCHED();
   return 0;
 }

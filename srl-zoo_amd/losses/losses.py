@@ -94,16 +94,35 @@ def inverseModelLoss(actions_pred, actions_st, weight, loss_manager):
     return weight * inverse_loss
 
 
+def _pairSqDiff(a, next_a, b, next_b):
+    """(sum((a-b)^2), sum((next_a-next_b)^2)) in ONE launch when (a, next_a) and (b, next_b) are the halves of batched
+    tensors (the product's batched model call, SRLModules.forwardPair) — each sum exactly what the per-frame kernel gives;
+    None otherwise."""
+    pa, pb = ops.pair_of(a, next_a), ops.pair_of(b, next_b)
+    if pa is None or pb is None:
+        return None
+    sums = ops.SqDiffSumPairFn.apply(pa, pb)
+    return sums[0], sums[1]
+
+
 def autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs, weight, loss_manager):
     """reconstruction error of both frames (reference losses.py:184-196)."""
-    ae_loss = reconstructionLoss(obs, decoded_obs) + reconstructionLoss(next_obs, decoded_next_obs)
+    pair = _pairSqDiff(obs, next_obs, decoded_obs, decoded_next_obs)
+    if pair is not None:
+        ae_loss = pair[0] / obs.numel() + pair[1] / next_obs.numel()
+    else:
+        ae_loss = reconstructionLoss(obs, decoded_obs) + reconstructionLoss(next_obs, decoded_next_obs)
     loss_manager.addToLosses('reconstruction_loss', weight, ae_loss)
     return weight * ae_loss
 
 
 def generationLoss(decoded, next_decoded, obs, next_obs, weight, loss_manager):
     """pixel-wise summed squared error of both frames (reference losses.py:199-214)."""
-    generation_loss = ops.SqDiffSumFn.apply(decoded, obs) + ops.SqDiffSumFn.apply(next_decoded, next_obs)
+    pair = _pairSqDiff(decoded, next_decoded, obs, next_obs)
+    if pair is not None:
+        generation_loss = pair[0] + pair[1]
+    else:
+        generation_loss = ops.SqDiffSumFn.apply(decoded, obs) + ops.SqDiffSumFn.apply(next_decoded, next_obs)
     loss_manager.addToLosses('generation_loss', weight, generation_loss)
     return weight * generation_loss
 

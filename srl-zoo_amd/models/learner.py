@@ -127,6 +127,24 @@ class BaseLearner(object):
             frames = ops.normalize_u8(frames)
         return frames
 
+    def _toDevicePair(self, frames, next_frames):
+        """Both frames of a minibatch -> (obs, next_obs) that are the two HALVES OF ONE device buffer, so that the batched
+        model call (SRLModules.forwardPair) and the pair-aware reconstruction loss need no concatenation copy."""
+        from srlz import ops
+        frames = frames.to(self.device, non_blocking=True)
+        next_frames = next_frames.to(self.device, non_blocking=True)
+        if frames.shape != next_frames.shape:
+            return self._toDevice(frames), self._toDevice(next_frames)
+        n = frames.shape[0]
+        if frames.dtype == th.uint8:
+            _, h, w, c = frames.shape
+            both = th.empty((2 * n, c, w, h), dtype=th.float32, device=self.device)
+            ops.normalize_u8(frames, out=both[:n])
+            ops.normalize_u8(next_frames, out=both[n:])
+        else:
+            both = ops.pair_cat(frames, next_frames)
+        return both[:n], both[n:]
+
     def _predFn(self, observations):
         """Observations -> states (np.ndarray), model in whatever mode the caller set."""
         return detachToNumpy(self.model.getStates(observations))
@@ -211,6 +229,10 @@ class SRL4robotics(BaseLearner):
         # hipGraph replay of the step body (see _graphStep), opt-in with SRLZ_GRAPH=1.  Measured on MI355X: 3 % at bs = 32
         # (3.94 vs 4.06 ms), nothing at bs >= 64 — the ~300 small kernels of a step cost ~10 us each ON THE GPU whether
         # they are enqueued one by one or replayed from a graph, so the cure for small minibatches is fewer kernels.
+        # The two frames of a step run as ONE batched model call with two BatchNorm groups (SRLModules.forwardPair): half the
+        # launches, twice the grid of every small layer, per-call BatchNorm semantics intact.  SRLZ_PAIR=0 restores the two
+        # separate calls (A/B, parity tests).
+        self._use_pair = os.environ.get("SRLZ_PAIR", "1") != "0"
         self._use_graph = os.environ.get("SRLZ_GRAPH", "0") == "1"
         self._graphs = {}
         self._frame_streams = None
@@ -281,6 +303,8 @@ class SRL4robotics(BaseLearner):
     def _forwardPair(self, x, next_x):
         """(self.model(x), self.model(next_x)) — in that program order for the BatchNorm running statistics, but
         enqueued on two streams."""
+        if self._use_pair and self._frame_streams is None and x.shape == next_x.shape:
+            return self.model.forwardPair(x, next_x)
         if self._frame_streams is None:
             return self.model(x), self.model(next_x)
         main = th.cuda.current_stream(self.device)
@@ -499,8 +523,8 @@ class SRL4robotics(BaseLearner):
             for minibatch_num, (minibatch_idx, obs, next_obs, noisy_obs, next_noisy_obs) in enumerate(feed):
                 validation_mode = int(minibatch_idx) in val_set
                 if self.use_dae:
-                    noisy_obs, next_noisy_obs = self._toDevice(noisy_obs), self._toDevice(next_noisy_obs)
-                obs, next_obs = self._toDevice(obs), self._toDevice(next_obs)
+                    noisy_obs, next_noisy_obs = self._toDevicePair(noisy_obs, next_noisy_obs)
+                obs, next_obs = self._toDevicePair(obs, next_obs)
                 actions_st = th.from_numpy(actions[minibatchlist[minibatch_idx]]).view(-1, 1).to(self.device)
 
                 rewards_st = None

@@ -57,6 +57,19 @@ class BaseModelSRL(nn.Module):
         raise NotImplementedError
 
 
+def forward_pair(forward, x, next_x):
+    """(forward(x), forward(next_x)) — the two model calls of a training step (reference models/learner.py:392-393) — as ONE
+    batched pass over [x ; next_x] with two BatchNorm groups (srlz.ops.batch_groups): half the kernel launches, twice the
+    work per launch, per-call BatchNorm semantics intact.  Tensors of the returned tuples are halves of batched tensors."""
+    xx = ops.pair_cat(x, next_x)
+    with ops.batch_groups(2):
+        out = forward(xx)
+    if isinstance(out, tuple):
+        halves = [ops.pair_split(t) for t in out]
+        return tuple(h[0] for h in halves), tuple(h[1] for h in halves)
+    return ops.pair_split(out)
+
+
 class BaseModelAutoEncoder(BaseModelSRL):
     """Auto-encoder family: owns the conv encoder and decoder stacks (reference models.py:36-114)."""
 
@@ -109,23 +122,37 @@ class BaseModelVAE(BaseModelAutoEncoder):
         # a second, identical encoder pass whose only effects are mu (bit-identical) and one more running-stat
         # update with the same batch statistics.  Reproduce exactly that without recomputing the pass.
         if self.training:
-            for i, (x_ref, mu, stats) in enumerate(self._recent):
+            for i, (x_ref, mu, stats, group) in enumerate(self._recent):
                 if x_ref is observations and x_ref._version == self._recent_versions[i]:
-                    hotpath.replay_encoder_bn(self.encoder_conv, stats)
+                    hotpath.replay_encoder_bn(self.encoder_conv, stats, group)
                     return mu
         return self.encode(observations)[0]
 
-    def _remember(self, x, mu, stats):
+    def _remember(self, x, mu, stats, group=0):
         if len(self._recent) >= 2:
             self._recent.pop(0)
             self._recent_versions.pop(0)
-        self._recent.append((x, mu, stats))
+        self._recent.append((x, mu, stats, group))
         self._recent_versions.append(x._version)
+
+    def rememberPair(self, x, next_x, mu, next_mu):
+        """After a batched forward over [x ; next_x]: make the learner's getStates(x) / getStates(next_x) (the quirk above)
+        find the halves — group 0 / group 1 of the statistics the batched pass recorded."""
+        _, _, stats, _ = self._recent.pop()
+        self._recent_versions.pop()
+        self._recent, self._recent_versions = [], []
+        self._remember(x, mu, stats, 0)
+        self._remember(next_x, next_mu, stats, 1)
 
     def reparameterize(self, mu, logvar):
         """z = eps * exp(0.5 logvar) + mu in training (eps from torch's generator, as the reference does), mu in eval."""
         if self.training:
-            eps = self.eps_fn(mu) if self.eps_fn is not None else th.empty_like(mu).normal_()
+            if self.eps_fn is None:
+                eps = th.empty_like(mu).normal_()
+            elif ops.cur_groups(True) > 1:  # (test hook) a batched pair: one draw per model call, in call order
+                eps = th.cat([self.eps_fn(part) for part in mu.chunk(ops.cur_groups(True))], 0)
+            else:
+                eps = self.eps_fn(mu)
             return ops.ReparamFn.apply(mu, logvar, eps)
         return mu
 

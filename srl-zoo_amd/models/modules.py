@@ -9,6 +9,16 @@ from .vae import CNNVAE
 from .forward_inverse import BaseForwardModel, BaseInverseModel, BaseRewardModel
 from .models import *  # noqa: F401,F403  (BaseModelSRL, CustomCNN, encodeOneHot, ... as in the reference)
 
+
+
+def _forward_pair(module, x, next_x):
+    out, next_out = forward_pair(module.forward, x, next_x)
+    if isinstance(module.model, BaseModelVAE) and module.model.training:
+        # forward -> (decoded, mu, logvar): the learner asks getStates(x), getStates(next_x) next (learner.py:402)
+        module.model.rememberPair(x, next_x, out[1], next_out[1])
+    return out, next_out
+
+
 OUT_OF_SCOPE = "model_type '{}' / losses {} are outside the MI355X hot path of this build (custom_cnn with " \
                "autoencoder | vae | dae | inverse | forward | reward | perceptual); use the reference implementation for them"
 
@@ -50,6 +60,10 @@ class SRLModules(BaseForwardModel, BaseInverseModel, BaseRewardModel):
 
     def forward(self, x):
         return self.model(x)
+
+    def forwardPair(self, x, next_x):
+        """(self(x), self(next_x)) of one training step as a single batched pass (models.forward_pair)."""
+        return _forward_pair(self, x, next_x)
 
     def encode(self, x):
         raise NotImplementedError()
@@ -118,6 +132,10 @@ class SRLModulesSplit(BaseForwardModel, BaseInverseModel, BaseRewardModel):
         elif "vae" in self.losses:
             return self.forwardVAE(x)
         return self.model.forward(x)
+
+    def forwardPair(self, x, next_x):
+        """(self(x), self(next_x)) of one training step as a single batched pass (models.forward_pair)."""
+        return _forward_pair(self, x, next_x)
 
     def splitRange(self, index):
         """Column range [lo, hi) of the state that `detachSplit(., index)` keeps; (0, 0) when `index` names no split.

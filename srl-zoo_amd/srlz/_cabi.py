@@ -18,17 +18,17 @@ class SrlzError(RuntimeError):
 
 class Conv64Desc(Structure):
     _fields_ = [("n", c_int), ("hi", c_int), ("wi", c_int), ("ho", c_int), ("wo", c_int), ("ksize", c_int),
-                ("stride", c_int), ("pad", c_int), ("transposed", c_int)]
+                ("stride", c_int), ("pad", c_int), ("transposed", c_int), ("groups", c_int)]
 
 
 class SkinnyDesc(Structure):
     _fields_ = [("n", c_int), ("c", c_int), ("himg", c_int), ("wimg", c_int), ("hf", c_int), ("wf", c_int),
-                ("kind", c_int)]
+                ("kind", c_int), ("groups", c_int)]
 
 
 class PoolDesc(Structure):
     _fields_ = [("n", c_int), ("h", c_int), ("w", c_int), ("hp", c_int), ("wp", c_int), ("pool_pad", c_int),
-                ("out_nchw", c_int)]
+                ("out_nchw", c_int), ("groups", c_int)]
 
 
 class BnBwdOperand(Structure):
@@ -67,17 +67,17 @@ _PROTOS = {
     "srlz_bn_relu_pool_bwd_sums": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, _PD, P]),
     "srlz_convT_out_fwd": (c_int, [P, P, P, P, P, _SK, P]),
     "srlz_convT_out_bwd_data": (c_int, [P, P, P, P, P, P, _SK, P]),
-    "srlz_bn_bwd_finalize_partials": (c_int, [P, c_int, P, P, P, P, c_size_t, P]),
+    "srlz_bn_bwd_finalize_partials": (c_int, [P, c_int, c_int, P, P, P, P, c_size_t, P]),
     "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _SK, P]),
-    "srlz_bn_finalize": (c_int, [P, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, c_size_t, P]),
+    "srlz_bn_finalize": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),
     "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),
     "srlz_bn_relu_pool_fwd": (c_int, [P, P, P, P, _PD, P]),
     "srlz_bn_bwd_workspace": (c_size_t, [c_longlong]),
     "srlz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, c_size_t, _PD, P]),
     "srlz_bn_relu_fwd": (c_int, [P, P, P, c_longlong, P]),
-    "srlz_bn_relu_bwd_sums": (c_int, [P, P, P, P, P, P, P, c_size_t, c_longlong, P]),
-    "srlz_bn_relu_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, c_longlong, P]),
+    "srlz_bn_relu_bwd_sums": (c_int, [P, P, P, P, P, P, P, c_size_t, c_longlong, c_int, P]),
+    "srlz_bn_relu_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, c_longlong, c_int, P]),
     "srlz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srlz_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "srlz_linear_workspace": (c_size_t, [c_int, c_int, c_int]),
@@ -88,6 +88,9 @@ _PROTOS = {
     "srlz_reduce_workspace": (c_size_t, [c_longlong]),
     "srlz_sqdiff_sum": (c_int, [P, P, c_longlong, P, P, c_size_t, P]),
     "srlz_sqdiff_grad": (c_int, [P, P, P, c_float, P, c_longlong, P]),
+    "srlz_sqdiff_sum_groups": (c_int, [P, P, c_longlong, c_int, P, P, c_size_t, P]),
+    "srlz_sqdiff_grad_groups": (c_int, [P, P, P, c_float, P, c_longlong, c_int, P]),
+    "srlz_join2": (c_int, [P, P, P, c_longlong, P]),
     "srlz_kl_sum": (c_int, [P, P, c_longlong, P, P, c_size_t, P]),
     "srlz_kl_grad": (c_int, [P, P, P, c_float, P, P, c_longlong, P]),
     "srlz_reparam_fwd": (c_int, [P, P, P, P, c_longlong, P]),

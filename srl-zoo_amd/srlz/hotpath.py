@@ -38,7 +38,8 @@ def _tick(bn, training):
     # nn.BatchNorm2d increments num_batches_tracked once per training-mode call (ordered with the other stream's
     # updates of the same layer when the two frames of a step run on two streams)
     if training and bn.num_batches_tracked is not None:
-        ops._ordered_bn_update(bn.running_mean, lambda: bn.num_batches_tracked.add_(1))
+        groups = ops.cur_groups(training)  # a batched pair is `groups` calls of the layer
+        ops._ordered_bn_update(bn.running_mean, lambda: bn.num_batches_tracked.add_(groups))
 
 
 def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
@@ -63,11 +64,12 @@ def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
     return _tap(name, 11, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn3), training, 0, True, stat_sink))
 
 
-def replay_encoder_bn(seq, stats):
+def replay_encoder_bn(seq, stats, group=0):
     """Second train-mode pass over the same batch (VAE getStates quirk, models/learner.py:402): running statistics
-    receive the same batch statistics once more and num_batches_tracked advances; outputs are unchanged."""
+    receive the same batch statistics once more and num_batches_tracked advances; outputs are unchanged.
+    `group`: which BatchNorm group's statistics (the batch was one half of a batched pair)."""
     for bn, st in zip((seq[1], seq[5], seq[9]), stats):
-        def update(bn=bn, st=st):
+        def update(bn=bn, st=st[128 * group:128 * (group + 1)]):
             ops.bn_replay(st, bn.running_mean, bn.running_var)
             bn.num_batches_tracked.add_(1)
         ops._ordered_bn_update(bn.running_mean, update)

@@ -14,6 +14,33 @@ from ._cabi import ptr, stream, Conv64Desc, SkinnyDesc, PoolDesc
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# ---- BatchNorm groups -------------------------------------------------------------------------------------------------
+# The reference calls the model twice per step, self.model(obs) and self.model(next_obs) (models/learner.py:392-393): two
+# independent BatchNorm calls.  Inside `with batch_groups(2):` a forward over the CONCATENATED batch [obs ; next_obs] is
+# that pair of calls as ONE launch per layer: every kernel treats images [g*N/G, (g+1)*N/G) as group g with its own batch
+# statistics / BatchNorm record, running statistics take the groups' momentum updates in order, num_batches_tracked
+# advances by G, weight gradients are summed over the groups by the kernels.  Eval mode has no batch statistics: one group.
+_GROUPS = 1
+
+
+class batch_groups(object):
+    def __init__(self, groups):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        global _GROUPS
+        self.prev, _GROUPS = _GROUPS, self.groups
+        return self
+
+    def __exit__(self, *exc):
+        global _GROUPS
+        _GROUPS = self.prev
+        return False
+
+
+def cur_groups(training):
+    return _GROUPS if training else 1
+
 _workspaces = {}
 
 # ---- optional per-launch timing (bench.py's roofline leg): HIP events recorded on the stream the kernels run on ----
@@ -88,7 +115,7 @@ def _conv64_flop(d):
 
 
 def _conv64_key(d, what):
-    return "%s s%d %dx%d->%dx%d %s" % ("convT" if d.transposed else "conv", d.stride, d.hi, d.wi, d.ho, d.wo, what)
+    return "%s s%d n%d %dx%d->%dx%d %s" % ("convT" if d.transposed else "conv", d.stride, d.n, d.hi, d.wi, d.ho, d.wo, what)
 
 
 def _ws(nbytes, device, slot=0):
@@ -167,12 +194,12 @@ def _check(t, name):
 # ----------------------------------------------------------------------------------------------------------------
 # conv1: nn.Conv2d(C, 64, 7, stride 2, pad 3, bias=False) — models/models.py:49
 # ----------------------------------------------------------------------------------------------------------------
-def _skinny_desc(n, c, himg, wimg, kind):
+def _skinny_desc(n, c, himg, wimg, kind, groups=1):
     if kind == 0:
         hf, wf = (himg + 6 - 7) // 2 + 1, (wimg + 6 - 7) // 2 + 1
     else:
         hf, wf = (himg - 4) // 2 + 1, (wimg - 4) // 2 + 1
-    return SkinnyDesc(n, c, himg, wimg, hf, wf, kind)
+    return SkinnyDesc(n, c, himg, wimg, hf, wf, kind, groups)
 
 
 class Conv1Fn(Function):
@@ -180,7 +207,7 @@ class Conv1Fn(Function):
     def forward(ctx, x, w, want_stats):
         x, w = _check(x, "conv1 input"), _check(w, "conv1 weight")
         n, c, h, wd = x.shape
-        d = _skinny_desc(n, c, h, wd, 0)
+        d = _skinny_desc(n, c, h, wd, 0, cur_groups(want_stats))
         y = torch.empty((n, d.hf, d.wf, 64), dtype=torch.float32, device=x.device)
         stats = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
         C.conv1_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), d, stream())
@@ -213,12 +240,12 @@ class Conv1Fn(Function):
 # ----------------------------------------------------------------------------------------------------------------
 # 64 -> 64 convs: conv3x3 (models/models.py:54,59,217-226) and ConvTranspose2d(64,64,3,2) (models.py:66,70,74,78)
 # ----------------------------------------------------------------------------------------------------------------
-def conv64_desc(n, hi, wi, stride, pad, transposed):
+def conv64_desc(n, hi, wi, stride, pad, transposed, groups=1):
     if transposed:
         ho, wo = (hi - 1) * stride - 2 * pad + 3, (wi - 1) * stride - 2 * pad + 3
     else:
         ho, wo = (hi + 2 * pad - 3) // stride + 1, (wi + 2 * pad - 3) // stride + 1
-    return Conv64Desc(n, hi, wi, ho, wo, 3, stride, pad, 1 if transposed else 0)
+    return Conv64Desc(n, hi, wi, ho, wo, 3, stride, pad, 1 if transposed else 0, groups)
 
 
 class Conv64Fn(Function):
@@ -227,7 +254,7 @@ class Conv64Fn(Function):
         x, w = _check(x, "conv64 input"), _check(w, "conv64 weight")
         n, hi, wi, ch = x.shape
         assert ch == 64 and tuple(w.shape) == (64, 64, 3, 3)
-        d = conv64_desc(n, hi, wi, stride, pad, transposed)
+        d = conv64_desc(n, hi, wi, stride, pad, transposed, cur_groups(want_stats))
         npk = C.conv64_packed_floats()
         packs = torch.empty((2, npk), dtype=torch.float32, device=x.device)
         C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())
@@ -293,17 +320,20 @@ def _ordered_bn_update(running_mean, fn):
 
 
 def _bn_params(stats, count, gamma, beta, running_mean, running_var, training, device, tick=None):
-    bnp = torch.empty(256, dtype=torch.float32, device=device)
+    """BatchNorm record(s) of a layer: training -> one 256-float record per group from the producing convolution's
+    per-tile partials (`count` = positions of ALL groups together), eval -> one record from the running statistics."""
+    groups = cur_groups(training)
+    bnp = torch.empty(256 * groups, dtype=torch.float32, device=device)
     batch_stat = None
     if training:
-        batch_stat = torch.empty(128, dtype=torch.float32, device=device)
+        batch_stat = torch.empty(128 * groups, dtype=torch.float32, device=device)
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, device)
 
         def update():
             if tick is not None:
-                tick.add_(1)  # num_batches_tracked
-            C.bn_finalize(ptr(stats), stats.shape[0], count, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, 1,
+                tick.add_(groups)  # num_batches_tracked
+            C.bn_finalize(ptr(stats), stats.shape[0], groups, count // groups, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, 1,
                           ptr(running_mean), ptr(running_var), ptr(bnp), ptr(batch_stat), ptr(ws), nbytes, stream())
         _ordered_bn_update(running_mean, update)
     else:
@@ -319,7 +349,7 @@ class BNReLUPoolFn(Function):
         y = _check(y, "bn input")
         n, h, w, _ = y.shape
         hp, wp = (h + 2 * pool_pad - 3) // 2 + 1, (w + 2 * pool_pad - 3) // 2 + 1
-        d = PoolDesc(n, h, w, hp, wp, pool_pad, 1 if out_nchw else 0)
+        d = PoolDesc(n, h, w, hp, wp, pool_pad, 1 if out_nchw else 0, cur_groups(training))
         bnp, batch_stat = _bn_params(stats, n * h * w, gamma, beta, running_mean, running_var, training, y.device)
         if stat_sink is not None and batch_stat is not None:
             stat_sink.append(batch_stat)
@@ -358,12 +388,12 @@ class EncInFn(Function):
     def forward(ctx, x, w, gamma, beta, running_mean, running_var, training, pool_pad, stat_sink):
         x, w = _check(x, "conv1 input"), _check(w, "conv1 weight")
         n, c, h, wd = x.shape
-        d = _skinny_desc(n, c, h, wd, 0)
+        d = _skinny_desc(n, c, h, wd, 0, cur_groups(training))
         y = torch.empty((n, d.hf, d.wf, 64), dtype=torch.float32, device=x.device)
         stats = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=x.device) if training else None
         C.conv1_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), d, stream())
         hp, wp = (d.hf + 2 * pool_pad - 3) // 2 + 1, (d.wf + 2 * pool_pad - 3) // 2 + 1
-        pd = PoolDesc(n, d.hf, d.wf, hp, wp, pool_pad, 0)
+        pd = PoolDesc(n, d.hf, d.wf, hp, wp, pool_pad, 0, cur_groups(training))
         bnp, batch_stat = _bn_params(stats, n * d.hf * d.wf, gamma, beta, running_mean, running_var, training, x.device)
         if stat_sink is not None and batch_stat is not None:
             stat_sink.append(batch_stat)
@@ -386,7 +416,7 @@ class EncInFn(Function):
         dev = y.device
         dgamma = _gbuf(ctx.params[0])
         dbeta = _gbuf(ctx.params[1])
-        sums = torch.empty(128, dtype=torch.float32, device=dev)
+        sums = torch.empty(128 * max(ctx.pdesc.groups, 1), dtype=torch.float32, device=dev)
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, dev)
         C.bn_relu_pool_bwd_sums(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(sums), ptr(dgamma), ptr(dbeta),
@@ -404,6 +434,11 @@ class EncInFn(Function):
 # (models/models.py:67-82: BatchNorm2d -> ReLU -> ConvTranspose2d).  Input = RAW output of the previous transposed
 # convolution + its BatchNorm statistics; the activated tensor relu(bn(y)) is never written to memory.
 # ----------------------------------------------------------------------------------------------------------------
+def _groups_of(bnp):
+    """Number of BatchNorm groups a record tensor holds (256 floats per group)."""
+    return bnp.numel() // 256
+
+
 def _bn_relu_backward(y, bnp, da, training, gb=(None, None)):
     dy = torch.empty_like(y)
     dgamma = _gbuf(gb[0], 64, y.device)
@@ -411,7 +446,7 @@ def _bn_relu_backward(y, bnp, da, training, gb=(None, None)):
     nbytes = C.bn_bwd_workspace(0)
     ws = _ws(nbytes, y.device)
     C.bn_relu_bwd(ptr(y), ptr(bnp), ptr(da), ptr(dy), ptr(dgamma), ptr(dbeta), 1 if training else 0, ptr(ws), nbytes,
-                  y.numel() // 64, stream())
+                  y.numel() // 64, _groups_of(bnp), stream())
     return dy, dgamma, dbeta
 
 
@@ -438,13 +473,14 @@ class BwdLink:
 
 def _bn_relu_backward_sums(y, bnp, da, gb=(None, None)):
     dev = y.device
-    sums = torch.empty(128, dtype=torch.float32, device=dev)
+    groups = _groups_of(bnp)
+    sums = torch.empty(128 * groups, dtype=torch.float32, device=dev)
     dgamma = _gbuf(gb[0], 64, dev)
     dbeta = _gbuf(gb[1], 64, dev)
     nbytes = C.bn_bwd_workspace(0)
     ws = _ws(nbytes, dev)
     C.bn_relu_bwd_sums(ptr(y), ptr(bnp), ptr(da), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, y.numel() // 64,
-                       stream())
+                       groups, stream())
     return sums, dgamma, dbeta
 
 
@@ -453,7 +489,7 @@ def _bn_backward_for_producer(link, y_prev, bnp, da, training, partial=None, gb=
     `partial`: per-tile partial sums already written by the epilogue of the kernel that produced `da`."""
     if link is not None:
         if partial is not None:
-            sums, dgamma, dbeta = _bn_backward_sums_from_partials(partial, gb)
+            sums, dgamma, dbeta = _bn_backward_sums_from_partials(partial, gb, _groups_of(bnp))
         else:
             sums, dgamma, dbeta = _bn_relu_backward_sums(y_prev, bnp, da, gb)
         link.put(y_prev, bnp, sums, training)
@@ -461,14 +497,15 @@ def _bn_backward_for_producer(link, y_prev, bnp, da, training, partial=None, gb=
     return _bn_relu_backward(y_prev, bnp, da, training, gb)
 
 
-def _bn_backward_sums_from_partials(partial, gb=(None, None)):
+def _bn_backward_sums_from_partials(partial, gb=(None, None), groups=1):
     dev = partial.device
-    sums = torch.empty(128, dtype=torch.float32, device=dev)
+    sums = torch.empty(128 * groups, dtype=torch.float32, device=dev)
     dgamma = _gbuf(gb[0], 64, dev)
     dbeta = _gbuf(gb[1], 64, dev)
     nbytes = C.bn_bwd_workspace(0)
     ws = _ws(nbytes, dev)
-    C.bn_bwd_finalize_partials(ptr(partial), partial.shape[0], ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes, stream())
+    C.bn_bwd_finalize_partials(ptr(partial), partial.shape[0], groups, ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), nbytes,
+                               stream())
     return sums, dgamma, dbeta
 
 
@@ -480,7 +517,7 @@ def _operand_from(link):
         return None, None, None
     y, bnp, sums, training = rec
     dy_out = torch.empty_like(y)
-    op = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), y.numel() // 64, 1 if training else 0,
+    op = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), y.numel() // 64 // _groups_of(bnp), 1 if training else 0,
                         dy_out.data_ptr())
     return op, dy_out, rec
 
@@ -495,7 +532,7 @@ class DecBlockFn(Function):
         y_prev, w = _check(y_prev, "decoder block input"), _check(w, "convT weight")
         n, hi, wi, _ = y_prev.shape
         bnp, _ = _bn_params(stats_prev, n * hi * wi, gamma, beta, running_mean, running_var, training, y_prev.device)
-        d = conv64_desc(n, hi, wi, 2, 0, True)
+        d = conv64_desc(n, hi, wi, 2, 0, True, cur_groups(training))
         packs = torch.empty((2, C.conv64_packed_floats()), dtype=torch.float32, device=y_prev.device)
         C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())
         y = torch.empty((n, d.ho, d.wo, 64), dtype=torch.float32, device=y_prev.device)
@@ -549,7 +586,7 @@ class DecOutFn(Function):
         n, hf, wf, _ = y_prev.shape
         bnp, _ = _bn_params(stats_prev, n * hf * wf, gamma, beta, running_mean, running_var, training, y_prev.device)
         c = w.shape[1]
-        d = SkinnyDesc(n, c, (hf - 1) * 2 + 4, (wf - 1) * 2 + 4, hf, wf, 1)
+        d = SkinnyDesc(n, c, (hf - 1) * 2 + 4, (wf - 1) * 2 + 4, hf, wf, 1, cur_groups(training))
         y = torch.empty((n, c, d.himg, d.wimg), dtype=torch.float32, device=y_prev.device)
         C.convT_out_fwd(ptr(y_prev), ptr(w), ptr(bias), ptr(y), ptr(bnp), d, stream())
         ctx.save_for_backward(y_prev, bnp, w)
@@ -756,6 +793,117 @@ class SqDiffSumFn(Function):
         return da, db
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# The two frames of a step as ONE batch (models/learner.py:392-393 calls the model on obs, then on next_obs).
+# pair_cat joins them (zero-copy when they already are the two halves of one buffer), the model runs once inside
+# batch_groups(2), pair_split hands the halves back to the loop body as views.  Losses that see both halves of a pair
+# (pair_of) reduce them in one launch and return ONE gradient for the batched tensor.
+# ----------------------------------------------------------------------------------------------------------------
+def pair_cat(a, b):
+    """[a ; b] along dim 0.  No copy when b starts where a ends in the same storage."""
+    a, b = _check(a, "pair half"), _check(b, "pair half")
+    if a.shape != b.shape:
+        raise C.SrlzError("pair_cat: the two halves differ in shape (%s vs %s)" % (tuple(a.shape), tuple(b.shape)))
+    shape = (2 * a.shape[0],) + tuple(a.shape[1:])
+    same = a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+    if same and b.storage_offset() == a.storage_offset() + a.numel() and not (a.requires_grad or b.requires_grad):
+        return torch.empty(0, dtype=a.dtype, device=a.device).set_(a.untyped_storage(), a.storage_offset(), shape)
+    return JoinFn.apply(a, b)
+
+
+class JoinFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
+        C.join2(ptr(a), ptr(b), ptr(out), a.numel(), stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        half = d.shape[0] // 2
+        return d[:half], d[half:]
+
+
+class SplitFn(Function):
+    """t [2B, ...] -> (t[:B], t[B:]) as views; the backward joins the two gradients (a missing one counts as zero)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        half = t.shape[0] // 2
+        ctx.half_shape = (half,) + tuple(t.shape[1:])
+        ctx.set_materialize_grads(False)
+        return t[:half], t[half:]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        if da is None and db is None:
+            return None
+        dev = (da if da is not None else db).device
+        out = torch.empty((2 * ctx.half_shape[0],) + ctx.half_shape[1:], dtype=torch.float32, device=dev)
+        half = out.shape[0] // 2
+        if da is not None and db is not None:
+            da, db = _check(da, "pair grad"), _check(db, "pair grad")
+            if da.numel() % 4 == 0 and da.data_ptr() % 16 == 0 and db.data_ptr() % 16 == 0:
+                C.join2(ptr(da), ptr(db), ptr(out), da.numel(), stream())
+            else:
+                out[:half].copy_(da)
+                out[half:].copy_(db)
+        else:
+            out.zero_()
+            (out[:half] if da is not None else out[half:]).copy_(da if da is not None else db)
+        return out
+
+
+def pair_split(t):
+    """The two halves of a batched tensor, remembered as a pair so that pair-aware consumers can find the whole."""
+    a, b = SplitFn.apply(t)
+    a._srlz_pair = (t, 0, b)
+    b._srlz_pair = (t, 1, a)
+    return a, b
+
+
+def pair_of(a, b):
+    """The batched tensor whose halves are exactly (a, b) — or None."""
+    ra = getattr(a, "_srlz_pair", None)
+    if ra is not None and ra[1] == 0 and ra[2] is b:
+        return ra[0]
+    if torch.is_tensor(a) and torch.is_tensor(b) and not (a.requires_grad or b.requires_grad) and a.is_cuda and b.is_cuda \
+            and a.dtype == torch.float32 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous() \
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() \
+            and b.storage_offset() == a.storage_offset() + a.numel():
+        return pair_cat(a, b)  # two adjacent constant tensors (obs, next_obs): a view over both
+    return None
+
+
+class SqDiffSumPairFn(Function):
+    """(sum((a0-b0)^2), sum((a1-b1)^2)) for the two halves of batched tensors a, b [2B, ...]: one launch, each sum exactly
+    what SqDiffSumFn computes on that half; one gradient tensor for each batched input."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _check(a, "loss input"), _check(b, "loss target")
+        assert a.shape == b.shape and a.shape[0] % 2 == 0
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        nbytes = C.reduce_workspace(a.numel())
+        ws = _ws(nbytes, a.device)
+        C.sqdiff_sum_groups(ptr(a), ptr(b), a.numel() // 2, 2, ptr(out), ptr(ws), nbytes, stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _check(g, "loss grad")
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            C.sqdiff_grad_groups(ptr(a), ptr(b), ptr(g), 2.0, ptr(da), a.numel() // 2, 2, stream())
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(b)
+            C.sqdiff_grad_groups(ptr(a), ptr(b), ptr(g), -2.0, ptr(db), a.numel() // 2, 2, stream())
+        return da, db
+
+
 class KLSumFn(Function):
     """-0.5 * sum(1 + logvar - mu^2 - exp(logvar)) — losses.py:253."""
 
@@ -838,13 +986,17 @@ class ConcatOneHotFn(Function):
         return dcat[:, :ctx.sdim].contiguous(), None, None
 
 
-def normalize_u8(frames):
-    """uint8 [N,H,W,C] device tensor -> normalised fp32 [N,C,W,H] (the reference's observation tensor)."""
+def normalize_u8(frames, out=None):
+    """uint8 [N,H,W,C] device tensor -> normalised fp32 [N,C,W,H] (the reference's observation tensor); `out`: where to
+    write it (a contiguous [N,C,W,H] fp32 tensor, e.g. one half of a pair buffer)."""
     if frames.device.type != "cuda" or frames.dtype != torch.uint8:
         raise C.SrlzError("normalize_u8 expects a uint8 tensor on the GPU")
     frames = frames.contiguous()
     n, h, w, c = frames.shape
-    out = torch.empty((n, c, w, h), dtype=torch.float32, device=frames.device)
+    if out is None:
+        out = torch.empty((n, c, w, h), dtype=torch.float32, device=frames.device)
+    elif tuple(out.shape) != (n, c, w, h) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise C.SrlzError("normalize_u8: `out` must be a contiguous float32 [N,C,W,H] tensor")
     C.normalize_u8(ptr(frames), ptr(out), n, h, w, c, stream())
     return out
 

@@ -211,7 +211,7 @@ def test_bn_relu_pool(C, n, h, pad, out_nchw, training):
         parts = _partials(nhwc(y)).to(DEV)
         bstat = torch.empty(128, device=DEV)
         fws = torch.empty(C.bn_bwd_workspace(0), dtype=torch.uint8, device=DEV)
-        C.bn_finalize(C.ptr(parts), parts.shape[0], n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
+        C.bn_finalize(C.ptr(parts), parts.shape[0], 1, n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
                       C.ptr(rvd), C.ptr(bnp), C.ptr(bstat), C.ptr(fws), fws.numel(), st)
         torch.cuda.synchronize()
         assert rel_err(rmd, rm_r) < 1e-5 and rel_err(rvd, rv_r) < 1e-5
@@ -252,7 +252,7 @@ def test_bn_relu(C, n, h, training):
     if training:
         parts = _partials(nhwc(y)).to(DEV)
         fws = torch.empty(C.bn_bwd_workspace(0), dtype=torch.uint8, device=DEV)
-        C.bn_finalize(C.ptr(parts), parts.shape[0], n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
+        C.bn_finalize(C.ptr(parts), parts.shape[0], 1, n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
                       C.ptr(rvd), C.ptr(bnp), None, C.ptr(fws), fws.numel(), st)
     else:
         C.bn_eval_params(C.ptr(gd), C.ptr(bd), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(bnp), st)
@@ -265,7 +265,7 @@ def test_bn_relu(C, n, h, training):
     nbytes = C.bn_bwd_workspace(0)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     C.bn_relu_bwd(C.ptr(yd), C.ptr(bnp), C.ptr(dad), C.ptr(dy), C.ptr(dgm), C.ptr(dbt), training, C.ptr(ws), nbytes,
-                  n * h * h, st)
+                  n * h * h, 1, st)
     torch.cuda.synchronize()
     assert rel_err(nchw(dy), yr.grad) < 5e-5
     assert rel_err(dgm, gr.grad) < 5e-5 and rel_err(dbt, br.grad) < 5e-5
@@ -536,12 +536,12 @@ def test_fused_bn_backward_operand(C, n, hi, s, p, t, training):
     bws = torch.empty(nbn, dtype=torch.uint8, device=DEV)
     if training:
         bstat = torch.empty(128, device=DEV)
-        C.bn_finalize(C.ptr(stats), stats.shape[0], n * ho * ho, C.ptr(gd), C.ptr(bed), 1e-5, 0.1, 1, C.ptr(rmd), C.ptr(rvd),
+        C.bn_finalize(C.ptr(stats), stats.shape[0], 1, n * ho * ho, C.ptr(gd), C.ptr(bed), 1e-5, 0.1, 1, C.ptr(rmd), C.ptr(rvd),
                       C.ptr(bnp), C.ptr(bstat), C.ptr(bws), nbn, st)
     else:
         C.bn_eval_params(C.ptr(gd), C.ptr(bed), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(bnp), st)
     sums, dgm, dbt = torch.empty(128, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
-    C.bn_relu_bwd_sums(C.ptr(y), C.ptr(bnp), C.ptr(dad), C.ptr(sums), C.ptr(dgm), C.ptr(dbt), C.ptr(bws), nbn, n * ho * ho, st)
+    C.bn_relu_bwd_sums(C.ptr(y), C.ptr(bnp), C.ptr(dad), C.ptr(sums), C.ptr(dgm), C.ptr(dbt), C.ptr(bws), nbn, n * ho * ho, 1, st)
     dy_out = torch.full((n, ho, ho, 64), float("nan"), device=DEV)
     op = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), n * ho * ho, training, dy_out.data_ptr())
     dx = torch.full((n, hi, hi, 64), float("nan"), device=DEV)
@@ -623,8 +623,8 @@ def test_convT_out_bwd_data_emits_bn_backward_sums(C, n, c, hf):
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
     out = [[torch.empty(k, device=DEV) for k in (128, 64, 64)] for _ in range(2)]
     C.bn_relu_bwd_sums(C.ptr(x_raw), C.ptr(bnp), C.ptr(da0), C.ptr(out[0][0]), C.ptr(out[0][1]), C.ptr(out[0][2]), C.ptr(ws), nb,
-                       n * hf * hf, st)
-    C.bn_bwd_finalize_partials(C.ptr(partial), partial.shape[0], C.ptr(out[1][0]), C.ptr(out[1][1]), C.ptr(out[1][2]), C.ptr(ws),
+                       n * hf * hf, 1, st)
+    C.bn_bwd_finalize_partials(C.ptr(partial), partial.shape[0], 1, C.ptr(out[1][0]), C.ptr(out[1][1]), C.ptr(out[1][2]), C.ptr(ws),
                                nb, st)
     torch.cuda.synchronize()
     assert torch.equal(da0, da1)

@@ -1,0 +1,168 @@
+"""The batched pair (GPU): `SRLModules.forwardPair(obs, next_obs)` — ONE model call over [obs ; next_obs] with two
+BatchNorm groups (include/srlz.h: `groups`) — against the two separate calls `model(obs)`, `model(next_obs)` the
+reference makes (models/learner.py:392-393).
+
+Forward: every output, every BatchNorm running statistic and counter must be BIT-IDENTICAL (per group the kernels do
+exactly the arithmetic of a single-group launch; the groups' momentum updates happen in call order).  Backward: the
+weight-gradient kernels sum over both groups in one launch, so parameter gradients agree up to summation order (1e-5 of
+the tensor's largest entry).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def build(losses, C=3, S=40, seed=3, split=None, inverse="linear"):
+    import preprocessing.preprocess as pre
+    from models.modules import SRLModules, SRLModulesSplit
+    pre.N_CHANNELS = C
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if split is not None:
+        m = SRLModulesSplit(state_dim=S, action_dim=6, cuda=True, model_type="custom_cnn", losses=losses,
+                            split_dimensions=split, inverse_model_type=inverse)
+    else:
+        m = SRLModules(state_dim=S, action_dim=6, cuda=True, model_type="custom_cnn", losses=losses, inverse_model_type=inverse)
+    return m.to("cuda")  # (SRLModules.cuda is the reference's bool attribute, not nn.Module.cuda)
+
+
+def run(model, losses, obs, nxt, act, pair, eps=None):
+    """forward (pair or two calls) + the loop body's losses + backward -> (outputs, buffers, grads)."""
+    import losses.losses as L
+    init = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    if eps is not None:
+        it = iter(eps)
+        model.model.eps_fn = lambda mu: next(it).to(mu.device)
+    if pair:
+        a, b = model.forwardPair(obs, nxt)
+    else:
+        a, b = model(obs), model(nxt)
+    lm = L.LossManager(model, None)
+    outs = OrderedDict()
+    if "vae" in losses:
+        (dec, mu, logvar), (ndec, nmu, nlogvar) = a, b
+        states, next_states = model.getStates(obs), model.getStates(nxt)
+        L.kullbackLeiblerLoss(mu, nmu, logvar, nlogvar, loss_manager=lm, beta=1.0)
+        L.generationLoss(dec, ndec, obs, nxt, weight=0.5e-6, loss_manager=lm)
+        outs.update(dec=dec, ndec=ndec, mu=mu, nmu=nmu, logvar=logvar, nlogvar=nlogvar)
+    elif "autoencoder" in losses:
+        (states, dec), (next_states, ndec) = a, b
+        L.autoEncoderLoss(obs, dec, nxt, ndec, weight=1.0, loss_manager=lm)
+        outs.update(dec=dec, ndec=ndec)
+    else:
+        states, next_states = a, b
+    outs.update(states=states, next_states=next_states)
+    if "forward" in losses:
+        L.forwardModelLoss(model.forwardModel(states, act), next_states, weight=1.0, loss_manager=lm)
+    if "inverse" in losses:
+        L.inverseModelLoss(model.inverseModel(states, next_states), act, weight=2.0, loss_manager=lm)
+    total = lm.computeTotalLoss()
+    total.backward()
+    torch.cuda.synchronize()
+    outs = OrderedDict((k, v.detach().clone()) for k, v in outs.items())
+    outs["losses"] = torch.tensor(lm.lossValues() + [float(total.detach())])
+    bufs = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k)
+    grads = OrderedDict((k, None if p.grad is None else p.grad.detach().clone()) for k, p in model.named_parameters())
+    model.load_state_dict(init)
+    return outs, bufs, grads
+
+
+CASES = [
+    ("ae", ["autoencoder"], 2, 3, None),
+    ("ae_odd", ["autoencoder", "inverse", "forward"], 3, 3, None),
+    ("vae", ["vae"], 2, 3, None),
+    ("vae_c6", ["vae"], 3, 6, None),
+    ("cnn", ["inverse", "forward"], 4, 3, None),
+    ("split_ae", ["autoencoder", "inverse", "forward"], 2, 3, OrderedDict([("autoencoder", 20), ("inverse", 20), ("forward", -1)])),
+]
+
+
+@pytest.mark.parametrize("name,losses,B,C,split", CASES, ids=[c[0] for c in CASES])
+def test_forward_pair_equals_two_calls(name, losses, B, C, split):
+    model = build(losses, C=C, split=split)
+    o, n, a = gu.golden_inputs(B, C, 6, seed=321)
+    obs, nxt, act = torch.from_numpy(o).cuda(), torch.from_numpy(n).cuda(), torch.from_numpy(a).view(-1, 1).cuda()
+    eps = None
+    if "vae" in losses:
+        torch.manual_seed(17)
+        eps = [torch.randn(B, 40), torch.randn(B, 40)]
+    two = run(model, losses, obs, nxt, act, pair=False, eps=eps)
+    one = run(model, losses, obs, nxt, act, pair=True, eps=eps)
+    for k in two[0]:
+        assert torch.equal(one[0][k], two[0][k]), "forward output %s differs (max %.3e)" % (
+            k, float((one[0][k].double() - two[0][k].double()).abs().max()))
+    for k in two[1]:
+        assert torch.equal(one[1][k], two[1][k]), "buffer %s differs" % k
+    for k, g2 in two[2].items():
+        g1 = one[2][k]
+        assert (g1 is None) == (g2 is None), k
+        if g2 is None:
+            continue
+        scale = max(float(g2.abs().max()), 1e-30)
+        if k in gu.NOISE_BIASES:
+            wk = k.replace(".bias", ".weight")
+            scale = max(float(two[2][wk].abs().max()), 1e-30)  # analytically zero: compare on the weight gradient's scale
+        err = float((g1.double() - g2.double()).abs().max()) / scale
+        assert err <= 1e-5, "grad %s: %.3e" % (k, err)
+
+
+def test_pair_over_adjacent_halves_is_zero_copy():
+    """obs / next_obs that are the two halves of one buffer (the learner's feed, bench.py) are batched without a copy, and the
+    pair-aware reconstruction loss finds both wholes."""
+    from srlz import ops
+    buf = torch.randn(4, 3, 224, 224, device="cuda")
+    a, b = buf[:2], buf[2:]
+    xx = ops.pair_cat(a, b)
+    assert xx.data_ptr() == buf.data_ptr() and tuple(xx.shape) == (4, 3, 224, 224)
+    assert ops.pair_of(a, b) is not None and ops.pair_of(b, a) is None
+    c = torch.randn(2, 3, 224, 224, device="cuda")
+    yy = ops.pair_cat(a, c)
+    assert yy.data_ptr() != buf.data_ptr() and torch.equal(yy[:2], a) and torch.equal(yy[2:], c)
+
+
+@pytest.mark.parametrize("losses", [["autoencoder", "inverse", "forward"], ["vae"]], ids=["aeif", "vae"])
+def test_train_step_pair_follows_two_call_path(losses):
+    """SRL4robotics.trainStep with the batched pair (default) against SRLZ_PAIR=0 over a few steps incl. a validation one."""
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from losses.losses import LossManager
+    pre.N_CHANNELS = 3
+    learner.BATCH_SIZE = 3
+
+    def trace(use_pair):
+        srl = learner.SRL4robotics(24, model_type="custom_cnn", seed=5, learning_rate=1e-4, cuda=True, losses=losses, n_actions=6,
+                                   log_folder="/tmp")
+        srl._use_pair = use_pair
+        lm = LossManager(srl.model, None)
+        rows = []
+        for step in range(4):
+            o, n, a = gu.golden_inputs(3, 3, 6, seed=900 + step)
+            if "vae" in losses:
+                torch.manual_seed(40 + step)
+                it = iter([torch.randn(3, 24), torch.randn(3, 24)])
+                srl.model.model.eps_fn = lambda mu: next(it).to(mu.device)
+            loss = srl.trainStep(torch.from_numpy(o).cuda(), torch.from_numpy(n).cuda(), torch.from_numpy(a).view(-1, 1).cuda(), lm,
+                                 validation_mode=(step == 2))
+            rows.append(lm.lossValues() + [float(loss.detach())])
+        torch.cuda.synchronize()
+        bufs = [b.detach().clone() for b in srl.model.buffers()]
+        return np.array(rows), bufs
+
+    two, bufs2 = trace(False)
+    one, bufs1 = trace(True)
+    assert np.array_equal(one[0], two[0])  # the first step starts from identical parameters: bit-identical losses
+    np.testing.assert_allclose(one, two, rtol=2e-5)
+    for x, y in zip(bufs1, bufs2):
+        if x.dtype == torch.long:
+            assert int(x) == int(y)
+        else:
+            assert float((x.double() - y.double()).abs().max()) <= 1e-3 * max(float(y.double().abs().max()), 1e-30)

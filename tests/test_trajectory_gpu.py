@@ -267,8 +267,11 @@ def test_train_step_rides_along_the_oracle(name):
 
 
 def test_staging_overflow_is_exercised():
-    """l1 + l2 + two frames = four gradient contributions per regularised weight: the fourth finds no staging bucket
-    (FlatParams.grad_buffer -> None) and must travel through autograd's own accumulation."""
+    """l1 + l2 + two separately encoded frames (SRLZ_PAIR=0 path) = four gradient contributions per regularised weight: the
+    fourth finds no staging bucket (FlatParams.grad_buffer -> None) and must travel through autograd's own accumulation.
+    The resulting step is checked against the oracle like any other."""
+    from losses.losses import LossManager
+    from oracle import torch_twin as T
     from srlz import optim
     calls = {"none": 0}
     orig = optim.FlatParams.grad_buffer
@@ -280,7 +283,23 @@ def test_staging_overflow_is_exercised():
         return buf
     optim.FlatParams.grad_buffer = spy
     try:
-        drive_product(["autoencoder"], 1, l1_reg=1e-5, l2_reg=1e-4)
+        srl = make_learner(["autoencoder"], l1_reg=1e-5, l2_reg=1e-4)
+        srl._use_pair = False
+        before = {k: v.detach().cpu().clone() for k, v in srl.model.state_dict().items()}
+        inp = step_inputs(["autoencoder"], 0, 2, 200)
+        rec = product_step(srl, LossManager(srl.model, None), ["autoencoder"], inp, False)
+        srl.flat_params.deliver()
+        grad = srl.flat_params.grad.double().cpu()
     finally:
         optim.FlatParams.grad_buffer = orig
     assert calls["none"] > 0
+    ref = T.train_step(T.clone_state(before), ["autoencoder"], inp["obs"], inp["next_obs"], inp["actions"], l1_reg=1e-5, l2_reg=1e-4)
+    assert abs(rec["total"] - ref["total"]) <= 1e-5 * abs(ref["total"])
+    pname = {id(p): n for n, p in srl.model.named_parameters()}
+    for p, off in zip(srl.flat_params.params, srl.flat_params.offsets):
+        nm = pname[id(p)]
+        gref = ref["grads"].get(nm)
+        if gref is None or nm in NOISE_BIASES:
+            continue
+        gref = gref.double().reshape(-1)
+        assert float((grad[off:off + p.numel()] - gref).norm()) <= 3e-2 * float(gref.norm()), nm

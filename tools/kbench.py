@@ -139,7 +139,7 @@ def bench_bn(sel):
         if sel("relu fwd"):
             report(label + " fwd", *timeit(lambda: C.bn_relu_fwd(C.ptr(y), C.ptr(bnp), C.ptr(a), N * h * h, st)), bytes_=8.0 * y.numel())
         if sel("relu bwd"):
-            report(label + " bwd (reduce+apply)", *timeit(lambda: C.bn_relu_bwd(C.ptr(y), C.ptr(bnp), C.ptr(da), C.ptr(dy), C.ptr(dg), C.ptr(db), 1, C.ptr(ws), nbw, N * h * h, st)),
+            report(label + " bwd (reduce+apply)", *timeit(lambda: C.bn_relu_bwd(C.ptr(y), C.ptr(bnp), C.ptr(da), C.ptr(dy), C.ptr(dg), C.ptr(db), 1, C.ptr(ws), nbw, N * h * h, 1, st)),
                    bytes_=12.0 * y.numel())
 
 
