@@ -55,37 +55,49 @@ def host_cores():
     return n
 
 
-def cpu_baseline(losses, sample_b=64, steps=2):
-    """The CPU oracle (oracle/torch_twin.py: the reference's torch ops, fp32) timed on this box's host cores."""
+def cpu_baseline(losses):
+    """The CPU oracle (oracle/torch_twin.py: the reference's own torch CPU ops, fp32, pinned to the reference by the golden
+    fixtures) timed on this box's host cores, SURVEY.md 8(d) protocol scaled to a bounded sample (~30 s of CPU work):
+    the same train step (forward x2, losses, backward, Adam) at the reference's default minibatch (bs = 32, BASELINE.json
+    configs[0]) with all usable cores and with 8 threads, and at bs = 64 with all cores; median step time after one warm-up.
+    `value` is the bs = 32 / all-cores figure.  kind = "port": a restatement of the reference path, not the reference's own
+    files (those cannot travel to the GPU box)."""
     from oracle import torch_twin as T
     import preprocessing.preprocess as pre
     from models.modules import SRLModules
     from golden_util import synthetic_obs
     cores = host_cores()
-    torch.set_num_threads(cores)
     pre.N_CHANNELS = 3
-    np.random.seed(1)
-    torch.manual_seed(1)
-    model = SRLModules(state_dim=200, action_dim=6, cuda=False, model_type="custom_cnn", losses=losses)
-    sd = T.clone_state(model.state_dict())
-    opt = T.TwinAdam(sd, 0.005)
-    obs, next_obs = synthetic_obs(sample_b, 3, 4321)
-    obs, next_obs = torch.from_numpy(obs), torch.from_numpy(next_obs)
-    actions = torch.randint(0, 6, (sample_b,))
-    eps = [torch.randn(sample_b, 200), torch.randn(sample_b, 200)] if "vae" in losses else [None, None]
 
-    def one():
-        T.train_step(sd, losses, obs, next_obs, actions, eps=eps[0], next_eps=eps[1])
-        opt.step(sd)
-    one()  # warm-up
-    t0 = time.time()
-    for _ in range(steps):
-        one()
-    dt = (time.time() - t0) / steps
-    return {"value": round(2 * sample_b / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d steps of the same train step at bs=%d (%d images each) after 1 warm-up; torch %s CPU fp32, "
-                      "%d threads; %.2f s/step" % (steps, sample_b, 2 * sample_b, torch.__version__,
-                                                   torch.get_num_threads(), dt)}
+    def run(bs, threads, steps):
+        torch.set_num_threads(threads)
+        np.random.seed(1)
+        torch.manual_seed(1)
+        model = SRLModules(state_dim=200, action_dim=6, cuda=False, model_type="custom_cnn", losses=losses)
+        sd = T.clone_state(model.state_dict())
+        opt = T.TwinAdam(sd, 0.005)
+        obs, next_obs = synthetic_obs(bs, 3, 4321)
+        obs, next_obs = torch.from_numpy(obs), torch.from_numpy(next_obs)
+        actions = torch.randint(0, 6, (bs,))
+        eps = [torch.randn(bs, 200), torch.randn(bs, 200)] if "vae" in losses else [None, None]
+        times = []
+        for i in range(steps + 1):
+            t0 = time.time()
+            T.train_step(sd, losses, obs, next_obs, actions, eps=eps[0], next_eps=eps[1])
+            opt.step(sd)
+            if i > 0:  # first step = warm-up
+                times.append(time.time() - t0)
+        med = float(np.median(times))
+        return {"bs": bs, "threads": threads, "steps": steps, "s_per_step": round(med, 3), "images_per_s": round(2 * bs / med, 2)}
+
+    runs = [run(32, cores, 5), run(32, min(8, cores), 3), run(64, cores, 3)]
+    torch.set_num_threads(cores)
+    head = runs[0]
+    return {"value": head["images_per_s"], "unit": "images/s", "cores": head["threads"], "kind": "port",
+            "sample": "median of %d train steps (fwd x2, losses, bwd, Adam) at bs=32 (64 images each) after 1 warm-up; torch %s CPU "
+                      "fp32, %d threads = all usable cores; %.2f s/step" % (head["steps"], torch.__version__, head["threads"],
+                                                                            head["s_per_step"]),
+            "runs": runs}
 
 
 def conv64_algorithmic_bytes(layer_key):
@@ -111,6 +123,22 @@ def committed_pmc_traffic(kernel):
     if not rec:
         return None, None
     return rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
+
+
+def committed_pmc_mfma(kernel):
+    """Matrix-pipe busy fraction and measured clock of `kernel` from the newest profiles/*_pmc_mfma.json (rocprofv3 PMC pass
+    of this same command, tools/profile_round.sh)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_mfma.json")))
+    if not files:
+        return None, None, None
+    try:
+        rec = json.load(open(files[-1]))["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None, None, None
+    if not rec:
+        return None, None, None
+    return rec["mfma_busy_frac"], rec["clock_ghz"], "profiles/" + os.path.basename(files[-1])
 
 
 def main():
@@ -233,6 +261,7 @@ def main():
                 alg_bytes += v["launches"] * conv64_algorithmic_bytes(key)
             alg_bytes /= max(1, k["launches"])
             traffic, traffic_src = committed_pmc_traffic("conv64_fwd_kernel<4, false>")
+            busy, clock, busy_src = committed_pmc_mfma("conv64_fwd_kernel<4, false>")
             out["roofline"] = {"kernel": "conv64_fwd_kernel<4,false> (3x3 64->64 conv / convT forward and data-gradient, all "
                                          "layers; the <4,true> instantiation = data-gradient with the BatchNorm backward "
                                          "fused into its operand load is listed under fused_dgrad_layers)",
@@ -240,6 +269,7 @@ def main():
                                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": round(alg_bytes),
+                               "mfma_busy_frac": busy, "clock_ghz": clock, "mfma_pmc_source": busy_src,
                                "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),
                                "layers": layers, "fused_dgrad_layers": fused}
