@@ -240,6 +240,7 @@ def main():
                                    "(%d frames fwd+bwd per step per GPU), Adam lr 0.005, data resident in HBM"
                                    % (" ".join(args.losses), args.state_dim, B, 2 * B),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "final_loss": round(last_losses[-1], 6)},
         }
         rep = ops.timers_report()

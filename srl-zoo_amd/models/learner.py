@@ -297,8 +297,12 @@ class SRL4robotics(BaseLearner):
             param.requires_grad = False
 
     def saveModel(self, path):
-        """th.save(state_dict) with the reference's keys and NCHW shapes (CPU tensors, loadable anywhere)."""
-        th.save(OrderedDict((k, v.detach().cpu().clone()) for k, v in self.model.state_dict().items()), path)
+        """th.save(state_dict) with the reference's keys and NCHW shapes (CPU tensors, loadable anywhere).  With several GPUs
+        every rank calls this: the BatchNorm running statistics are averaged over the ranks first (a collective), rank 0
+        writes the file."""
+        sd = optim.average_running_stats(OrderedDict((k, v.detach().clone()) for k, v in self.model.state_dict().items()))
+        if self.rank == 0:
+            th.save(OrderedDict((k, v.cpu()) for k, v in sd.items()), path)
 
     def _forwardPair(self, x, next_x):
         """(self.model(x), self.model(next_x)) — in that program order for the BatchNorm running statistics, but
@@ -451,11 +455,17 @@ class SRL4robotics(BaseLearner):
 
         loss = loss_manager.computeTotalLoss()
         loss.backward()  # the reference backpropagates on validation minibatches too (learner.py:487-489)
+        # the step's scalars ride in the tail of the gradient bucket: with several GPUs every rank reads the SAME (mean)
+        # losses back, so the NaN exit and the best-model decision are taken by all ranks together
+        self.flat_params.put_scalars([loss] + list(loss_manager.losses))
         if not validation_mode:
             grad_scale = optim.allreduce_gradients(self.flat_params)
             self.optimizer.step(grad_scale)
         else:
             self.flat_params.discard()
+            optim.allreduce_scalars(self.flat_params)
+        if hasattr(self.model.model, "forgetRecent"):
+            self.model.model.forgetRecent()  # (VAE) the cached mu of this step's forwards is stale from here on
         self._last_obs = obs
         return loss
 
@@ -485,8 +495,20 @@ class SRL4robotics(BaseLearner):
                                                                (len(minibatchlist) - n_val_batches) * BATCH_SIZE))
         print("{} minibatches for validation, {} samples".format(n_val_batches, n_val_batches * BATCH_SIZE))
         assert n_val_batches > 0, "Not enough sample to create a validation set"
+        if self.world_size > 1:  # minibatches are sharded train / validation separately, ragged tails dropped
+            assert n_val_batches // self.world_size > 0 and (len(minibatchlist) - n_val_batches) // self.world_size > 0, \
+                "Not enough minibatches for {} GPUs: every rank needs at least one training and one validation " \
+                "minibatch per epoch ({} / {} available)".format(self.world_size, len(minibatchlist) - n_val_batches,
+                                                                n_val_batches)
 
         n_actions = int(np.max(actions) + 1)
+        # the cross-entropy / one-hot kernels index by target: reject what nn.CrossEntropyLoss / scatter_ would reject
+        if (self.use_inverse_loss or self.use_forward_loss) and (n_actions > self.dim_action or int(np.min(actions)) < 0):
+            raise ValueError("actions must lie in [0, {}) (n_actions of the model), found [{}, {}]".format(
+                self.dim_action, int(np.min(actions)), int(np.max(actions))))
+        if self.use_reward_loss and not set(np.unique(rewards).tolist()) <= {-1, 0, 1}:
+            raise ValueError("the reward head has two classes: rewards must be -1 / 0 / 1 (-1 is mapped to 0), found {}".format(
+                sorted(set(np.unique(rewards).tolist()))))
         print("{} unique actions / {} actions".format(len(set(actions)), n_actions))
         print("Number of observations per action")
         print(np.array([np.sum(actions == i) for i in range(n_actions)], dtype=np.int64))
@@ -536,14 +558,14 @@ class SRL4robotics(BaseLearner):
                 loss = self.trainStep(obs, next_obs, actions_st, loss_manager, validation_mode, noisy_obs,
                                       next_noisy_obs, rewards_st)
                 feed.advance()  # next minibatch's H2D copy overlaps this step (issued before the host waits below)
-                # one D2H copy for every scalar of this step
-                values = th.stack([l.detach().reshape(()) for l in loss_manager.losses] + [loss.detach()]).tolist()
-                loss_manager.updateLossHistory(values[:-1])
+                # one D2H copy for every scalar of this step (total first; the mean over the ranks when there are several)
+                values = self.flat_params.read_scalars(1 + len(loss_manager.losses))
+                loss_manager.updateLossHistory(values[1:])
                 if validation_mode:
-                    val_loss += values[-1]
+                    val_loss += values[0]
                     val_batches += 1
                 else:
-                    epoch_loss += values[-1]
+                    epoch_loss += values[0]
                     epoch_batches += 1
 
             train_loss = epoch_loss / float(max(epoch_batches, 1))
@@ -558,10 +580,10 @@ class SRL4robotics(BaseLearner):
                 if epoch + 1 < n_epochs:
                     loss_history[key].append(0)
 
+            # (train_loss / val_loss are identical on every rank — see trainStep — so all ranks branch alike here)
             if val_loss < best_error:
                 best_error = val_loss
-                if self.rank == 0:
-                    self.saveModel(best_model_path)
+                self.saveModel(best_model_path)
 
             if np.isnan(train_loss):
                 printRed("NaN Loss, consider increasing NOISE_STD in the gaussian noise layer")

@@ -135,6 +135,11 @@ class BaseModelVAE(BaseModelAutoEncoder):
         self._recent.append((x, mu, stats, group))
         self._recent_versions.append(x._version)
 
+    def forgetRecent(self):
+        """Drop the remembered forwards: after an optimiser step their mu is stale (a later getStates must re-encode, as
+        the reference would), and they pin two input batches."""
+        self._recent, self._recent_versions = [], []
+
     def rememberPair(self, x, next_x, mu, next_mu):
         """After a batched forward over [x ; next_x]: make the learner's getStates(x) / getStates(next_x) (the quirk above)
         find the halves — group 0 / group 1 of the statistics the batched pass recorded."""

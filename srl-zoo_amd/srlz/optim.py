@@ -15,6 +15,7 @@ class FlatParams(object):
     """Re-homes every parameter of `module` into one contiguous fp32 buffer (+ a matching gradient buffer)."""
 
     ALIGN = 4  # floats (16 bytes)
+    TAIL = 16  # loss scalars riding behind the gradients (slot 0 = total loss: a NaN / inf on ANY rank shows on EVERY rank)
 
     def __init__(self, module):
         params = [p for p in module.parameters() if p.requires_grad]
@@ -26,7 +27,11 @@ class FlatParams(object):
             offsets.append(total)
             total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        # the gradient BUCKET = every parameter's gradient + a short tail of per-step scalars (total loss, the individual
+        # losses): whatever is exchanged between the GPUs of a node travels in this one buffer, one collective per step
+        self.bucket = torch.zeros(total + self.TAIL, dtype=torch.float32, device=device)
+        self.grad = self.bucket[:total]
+        self.tail = self.bucket[total:]
         self.params, self.offsets = params, offsets
         with torch.no_grad():
             for i, (p, off) in enumerate(zip(params, offsets)):
@@ -68,6 +73,19 @@ class FlatParams(object):
         if self._dirty:
             self.stage.zero_()
             self._dirty = False
+
+    def put_scalars(self, scalars):
+        """Per-step scalars (0-dim device tensors; total loss first) into the bucket tail, with one launch."""
+        if len(scalars) > self.TAIL:
+            raise ValueError("at most %d scalars ride in the gradient bucket (got %d)" % (self.TAIL, len(scalars)))
+        torch.stack([s.detach().reshape(()) for s in scalars], out=self.tail[:len(scalars)])
+
+    def read_scalars(self, count):
+        """The first `count` tail slots as Python floats, averaged over the ranks (they were summed by the collective) —
+        the step's ONE device->host copy.  Identical on every rank after allreduce_gradients / allreduce_scalars."""
+        _, size = world()
+        values = self.tail[:count].tolist()
+        return values if size == 1 else [v / size for v in values]
 
     def zero_grad(self):
         self.grad.zero_()
@@ -129,10 +147,49 @@ def world():
 
 
 def allreduce_gradients(flat_params):
-    """One all-reduce (sum) of the whole gradient bucket; returns the scale Adam must apply (1/world_size)."""
+    """One all-reduce (sum) of the whole bucket — gradients AND the scalar tail (FlatParams.put_scalars), so a NaN loss on
+    one rank reaches every rank with the gradients (reference models/learner.py:520-522: NaN -> exit code 11; every rank must
+    take that exit together, or the others hang in their next collective).  Returns the scale Adam applies (1/world_size)."""
     flat_params.deliver()
     rank, size = world()
     if size == 1:
         return 1.0
-    dist.all_reduce(flat_params.grad, op=dist.ReduceOp.SUM)
+    dist.all_reduce(flat_params.bucket, op=dist.ReduceOp.SUM)
     return 1.0 / size
+
+
+def allreduce_scalars(flat_params):
+    """Validation minibatches take no optimiser step: only the scalar tail is exchanged (ranks validate in lock-step,
+    preprocessing/data_loader.py::shardOrder)."""
+    _, size = world()
+    if size > 1:
+        dist.all_reduce(flat_params.tail, op=dist.ReduceOp.SUM)
+
+
+def average_running_stats(state_dict):
+    """BatchNorm running statistics averaged over the ranks IN `state_dict` (a copy about to be checkpointed): batch
+    statistics are rank-local during training (the reference's per-call semantics), the saved model must not depend on which
+    rank wrote it.  One small all-reduce per checkpoint; every rank must call it."""
+    _, size = world()
+    keys = [k for k, v in state_dict.items() if "running_" in k and v.is_floating_point()]
+    if size == 1 or not keys:
+        return state_dict
+    flat = torch.cat([state_dict[k].reshape(-1).float() for k in keys])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= size
+    off = 0
+    for k in keys:
+        n = state_dict[k].numel()
+        state_dict[k] = flat[off:off + n].view(state_dict[k].shape).to(state_dict[k].dtype).clone()
+        off += n
+    return state_dict
+
+
+def share_from_rank0(obj):
+    """`obj` as rank 0 computed it, on every rank (log-folder names carry a wall-clock timestamp)."""
+    _, size = world()
+    if size == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]

@@ -20,6 +20,7 @@ import preprocessing.preprocess  # noqa: F401  (N_CHANNELS is set below)
 import models.learner as learner
 from models.learner import SRL4robotics
 from pipeline import getLogFolderName, saveConfig, correlationCall
+from srlz import optim
 from utils import parseDataFolder, createFolder, loadData, buildConfig, parseLossArguments
 
 LOSS_CHOICES = ["forward", "inverse", "reward", "priors", "episode-prior", "reward-prior", "triplet",
@@ -139,13 +140,18 @@ if __name__ == '__main__':
         images_path = ground_truth['images_path']
 
     exp_config = buildConfig(args)
-    if args.log_folder == "":
-        createFolder("logs/{}".format(exp_config['data-folder']), "Dataset log folder already exist")
-        log_folder, experiment_name = getLogFolderName(exp_config)
-        args.log_folder = log_folder
+    # the folder name carries a wall-clock timestamp: rank 0 decides and creates, the other ranks are told
+    if rank == 0:
+        if args.log_folder == "":
+            createFolder("logs/{}".format(exp_config['data-folder']), "Dataset log folder already exist")
+            log_folder, experiment_name = getLogFolderName(exp_config)
+        else:
+            log_folder = args.log_folder
+            createFolder(log_folder, "Log folder already exist")
+            experiment_name = "{}_{}".format(args.model_type, losses)
     else:
-        createFolder(args.log_folder, "Log folder already exist")
-        experiment_name = "{}_{}".format(args.model_type, losses)
+        log_folder = experiment_name = None
+    args.log_folder, experiment_name = optim.share_from_rank0((log_folder, experiment_name))
 
     exp_config['log-folder'] = args.log_folder
     exp_config['experiment-name'] = experiment_name

@@ -1,0 +1,93 @@
+"""Data-parallel step on REAL GPUs (skipped unless >= 2 are visible): one process per GPU, torch.distributed backend "nccl"
+(= RCCL over xGMI), `SRL4robotics.trainStep` on a different minibatch per rank.
+
+SURVEY.md 8(e) parity check: the all-reduced gradient every rank's Adam consumes == the mean over the ranks of the CPU
+oracle's single-rank gradients on the same minibatches and the same weights; parameters stay bit-identical across ranks
+after the step; every rank reads back the same (mean) loss scalars.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(os.path.dirname(here), "srl-zoo_amd"), os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    import torch.distributed as dist
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    import golden_util as gu
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from losses.losses import LossManager
+    from oracle import torch_twin as T
+    pre.N_CHANNELS = 3
+    learner.BATCH_SIZE = 2
+    losses = ["autoencoder", "inverse", "forward"]
+    srl = learner.SRL4robotics(40, model_type="custom_cnn", seed=1, learning_rate=1e-4, cuda=True, losses=losses, n_actions=6,
+                               log_folder="/tmp")
+    assert (srl.rank, srl.world_size) == (rank, world)
+    before = {k: v.detach().cpu().clone() for k, v in srl.model.state_dict().items()}
+    fp, opt = srl.flat_params, srl.optimizer
+    taken = {}
+    real_step = opt.step
+
+    def spy(grad_scale=1.0):
+        fp.deliver()
+        taken["grad"] = (fp.grad.detach() * grad_scale).double().cpu()
+        return real_step(grad_scale)
+    opt.step = spy
+    batches = [gu.golden_inputs(2, 3, 6, seed=700 + r) for r in range(world)]
+    o, n, a = batches[rank]
+    lm = LossManager(srl.model, None)
+    dev = srl.device
+    srl.trainStep(torch.from_numpy(o).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(a).view(-1, 1).to(dev), lm)
+    values = fp.read_scalars(1 + len(lm.losses))
+    torch.cuda.synchronize()
+
+    # ---- oracle: every rank's gradient on its minibatch from the common weights, averaged
+    torch.set_num_threads(4)
+    refs = [T.train_step(T.clone_state(before), losses, *(torch.from_numpy(x) for x in b)) for b in batches]
+    pname = {id(p): nm for nm, p in srl.model.named_parameters()}
+    for p, off in zip(fp.params, fp.offsets):
+        nm = pname[id(p)]
+        if nm in gu.NOISE_BIASES:
+            continue
+        gref = sum(r["grads"][nm].double().reshape(-1) for r in refs) / world
+        got = taken["grad"][off:off + p.numel()]
+        assert float((got - gref).norm()) <= 3e-2 * float(gref.norm()), nm
+        assert abs(float(got.norm()) - float(gref.norm())) <= 5e-3 * float(gref.norm()), nm
+    mean_total = sum(r["total"] for r in refs) / world
+    assert abs(values[0] - mean_total) <= 1e-5 * abs(mean_total)
+
+    # ---- identical parameters and identical read-back scalars on every rank
+    digest = torch.tensor([float(fp.flat.double().sum()), float(fp.flat.double().abs().sum())] + values, dtype=torch.float64, device=dev)
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on one node")
+def test_two_gpu_step_matches_mean_of_oracle_gradients():
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port()), nprocs=world, join=True)

@@ -1,5 +1,6 @@
 """The N > 1 path on CPU: two processes, torch.distributed `gloo` (world_size 2) — one all-reduce of the flat gradient
-bucket per step, identical parameters on every rank afterwards, lock-step sharding of the minibatch order."""
+bucket per step (gradients + the scalar tail: a NaN loss on one rank is seen by all), identical parameters on every rank
+afterwards, lock-step sharding of the minibatch order, rank-averaged BatchNorm statistics in a checkpoint, one log folder."""
 import os
 import socket
 
@@ -68,6 +69,28 @@ def _worker(rank, world, port, out_dir):
     dist.all_gather(sizes, torch.tensor([len(mine)]))
     assert len({int(s) for s in sizes}) == 1
     np.save(os.path.join(out_dir, "shard%d.npy" % rank), mine)
+
+    # ---- the scalar tail: every rank reads back the SAME mean losses; one rank's NaN reaches all (exit code 11 together)
+    flat.zero_grad()
+    flat.put_scalars([torch.tensor(2.0 + rank), torch.tensor(10.0 * (rank + 1))])
+    optim.allreduce_gradients(flat)
+    assert flat.read_scalars(2) == [2.5, 15.0]
+    flat.put_scalars([torch.tensor(float("nan") if rank == 1 else 1.0), torch.tensor(1.0)])
+    optim.allreduce_scalars(flat)  # (a validation minibatch: no gradients exchanged)
+    vals = flat.read_scalars(2)
+    assert np.isnan(vals[0]) and vals[1] == 1.0
+    # ---- checkpoint: BatchNorm running statistics are the ranks' average, counters and parameters untouched
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    key = "model.encoder_conv.1.running_mean"
+    sd[key] = torch.full_like(sd[key], float(rank))
+    sd["model.encoder_conv.1.running_var"] = torch.full_like(sd[key], 1.0 + 2.0 * rank)
+    avg = optim.average_running_stats(sd)
+    assert torch.allclose(avg[key], torch.full_like(avg[key], 0.5))
+    assert torch.allclose(avg["model.encoder_conv.1.running_var"], torch.full_like(avg[key], 2.0))
+    assert avg["model.encoder_conv.1.num_batches_tracked"].dtype == torch.long
+    assert torch.equal(avg["model.encoder_conv.0.weight"], model.state_dict()["model.encoder_conv.0.weight"])
+    # ---- one log folder for all ranks (train.py): rank 0's choice
+    assert optim.share_from_rank0("logs/run_%d" % rank) == "logs/run_0"
     dist.barrier()
     dist.destroy_process_group()
 
