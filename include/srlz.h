@@ -107,6 +107,26 @@ int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw_ref, float
                            void* ws, size_t ws_bytes, const srlz_conv64_desc* d, srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * convN — FORWARD-ONLY 3x3 (pad 1, stride 1/2) and 1x1 (stride 2) convolutions without bias for Cin, Cout multiples of 64:
+ * the frozen ResNet-18 trunk behind EmbeddingNet (models/triplet.py:6-39; torchvision 0.2.1 resnet18: BasicBlock conv3x3
+ * layers and the 1x1 downsample convolutions).  Same fp32-MFMA implicit GEMM as the 64->64 family; no gradient exists
+ * because the reference freezes the trunk (triplet.py:17-19).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int n, hi, wi, ho, wo; /* NHWC activations: x [n,hi,wi,cin] -> y [n,ho,wo,cout] */
+  int cin, cout;         /* multiples of 64 */
+  int ksize, stride, pad; /* (3, 1|2, 1) or (1, 2, 0) */
+} srlz_convn_desc;
+size_t srlz_convn_packed_floats(const srlz_convn_desc* d);
+/* w_ref [cout,cin,k,k] (torch layout) -> the kernel's packed copy (srlz_convn_packed_floats floats) */
+int srlz_convn_pack_weights(const float* w_ref, float* wpack, const srlz_convn_desc* d, srlz_stream_t stream);
+/* per-tile BatchNorm partial records per block of 64 output channels (stats_partial is [cout/64][tiles][128]) */
+int srlz_convn_fwd_tiles(const srlz_convn_desc* d);
+/* y = conv(x); x_bnp (may be NULL): the input is relu(batchnorm(x)) with one 256-float record per block of 64 input channels */
+int srlz_convn_fwd(const float* x, const float* wpack, float* y, float* stats_partial, const float* x_bnp,
+                   const srlz_convn_desc* d, srlz_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * "Skinny" convolutions: one side has C in {3,6,9} image channels stored NCHW, the other 64 channels NHWC.
  *   kind 0: nn.Conv2d(C,64,k=7,s=2,p=3,bias=False)       models/models.py:49   (encoder conv1)
  *   kind 1: nn.ConvTranspose2d(64,C,k=4,s=2)             models/models.py:82   (decoder's last layer)
@@ -174,6 +194,20 @@ int srlz_bn_finalize(const float* stats_partial, int n_partials, int groups, lon
                      const float* beta, float eps, float momentum, int repeat, float* running_mean,
                      float* running_var, float* bnp, float* batch_stat, void* ws, size_t ws_bytes,
                      srlz_stream_t stream);
+/* A C-channel BatchNorm (C = 64 * chunks) of the frozen ResNet-18 trunk as `chunks` independent 64-channel layers:
+ * stats_partial is srlz_convn_fwd's [chunks][tiles][128]; gamma / beta / running_* hold C floats; bnp receives `chunks`
+ * records of 256 floats (training-mode forward of nn.BatchNorm2d: batch statistics + one momentum update; the trunk's
+ * parameters are frozen but the reference leaves it in train() mode, models/learner.py:365 — so its statistics do move). */
+int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, int chunks, long long count, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                            float* bnp, void* ws, size_t ws_bytes, srlz_stream_t stream);
+int srlz_bn_eval_params_chunks(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                               float eps, int chunks, float* bnp, srlz_stream_t stream);
+/* out = relu(bn(a) + (b_bnp ? bn(b) : b)) over pixels x 64*chunks — BasicBlock's `out = relu(bn2(out) + identity)` */
+int srlz_bn_add_relu(const float* a, const float* a_bnp, const float* b, const float* b_bnp, float* out, long long pixels,
+                     int chunks, srlz_stream_t stream);
+/* out[n,c] = mean over hw of x[n,hw,c] — resnet18.avgpool */
+int srlz_avgpool_nhwc(const float* x, float* out, int n, int hw, int c, srlz_stream_t stream);
 /* Eval-mode bnp from running statistics. */
 int srlz_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, float* bnp, srlz_stream_t stream);
@@ -272,6 +306,15 @@ int srlz_reparam_bwd(const float* dz, const float* logvar, const float* eps, flo
  * dlogits (may be NULL) = (softmax - onehot)/B */
 int srlz_cross_entropy(const float* logits, const int64_t* target, int B, int A, float* out, float* dlogits,
                        srlz_stream_t stream);
+/* nn.PReLU() with one slope — EmbeddingNet.fc[0], models/triplet.py:24 */
+int srlz_prelu_fwd(const float* x, const float* slope, float* y, long long n, srlz_stream_t stream);
+int srlz_prelu_bwd(const float* x, const float* slope, const float* dy, float* dx, float* dslope, long long n,
+                   srlz_stream_t stream);
+/* tripletLoss losses/losses.py:360-376: out[0] = mean_b relu(|s-p|^2 - |s-n|^2 + alpha); hinge[B] = active rows (for bwd) */
+int srlz_triplet_fwd(const float* s, const float* p, const float* n, int B, int S, float alpha, float* out, float* hinge,
+                     srlz_stream_t stream);
+int srlz_triplet_bwd(const float* s, const float* p, const float* n, const float* hinge, const float* g, int B, int S,
+                     float* ds, float* dp, float* dn, srlz_stream_t stream);
 /* cat[b,:] = [s[b,:S], onehot(a[b])]          forwardModel forward_inverse.py:21-31 + encodeOneHot models.py:229-237 */
 int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, int B, int S, int A, srlz_stream_t stream);
 

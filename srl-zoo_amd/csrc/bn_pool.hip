@@ -48,6 +48,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int n_par
                                    float momentum, int repeat, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ bnp,
                                    float* __restrict__ batch_stat, int groups) {
+  // blockIdx.x > 0 only in CHANNEL-BLOCK mode (srlz_bn_finalize_chunks: a C-channel BatchNorm handled as C/64 independent
+  // 64-channel layers, one block each): everything per-channel moves on by 64, the staged partials by one block's rows
+  gamma += blockIdx.x * 64; beta += blockIdx.x * 64;
+  if (running_mean) running_mean += blockIdx.x * 64;
+  if (running_var) running_var += blockIdx.x * 64;
+  bnp += blockIdx.x * 256;
+  partial += (size_t)blockIdx.x * n_partials * 128;
   // one block of 256 threads: thread (c = tid & 63, part = tid >> 6) sums a strided quarter of the partial records
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
   __shared__ double sm[2][4][64];
@@ -482,6 +489,94 @@ extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, int 
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double*)staged, g, (double)count,
                      gamma, beta, eps, momentum, repeat, running_mean, running_var, bnp, batch_stat, G);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, int chunks, long long count, const float* gamma,
+                                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                       float* bnp, void* ws, size_t ws_bytes, srlz_stream_t stream) {
+  SRLZ_REQUIRE(stats_partial && gamma && beta && bnp && ws, SRLZ_ERR_NULL, "bn_finalize_chunks: null pointer");
+  SRLZ_REQUIRE(tiles > 0 && count > 0 && chunks >= 1 && chunks <= MAX_GROUPS, SRLZ_ERR_BAD_DESC,
+               "bn_finalize_chunks: %d tiles, %d channel blocks", tiles, chunks);
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_finalize_chunks: workspace too small");
+  double* staged = (double*)ws;
+  const int g = stage_blocks(tiles);
+  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, chunks), dim3(256), 0, as_stream(stream), stats_partial, tiles, staged);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(chunks), dim3(256), 0, as_stream(stream), (const double*)staged, g, (double)count,
+                     gamma, beta, eps, momentum, 1, running_mean, running_var, bnp, (float*)nullptr, 1);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+// eval-mode records for a C-channel BatchNorm: one 256-float record per block of 64 channels
+__global__ void bn_eval_params_chunks_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                             float* bnp) {
+  const int c = threadIdx.x, ch = blockIdx.x * 64 + c;
+  const float invstd = 1.f / sqrtf(rv[ch] + eps);
+  const float scale = gamma[ch] * invstd;
+  float* rec = bnp + blockIdx.x * 256;
+  rec[c] = rm[ch]; rec[64 + c] = invstd; rec[128 + c] = scale; rec[192 + c] = beta[ch] - rm[ch] * scale;
+}
+
+extern "C" int srlz_bn_eval_params_chunks(const float* gamma, const float* beta, const float* running_mean,
+                                          const float* running_var, float eps, int chunks, float* bnp, srlz_stream_t stream) {
+  SRLZ_REQUIRE(gamma && beta && running_mean && running_var && bnp && chunks >= 1, SRLZ_ERR_NULL, "bn_eval_params_chunks: null pointer");
+  hipLaunchKernelGGL(bn_eval_params_chunks_kernel, dim3(chunks), dim3(64), 0, as_stream(stream), gamma, beta, running_mean,
+                     running_var, eps, bnp);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+// out = relu(bn_a(a) + (b_bnp ? bn_b(b) : b)) over `pixels` x C, C = 64 * chunks — the tail of a ResNet BasicBlock
+// (torchvision resnet.py: out = self.bn2(out); out += identity; out = self.relu(out)); records per block of 64 channels
+__global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restrict__ a, const float* __restrict__ a_bnp,
+                                                         const float* __restrict__ b, const float* __restrict__ b_bnp,
+                                                         float* __restrict__ out, long long pixels, int chunks) {
+  const int q4 = chunks * 16;  // float4 per pixel
+  const long long total = pixels * q4;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(id % q4);
+    const int chunk = cq >> 4, c4 = cq & 15;
+    const f32x4 sa = *(const f32x4*)(a_bnp + chunk * 256 + 128 + c4 * 4), ha = *(const f32x4*)(a_bnp + chunk * 256 + 192 + c4 * 4);
+    const f32x4 va = *(const f32x4*)(a + id * 4);
+    f32x4 vb = *(const f32x4*)(b + id * 4);
+    if (b_bnp) {
+      const f32x4 sb = *(const f32x4*)(b_bnp + chunk * 256 + 128 + c4 * 4), hb = *(const f32x4*)(b_bnp + chunk * 256 + 192 + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vb[j] = vb[j] * sb[j] + hb[j];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float z = (va[j] * sa[j] + ha[j]) + vb[j]; o[j] = z > 0.f ? z : 0.f; }
+    *(f32x4*)(out + id * 4) = o;
+  }
+}
+
+extern "C" int srlz_bn_add_relu(const float* a, const float* a_bnp, const float* b, const float* b_bnp, float* out,
+                                long long pixels, int chunks, srlz_stream_t stream) {
+  SRLZ_REQUIRE(a && a_bnp && b && out, SRLZ_ERR_NULL, "bn_add_relu: null pointer");
+  SRLZ_REQUIRE(pixels > 0 && chunks >= 1, SRLZ_ERR_BAD_DESC, "bn_add_relu: empty tensor");
+  hipLaunchKernelGGL(bn_add_relu_kernel, dim3(grid_for(pixels * chunks * 16, 256)), dim3(256), 0, as_stream(stream), a, a_bnp, b,
+                     b_bnp, out, pixels, chunks);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+// out[n][c] = mean over hw of x[n][hw][c]  (nn.AdaptiveAvgPool2d((1,1)) / AvgPool2d(7) of torchvision's resnet18)
+__global__ void avgpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out, int hw, int c) {
+  const int n = blockIdx.x;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < hw; ++p) s += x[((size_t)n * hw + p) * c + ch];
+    out[(size_t)n * c + ch] = s / (float)hw;
+  }
+}
+
+extern "C" int srlz_avgpool_nhwc(const float* x, float* out, int n, int hw, int c, srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && out && n > 0 && hw > 0 && c > 0, SRLZ_ERR_NULL, "avgpool: bad arguments");
+  hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(n), dim3(256), 0, as_stream(stream), x, out, hw, c);
   SRLZ_LAUNCHED();
   return 0;
 }

@@ -165,7 +165,9 @@ __device__ __forceinline__ OpFuse fuse_for_group(OpFuse f, int grp, long long go
 template <bool SWZ, int BATCH = 8, int NTHREADS = 256, bool BWD = false>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
                                            int stride, int cls, int PW, int PH, int total_q, int qstart,
-                                           int nrows, const OpFuse f = SRLZ_NO_FUSE, int core_lo = 0, int core_n = 0) {
+                                           int nrows, const OpFuse f = SRLZ_NO_FUSE, int core_lo = 0, int core_n = 0,
+                                           int cstride = 64, int coff = 0) {
+  // cstride / coff: the tensor has `cstride` channels per pixel and this call stages channels [coff, coff + 64) (convN_*)
   const float* __restrict__ bnp = f.bnp;
   // Loads are issued in batches of 8 rows per thread before any LDS store, so the HBM/L2 latency is paid once per
   // batch instead of once per row; (n, a, b) of a thread's rows are advanced incrementally (rows are NTHREADS/16 apart), the
@@ -206,7 +208,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
       const bool ok = base + RP * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W;
       okmask |= (ok ? 1u : 0u) << j;
       if (ok) {
-        const size_t off = ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4;
+        const size_t off = ((size_t)((n1 - 1) * H + y) * W + x) * cstride + coff + slot * 4;
         v[j] = *(const f32x4*)(src + off);
         if (BWD) { yv[j] = *(const f32x4*)(f.y + off); offs[j] = off; }
       }
@@ -814,7 +816,214 @@ static int wgrad_grid(const ConvProg& P) {
   return g * P.G;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// convN: the same virtual-grid implicit GEMM for Cin, Cout in {64, 128, 256, 512} — FORWARD ONLY.  It exists for the frozen
+// ResNet-18 trunk of EmbeddingNet (/root/reference/models/triplet.py:6-39 -> torchvision resnet18: 3x3 convolutions of
+// stride 1 / 2 and 1x1 stride-2 downsample convolutions, all without bias); nothing is ever back-propagated through it.
+// blockIdx.y = block of 64 output channels; the input channels are walked in blocks of 64 around the nine taps with the
+// accumulators kept; weights are packed [cout block][cin block][tap][64][64].  A 1x1 stride-2 convolution runs as the 3x3
+// stride-2 pad-1 program with only the centre tap non-zero (same output size, same sampled pixels; its 8 zero taps cost
+// ~4 % of the trunk's FLOP).  x_bnp: one 256-float BatchNorm record per block of 64 input channels.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restrict__ src, const float* __restrict__ wpack,
+                                                          float* __restrict__ dst, float* __restrict__ stats_partial,
+                                                          const ConvProg P, int ntiles, int nci, int nco,
+                                                          const float* __restrict__ src_bnp) {
+  constexpr int NT = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* As = (float*)smem;
+  float* Bs = As + (TM + P.span) * 64;
+  int* rowinfo = (int*)(Bs + 4096);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int co = blockIdx.y;
+  const int q0 = tile * TM;
+  const int cin = nci * 64, cout = nco * 64;
+
+  if (tid < TM) {
+    const int q = q0 + tid;
+    int n = -1, ya = 0, xb = 0;
+    if (q < P.total_q) {
+      n = q / P.PHW;
+      const int rem = q - n * P.PHW;
+      const int a = rem / P.PW;
+      ya = a * P.ds;
+      xb = (rem - a * P.PW) * P.ds;
+    }
+    rowinfo[tid] = n; rowinfo[TM + tid] = ya; rowinfo[2 * TM + tid] = xb;
+  }
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  constexpr int BV = 1024 / NT;
+  f32x4 breg[BV];
+  const float* wbase = wpack + (size_t)co * nci * NTAPS * 4096;
+  {
+    const f32x4* wsrc = (const f32x4*)(wbase + (size_t)P.tw[0] * 4096);
+#pragma unroll
+    for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
+  }
+  for (int ci = 0; ci < nci; ++ci) {
+    int cur_src = -1;
+    const OpFuse fuse = OpFuse{src_bnp ? src_bnp + ci * 256 : nullptr, nullptr, nullptr, 0.f, 0, nullptr};
+#pragma unroll
+    for (int ti = 0; ti < NTAPS; ++ti) {
+      const int tsrc = P.tsrc[ti];
+      __syncthreads();
+      if (tsrc != cur_src) {
+        stage_rows<true, 8, NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span, fuse, 0, 0,
+                                cin, ci * 64);
+        cur_src = tsrc;
+      }
+      {
+        f32x4* wdst = (f32x4*)Bs;
+#pragma unroll
+        for (int i = 0; i < BV; ++i) wdst[i * NT + tid] = breg[i];
+      }
+      __syncthreads();
+      if (ti + 1 < NTAPS || ci + 1 < nci) {
+        const int nti = (ti + 1 < NTAPS) ? ti + 1 : 0, nci_ = (ti + 1 < NTAPS) ? ci : ci + 1;
+        const f32x4* wsrc = (const f32x4*)(wbase + ((size_t)nci_ * NTAPS + P.tw[nti]) * 4096);
+#pragma unroll
+        for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
+      }
+      const int R = wave * 32 + l31 + P.toff[ti] - P.min_off;
+      const float* arow = As + R * 64;
+      const int akey = R & 15;
+      const float* brow = Bs + l31 * 64;
+      const int bkey = lane & 15;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const int slot = kc * 2 + h;
+        const f32x4 a = *(const f32x4*)(arow + ((slot ^ akey) << 2));
+        const f32x4 b0 = *(const f32x4*)(brow + ((slot ^ bkey) << 2));
+        const f32x4 b1 = *(const f32x4*)(brow + 2048 + ((slot ^ bkey) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0[r], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1[r], acc[1], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int n = rowinfo[row];
+    const int y = rowinfo[TM + row], x = rowinfo[2 * TM + row];
+    if (n >= 0 && y < P.Hd && x < P.Wd) {
+      float* o = dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * cout + co * 64 + l31;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float v = acc[j][r];
+        o[32 * j] = v;
+        sum[j] += v; sq[j] += v * v;
+      }
+    }
+  }
+  if (stats_partial) {
+    __syncthreads();
+    float* red = Bs;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      sum[j] += __shfl_xor(sum[j], 32, 64);
+      sq[j] += __shfl_xor(sq[j], 32, 64);
+      if (h == 0) {
+        red[wave * 128 + j * 32 + l31] = sum[j];
+        red[wave * 128 + 64 + j * 32 + l31] = sq[j];
+      }
+    }
+    __syncthreads();
+    // chunk-major: the partial records of one 64-channel block are contiguous (what srlz_bn_finalize_chunks reduces)
+    if (tid < 128) stats_partial[((size_t)co * ntiles + tile) * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+  }
+}
+
+// w_ref [Cout][Cin][k][k] (k = 3 or 1) -> packed [cout block][cin block][tap][n][swizzled k]; a 1x1 kernel becomes the centre tap
+__global__ void convN_pack_kernel(const float* __restrict__ w_ref, float* __restrict__ pf, int nci, int nco, int ksize) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)nco * nci * NTAPS * 4096;
+  if (id >= total) return;
+  const int k = (int)(id & 63), n = (int)((id >> 6) & 63);
+  const long long blk = id >> 12;
+  const int tap = (int)(blk % NTAPS);
+  const int ci = (int)((blk / NTAPS) % nci), co = (int)(blk / NTAPS / nci);
+  const int cin = nci * 64;
+  float v;
+  if (ksize == 3) v = w_ref[((size_t)(co * 64 + n) * cin + ci * 64 + k) * 9 + tap];
+  else v = (tap == 4) ? w_ref[(size_t)(co * 64 + n) * cin + ci * 64 + k] : 0.f;
+  pf[blk * 4096 + n * 64 + ((((k >> 2) ^ (n & 15)) << 2) | (k & 3))] = v;
+}
+
+static int check_convn(const srlz_convn_desc* d) {
+  SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "convn: null descriptor");
+  SRLZ_REQUIRE(d->n > 0 && d->cin > 0 && d->cout > 0 && d->cin % 64 == 0 && d->cout % 64 == 0, SRLZ_ERR_BAD_DESC,
+               "convn: channels must be multiples of 64 (cin=%d cout=%d)", d->cin, d->cout);
+  const bool k3 = d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2);
+  const bool k1 = d->ksize == 1 && d->pad == 0 && d->stride == 2;
+  SRLZ_REQUIRE(k3 || k1, SRLZ_ERR_BAD_DESC, "convn: 3x3 pad 1 stride 1/2 or 1x1 stride 2 only (k=%d s=%d p=%d)", d->ksize, d->stride,
+               d->pad);
+  const int eho = (d->hi + 2 * d->pad - d->ksize) / d->stride + 1, ewo = (d->wi + 2 * d->pad - d->ksize) / d->stride + 1;
+  SRLZ_REQUIRE(eho == d->ho && ewo == d->wo, SRLZ_ERR_BAD_DESC, "convn: output size %dx%d inconsistent (expected %dx%d)", d->ho,
+               d->wo, eho, ewo);
+  return 0;
+}
+
+static int convn_program(ConvProg* P, const srlz_convn_desc* d) {
+  // (a 1x1 stride-2 pad-0 convolution samples exactly the centre-tap pixels of the 3x3 stride-2 pad-1 program)
+  const int rc = build_program(P, 1, d->stride, 1, d->n, d->hi, d->wi, d->ho, d->wo, 1);
+  SRLZ_REQUIRE(rc == 0, SRLZ_ERR_BAD_DESC, "convn: cannot build a grid program for this descriptor");
+  return 0;
+}
+
 }  // namespace
+
+extern "C" size_t srlz_convn_packed_floats(const srlz_convn_desc* d) {
+  if (check_convn(d)) return 0;
+  return (size_t)(d->cin / 64) * (d->cout / 64) * NTAPS * 4096;
+}
+
+extern "C" int srlz_convn_pack_weights(const float* w_ref, float* wpack, const srlz_convn_desc* d, srlz_stream_t stream) {
+  if (int rc = check_convn(d)) return rc;
+  SRLZ_REQUIRE(w_ref && wpack, SRLZ_ERR_NULL, "convn_pack: null pointer");
+  const long long total = (long long)(d->cin / 64) * (d->cout / 64) * NTAPS * 4096;
+  hipLaunchKernelGGL(convN_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w_ref, wpack,
+                     d->cin / 64, d->cout / 64, d->ksize);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_convn_fwd_tiles(const srlz_convn_desc* d) {
+  if (check_convn(d)) return -1;
+  ConvProg P;
+  if (convn_program(&P, d)) return -1;
+  return P.tpg;
+}
+
+extern "C" int srlz_convn_fwd(const float* x, const float* wpack, float* y, float* stats_partial, const float* x_bnp,
+                              const srlz_convn_desc* d, srlz_stream_t stream) {
+  if (int rc = check_convn(d)) return rc;
+  SRLZ_REQUIRE(x && wpack && y, SRLZ_ERR_NULL, "convn_fwd: null pointer");
+  ConvProg P;
+  if (int rc = convn_program(&P, d)) return rc;
+  const int ntiles = P.tpg;
+  const size_t lds = fwd_lds_bytes(P);
+  SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "convn: tile needs %zu bytes of LDS", lds);
+  SRLZ_MAX_LDS(convN_fwd_kernel, lds);
+  hipLaunchKernelGGL(convN_fwd_kernel, dim3(ntiles, d->cout / 64), dim3(256), lds, as_stream(stream), x, wpack, y, stats_partial, P,
+                     ntiles, d->cin / 64, d->cout / 64, x_bnp);
+  SRLZ_LAUNCHED();
+  return 0;
+}
 
 extern "C" size_t srlz_conv64_packed_floats(void) { return (size_t)NTAPS * 4096; }
 

@@ -252,6 +252,69 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   }
 }
 
+// nn.PReLU() (one slope, init 0.25) — EmbeddingNet.fc[0], /root/reference/models/triplet.py:24
+__global__ void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope, float* __restrict__ y, long long n) {
+  const float a = slope[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = x[i] > 0.f ? x[i] : a * x[i];
+}
+
+// dx = dy * (x > 0 ? 1 : a);  dslope = sum dy * x * [x <= 0]   (one block: the tensor is [B, 128]; fp64 sum, fixed order)
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
+                                                       const float* __restrict__ dy, float* __restrict__ dx,
+                                                       float* __restrict__ dslope, long long n) {
+  const float a = slope[0];
+  double acc = 0.0;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float xi = x[i], g = dy[i];
+    dx[i] = xi > 0.f ? g : a * g;
+    if (!(xi > 0.f)) acc += (double)(g * xi);
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dslope[0] = (float)(sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// tripletLoss, /root/reference/losses/losses.py:360-376: mean_b relu(|s-p|^2 - |s-n|^2 + alpha).  One block; hinge[b] keeps
+// which rows are active for the backward.
+__global__ __launch_bounds__(256) void triplet_fwd_kernel(const float* __restrict__ s, const float* __restrict__ p,
+                                                         const float* __restrict__ ng, int B, int S, float alpha,
+                                                         float* __restrict__ out, float* __restrict__ hinge) {
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float dp = 0.f, dn = 0.f;
+    for (int j = 0; j < S; ++j) {
+      const float sv = s[(size_t)b * S + j];
+      const float a = sv - p[(size_t)b * S + j], c = sv - ng[(size_t)b * S + j];
+      dp += a * a; dn += c * c;
+    }
+    const float l = dp - dn + alpha;
+    hinge[b] = l > 0.f ? 1.f : 0.f;
+    acc += (double)(l > 0.f ? l : 0.f);
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) / (double)B);
+}
+
+// d/ds = g/B * hinge * 2 (n - p) ; d/dp = -g/B * hinge * 2 (s - p) ; d/dn = g/B * hinge * 2 (s - n)
+__global__ void triplet_bwd_kernel(const float* __restrict__ s, const float* __restrict__ p, const float* __restrict__ ng,
+                                   const float* __restrict__ hinge, const float* __restrict__ g, int B, int S,
+                                   float* __restrict__ ds, float* __restrict__ dp, float* __restrict__ dn) {
+  const float c = g[0] / (float)B;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * S; i += gridDim.x * blockDim.x) {
+    const float hb = hinge[i / S] * c;
+    const float sv = s[i], pv = p[i], nv = ng[i];
+    ds[i] = hb * 2.f * (nv - pv);
+    dp[i] = -hb * 2.f * (sv - pv);
+    dn[i] = hb * 2.f * (sv - nv);
+  }
+}
+
 static int blocks_for(long long n, int cap) {
   long long b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -362,6 +425,39 @@ extern "C" int srlz_reparam_bwd(const float* dz, const float* logvar, const floa
   SRLZ_REQUIRE(dz && logvar && eps && dmu && dlogvar, SRLZ_ERR_NULL, "reparam_bwd: null pointer");
   hipLaunchKernelGGL(reparam_bwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), dz, logvar, eps, dmu,
                      dlogvar, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_prelu_fwd(const float* x, const float* slope, float* y, long long n, srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && slope && y, SRLZ_ERR_NULL, "prelu_fwd: null pointer");
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), x, slope, y, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_prelu_bwd(const float* x, const float* slope, const float* dy, float* dx, float* dslope, long long n,
+                              srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && slope && dy && dx && dslope, SRLZ_ERR_NULL, "prelu_bwd: null pointer");
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, slope, dy, dx, dslope, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_triplet_fwd(const float* s, const float* p, const float* n, int B, int S, float alpha, float* out,
+                                float* hinge, srlz_stream_t stream) {
+  SRLZ_REQUIRE(s && p && n && out && hinge, SRLZ_ERR_NULL, "triplet_fwd: null pointer");
+  SRLZ_REQUIRE(B > 0 && S > 0, SRLZ_ERR_BAD_DESC, "triplet_fwd: empty batch");
+  hipLaunchKernelGGL(triplet_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), s, p, n, B, S, alpha, out, hinge);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_triplet_bwd(const float* s, const float* p, const float* n, const float* hinge, const float* g, int B, int S,
+                                float* ds, float* dp, float* dn, srlz_stream_t stream) {
+  SRLZ_REQUIRE(s && p && n && hinge && g && ds && dp && dn, SRLZ_ERR_NULL, "triplet_bwd: null pointer");
+  hipLaunchKernelGGL(triplet_bwd_kernel, dim3(blocks_for((long long)B * S, 1024)), dim3(256), 0, as_stream(stream), s, p, n, hinge,
+                     g, B, S, ds, dp, dn);
   SRLZ_LAUNCHED();
   return 0;
 }

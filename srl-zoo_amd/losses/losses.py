@@ -1,7 +1,7 @@
 """LossManager and the hot-path losses (reference losses/losses.py:19-59, 102-170, 172-214, 239-256).
 
 Same function names, argument order and return values as the reference; the reductions and their gradients run as
-fused HIP kernels (srlz/ops.py).  Losses of other SRL methods (priors, triplet, episode/reward priors) are outside the
+fused HIP kernels (srlz/ops.py).  Losses of other SRL methods (priors, episode/reward priors) are outside the
 hot path and not provided.
 """
 from __future__ import print_function, division, absolute_import
@@ -142,3 +142,10 @@ def kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager, beta=1):
     kl_divergence = ops.KLSumFn.apply(mu, logvar) + ops.KLSumFn.apply(next_mu, next_logvar)
     loss_manager.addToLosses('kl_loss', beta, kl_divergence)
     return beta * kl_divergence
+
+
+def tripletLoss(states, p_states, n_states, weight, loss_manager, alpha=0.2):
+    """Time-contrastive triplet loss: mean relu(|s - p|^2 - |s - n|^2 + alpha) (reference losses.py:360-376)."""
+    tcn_triplet_loss = ops.TripletLossFn.apply(states, p_states, n_states, alpha)
+    loss_manager.addToLosses('triplet_loss', weight, tcn_triplet_loss)
+    return weight * tcn_triplet_loss

@@ -21,7 +21,7 @@ import numpy as np
 import torch as th
 
 from losses.losses import LossManager, autoEncoderLoss, forwardModelLoss, inverseModelLoss, kullbackLeiblerLoss, \
-    generationLoss, rewardModelLoss, l1Loss, l2Loss, perceptualSimilarityLoss
+    generationLoss, rewardModelLoss, l1Loss, l2Loss, perceptualSimilarityLoss, tripletLoss
 from pipeline import NAN_ERROR
 from preprocessing.data_loader import DataLoader
 from utils import printRed, detachToNumpy, printYellow
@@ -41,7 +41,7 @@ BALANCED_SAMPLING = False
 # build-specific: ship decoded frames as uint8 and normalise on the GPU (bit-identical, 4x less PCIe traffic)
 RAW_UINT8_INPUT = True
 
-SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "reward", "perceptual", "random"}
+SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "reward", "perceptual", "random", "triplet"}
 
 
 def _requireGpu(cuda):
@@ -201,7 +201,12 @@ class SRL4robotics(BaseLearner):
         self.use_autoencoder = "autoencoder" in losses
         self.use_vae = "vae" in losses
         self.use_dae = "dae" in losses
-        self.use_triplets = False
+        self.use_triplets = "triplet" in losses
+        if self.use_triplets and (self.use_vae or self.use_autoencoder or self.use_dae):
+            # the reference itself crashes on `vae triplet` (mu / logvar are never bound, learner.py:383-414 vs 457-459) and
+            # silently drops the auto-encoder for the EmbeddingNet: there is no behaviour to reproduce
+            raise NotImplementedError("'triplet' replaces the model by EmbeddingNet (reference modules.py:71-73): it cannot be "
+                                      "combined with autoencoder / vae / dae")
         self.perceptual_similarity_loss = "perceptual" in losses
         self.path_to_dae = path_to_dae
         self.denoiser = None
@@ -409,7 +414,14 @@ class SRL4robotics(BaseLearner):
         loss_manager.resetLosses()
 
         decoded_obs = decoded_next_obs = None
-        if self.use_autoencoder:
+        if self.use_triplets:
+            # anchor / positive / negative views stacked along channels (reference learner.py:383-391); the frozen trunk runs
+            # once per view (six passes per step, each with its own BatchNorm batch statistics, as in the reference)
+            states, positive_states, negative_states = self.model.forwardTriplets(
+                obs[:, :3].contiguous(), obs[:, 3:6].contiguous(), obs[:, 6:].contiguous())
+            next_states, _next_positive, _next_negative = self.model.forwardTriplets(
+                next_obs[:, :3].contiguous(), next_obs[:, 3:6].contiguous(), next_obs[:, 6:].contiguous())
+        elif self.use_autoencoder:
             (states, decoded_obs), (next_states, decoded_next_obs) = self._forwardPair(obs, next_obs)
         elif self.use_dae:
             (states, decoded_obs), (next_states, decoded_next_obs) = self._forwardPair(noisy_obs, next_noisy_obs)
@@ -452,6 +464,9 @@ class SRL4robotics(BaseLearner):
                                          loss_manager=loss_manager)
             else:
                 generationLoss(decoded_obs, decoded_next_obs, obs, next_obs, weight=w['vae'], loss_manager=loss_manager)
+
+        if self.use_triplets:
+            tripletLoss(states, positive_states, negative_states, weight=w['triplet'], loss_manager=loss_manager, alpha=0.2)
 
         loss = loss_manager.computeTotalLoss()
         loss.backward()  # the reference backpropagates on validation minibatches too (learner.py:487-489)
@@ -517,11 +532,11 @@ class SRL4robotics(BaseLearner):
             self.loadDenoiser(th.load(self.path_to_dae, map_location=self.device))
 
         data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
-                                 use_triplets=False, is_training=True, apply_occlusion=self.use_dae,
+                                 use_triplets=self.use_triplets, is_training=True, apply_occlusion=self.use_dae,
                                  occlusion_percentage=self.occlusion_percentage, rank=self.rank,
                                  world_size=self.world_size, val_indices=val_indices, raw_uint8=RAW_UINT8_INPUT and not self.use_dae)
         test_data_loader = DataLoader(test_minibatchlist, images_path, n_workers=N_WORKERS,
-                                      multi_view=self.multi_view, use_triplets=False, max_queue_len=1,
+                                      multi_view=self.multi_view, use_triplets=self.use_triplets, max_queue_len=1,
                                       is_training=False, apply_occlusion=self.use_dae,
                                       occlusion_percentage=self.occlusion_percentage,
                                       raw_uint8=RAW_UINT8_INPUT and not self.use_dae)

@@ -6,6 +6,7 @@ from __future__ import print_function, division, absolute_import
 from srlz import ops
 from .autoencoders import CNNAutoEncoder
 from .vae import CNNVAE
+from .triplet import EmbeddingNet
 from .forward_inverse import BaseForwardModel, BaseInverseModel, BaseRewardModel
 from .models import *  # noqa: F401,F403  (BaseModelSRL, CustomCNN, encodeOneHot, ... as in the reference)
 
@@ -20,7 +21,7 @@ def _forward_pair(module, x, next_x):
 
 
 OUT_OF_SCOPE = "model_type '{}' / losses {} are outside the MI355X hot path of this build (custom_cnn with " \
-               "autoencoder | vae | dae | inverse | forward | reward | perceptual); use the reference implementation for them"
+               "autoencoder | vae | dae | inverse | forward | reward | perceptual | triplet); use the reference implementation for them"
 
 
 class SRLModules(BaseForwardModel, BaseInverseModel, BaseRewardModel):
@@ -46,7 +47,7 @@ class SRLModules(BaseForwardModel, BaseInverseModel, BaseRewardModel):
         self.initInverseNet(state_dim, action_dim, model_type=inverse_model_type)
         self.initRewardNet(state_dim)
 
-        if model_type != "custom_cnn" or "triplet" in self.losses:
+        if model_type != "custom_cnn":
             raise NotImplementedError(OUT_OF_SCOPE.format(model_type, self.losses))
         if "autoencoder" in self.losses or "dae" in self.losses:
             self.model = CNNAutoEncoder(state_dim)
@@ -54,6 +55,9 @@ class SRLModules(BaseForwardModel, BaseInverseModel, BaseRewardModel):
             self.model = CNNVAE(state_dim)
         else:
             self.model = CustomCNN(state_dim)
+        if "triplet" in self.losses:
+            # (reference modules.py:71-73: whatever was built above is replaced — after it consumed its share of the RNG)
+            self.model = EmbeddingNet(state_dim)
 
     def getStates(self, observations):
         return self.model.getStates(observations)
@@ -66,10 +70,13 @@ class SRLModules(BaseForwardModel, BaseInverseModel, BaseRewardModel):
         return _forward_pair(self, x, next_x)
 
     def encode(self, x):
+        if "triplet" in self.losses:
+            return self.model(x)
         raise NotImplementedError()
 
     def forwardTriplets(self, anchor, positive, negative):
-        raise NotImplementedError(OUT_OF_SCOPE.format(self.model_type, ["triplet"]))
+        """(model(anchor), model(positive), model(negative)) — reference modules.py:92-100."""
+        return self.model(anchor), self.model(positive), self.model(negative)
 
 
 class SRLModulesSplit(BaseForwardModel, BaseInverseModel, BaseRewardModel):

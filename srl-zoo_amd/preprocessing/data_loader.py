@@ -15,6 +15,8 @@ Image decoding is host-side I/O, not a kernel: OpenCV is used when importable (a
 """
 from __future__ import print_function, division, absolute_import
 
+import glob
+import random
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -124,7 +126,8 @@ class DataLoader(object):
         :param images_path: (np.array) image paths (without the 'data/' prefix)
         :param n_workers: (int) decoding threads
         :param multi_view: (bool) stack the two camera views along channels
-        :param use_triplets: (bool) out of scope (needs the ResNet path); rejected
+        :param use_triplets: (bool) with multi_view: add a NEGATIVE observation (view 1 of a random other time step of the
+                             same record) as channels 6..8 — the time-contrastive triplets of EmbeddingNet
         :param infinite_loop: (bool) restart after each epoch
         :param max_queue_len: (int) minibatches prepared ahead
         :param is_training: (bool) True: yield (idx, obs, next_obs, noisy, next_noisy) in shuffled order;
@@ -139,8 +142,9 @@ class DataLoader(object):
                             minibatches are sharded separately (train first) so all ranks stay in lock-step
         """
         super(DataLoader, self).__init__()
-        if use_triplets:
-            raise NotImplementedError("triplet loading is outside the MI355X hot-path build")
+        if use_triplets and not multi_view:
+            raise ValueError("triplets need the two camera views of a multi-view dataset")
+        self.use_triplets = use_triplets
         self.n_workers = n_workers
         self.infinite_loop = infinite_loop
         self.n_minibatches = len(minibatchlist)
@@ -195,12 +199,14 @@ class DataLoader(object):
                     paths = np.concatenate((self.images_path[idx], self.images_path[idx + 1]))
                 else:
                     paths = self.images_path[idx]
-                clean = list(pool.map(lambda p: self._makeBatchElement(p, self.multi_view, raw_uint8=self.raw_uint8), paths))
+                clean = list(pool.map(lambda p: self._makeBatchElement(p, self.multi_view, self.use_triplets,
+                                                                       raw_uint8=self.raw_uint8), paths))
                 batch = th.cat(clean, dim=0) if clean else th.zeros(0)
                 noisy = None
                 if self.apply_occlusion:
                     occl = list(pool.map(lambda p: self._makeBatchElement(
-                        p, self.multi_view, apply_occlusion=True, occlusion_percentage=self.occlusion_percentage), paths))
+                        p, self.multi_view, self.use_triplets, apply_occlusion=True,
+                        occlusion_percentage=self.occlusion_percentage), paths))
                     noisy = th.cat(occl, dim=0)
                 if self.shuffle:
                     half = len(paths) // 2
@@ -222,12 +228,24 @@ class DataLoader(object):
         (raw_uint8: the decoded RGB frame(s) as uint8 [1, H, W, C])."""
         stem = 'data/' + image_path.split('.jpg')[0]
         names = ["{}_{}.jpg".format(stem, i + 1) for i in range(2)] if multi_view else ["{}.jpg".format(stem)]
+        occlude = [apply_occlusion] * len(names)
+        if multi_view and use_triplets:
+            # negative observation (reference data_loader.py:219-243): camera 1 of a random OTHER time step of the same
+            # record, drawn with Python's `random` as the reference does; it is never occluded
+            extra_chars = '_1.jpg'
+            digits_path = glob.glob(stem[:-6] + '[0-9]*' + extra_chars)
+            current = int(stem[-6:])
+            all_frame_steps = [int(k[:-len(extra_chars)][-6:]) for k in digits_path]
+            all_frame_steps.remove(current)
+            negative = all_frame_steps[random.randint(0, len(all_frame_steps) - 1)]
+            names.append('{}{:06d}_1.jpg'.format(stem[:-6], negative))
+            occlude.append(False)
         views = []
-        for name in names:
+        for name, occ in zip(names, occlude):
             rgb = _imread_rgb(name)
             if rgb is None:
                 raise ValueError("tried to load {}, but it was not found".format(name))
-            views.append(np.ascontiguousarray(rgb) if raw_uint8 else _normalised(rgb, apply_occlusion, occlusion_percentage))
+            views.append(np.ascontiguousarray(rgb) if raw_uint8 else _normalised(rgb, occ, occlusion_percentage))
         im = np.dstack(views) if multi_view else views[0]
         if raw_uint8:
             return th.from_numpy(np.ascontiguousarray(im).reshape((1,) + im.shape))

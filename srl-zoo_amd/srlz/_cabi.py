@@ -31,6 +31,11 @@ class PoolDesc(Structure):
                 ("out_nchw", c_int), ("groups", c_int)]
 
 
+class ConvNDesc(Structure):
+    _fields_ = [("n", c_int), ("hi", c_int), ("wi", c_int), ("ho", c_int), ("wo", c_int), ("cin", c_int), ("cout", c_int),
+                ("ksize", c_int), ("stride", c_int), ("pad", c_int)]
+
+
 class BnBwdOperand(Structure):
     """srlz_bn_bwd_operand: raw device pointers + count; build with bn_bwd_operand() so the tensors stay referenced."""
     _fields_ = [("y", c_void_p), ("bnp", c_void_p), ("sums", c_void_p), ("count", c_longlong), ("training", c_int),
@@ -42,6 +47,7 @@ _BO = POINTER(BnBwdOperand)
 _C64 = POINTER(Conv64Desc)
 _SK = POINTER(SkinnyDesc)
 _PD = POINTER(PoolDesc)
+_CN = POINTER(ConvNDesc)
 
 # name -> (restype, argtypes); restype c_int functions are status-checked
 _PROTOS = {
@@ -58,6 +64,18 @@ _PROTOS = {
     "srlz_conv64_debug_program": (c_int, [_C64, c_int, POINTER(c_int), c_int]),
     "srlz_debug_placement": (c_int, [P, c_int, c_int, c_int, P]),
     "srlz_debug_mfma_peak": (c_int, [P, c_int, c_int, P]),
+    "srlz_convn_packed_floats": (c_size_t, [_CN]),
+    "srlz_convn_pack_weights": (c_int, [P, P, _CN, P]),
+    "srlz_convn_fwd_tiles": (c_int, [_CN]),
+    "srlz_convn_fwd": (c_int, [P, P, P, P, P, _CN, P]),
+    "srlz_bn_finalize_chunks": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, P, P, P, P, c_size_t, P]),
+    "srlz_bn_eval_params_chunks": (c_int, [P, P, P, P, c_float, c_int, P, P]),
+    "srlz_bn_add_relu": (c_int, [P, P, P, P, P, c_longlong, c_int, P]),
+    "srlz_avgpool_nhwc": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "srlz_prelu_fwd": (c_int, [P, P, P, c_longlong, P]),
+    "srlz_prelu_bwd": (c_int, [P, P, P, P, P, c_longlong, P]),
+    "srlz_triplet_fwd": (c_int, [P, P, P, c_int, c_int, c_float, P, P, P]),
+    "srlz_triplet_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "srlz_skinny_tiles": (c_int, [_SK]),
     "srlz_conv1_fwd": (c_int, [P, P, P, P, _SK, P]),
     "srlz_skinny_bwd_weight_workspace": (c_size_t, [_SK]),
@@ -107,7 +125,7 @@ _PROTOS = {
 }
 
 # entry points whose int return value is data, not a status
-_NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles",
+_NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
                "srlz_conv64_debug_program"}
 
 EXPORTED = sorted(_PROTOS.keys())

@@ -112,6 +112,90 @@ def _record_activation(idx, y, st, bn, training):
         TAPS["decoder_conv.%d" % idx] = ops.bn_relu_materialise(y.detach(), bnp)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Frozen ResNet-18 trunk of EmbeddingNet (reference models/triplet.py:16 -> torchvision resnet18), FORWARD ONLY.
+# ---------------------------------------------------------------------------------------------------------------------
+def _packed(conv, d):
+    """The kernel-layout copy of a frozen convolution's weights, kept on the module and rebuilt only if the parameter was
+    moved or written (load_state_dict, .to(device))."""
+    key = (conv.weight.data_ptr(), conv.weight._version)
+    cached = getattr(conv, "_srlz_pack", None)
+    if cached is None or cached[0] != key:
+        pk = torch.empty(ops.C.convn_packed_floats(d), dtype=torch.float32, device=conv.weight.device)
+        ops.C.convn_pack_weights(ops.ptr(conv.weight), ops.ptr(pk), d, ops.stream())
+        cached = (key, pk)
+        conv._srlz_pack = cached
+    return cached[1]
+
+
+def _bn_record(bn, stats, tiles, count, training, device):
+    """One 256-float record per block of 64 channels of a C-channel BatchNorm2d (train: batch statistics + momentum update
+    of the running statistics + num_batches_tracked; eval: running statistics)."""
+    chunks = bn.num_features // 64
+    bnp = torch.empty(256 * chunks, dtype=torch.float32, device=device)
+    if training:
+        nbytes = ops.C.bn_bwd_workspace(0)
+        ws = ops._ws(nbytes, device)
+        bn.num_batches_tracked.add_(1)
+        ops.C.bn_finalize_chunks(ops.ptr(stats), tiles, chunks, count, ops.ptr(bn.weight), ops.ptr(bn.bias), ops.BN_EPS,
+                                 ops.BN_MOMENTUM, ops.ptr(bn.running_mean), ops.ptr(bn.running_var), ops.ptr(bnp), ops.ptr(ws),
+                                 nbytes, ops.stream())
+    else:
+        ops.C.bn_eval_params_chunks(ops.ptr(bn.weight), ops.ptr(bn.bias), ops.ptr(bn.running_mean), ops.ptr(bn.running_var),
+                                    ops.BN_EPS, chunks, ops.ptr(bnp), ops.stream())
+    return bnp
+
+
+def _convn(x, conv, bn, training, x_bnp=None):
+    """raw = conv(x or relu(bn_prev(x))) for an NHWC tensor + the BatchNorm record of `bn` over that output."""
+    n, hi, wi, cin = x.shape
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    ho, wo = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
+    d = ops.ConvNDesc(n, hi, wi, ho, wo, cin, conv.out_channels, k, s, p)
+    y = torch.empty((n, ho, wo, conv.out_channels), dtype=torch.float32, device=x.device)
+    tiles = ops.C.convn_fwd_tiles(d)
+    stats = torch.empty((conv.out_channels // 64, tiles, 128), dtype=torch.float32, device=x.device) if training else None
+    ops.C.convn_fwd(ops.ptr(x), ops.ptr(_packed(conv, d)), ops.ptr(y), ops.ptr(stats), ops.ptr(x_bnp), d, ops.stream())
+    return y, _bn_record(bn, stats, tiles, n * ho * wo, training, x.device)
+
+
+def resnet18_forward(trunk, x, training):
+    """torchvision resnet18 up to (and including) avgpool: x [B,3,224,224] (reference layout) -> [B,512] features.
+    Forward only (the trunk is frozen, reference models/triplet.py:17-19): runs under no_grad, the result carries no
+    gradient.  `training` selects BatchNorm's mode exactly as nn.Module.train()/eval() would."""
+    require_gpu(x, "resnet18 trunk")
+    with torch.no_grad():
+        x = ops._check(x, "resnet18 input")
+        n, c, h, w = x.shape
+        assert c == 3, "the ResNet-18 trunk takes one 3-channel view at a time"
+        # stem: Conv2d(3,64,7,2,3) -> BatchNorm2d -> ReLU -> MaxPool2d(3,2,1): the kernels of the auto-encoder's first block
+        d = ops._skinny_desc(n, c, h, w, 0)
+        y = torch.empty((n, d.hf, d.wf, 64), dtype=torch.float32, device=x.device)
+        tiles = ops.C.skinny_tiles(d)
+        stats = torch.empty((1, tiles, 128), dtype=torch.float32, device=x.device) if training else None
+        ops.C.conv1_fwd(ops.ptr(x), ops.ptr(trunk.conv1.weight), ops.ptr(y), ops.ptr(stats), d, ops.stream())
+        bnp = _bn_record(trunk.bn1, stats, tiles, n * d.hf * d.wf, training, x.device)
+        hp, wp = (d.hf + 2 - 3) // 2 + 1, (d.wf + 2 - 3) // 2 + 1
+        act = torch.empty((n, hp, wp, 64), dtype=torch.float32, device=x.device)
+        ops.C.bn_relu_pool_fwd(ops.ptr(y), ops.ptr(bnp), ops.ptr(act), None, ops.PoolDesc(n, d.hf, d.wf, hp, wp, 1, 0, 1), ops.stream())
+        for layer in (trunk.layer1, trunk.layer2, trunk.layer3, trunk.layer4):
+            for block in layer:
+                c1, rec1 = _convn(act, block.conv1, block.bn1, training)
+                c2, rec2 = _convn(c1, block.conv2, block.bn2, training, x_bnp=rec1)
+                out = torch.empty_like(c2)
+                pixels, chunks = c2.numel() // c2.shape[3], c2.shape[3] // 64
+                if block.downsample is not None:
+                    cd, recd = _convn(act, block.downsample[0], block.downsample[1], training)
+                    ops.C.bn_add_relu(ops.ptr(c2), ops.ptr(rec2), ops.ptr(cd), ops.ptr(recd), ops.ptr(out), pixels, chunks, ops.stream())
+                else:
+                    ops.C.bn_add_relu(ops.ptr(c2), ops.ptr(rec2), ops.ptr(act), None, ops.ptr(out), pixels, chunks, ops.stream())
+                act = out
+        n, ho, wo, ch = act.shape
+        feat = torch.empty((n, ch), dtype=torch.float32, device=x.device)
+        ops.C.avgpool_nhwc(ops.ptr(act), ops.ptr(feat), n, ho * wo, ch, ops.stream())
+    return feat
+
+
 def linear(layer, x, relu=False):
     return ops.LinearFn.apply(x, layer.weight, layer.bias, relu)
 

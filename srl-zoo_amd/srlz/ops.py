@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from . import _cabi as C
-from ._cabi import ptr, stream, Conv64Desc, SkinnyDesc, PoolDesc
+from ._cabi import ptr, stream, Conv64Desc, SkinnyDesc, PoolDesc, ConvNDesc
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -965,6 +965,52 @@ class CrossEntropyFn(Function):
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
         return dlogits * g, None
+
+
+class PReLUFn(Function):
+    """nn.PReLU() with a single slope — EmbeddingNet.fc[0], reference models/triplet.py:24."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        x, slope = _check(x, "prelu input"), _check(slope, "prelu slope")
+        assert slope.numel() == 1
+        y = torch.empty_like(x)
+        C.prelu_fwd(ptr(x), ptr(slope), ptr(y), x.numel(), stream())
+        ctx.save_for_backward(x, slope)
+        ctx.params = (slope,)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, slope = ctx.saved_tensors
+        dy = _check(dy, "prelu dy")
+        dx = torch.empty_like(x)
+        ds = _gbuf(ctx.params[0])
+        C.prelu_bwd(ptr(x), ptr(slope), ptr(dy), ptr(dx), ptr(ds), x.numel(), stream())
+        return dx, _give(ctx.params[0], ds)
+
+
+class TripletLossFn(Function):
+    """mean_b relu(|s - p|^2 - |s - n|^2 + alpha) — tripletLoss, reference losses/losses.py:360-376."""
+
+    @staticmethod
+    def forward(ctx, s, p, n, alpha):
+        s, p, n = _check(s, "anchor states"), _check(p, "positive states"), _check(n, "negative states")
+        assert s.shape == p.shape == n.shape and s.dim() == 2
+        b, sd = s.shape
+        out = torch.empty((), dtype=torch.float32, device=s.device)
+        hinge = torch.empty(b, dtype=torch.float32, device=s.device)
+        C.triplet_fwd(ptr(s), ptr(p), ptr(n), b, sd, alpha, ptr(out), ptr(hinge), stream())
+        ctx.save_for_backward(s, p, n, hinge)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, p, n, hinge = ctx.saved_tensors
+        g = g.contiguous()
+        ds, dp, dn = torch.empty_like(s), torch.empty_like(p), torch.empty_like(n)
+        C.triplet_bwd(ptr(s), ptr(p), ptr(n), ptr(hinge), ptr(g), s.shape[0], s.shape[1], ptr(ds), ptr(dp), ptr(dn), stream())
+        return ds, dp, dn, None
 
 
 class ConcatOneHotFn(Function):

@@ -113,9 +113,9 @@ def test_unsupported_configurations_are_rejected_loudly():
     with pytest.raises(NotImplementedError):
         SRLModules(state_dim=3, model_type="resnet", losses=["inverse"])
     with pytest.raises(NotImplementedError):
-        SRLModules(state_dim=3, model_type="custom_cnn", losses=["triplet"])
-    with pytest.raises(NotImplementedError):
         SRL4robotics(3, model_type="custom_cnn", losses=["priors"], cuda=True)
+    with pytest.raises(NotImplementedError):  # the reference itself crashes on this combination (SURVEY.md 8a note)
+        SRL4robotics(3, model_type="custom_cnn", losses=["vae", "triplet"], cuda=True, multi_view=True)
 
 
 def test_state_dict_keys_and_flat_params():

@@ -111,3 +111,35 @@ def test_raw_uint8_stream(dataset):
     with pytest.raises(ValueError):
         DataLoader(ml, paths, is_training=True, raw_uint8=True, apply_occlusion=True)
     del raw
+
+
+def test_triplet_stream(tmp_path):
+    """multi_view + use_triplets (reference data_loader.py:207-245): channels 0-2 = camera 1, 3-5 = camera 2 of the frame,
+    6-8 = camera 1 of ANOTHER time step of the same record (the negative), in float and in raw-uint8 form."""
+    from PIL import Image
+    from preprocessing.data_loader import DataLoader
+    name, paths, *_ = make_dataset(str(tmp_path), name="tiny_mv", n_episodes=2, ep_len=6, multi_view=True)
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        def view(path, v):
+            im = np.asarray(Image.open("data/%s_%d.jpg" % (path, v)).convert("RGB")).astype(np.float32) / 255.0
+            im = (im - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)
+            return im.transpose(2, 1, 0)
+        el = DataLoader._makeBatchElement(paths[2], multi_view=True, use_triplets=True)
+        assert tuple(el.shape) == (1, 9, 224, 224)
+        np.testing.assert_allclose(el[0, :3].numpy(), view(paths[2], 1), atol=1e-6)
+        np.testing.assert_allclose(el[0, 3:6].numpy(), view(paths[2], 2), atol=1e-6)
+        others = [p for p in paths[:6] if p != paths[2]]  # the other frames of record 0
+        assert any(np.allclose(el[0, 6:].numpy(), view(p, 1), atol=1e-6) for p in others)
+        assert not np.allclose(el[0, 6:].numpy(), view(paths[2], 1), atol=1e-6)
+        raw = DataLoader._makeBatchElement(paths[8], multi_view=True, use_triplets=True, raw_uint8=True)
+        assert raw.dtype == torch.uint8 and tuple(raw.shape) == (1, 224, 224, 9)
+        loader = DataLoader([np.array([0, 1]), np.array([6, 7])], paths, n_workers=2, multi_view=True, use_triplets=True,
+                            is_training=True, infinite_loop=False)
+        items = list(loader)
+        assert len(items) == 2 and all(tuple(it[1].shape) == (2, 9, 224, 224) and tuple(it[2].shape) == (2, 9, 224, 224) for it in items)
+        with pytest.raises(ValueError):
+            DataLoader([np.array([0])], paths, use_triplets=True)  # needs multi_view
+    finally:
+        os.chdir(cwd)

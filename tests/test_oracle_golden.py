@@ -205,6 +205,48 @@ def test_loss_kats():
     assert abs(fw.item() - float(g["forward_w1"])) < 1e-6
     inv = 2.0 * torch.nn.functional.cross_entropy(Tn("logits"), Tn("act").view(-1))
     assert abs(inv.item() - float(g["inverse_w2"])) < 1e-6
+    tri = T.triplet_loss(Tn("tri_s"), Tn("tri_p"), Tn("tri_n"), 0.2)  # the reference's tripletLoss (losses.py:360-376)
+    assert abs(tri.item() - float(g["triplet_w1"])) < 1e-6
+
+
+def test_embedding_net_construction_and_trunk_restatement():
+    """`--losses triplet`: SRLModules swaps in EmbeddingNet (reference modules.py:71-73) — a frozen ResNet-18 with
+    torchvision's state_dict keys + a trainable head.  The oracle's functional trunk (PARITY UNPINNED, see torch_twin) must at
+    least agree with executing the module tree the way torchvision's ResNet.forward does, in both BatchNorm modes."""
+    import torch.nn.functional as F
+    torch.set_num_threads(4)
+    model = build(["triplet", "inverse"], S=8)
+    net = model.model
+    sd = model.state_dict()
+    assert "model.conv_layers.layer2.0.downsample.0.weight" in sd and "model.conv_layers.layer4.1.bn2.running_var" in sd
+    assert tuple(sd["model.conv_layers.fc.weight"].shape) == (128, 512) and tuple(sd["model.fc.1.weight"].shape) == (8, 128)
+    assert sd["model.fc.0.weight"].numel() == 1 and float(sd["model.fc.0.weight"]) == 0.25
+    trainable = [k for k, p in model.named_parameters() if p.requires_grad and k.startswith("model.")]
+    assert trainable == ["model.conv_layers.fc.weight", "model.conv_layers.fc.bias", "model.fc.0.weight", "model.fc.1.weight",
+                         "model.fc.1.bias"]
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+
+    def torchvision_forward(t, z):  # torchvision.models.resnet.ResNet.forward / BasicBlock.forward, on the real modules
+        z = t.maxpool(t.relu(t.bn1(t.conv1(z))))
+        for layer in (t.layer1, t.layer2, t.layer3, t.layer4):
+            for b in layer:
+                out = b.relu(b.bn1(b.conv1(z)))
+                out = b.bn2(b.conv2(out))
+                z = b.relu(out + (z if b.downsample is None else b.downsample(z)))
+        return t.avgpool(z).view(z.size(0), -1)
+
+    for training in (True, False):
+        state = T.clone_state(sd, requires_grad=False)
+        net.conv_layers.train(training)
+        with torch.no_grad():
+            ref = torchvision_forward(net.conv_layers, x)
+        got = T.resnet18_features(state, x, training)
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        if training:  # the twin moved its copy of the running statistics exactly like the modules moved theirs
+            after = model.state_dict()
+            for k in ("model.conv_layers.bn1.running_mean", "model.conv_layers.layer3.0.downsample.1.running_var"):
+                assert float((state[k] - after[k]).abs().max()) <= 1e-6 * max(float(after[k].abs().max()), 1e-30), k
+            assert int(state["model.conv_layers.layer4.1.bn2.num_batches_tracked"]) == 1
 
 
 def test_head_kats():

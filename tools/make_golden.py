@@ -260,6 +260,10 @@ def loss_kats(th, RL):
     out["kl_beta2"] = np.array(RL.kullbackLeiblerLoss(T(mu), T(nmu), T(lv), T(nlv), lm, beta=2.0).item())
     out["forward_w1"] = np.array(RL.forwardModelLoss(T(mu), T(nmu), 1.0, lm).item())
     out["inverse_w2"] = np.array(RL.inverseModelLoss(T(logits), T(act), 2.0, lm).item())
+    sa, sp, sn = rs.randn(5, 7).astype(np.float32), rs.randn(5, 7).astype(np.float32), rs.randn(5, 7).astype(np.float32)
+    out["in/tri_s"], out["in/tri_p"], out["in/tri_n"] = sa, sp, sn
+    lm2 = RL.LossManager(M(), {})
+    out["triplet_w1"] = np.array(RL.tripletLoss(T(sa), T(sp), T(sn), 1.0, lm2, alpha=0.2).item())
     out["total"] = np.array(lm.computeTotalLoss().item())
     lm.updateLossHistory()
     lm.updateLossHistory()
