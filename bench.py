@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--batch-size", type=int, default=256, help="per-GPU minibatch (samples; 2 frames each)")
     ap.add_argument("--losses", nargs="+", default=["autoencoder"])
     ap.add_argument("--state-dim", type=int, default=200)
+    ap.add_argument("--channels", type=int, default=3, choices=[3, 6, 9],
+                    help="input channels: 6 = --multi-view (two stacked cameras, BASELINE.json configs[4] `vae` half); "
+                         "`--losses triplet` forces 9 (anchor / positive / negative views, configs[4] `triplet` half)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--host-input", action="store_true",
@@ -181,15 +184,18 @@ def main():
 
     B = args.batch_size
     learner.BATCH_SIZE = B
+    import preprocessing.preprocess as pre
+    channels = 9 if "triplet" in args.losses else args.channels
+    pre.N_CHANNELS = channels
     quiet = open(os.devnull, "w")
     stdout, sys.stdout = sys.stdout, quiet  # the learner prints its banner; keep stdout to the JSON line
     try:
         srl = SRL4robotics(args.state_dim, model_type="custom_cnn", seed=1, learning_rate=0.005, cuda=True,
-                           losses=list(args.losses), n_actions=6, beta=1.0, log_folder="/tmp")
+                           losses=list(args.losses), n_actions=6, beta=1.0, log_folder="/tmp", multi_view=channels > 3)
     finally:
         sys.stdout = stdout
     loss_manager = LossManager(srl.model, None)
-    obs, next_obs, actions = synthetic_batch(B, 3, 1234 + rank, device)
+    obs, next_obs, actions = synthetic_batch(B, channels, 1234 + rank, device)
     rewards = None
     if "reward" in args.losses:
         rewards = torch.from_numpy(np.random.RandomState(99 + rank).randint(0, 2, (B,)).astype(np.int64)).to(device)
@@ -236,9 +242,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if host_frames is None else "synthetic, uint8 frames in pinned host memory every step (PCIe-inclusive)",
             "samples_per_s": round(B * world * args.steps / dt, 1),
-            "config": {"workload": "synthetic 224x224x3 obs, --losses %s, custom_cnn, state-dim %d, bs=%d per GPU "
+            "config": {"workload": "synthetic 224x224x%d obs, --losses %s, custom_cnn, state-dim %d, bs=%d per GPU "
                                    "(%d frames fwd+bwd per step per GPU), Adam lr 0.005, data resident in HBM"
-                                   % (" ".join(args.losses), args.state_dim, B, 2 * B),
+                                   % (channels, " ".join(args.losses), args.state_dim, B, 2 * B),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "final_loss": round(last_losses[-1], 6)},

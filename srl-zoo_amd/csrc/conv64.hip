@@ -777,6 +777,7 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
   // 4 waves (32x64 per wave) is the default; SRLZ_NW=8 selects 8 waves of 32x32 (measured within +-3 %: the kernel is
   // bound by the power-limited matrix rate, not by latency hiding)
   static const int nw = [] { const char* e = getenv("SRLZ_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
+  static const int nw_bwd = [] { const char* e = getenv("SRLZ_NW_BWD"); return e ? ((atoi(e) == 8) ? 8 : 4) : nw; }();
 #define SRLZ_FWD_LAUNCH(NWV, BWDV)                                                                                          \
   do {                                                                                                                     \
     SRLZ_MAX_LDS((conv64_fwd_kernel<NWV, BWDV>), lds);                                                                      \
@@ -784,7 +785,7 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
                        P, ntiles, src_fuse);                                                                               \
   } while (0)
   if (src_fuse.y) {
-    if (nw == 8) SRLZ_FWD_LAUNCH(8, true);
+    if (nw_bwd == 8) SRLZ_FWD_LAUNCH(8, true);
     else SRLZ_FWD_LAUNCH(4, true);
   } else {
     if (nw == 8) SRLZ_FWD_LAUNCH(8, false);

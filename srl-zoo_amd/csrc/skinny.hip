@@ -170,28 +170,28 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // BNBWD: this lane's 2 x 32 values of y_raw are requested now and consumed in the epilogue, behind the tile's MFMAs
-    float yv[BNBWD ? 2 : 1][BNBWD ? 2 : 1][16];
-    if (BNBWD) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int oy = oy0 + wave * 4 + mt * 2 + (i >> 4), ox = ox0 + (i & 15);
-          float a0 = 0.f, a1 = 0.f;
-          if (oy < HF && ox < WF) {
-            const float* yp = y_raw + ((size_t)(n * HF + oy) * WF + ox) * 64 + l31;
-            a0 = yp[0]; a1 = yp[32];
-          }
-          yv[BNBWD ? mt : 0][0][r] = a0; yv[BNBWD ? mt : 0][BNBWD ? 1 : 0][r] = a1;
-        }
-    }
+    // Epilogue layout: lane (g = lane >> 4, slot = lane & 15) owns channels [4*slot, 4*slot+4) of pixel column 4*it + g of tile
+    // row  wave*4 + rowq  (rowq = 0..3, it = 0..3): every global access of the epilogue is a 16-byte one (a dword-per-lane
+    // access pattern sustains only ~5 B/cycle/CU here — it was the bound of the ConvTranspose-5 data gradient).
+    const int eg = lane >> 4, eslot = lane & 15;
+    // BNBWD: this lane's 16 x float4 of y_raw are requested before the MFMA loop and consumed in the epilogue
+    f32x4 yv[BNBWD ? 16 : 1];
 
     for (int cg = 0; cg < ncg; ++cg) {
       __syncthreads();
       stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
       if (ncg > 1) stage_weights(cg);
+      if (BNBWD && cg == 0) {  // (after the image loads: they are waited for first, these stay in flight behind the MFMAs)
+#pragma unroll
+        for (int rowq = 0; rowq < 4; ++rowq)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int oy = oy0 + wave * 4 + rowq, ox = ox0 + it * 4 + eg;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oy < HF && ox < WF) v = *(const f32x4*)(y_raw + ((size_t)(n * HF + oy) * WF + ox) * 64 + eslot * 4);
+            yv[BNBWD ? rowq * 4 + it : 0] = v;
+          }
+      }
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -204,38 +204,54 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
     }
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    float mean0 = 0.f, mean1 = 0.f, inv0 = 0.f, inv1 = 0.f, sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f;
+    __syncthreads();  // every wave is done reading the image window: T becomes the transposition buffer (4 KB per wave)
+    float* Ew = T + wave * 1024;  // [16 pixels of one tile row][64 channels]
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bmean = s1, binv = s1, bsc = s1, bsh = s1;
     if (BNBWD) {
       const float* __restrict__ yb = y_bnp + (n / npg) * 256;
-      mean0 = yb[l31]; mean1 = yb[32 + l31]; inv0 = yb[64 + l31]; inv1 = yb[96 + l31];
-      sc0 = yb[128 + l31]; sc1 = yb[160 + l31]; sh0 = yb[192 + l31]; sh1 = yb[224 + l31];
+      bmean = *(const f32x4*)(yb + eslot * 4); binv = *(const f32x4*)(yb + 64 + eslot * 4);
+      bsc = *(const f32x4*)(yb + 128 + eslot * 4); bsh = *(const f32x4*)(yb + 192 + eslot * 4);
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int rowq = 0; rowq < 4; ++rowq) {
+      const int mt = rowq >> 1, half = rowq & 1;
+      // accumulator register r = 8*half + rr of M-tile mt holds pixel (rr & 3) + 8*(rr >> 2) + 4*h of tile row wave*4 + rowq
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int oy = oy0 + wave * 4 + mt * 2 + (i >> 4), ox = ox0 + (i & 15);
+      for (int rr = 0; rr < 8; ++rr) {
+        const int il = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        Ew[il * 64 + l31] = acc[mt][0][8 * half + rr];
+        Ew[il * 64 + 32 + l31] = acc[mt][1][8 * half + rr];
+      }
+      // (wave-private region: the compiler's lgkmcnt wait orders these writes before the reads below)
+      const int oy = oy0 + wave * 4 + rowq;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int pl = it * 4 + eg, ox = ox0 + pl;
+        const f32x4 v = *(const f32x4*)(Ew + pl * 64 + eslot * 4);
         if (oy < HF && ox < WF) {
-          const float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
-          float* o = feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + l31;
-          o[0] = v0; o[32] = v1;
+          *(f32x4*)(feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + eslot * 4) = v;
           if (BNBWD) {
-            const float y0 = yv[BNBWD ? mt : 0][0][r], y1 = yv[BNBWD ? mt : 0][BNBWD ? 1 : 0][r];
-            if (y0 * sc0 + sh0 > 0.f) { s0 += v0; q0 += v0 * ((y0 - mean0) * inv0); }
-            if (y1 * sc1 + sh1 > 0.f) { s1 += v1; q1 += v1 * ((y1 - mean1) * inv1); }
+            const f32x4 yy = yv[BNBWD ? rowq * 4 + it : 0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (yy[e] * bsc[e] + bsh[e] > 0.f) { s1[e] += v[e]; s2[e] += v[e] * ((yy[e] - bmean[e]) * binv[e]); }
           } else {
-            s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
           }
         }
       }
+    }
     if (stats_partial) {
-      s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-      s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-      if (h == 0) {
-        red[wave * 128 + l31] = s0; red[wave * 128 + 32 + l31] = s1;
-        red[wave * 128 + 64 + l31] = q0; red[wave * 128 + 96 + l31] = q1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += __shfl_xor(s1[e], 16, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
+        s2[e] += __shfl_xor(s2[e], 16, 64); s2[e] += __shfl_xor(s2[e], 32, 64);
+      }
+      if (eg == 0) {
+        *(f32x4*)(red + wave * 128 + eslot * 4) = s1;
+        *(f32x4*)(red + wave * 128 + 64 + eslot * 4) = s2;
       }
       __syncthreads();
       if (tid < 128) stats_partial[(size_t)tile * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
