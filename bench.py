@@ -202,13 +202,36 @@ def main():
 
     host_frames = None
     if args.host_input:
+        # what the loader hands over every step (DataLoader(raw_uint8=True)): uint8 frames in pinned host memory.  As in
+        # SRL4robotics.learn() (_DeviceFeed), the NEXT step's frames cross PCIe on a copy stream while this step computes;
+        # normalisation + layout change happen on the GPU (srlz_normalize_u8).
         rs = np.random.RandomState(4321 + rank)
-        host_frames = [torch.from_numpy(rs.randint(0, 256, (B, 224, 224, 3)).astype(np.uint8)).pin_memory() for _ in range(2)]
+        host_frames = [[torch.from_numpy(rs.randint(0, 256, (B, 224, 224, channels)).astype(np.uint8)).pin_memory()
+                        for _ in range(2)] for _ in range(2)]  # two alternating minibatches
+        copy_stream = torch.cuda.Stream(device=device)
+        ahead = {}
+
+        def upload(i):
+            with torch.cuda.stream(copy_stream):
+                dev = [t.to(device, non_blocking=True) for t in host_frames[i % 2]]
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+            ahead[i] = (dev, ev)
+        upload(0)
+    counter = [0]
 
     def step():
         if host_frames is None:
             return srl.trainStep(obs, next_obs, actions, loss_manager, rewards_st=rewards)
-        o, no = srl._toDevicePair(host_frames[0], host_frames[1])  # H2D (uint8) + normalise on the GPU
+        i = counter[0]
+        counter[0] += 1
+        dev, ev = ahead.pop(i)
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(ev)
+        for t in dev:
+            t.record_stream(cur)
+        upload(i + 1)  # next minibatch travels while this step runs
+        o, no = srl._toDevicePair(dev[0], dev[1])  # uint8 -> normalised fp32 halves of one buffer, on the GPU
         return srl.trainStep(o, no, actions, loss_manager, rewards_st=rewards)
 
     def sync():
