@@ -43,7 +43,7 @@ static int stage_blocks(int nrows) {
 // `groups` independent BatchNorm calls (one per group of images) are finalised one after the other by the same block:
 // group g's staged partials are partial[g*n_partials ..], its records bnp[g*256 ..] / batch_stat[g*128 ..], and the running
 // statistics receive the groups' momentum updates IN ORDER (obs, then next_obs — models/learner.py:392-393).
-__global__ void bn_finalize_kernel(const double* __restrict__ partial, int n_partials, double count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ partial, int n_partials, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, int repeat, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ bnp,
@@ -55,16 +55,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int n_par
   if (running_var) running_var += blockIdx.x * 64;
   bnp += blockIdx.x * 256;
   partial += (size_t)blockIdx.x * n_partials * 128;
-  // one block of 256 threads: thread (c = tid & 63, part = tid >> 6) sums a strided quarter of the partial records
+  // one block of 1024 threads: thread (c = tid & 63, part = tid >> 6) sums a strided sixteenth of the partial records
+  // (the chain of dependent loads, not bandwidth, is what this kernel waits for)
+  constexpr int NP = 16;
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-  __shared__ double sm[2][4][64];
+  __shared__ double sm[2][NP][64];
   float rm = 0.f, rv = 0.f;
   const bool upd = running_mean && running_var;
   if (part == 0 && upd) { rm = running_mean[c]; rv = running_var[c]; }
   for (int g = 0; g < groups; ++g) {
     const double* pg = partial + (size_t)g * n_partials * 128;
     double s = 0.0, q = 0.0;
-    for (int i = part; i < n_partials; i += 4) {
+    for (int i = part; i < n_partials; i += NP) {
       s += pg[(size_t)i * 128 + c];
       q += pg[(size_t)i * 128 + 64 + c];
     }
@@ -72,8 +74,9 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int n_par
     sm[0][part][c] = s; sm[1][part][c] = q;
     __syncthreads();
     if (part == 0) {
-      s = sm[0][0][c] + sm[0][1][c] + sm[0][2][c] + sm[0][3][c];
-      q = sm[1][0][c] + sm[1][1][c] + sm[1][2][c] + sm[1][3][c];
+      s = 0.0; q = 0.0;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) { s += sm[0][k][c]; q += sm[1][k][c]; }
       const double mean = s / count;
       double var = q / count - mean * mean;
       if (var < 0.0) var = 0.0;
@@ -487,7 +490,7 @@ extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, int 
   const int g = stage_blocks(per);  // per group exactly what a single-group call uses: results are bit-identical to G calls
   hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, G), dim3(256), 0, as_stream(stream), stats_partial, per, staged);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double*)staged, g, (double)count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (const double*)staged, g, (double)count,
                      gamma, beta, eps, momentum, repeat, running_mean, running_var, bnp, batch_stat, G);
   SRLZ_LAUNCHED();
   return 0;
@@ -504,7 +507,7 @@ extern "C" int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, in
   const int g = stage_blocks(tiles);
   hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, chunks), dim3(256), 0, as_stream(stream), stats_partial, tiles, staged);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(chunks), dim3(256), 0, as_stream(stream), (const double*)staged, g, (double)count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(chunks), dim3(1024), 0, as_stream(stream), (const double*)staged, g, (double)count,
                      gamma, beta, eps, momentum, 1, running_mean, running_var, bnp, (float*)nullptr, 1);
   SRLZ_LAUNCHED();
   return 0;
