@@ -176,6 +176,11 @@ def main():
         warm = torch.zeros(1 << 20, device=device)
         torch.distributed.all_reduce(warm)
         torch.cuda.synchronize()
+        from srlz import optim as _optim
+        if _optim.native_comm_requested():  # SRLZ_COMM=rccl: the library's own RCCL communicator (include/srlz.h)
+            _optim.init_native_comm()
+            _optim._sum_across_ranks(warm)
+            torch.cuda.synchronize()
 
     import models.learner as learner
     from models.learner import SRL4robotics

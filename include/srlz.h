@@ -360,6 +360,21 @@ int srlz_adam_step_dev(float* p, const float* g, float* m, float* v, long long n
                        double eps, int* step_dev, float* bc_dev, float grad_scale, srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Data-parallel exchange over RCCL (xGMI): one process per GPU, ONE in-place sum all-reduce of the flat fp32 bucket per
+ * training step (gradients + scalar tail).  New — the reference is single-device (models/learner.py:65,187); the call
+ * sits between loss.backward() (learner.py:489) and optimizer.step() (learner.py:495).
+ * Rank 0 calls srlz_comm_unique_id() and shares the srlz_comm_unique_id_bytes() bytes with every rank (any host
+ * rendezvous); every rank then calls srlz_comm_init() once with its HIP device current.  RCCL is dlopen'ed on first use
+ * (the copy already loaded into the process is reused).  id buffers are HOST memory.
+ * ------------------------------------------------------------------------------------------------------------ */
+size_t srlz_comm_unique_id_bytes(void);
+int srlz_comm_unique_id(void* id_out_host);
+int srlz_comm_init(const void* id_host, int rank, int world);
+int srlz_comm_world(void); /* 0 before srlz_comm_init */
+int srlz_comm_allreduce_f32(float* buf, long long n, srlz_stream_t stream);
+int srlz_comm_destroy(void);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Debug / calibration hooks (not on the product path).
  * ------------------------------------------------------------------------------------------------------------ */
 /* Host-only: dump the virtual-grid program of a 64->64 convolution (tests interpret it on the CPU).

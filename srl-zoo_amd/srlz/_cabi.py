@@ -120,13 +120,19 @@ _PROTOS = {
     "srlz_param_norms": (c_int, [P, P, c_int, c_int, c_float, P, P, P]),
     "srlz_param_norms_grad": (c_int, [P, P, P, c_int, c_int, P, P, c_float, P]),
     "srlz_fold_grads": (c_int, [P, P, c_longlong, c_int, P]),
+    "srlz_comm_unique_id_bytes": (c_size_t, []),
+    "srlz_comm_unique_id": (c_int, [P]),
+    "srlz_comm_init": (c_int, [P, c_int, c_int]),
+    "srlz_comm_world": (c_int, []),
+    "srlz_comm_allreduce_f32": (c_int, [P, c_longlong, P]),
+    "srlz_comm_destroy": (c_int, []),
     "srlz_adam_step": (c_int, [P, P, P, P, c_longlong, c_double, c_double, c_double, c_double, c_int, c_float, P]),
     "srlz_adam_step_dev": (c_int, [P, P, P, P, c_longlong, c_double, c_double, c_double, c_double, P, P, c_float, P]),
 }
 
 # entry points whose int return value is data, not a status
 _NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
-               "srlz_conv64_debug_program"}
+               "srlz_conv64_debug_program", "srlz_comm_world"}
 
 EXPORTED = sorted(_PROTOS.keys())
 

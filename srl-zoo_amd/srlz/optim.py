@@ -140,6 +140,53 @@ class FusedAdam(object):
         return int(self.t_dev.item()) if self.device_step else self.t
 
 
+# ---- which collective moves the bucket -------------------------------------------------------------------------------------
+# Default: torch.distributed's all_reduce (backend "nccl" = RCCL), because the launcher, the rendezvous and the process group
+# are torch.distributed's anyway.  SRLZ_COMM=rccl routes the same in-place sum through the library's own C-ABI entry point
+# (srlz_comm_allreduce_f32, include/srlz.h) on a communicator created from a unique id that rank 0 shares through the
+# process group's store — what a host without torch.distributed would bind.
+_native_ready = False
+
+
+def native_comm_requested():
+    import os
+    return os.environ.get("SRLZ_COMM", "torch").lower() == "rccl"
+
+
+def init_native_comm():
+    """Create the process's RCCL communicator through the C ABI (idempotent).  Call after init_process_group (world > 1)
+    with the rank's GPU current."""
+    global _native_ready
+    if _native_ready:
+        return
+    import ctypes
+    from . import _cabi as C
+    rank, size = world()
+    nbytes = C.comm_unique_id_bytes()
+    buf = ctypes.create_string_buffer(nbytes)
+    if rank == 0:
+        C.comm_unique_id(buf)
+    payload = share_from_rank0(buf.raw)
+    C.comm_init(ctypes.create_string_buffer(payload, nbytes), rank, size)
+    _native_ready = True
+
+
+def destroy_native_comm():
+    global _native_ready
+    if _native_ready:
+        from . import _cabi as C
+        C.comm_destroy()
+        _native_ready = False
+
+
+def _sum_across_ranks(t):
+    if _native_ready:
+        from . import _cabi as C
+        C.comm_allreduce_f32(C.ptr(t), t.numel(), C.stream())
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -154,7 +201,7 @@ def allreduce_gradients(flat_params):
     rank, size = world()
     if size == 1:
         return 1.0
-    dist.all_reduce(flat_params.bucket, op=dist.ReduceOp.SUM)
+    _sum_across_ranks(flat_params.bucket)
     return 1.0 / size
 
 
@@ -163,7 +210,7 @@ def allreduce_scalars(flat_params):
     preprocessing/data_loader.py::shardOrder)."""
     _, size = world()
     if size > 1:
-        dist.all_reduce(flat_params.tail, op=dist.ReduceOp.SUM)
+        _sum_across_ranks(flat_params.tail)
 
 
 def average_running_stats(state_dict):

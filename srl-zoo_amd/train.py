@@ -96,6 +96,8 @@ def initDistributed():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     th.cuda.set_device(local_rank)
     th.distributed.init_process_group(backend="nccl")
+    if optim.native_comm_requested():  # SRLZ_COMM=rccl: the bucket travels through srlz_comm_allreduce_f32 (include/srlz.h)
+        optim.init_native_comm()
     return th.distributed.get_rank(), world_size
 
 

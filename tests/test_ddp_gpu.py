@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port):
+def _worker(rank, world, port, native):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.join(os.path.dirname(here), "srl-zoo_amd"), os.path.dirname(here), here):
@@ -33,6 +33,9 @@ def _worker(rank, world, port):
     torch.cuda.set_device(rank)
     import torch.distributed as dist
     dist.init_process_group("nccl", rank=rank, world_size=world)
+    if native:  # the bucket travels through srlz_comm_allreduce_f32 instead of torch.distributed.all_reduce
+        from srlz import optim
+        optim.init_native_comm()
     import golden_util as gu
     import models.learner as learner
     import preprocessing.preprocess as pre
@@ -83,11 +86,15 @@ def _worker(rank, world, port):
     dist.all_gather(gathered, digest)
     assert all(torch.equal(gathered[0], t) for t in gathered)
     dist.barrier()
+    if native:
+        from srlz import optim
+        optim.destroy_native_comm()
     dist.destroy_process_group()
 
 
 @pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on one node")
-def test_two_gpu_step_matches_mean_of_oracle_gradients():
+@pytest.mark.parametrize("native", [False, True], ids=["torch_distributed", "srlz_comm"])
+def test_two_gpu_step_matches_mean_of_oracle_gradients(native):
     import torch.multiprocessing as mp
     world = 2
-    mp.spawn(_worker, args=(world, _free_port()), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), native), nprocs=world, join=True)

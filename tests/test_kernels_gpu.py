@@ -648,3 +648,29 @@ def test_conv1_bwd_data(C, n, c, h):
     C.conv1_bwd_data(C.ptr(dyd), C.ptr(wd), C.ptr(dx), d, C.stream())
     torch.cuda.synchronize()
     assert rel_err(dx, xr.grad) < 2e-5
+
+
+def test_native_comm_single_rank(C):
+    """srlz_comm_* over RCCL (include/srlz.h) with a one-rank communicator on this GPU: unique id, init, in-place sum
+    all-reduce (the identity for one rank), world size, destroy — the C-ABI path a host without torch.distributed binds
+    (SRLZ_COMM=rccl routes the training step's bucket through it; >= 2 ranks are covered by tests/test_ddp_gpu.py)."""
+    import ctypes
+    assert C.comm_world() == 0
+    n = C.comm_unique_id_bytes()
+    assert n == 128
+    buf = ctypes.create_string_buffer(n)
+    C.comm_unique_id(buf)
+    assert any(b != 0 for b in buf.raw)
+    C.comm_init(buf, 0, 1)
+    try:
+        assert C.comm_world() == 1
+        with pytest.raises(C.SrlzError):
+            C.comm_init(buf, 0, 1)  # one communicator per process
+        x = torch.randn(1 << 20, device=DEV)
+        ref = x.clone()
+        C.comm_allreduce_f32(C.ptr(x), x.numel(), C.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+    finally:
+        C.comm_destroy()
+    assert C.comm_world() == 0
