@@ -227,13 +227,11 @@ class SRL4robotics(BaseLearner):
         self.model = self.model.to(self.device)
         self.rank, self.world_size = optim.world()
 
-        # the two frames of a step (obs, next_obs) are independent until the losses: they are encoded/decoded on two
-        # HIP streams so one frame's kernel tails, small layers and HBM-bound passes overlap the other's (autograd runs
-        # each frame's backward on its forward stream).  Opt-in (SRLZ_TWO_STREAMS=1): measured +1 % on MI355X because the big
-        # kernels already fill the chip; the default runs the frames back to back.
-        # hipGraph replay of the step body (see _graphStep), opt-in with SRLZ_GRAPH=1.  Measured on MI355X: 3 % at bs = 32
-        # (3.94 vs 4.06 ms), nothing at bs >= 64 — the ~300 small kernels of a step cost ~10 us each ON THE GPU whether
-        # they are enqueued one by one or replayed from a graph, so the cure for small minibatches is fewer kernels.
+        # SRLZ_TWO_STREAMS=1 (only meaningful with SRLZ_PAIR=0): the two frames of a step encoded / decoded / back-propagated on
+        # two HIP streams — round 1's way of overlapping them (16.7 vs 18.2 ms); superseded by the batched pair below.
+        # SRLZ_GRAPH=1: hipGraph replay of the step body (see _graphStep).  Measured on MI355X: 3 % at bs = 32, nothing at
+        # bs >= 64 — the small kernels of a step cost ~10 us each ON THE GPU whether they are enqueued one by one or replayed
+        # from a graph, so the cure for small minibatches is fewer kernels (which is what the batched pair delivers).
         # The two frames of a step run as ONE batched model call with two BatchNorm groups (SRLModules.forwardPair): half the
         # launches, twice the grid of every small layer, per-call BatchNorm semantics intact.  SRLZ_PAIR=0 restores the two
         # separate calls (A/B, parity tests).

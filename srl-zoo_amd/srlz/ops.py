@@ -129,12 +129,10 @@ def _ws(nbytes, device, slot=0):
     return buf
 
 
-# ---- side stream: weight gradients are off the critical path of backward (nothing downstream of a layer's dW until the
-# optimiser), so they run on a second HIP stream concurrently with the data-gradient chain and, above all, with the
-# HBM-bound BatchNorm-backward kernels that follow it on the main stream (MFMA-bound + HBM-bound work co-resident on
-# the same CUs).  Opt-in with SRLZ_SIDE_STREAM=1: measured +2 % step throughput on MI355X (the big kernels already
-# fill every CU's LDS), at the price of per-kernel timings that no longer describe a kernel running alone — so the
-# default keeps one stream, which is also what bench.py's roofline leg and the rocprofv3 summaries in profiles/ assume.
+# ---- side stream (SRLZ_SIDE_STREAM=1, off by default): weight gradients are off the critical path of backward (nothing
+# downstream of a layer's dW until the optimiser), so they CAN run on a second HIP stream concurrently with the data-gradient
+# chain.  Measured on MI355X it loses: 18.7 vs 17.3 ms per step (round 2), 19.9 vs 18.2 (round 1) — both kernels of such a
+# pair fill the CUs' LDS, so they time-share the chip instead of overlapping.  Kept as an A/B switch only.
 import os as _os
 _USE_SIDE = _os.environ.get("SRLZ_SIDE_STREAM", "0") != "0"
 _side_streams = {}
