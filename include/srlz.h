@@ -192,15 +192,16 @@ int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* 
  * next_obs, models/learner.py:392-393).  Per group the arithmetic is exactly that of a single-group call. */
 int srlz_bn_finalize(const float* stats_partial, int n_partials, int groups, long long count, const float* gamma,
                      const float* beta, float eps, float momentum, int repeat, float* running_mean,
-                     float* running_var, float* bnp, float* batch_stat, void* ws, size_t ws_bytes,
-                     srlz_stream_t stream);
+                     float* running_var, long long* num_batches_tracked /* int64 counter += groups; may be NULL */,
+                     float* bnp, float* batch_stat, void* ws, size_t ws_bytes, srlz_stream_t stream);
 /* A C-channel BatchNorm (C = 64 * chunks) of the frozen ResNet-18 trunk as `chunks` independent 64-channel layers:
  * stats_partial is srlz_convn_fwd's [chunks][tiles][128]; gamma / beta / running_* hold C floats; bnp receives `chunks`
  * records of 256 floats (training-mode forward of nn.BatchNorm2d: batch statistics + one momentum update; the trunk's
  * parameters are frozen but the reference leaves it in train() mode, models/learner.py:365 — so its statistics do move). */
 int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, int chunks, long long count, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                            float* bnp, void* ws, size_t ws_bytes, srlz_stream_t stream);
+                            long long* num_batches_tracked /* += 1; may be NULL */, float* bnp, void* ws, size_t ws_bytes,
+                            srlz_stream_t stream);
 int srlz_bn_eval_params_chunks(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                float eps, int chunks, float* bnp, srlz_stream_t stream);
 /* out = relu(bn(a) + (b_bnp ? bn(b) : b)) over pixels x 64*chunks — BasicBlock's `out = relu(bn2(out) + identity)` */
@@ -285,9 +286,14 @@ int srlz_sqdiff_sum_groups(const float* a, const float* b, long long n_per_group
 /* da[i] = coef_dev[0] * coef * (a[i]-b[i])   (gradient of the above w.r.t. a; coef_dev may be NULL = 1) */
 int srlz_sqdiff_grad(const float* a, const float* b, const float* coef_dev, float coef, float* da, long long n,
                      srlz_stream_t stream);
-/* grouped form: slice g is scaled by coef_dev[g] * coef */
-int srlz_sqdiff_grad_groups(const float* a, const float* b, const float* coef_dev, float coef, float* da,
-                            long long n_per_group, int groups, srlz_stream_t stream);
+/* grouped form: slice g is scaled by (coef_dev[g * coef_stride] / div) * coef   (coef_stride 0: one shared upstream scalar) */
+int srlz_sqdiff_grad_groups(const float* a, const float* b, const float* coef_dev, int coef_stride, float div, float coef,
+                            float* da, long long n_per_group, int groups, srlz_stream_t stream);
+/* The loss of a batched pair a = [a0 ; a1], b = [b0 ; b1] in one go: sums[g] = sum((a_g - b_g)^2) and
+ * comb[0] = sums[0]/n + sums[1]/n (mean != 0: autoEncoderLoss, losses.py:184-196) or sums[0] + sums[1] (generationLoss,
+ * losses.py:199-214), rounded like the reference's separate fp32 operations. */
+int srlz_sqdiff_pair_loss(const float* a, const float* b, long long n_per_group, int mean, float* sums, float* comb,
+                          void* ws, size_t ws_bytes, srlz_stream_t stream);
 /* out = [a ; b] (n_each floats each) — joins the halves of a batched pair (th.cat of learner.py's obs / next_obs) */
 int srlz_join2(const float* a, const float* b, float* out, long long n_each, srlz_stream_t stream);
 /* out[0] = -0.5*sum(1 + logvar - mu^2 - exp(logvar))      kullbackLeiblerLoss 239-256 */

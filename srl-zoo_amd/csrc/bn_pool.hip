@@ -47,7 +47,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, int repeat, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ bnp,
-                                   float* __restrict__ batch_stat, int groups) {
+                                   float* __restrict__ batch_stat, int groups, long long* __restrict__ tick) {
+  // tick (may be NULL): nn.BatchNorm2d.num_batches_tracked, advanced by the number of calls this launch stands for
+  if (tick && blockIdx.x == 0 && threadIdx.x == 0) tick[0] += groups;
   // blockIdx.x > 0 only in CHANNEL-BLOCK mode (srlz_bn_finalize_chunks: a C-channel BatchNorm handled as C/64 independent
   // 64-channel layers, one block each): everything per-channel moves on by 64, the staged partials by one block's rows
   gamma += blockIdx.x * 64; beta += blockIdx.x * 64;
@@ -478,8 +480,8 @@ static int check_pool(const srlz_pool_desc* d) {
 
 extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, int groups, long long count, const float* gamma,
                                 const float* beta, float eps, float momentum, int repeat, float* running_mean,
-                                float* running_var, float* bnp, float* batch_stat, void* ws, size_t ws_bytes,
-                                srlz_stream_t stream) {
+                                float* running_var, long long* num_batches_tracked, float* bnp, float* batch_stat, void* ws,
+                                size_t ws_bytes, srlz_stream_t stream) {
   SRLZ_REQUIRE(stats_partial && gamma && beta && bnp && ws, SRLZ_ERR_NULL, "bn_finalize: null pointer");
   const int G = norm_groups(groups);
   SRLZ_REQUIRE(n_partials > 0 && count > 0 && G <= MAX_GROUPS && n_partials % G == 0, SRLZ_ERR_BAD_DESC,
@@ -491,14 +493,15 @@ extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, int 
   hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, G), dim3(256), 0, as_stream(stream), stats_partial, per, staged);
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (const double*)staged, g, (double)count,
-                     gamma, beta, eps, momentum, repeat, running_mean, running_var, bnp, batch_stat, G);
+                     gamma, beta, eps, momentum, repeat, running_mean, running_var, bnp, batch_stat, G, num_batches_tracked);
   SRLZ_LAUNCHED();
   return 0;
 }
 
 extern "C" int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, int chunks, long long count, const float* gamma,
                                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                                       float* bnp, void* ws, size_t ws_bytes, srlz_stream_t stream) {
+                                       long long* num_batches_tracked, float* bnp, void* ws, size_t ws_bytes,
+                                       srlz_stream_t stream) {
   SRLZ_REQUIRE(stats_partial && gamma && beta && bnp && ws, SRLZ_ERR_NULL, "bn_finalize_chunks: null pointer");
   SRLZ_REQUIRE(tiles > 0 && count > 0 && chunks >= 1 && chunks <= MAX_GROUPS, SRLZ_ERR_BAD_DESC,
                "bn_finalize_chunks: %d tiles, %d channel blocks", tiles, chunks);
@@ -508,7 +511,7 @@ extern "C" int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, in
   hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, chunks), dim3(256), 0, as_stream(stream), stats_partial, tiles, staged);
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(chunks), dim3(1024), 0, as_stream(stream), (const double*)staged, g, (double)count,
-                     gamma, beta, eps, momentum, 1, running_mean, running_var, bnp, (float*)nullptr, 1);
+                     gamma, beta, eps, momentum, 1, running_mean, running_var, bnp, (float*)nullptr, 1, num_batches_tracked);
   SRLZ_LAUNCHED();
   return 0;
 }

@@ -55,10 +55,11 @@ __global__ void reduce_final(const double* __restrict__ partial, int nb, float* 
 
 __global__ __launch_bounds__(256) void sqdiff_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ coef_dev, float coef,
-                                                         float* __restrict__ da, long long n) {
-  // blockIdx.y = group: its slice of n elements and its own upstream coefficient coef_dev[group]
+                                                         float* __restrict__ da, long long n, int coef_stride, float div) {
+  // blockIdx.y = group: its slice of n elements and its upstream coefficient coef_dev[group * coef_stride] (stride 0: one
+  // shared scalar); g = (upstream / div) * coef in exactly that order — what autograd computes for sum(..)/numel
   a += (size_t)blockIdx.y * n; b += (size_t)blockIdx.y * n; da += (size_t)blockIdx.y * n;
-  const float g = (coef_dev ? coef_dev[blockIdx.y] : 1.f) * coef;
+  const float g = ((coef_dev ? coef_dev[blockIdx.y * coef_stride] : 1.f) / div) * coef;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -341,6 +342,21 @@ static int reduce_launch(const float* a, const float* b, long long n, int groups
   return 0;
 }
 
+// The loss of a batched pair in one go: sums[g] = group g's sum (as reduce_final gives it) and
+// comb[0] = sums[0]/n + sums[1]/n (mode 1: reconstructionLoss x 2, losses.py:172-196) or sums[0] + sums[1] (mode 0:
+// F.mse_loss(sum) x 2, losses.py:199-214) with the roundings of the reference's separate fp32 operations.
+__global__ void pair_loss_final(const double* __restrict__ partial, int nb, float* __restrict__ sums, float* __restrict__ comb,
+                                float n, int mode) {
+  const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;  // one wave per group
+  double s = 0.0;
+  for (int i = lane; i < nb; i += 64) s += partial[(size_t)g * nb + i];
+  s = wave_sum_d(s);
+  __shared__ float sm[2];
+  if (lane == 0) { sm[g] = (float)s; sums[g] = (float)s; }
+  __syncthreads();
+  if (threadIdx.x == 0) comb[0] = mode ? (sm[0] / n + sm[1] / n) : (sm[0] + sm[1]);
+}
+
 // out = [a ; b] (n floats each): joins the two halves of a batched pair when they do not already sit next to each other
 __global__ __launch_bounds__(256) void join2_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                    float* __restrict__ out, long long n) {
@@ -373,18 +389,34 @@ extern "C" int srlz_sqdiff_grad(const float* a, const float* b, const float* coe
                                 srlz_stream_t stream) {
   SRLZ_REQUIRE(a && b && da, SRLZ_ERR_NULL, "sqdiff_grad: null pointer");
   hipLaunchKernelGGL(sqdiff_grad_kernel, dim3(blocks_for((n + 3) / 4, 8192)), dim3(256), 0, as_stream(stream), a, b, coef_dev,
-                     coef, da, n);
+                     coef, da, n, 0, 1.0f);
   SRLZ_LAUNCHED();
   return 0;
 }
 
-extern "C" int srlz_sqdiff_grad_groups(const float* a, const float* b, const float* coef_dev, float coef, float* da,
-                                       long long n_per_group, int groups, srlz_stream_t stream) {
+extern "C" int srlz_sqdiff_grad_groups(const float* a, const float* b, const float* coef_dev, int coef_stride, float div,
+                                       float coef, float* da, long long n_per_group, int groups, srlz_stream_t stream) {
   SRLZ_REQUIRE(a && b && da && coef_dev, SRLZ_ERR_NULL, "sqdiff_grad_groups: null pointer");
-  SRLZ_REQUIRE(groups >= 1 && groups <= MAX_GROUPS && (groups == 1 || (n_per_group & 3) == 0), SRLZ_ERR_BAD_DESC,
+  SRLZ_REQUIRE(groups >= 1 && groups <= MAX_GROUPS && (groups == 1 || (n_per_group & 3) == 0) && div != 0.f &&
+               (coef_stride == 0 || coef_stride == 1), SRLZ_ERR_BAD_DESC,
                "sqdiff_grad_groups: groups = %d, %lld elements each", groups, n_per_group);
   hipLaunchKernelGGL(sqdiff_grad_kernel, dim3(blocks_for((n_per_group + 3) / 4, 8192 / groups), groups), dim3(256), 0,
-                     as_stream(stream), a, b, coef_dev, coef, da, n_per_group);
+                     as_stream(stream), a, b, coef_dev, coef, da, n_per_group, coef_stride, div);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_sqdiff_pair_loss(const float* a, const float* b, long long n_per_group, int mean, float* sums, float* comb,
+                                     void* ws, size_t ws_bytes, srlz_stream_t stream) {
+  SRLZ_REQUIRE(a && b && sums && comb && ws, SRLZ_ERR_NULL, "sqdiff_pair_loss: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= 2 * RED_BLOCKS * sizeof(double), SRLZ_ERR_WORKSPACE, "sqdiff_pair_loss: workspace too small");
+  SRLZ_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && (n_per_group & 3) == 0 && n_per_group > 0, SRLZ_ERR_BAD_DESC,
+               "sqdiff_pair_loss: halves must be 16-byte aligned multiples of 4 floats");
+  hipStream_t st = as_stream(stream);
+  const int nb = blocks_for((n_per_group + 3) / 4, RED_BLOCKS);  // per group the geometry of a single-group srlz_sqdiff_sum
+  hipLaunchKernelGGL(reduce_partial<0>, dim3(nb, 2), dim3(256), 0, st, a, b, n_per_group, (double*)ws);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(pair_loss_final, dim3(1), dim3(128), 0, st, (const double*)ws, nb, sums, comb, (float)n_per_group, mean);
   SRLZ_LAUNCHED();
   return 0;
 }

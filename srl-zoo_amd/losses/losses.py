@@ -94,23 +94,20 @@ def inverseModelLoss(actions_pred, actions_st, weight, loss_manager):
     return weight * inverse_loss
 
 
-def _pairSqDiff(a, next_a, b, next_b):
-    """(sum((a-b)^2), sum((next_a-next_b)^2)) in ONE launch when (a, next_a) and (b, next_b) are the halves of batched
-    tensors (the product's batched model call, SRLModules.forwardPair) — each sum exactly what the per-frame kernel gives;
-    None otherwise."""
+def _pairSqDiff(a, next_a, b, next_b, mean):
+    """sum((a-b)^2)/numel + sum((next_a-next_b)^2)/numel (mean) or the plain sum of the two sums, as ONE op when (a, next_a) and
+    (b, next_b) are the halves of batched tensors (the product's batched model call, SRLModules.forwardPair) — every
+    intermediate rounded exactly as the per-frame path rounds it; None otherwise."""
     pa, pb = ops.pair_of(a, next_a), ops.pair_of(b, next_b)
     if pa is None or pb is None:
         return None
-    sums = ops.SqDiffSumPairFn.apply(pa, pb)
-    return sums[0], sums[1]
+    return ops.SqDiffPairLossFn.apply(pa, pb, mean)
 
 
 def autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs, weight, loss_manager):
     """reconstruction error of both frames (reference losses.py:184-196)."""
-    pair = _pairSqDiff(obs, next_obs, decoded_obs, decoded_next_obs)
-    if pair is not None:
-        ae_loss = pair[0] / obs.numel() + pair[1] / next_obs.numel()
-    else:
+    ae_loss = _pairSqDiff(obs, next_obs, decoded_obs, decoded_next_obs, True)
+    if ae_loss is None:
         ae_loss = reconstructionLoss(obs, decoded_obs) + reconstructionLoss(next_obs, decoded_next_obs)
     loss_manager.addToLosses('reconstruction_loss', weight, ae_loss)
     return weight * ae_loss
@@ -118,10 +115,8 @@ def autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs, weight, loss_m
 
 def generationLoss(decoded, next_decoded, obs, next_obs, weight, loss_manager):
     """pixel-wise summed squared error of both frames (reference losses.py:199-214)."""
-    pair = _pairSqDiff(decoded, next_decoded, obs, next_obs)
-    if pair is not None:
-        generation_loss = pair[0] + pair[1]
-    else:
+    generation_loss = _pairSqDiff(decoded, next_decoded, obs, next_obs, False)
+    if generation_loss is None:
         generation_loss = ops.SqDiffSumFn.apply(decoded, obs) + ops.SqDiffSumFn.apply(next_decoded, next_obs)
     loss_manager.addToLosses('generation_loss', weight, generation_loss)
     return weight * generation_loss

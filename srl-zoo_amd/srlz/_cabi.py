@@ -68,7 +68,7 @@ _PROTOS = {
     "srlz_convn_pack_weights": (c_int, [P, P, _CN, P]),
     "srlz_convn_fwd_tiles": (c_int, [_CN]),
     "srlz_convn_fwd": (c_int, [P, P, P, P, P, _CN, P]),
-    "srlz_bn_finalize_chunks": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, P, P, P, P, c_size_t, P]),
+    "srlz_bn_finalize_chunks": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params_chunks": (c_int, [P, P, P, P, c_float, c_int, P, P]),
     "srlz_bn_add_relu": (c_int, [P, P, P, P, P, c_longlong, c_int, P]),
     "srlz_avgpool_nhwc": (c_int, [P, P, c_int, c_int, c_int, P]),
@@ -87,7 +87,7 @@ _PROTOS = {
     "srlz_convT_out_bwd_data": (c_int, [P, P, P, P, P, P, _SK, P]),
     "srlz_bn_bwd_finalize_partials": (c_int, [P, c_int, c_int, P, P, P, P, c_size_t, P]),
     "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _SK, P]),
-    "srlz_bn_finalize": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, c_size_t, P]),
+    "srlz_bn_finalize": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),
     "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),
     "srlz_bn_relu_pool_fwd": (c_int, [P, P, P, P, _PD, P]),
@@ -107,7 +107,8 @@ _PROTOS = {
     "srlz_sqdiff_sum": (c_int, [P, P, c_longlong, P, P, c_size_t, P]),
     "srlz_sqdiff_grad": (c_int, [P, P, P, c_float, P, c_longlong, P]),
     "srlz_sqdiff_sum_groups": (c_int, [P, P, c_longlong, c_int, P, P, c_size_t, P]),
-    "srlz_sqdiff_grad_groups": (c_int, [P, P, P, c_float, P, c_longlong, c_int, P]),
+    "srlz_sqdiff_grad_groups": (c_int, [P, P, P, c_int, c_float, c_float, P, c_longlong, c_int, P]),
+    "srlz_sqdiff_pair_loss": (c_int, [P, P, c_longlong, c_int, P, P, P, c_size_t, P]),
     "srlz_join2": (c_int, [P, P, P, c_longlong, P]),
     "srlz_kl_sum": (c_int, [P, P, c_longlong, P, P, c_size_t, P]),
     "srlz_kl_grad": (c_int, [P, P, P, c_float, P, P, c_longlong, P]),

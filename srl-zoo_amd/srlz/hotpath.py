@@ -31,15 +31,15 @@ _DEFER_BN_BWD = os.environ.get("SRLZ_DEFER_BN_BWD", "1") != "0"
 
 
 def _bn_args(bn):
+    # nn.BatchNorm2d increments num_batches_tracked once per training-mode call: the counter travels with the running mean
+    # (ops._bn_params hands it to srlz_bn_finalize, which advances it by the number of calls the launch stands for)
+    bn.running_mean._srlz_tick = bn.num_batches_tracked
     return bn.weight, bn.bias, bn.running_mean, bn.running_var
 
 
 def _tick(bn, training):
-    # nn.BatchNorm2d increments num_batches_tracked once per training-mode call (ordered with the other stream's
-    # updates of the same layer when the two frames of a step run on two streams)
-    if training and bn.num_batches_tracked is not None:
-        groups = ops.cur_groups(training)  # a batched pair is `groups` calls of the layer
-        ops._ordered_bn_update(bn.running_mean, lambda: bn.num_batches_tracked.add_(groups))
+    """(kept as a no-op marker of where the reference's layer call sits; the count happens inside srlz_bn_finalize)"""
+    return None
 
 
 def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
@@ -136,10 +136,9 @@ def _bn_record(bn, stats, tiles, count, training, device):
     if training:
         nbytes = ops.C.bn_bwd_workspace(0)
         ws = ops._ws(nbytes, device)
-        bn.num_batches_tracked.add_(1)
         ops.C.bn_finalize_chunks(ops.ptr(stats), tiles, chunks, count, ops.ptr(bn.weight), ops.ptr(bn.bias), ops.BN_EPS,
-                                 ops.BN_MOMENTUM, ops.ptr(bn.running_mean), ops.ptr(bn.running_var), ops.ptr(bnp), ops.ptr(ws),
-                                 nbytes, ops.stream())
+                                 ops.BN_MOMENTUM, ops.ptr(bn.running_mean), ops.ptr(bn.running_var),
+                                 ops.ptr(bn.num_batches_tracked), ops.ptr(bnp), ops.ptr(ws), nbytes, ops.stream())
     else:
         ops.C.bn_eval_params_chunks(ops.ptr(bn.weight), ops.ptr(bn.bias), ops.ptr(bn.running_mean), ops.ptr(bn.running_var),
                                     ops.BN_EPS, chunks, ops.ptr(bnp), ops.stream())

@@ -321,6 +321,8 @@ def _bn_params(stats, count, gamma, beta, running_mean, running_var, training, d
     """BatchNorm record(s) of a layer: training -> one 256-float record per group from the producing convolution's
     per-tile partials (`count` = positions of ALL groups together), eval -> one record from the running statistics."""
     groups = cur_groups(training)
+    if tick is None:
+        tick = getattr(running_mean, "_srlz_tick", None)  # num_batches_tracked of the layer (hotpath._bn_args)
     bnp = torch.empty(256 * groups, dtype=torch.float32, device=device)
     batch_stat = None
     if training:
@@ -328,11 +330,9 @@ def _bn_params(stats, count, gamma, beta, running_mean, running_var, training, d
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, device)
 
-        def update():
-            if tick is not None:
-                tick.add_(groups)  # num_batches_tracked
+        def update():  # (tick = num_batches_tracked: advanced by `groups` inside the same launch)
             C.bn_finalize(ptr(stats), stats.shape[0], groups, count // groups, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, 1,
-                          ptr(running_mean), ptr(running_var), ptr(bnp), ptr(batch_stat), ptr(ws), nbytes, stream())
+                          ptr(running_mean), ptr(running_var), ptr(tick), ptr(bnp), ptr(batch_stat), ptr(ws), nbytes, stream())
         _ordered_bn_update(running_mean, update)
     else:
         C.bn_eval_params(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS, ptr(bnp), stream())
@@ -873,33 +873,37 @@ def pair_of(a, b):
     return None
 
 
-class SqDiffSumPairFn(Function):
-    """(sum((a0-b0)^2), sum((a1-b1)^2)) for the two halves of batched tensors a, b [2B, ...]: one launch, each sum exactly
-    what SqDiffSumFn computes on that half; one gradient tensor for each batched input."""
+class SqDiffPairLossFn(Function):
+    """The reconstruction (mean=True: sum/numel per frame, added) or generation (mean=False: sums added) loss of BOTH frames
+    from batched tensors a, b [2B, ...] as ONE scalar: two launches forward, one backward, no scalar glue kernels.  Each
+    frame's sum and the combination are rounded exactly like the two-call path's separate fp32 operations."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, mean):
         a, b = _check(a, "loss input"), _check(b, "loss target")
         assert a.shape == b.shape and a.shape[0] % 2 == 0
-        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        sums = torch.empty(2, dtype=torch.float32, device=a.device)
+        comb = torch.empty((), dtype=torch.float32, device=a.device)
         nbytes = C.reduce_workspace(a.numel())
         ws = _ws(nbytes, a.device)
-        C.sqdiff_sum_groups(ptr(a), ptr(b), a.numel() // 2, 2, ptr(out), ptr(ws), nbytes, stream())
+        C.sqdiff_pair_loss(ptr(a), ptr(b), a.numel() // 2, 1 if mean else 0, ptr(sums), ptr(comb), ptr(ws), nbytes, stream())
         ctx.save_for_backward(a, b)
-        return out
+        ctx.div = float(a.numel() // 2) if mean else 1.0
+        return comb
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = _check(g, "loss grad")
         da = db = None
+        n = a.numel() // 2
         if ctx.needs_input_grad[0]:
             da = torch.empty_like(a)
-            C.sqdiff_grad_groups(ptr(a), ptr(b), ptr(g), 2.0, ptr(da), a.numel() // 2, 2, stream())
+            C.sqdiff_grad_groups(ptr(a), ptr(b), ptr(g), 0, ctx.div, 2.0, ptr(da), n, 2, stream())
         if ctx.needs_input_grad[1]:
             db = torch.empty_like(b)
-            C.sqdiff_grad_groups(ptr(a), ptr(b), ptr(g), -2.0, ptr(db), a.numel() // 2, 2, stream())
-        return da, db
+            C.sqdiff_grad_groups(ptr(a), ptr(b), ptr(g), 0, ctx.div, -2.0, ptr(db), n, 2, stream())
+        return da, db, None
 
 
 class KLSumFn(Function):

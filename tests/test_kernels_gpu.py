@@ -212,7 +212,7 @@ def test_bn_relu_pool(C, n, h, pad, out_nchw, training):
         bstat = torch.empty(128, device=DEV)
         fws = torch.empty(C.bn_bwd_workspace(0), dtype=torch.uint8, device=DEV)
         C.bn_finalize(C.ptr(parts), parts.shape[0], 1, n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
-                      C.ptr(rvd), C.ptr(bnp), C.ptr(bstat), C.ptr(fws), fws.numel(), st)
+                      C.ptr(rvd), None, C.ptr(bnp), C.ptr(bstat), C.ptr(fws), fws.numel(), st)
         torch.cuda.synchronize()
         assert rel_err(rmd, rm_r) < 1e-5 and rel_err(rvd, rv_r) < 1e-5
     else:
@@ -253,7 +253,7 @@ def test_bn_relu(C, n, h, training):
         parts = _partials(nhwc(y)).to(DEV)
         fws = torch.empty(C.bn_bwd_workspace(0), dtype=torch.uint8, device=DEV)
         C.bn_finalize(C.ptr(parts), parts.shape[0], 1, n * h * h, C.ptr(gd), C.ptr(bd), 1e-5, 0.1, 1, C.ptr(rmd),
-                      C.ptr(rvd), C.ptr(bnp), None, C.ptr(fws), fws.numel(), st)
+                      C.ptr(rvd), None, C.ptr(bnp), None, C.ptr(fws), fws.numel(), st)
     else:
         C.bn_eval_params(C.ptr(gd), C.ptr(bd), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(bnp), st)
     a = torch.full((n, h, h, 64), float("nan"), device=DEV)
@@ -537,7 +537,7 @@ def test_fused_bn_backward_operand(C, n, hi, s, p, t, training):
     if training:
         bstat = torch.empty(128, device=DEV)
         C.bn_finalize(C.ptr(stats), stats.shape[0], 1, n * ho * ho, C.ptr(gd), C.ptr(bed), 1e-5, 0.1, 1, C.ptr(rmd), C.ptr(rvd),
-                      C.ptr(bnp), C.ptr(bstat), C.ptr(bws), nbn, st)
+                      None, C.ptr(bnp), C.ptr(bstat), C.ptr(bws), nbn, st)
     else:
         C.bn_eval_params(C.ptr(gd), C.ptr(bed), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(bnp), st)
     sums, dgm, dbt = torch.empty(128, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
