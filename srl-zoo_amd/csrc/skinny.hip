@@ -10,6 +10,7 @@
 // ds_read_b32) and is re-used by all taps; im2col is never materialised.  fp32 MFMA 32x32x2 (16x16x4 for the
 // 48-column convT GEMM).  Channels are processed in groups of 3 (C=6/9 multi-view loops over groups).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -372,7 +373,13 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
                                                              const float* __restrict__ feat,
                                                              float* __restrict__ partial, int N, int C, int H, int W,
                                                              int HF, int WF, int tiles_y, int tiles_x,
-                                                             const float* __restrict__ feat_bnp, const PoolFuse pf, int npg) {
+                                                             const float* __restrict__ feat_bnp, const PoolFuse pf, int npg,
+                                                             int dephase) {
+  // dephase: the second resident workgroup of every CU (blocks >= gridDim.x / 2 of the persistent grid) starts `dephase`
+  // x ~8k cycles late, so that its operand-staging phases fall into the other workgroup's MFMA phases instead of both
+  // staging (and then both multiplying) at the same time
+  if (dephase > 0 && blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < dephase; ++i) __builtin_amdgcn_s_sleep(127);
   // npg = images per BatchNorm group: image n uses the records feat_bnp / pf.bnp [(n / npg) * 256 ..], pf.sums [(n / npg) * 128 ..]
   constexpr int KT = Geo<K>::KT;
   constexpr int NT = (KT + 31) / 32;
@@ -814,8 +821,9 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
   float* partial = (float*)ws;
   PoolFuse pf = {};
   if (pfuse) pf = *pfuse;
+  static const int dephase = [] { const char* e = getenv("SRLZ_DEPHASE"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                     d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d));
+                     d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,

@@ -15,7 +15,7 @@ mkdir -p gpurun_out
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_ae_bs256.json 2> gpurun_out/${tag}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --losses vae > gpurun_out/${tag}_bench_vae_bs256.json 2>> gpurun_out/${tag}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --losses autoencoder inverse forward > gpurun_out/${tag}_bench_aeif_bs256.json 2>> gpurun_out/${tag}_bench.err
-python bench.py --steps 50 --warmup 10 --no-cpu-baseline --batch-size 32 > gpurun_out/${tag}_bench_ae_bs32.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-timers --batch-size 32 > gpurun_out/${tag}_bench_ae_bs32.json 2>> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline \
     > gpurun_out/${tag}_bench_ae_bs256_profiled.json 2> /dev/null
 cp "$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_bench_ae_bs256_kernel_stats.csv
