@@ -310,7 +310,10 @@ class SRL4robotics(BaseLearner):
     def _forwardPair(self, x, next_x):
         """(self.model(x), self.model(next_x)) — in that program order for the BatchNorm running statistics, but
         enqueued on two streams."""
-        if self._use_pair and self._frame_streams is None and x.shape == next_x.shape:
+        # (one launch takes at most 65535 / 57 = 1149 images — the pooling kernels' grid.y, DESIGN.md §2 — so a batched pair
+        # needs 2 B <= 1149; larger minibatches fall back to the two calls)
+        if self._use_pair and self._frame_streams is None and x.shape == next_x.shape and 2 * x.shape[0] <= 1149 \
+                and not self.use_triplets:
             return self.model.forwardPair(x, next_x)
         if self._frame_streams is None:
             return self.model(x), self.model(next_x)

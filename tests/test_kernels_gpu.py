@@ -111,7 +111,7 @@ def test_conv64_deterministic(C):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("n,c,h", [(2, 3, 224), (1, 6, 224), (2, 3, 64)])
+@pytest.mark.parametrize("n,c,h", [(2, 3, 224), (1, 6, 224), (2, 3, 64), (1, 9, 96)])
 def test_conv1(C, n, c, h):
     g = torch.Generator().manual_seed(c * 100 + h)
     x = torch.randn(n, c, h, h, generator=g)
@@ -141,7 +141,7 @@ def test_conv1(C, n, c, h):
     assert rel_err(dw, wr.grad) < 2e-5
 
 
-@pytest.mark.parametrize("n,c,hf", [(2, 3, 111), (1, 6, 111), (3, 3, 20)])
+@pytest.mark.parametrize("n,c,hf", [(2, 3, 111), (1, 6, 111), (3, 3, 20), (1, 9, 30)])
 def test_convT_out(C, n, c, hf):
     g = torch.Generator().manual_seed(c * 10 + hf)
     himg = (hf - 1) * 2 + 4
@@ -459,7 +459,7 @@ def test_fused_bn_relu_operand(C):
     assert rel_err(dwt, wtr.grad) < 2e-5
 
 
-@pytest.mark.parametrize("n,c", [(3, 3), (2, 6)])
+@pytest.mark.parametrize("n,c", [(3, 3), (2, 6), (2, 9)])
 def test_normalize_u8_bit_exact(C, n, c):
     """uint8 frames -> normalised fp32 [N,C,W,H]: bit-identical to the host arithmetic of the reference's loader."""
     from preprocessing.utils import preprocessInput
