@@ -277,6 +277,13 @@ def main():
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "final_loss": round(last_losses[-1], 6)},
         }
+        # whole-step arithmetic intensity check (2317.3 MFLOP per 224x224x3 image and train step for the AE,
+        # 2320.0 for the VAE; heads are negligible): algorithmic FLOP of the step / wall time, against the same fp32-matrix peak
+        if channels == 3 and "triplet" not in args.losses:
+            per_image = 2320.0e6 if "vae" in args.losses else 2317.3e6
+            step_tf = per_image * 2 * B / (dt / args.steps) / 1e12
+            out["step_roofline"] = {"algorithmic_tflop_per_step": round(per_image * 2 * B / 1e12, 4),
+                                    "achieved_tflops": round(step_tf, 2), "frac_of_fp32_mfma_peak": round(step_tf / PEAK_FP32_MFMA_TFLOPS, 4)}
         rep = ops.timers_report()
         k = rep.get("conv64_fwd_kernel")
         if k and k["ms"] > 0:
