@@ -811,7 +811,8 @@ static int make_bwd_fuse(OpFuse* f, const srlz_bn_bwd_operand* o, const char* wh
 static int wgrad_grid(const ConvProg& P) {
   const int tk = wgrad_tk(P);
   const int nchunks = (P.total_q + tk - 1) / tk;  // per group
-  int g = 2 * srlz_device_cus() / P.G;            // per group
+  static const int per_cu = [] { const char* e = getenv("SRLZ_WGRAD_PER_CU"); return (e && atoi(e) == 1) ? 1 : 2; }();
+  int g = per_cu * srlz_device_cus() / P.G;      // per group
   if (g > nchunks) g = nchunks;
   if (g < 1) g = 1;
   return g * P.G;

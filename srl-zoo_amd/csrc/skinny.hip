@@ -773,8 +773,9 @@ static size_t conv_lds() { return (size_t)(Geo<K>::TILE_FLOATS + Geo<K>::KS * 12
 
 static int images_per_group(const srlz_skinny_desc* d) { return d->n / (d->groups > 1 ? d->groups : 1); }
 
-static int persistent_grid(int ntiles) {
-  int g = 2 * srlz_device_cus();
+static int persistent_grid(int ntiles, bool wgrad = false) {
+  static const int wgrad_per_cu = [] { const char* e = getenv("SRLZ_WGRAD_PER_CU"); return (e && atoi(e) == 1) ? 1 : 2; }();
+  int g = (wgrad ? wgrad_per_cu : 2) * srlz_device_cus();
   return g > ntiles ? ntiles : g;
 }
 
@@ -804,7 +805,7 @@ template <int K>
 static size_t wgrad_ws(const srlz_skinny_desc* d) {
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
-  const int g = persistent_grid(d->n * ty * tx);
+  const int g = persistent_grid(d->n * ty * tx, true);
   return (size_t)(d->c / 3) * g * 2 * 64 * NT * 32 * sizeof(float) + (size_t)d->n * d->c * sizeof(double);
 }
 
@@ -814,7 +815,7 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
-  const int g = persistent_grid(ntiles);
+  const int g = persistent_grid(ntiles, true);
   SRLZ_REQUIRE(ws_bytes >= wgrad_ws<K>(d), SRLZ_ERR_WORKSPACE, "skinny wgrad: workspace too small (%zu)", ws_bytes);
   SRLZ_REQUIRE(K == 4 || feat_bnp == nullptr, SRLZ_ERR_BAD_DESC, "skinny wgrad: a fused forward operand exists for the 4x4 layer only");
   const size_t lds = (size_t)(Geo<K>::TILE_FLOATS + 128 * 64) * 4;
