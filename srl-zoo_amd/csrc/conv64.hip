@@ -38,7 +38,7 @@ struct ConvProg {
   int tsrc[NTAPS], tdst[NTAPS], toff[NTAPS], tw[NTAPS];
   int min_off, span;
   int s2;          // 1 if taps are grouped {4,2,2,1} by class, 0 if a single group of 9
-  int dbg;         // ablation switches for tools/kbench.py (env SRLZ_ABLATE): 1 skip A staging, 2 skip epilogue, 4 skip B staging
+  int dbg;         // ablation switches for tools/kbench.py (env SRLZ_ABLATE): 1 skip A staging, 2 skip epilogue
 };
 
 struct Axis {
@@ -203,24 +203,35 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
     unsigned okmask = 0;
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
-      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int y = a * stride + cy, x = b * stride + cx;
       const bool ok = base + RP * j < nrows && n1 >= 1 && n1 <= N1max && y < H && x < W;
       okmask |= (ok ? 1u : 0u) << j;
-      if (ok) {
-        const size_t off = ((size_t)((n1 - 1) * H + y) * W + x) * cstride + coff + slot * 4;
-        v[j] = *(const f32x4*)(src + off);
-        if (BWD) { yv[j] = *(const f32x4*)(f.y + off); offs[j] = off; }
-      }
+      // Branch-free: a padding row reads pixel 0 (always valid) and is zeroed when it is consumed.  With a load inside a branch the
+      // compiler cannot tell, after the join, which loads are still in flight; every later first write of a register such a load
+      // once targeted then gets "s_waitcnt vmcnt(0)" — in the caller that was the first MFMA of each tap, i.e. the prefetch of the
+      // next weight slab was waited for before the MFMAs it is meant to hide behind.
+      const size_t off = (ok ? ((size_t)((n1 - 1) * H + y) * W + x) * cstride : (size_t)0) + coff + slot * 4;
+      v[j] = *(const f32x4*)(src + off);
+      if (BWD) { yv[j] = *(const f32x4*)(f.y + off); offs[j] = off; }
       b += sb; a += sa;
       if (b >= PW) { b -= PW; ++a; }
       if (a >= PH) { a -= PH; ++n1; }
+    }
+    // All loads of the batch are waited for HERE, once, in straight-line code: the rows below are consumed inside branches, and
+    // after a branch join the compiler no longer knows which loads have landed.  It then protects every later re-use of one of
+    // these registers with "s_waitcnt vmcnt(0)": in the fused data-gradient that wait sat behind every dy_out store (one HBM
+    // round trip per store), in the caller's tap loop in front of the first MFMA of every tap (defeating the slab prefetch).
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      asm volatile("" : "+v"(v[j]));
+      if (BWD) asm volatile("" : "+v"(yv[BWD ? j : 0]));
     }
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       const int R = base + RP * j;
       if (R < nrows) {
-        if (bnp && ((okmask >> j) & 1u)) {
+        if (!((okmask >> j) & 1u)) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (bnp) {
           if (BWD) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -355,17 +366,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
       }
       cur_src = tsrc;
     }
-    if (!(P.dbg & 4)) {
+    {
       f32x4* wdst = (f32x4*)Bs;
 #pragma unroll
       for (int i = 0; i < BV; ++i) wdst[i * NT + tid] = breg[i];
     }
     __syncthreads();
-    if (ti + 1 < NTAPS && !(P.dbg & 4)) {
+    if (ti + 1 < NTAPS) {  // (compile-time condition: a run-time one turns the requests into a branch the MFMAs get hoisted above)
       const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[ti + 1] * 4096);
 #pragma unroll
       for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
     }
+    __builtin_amdgcn_sched_barrier(0);  // the slab requests go out HERE, ahead of the tap's MFMAs (the scheduler sinks them otherwise)
     const int R = wrow * 32 + l31 + P.toff[ti] - P.min_off;
     const float* arow = As + R * 64;
     const int akey = R & 15;

@@ -78,41 +78,81 @@ __device__ __forceinline__ void stage_image(float* __restrict__ T, const float* 
 }
 
 // The same staging split in two (request into registers / land in LDS) for software-pipelined callers.
+// Element j of a thread is window element idx = tid + 256*j = (channel c, window row, window column xl); its decomposition is
+// tile-independent and is kept PACKED in one register per element (pk, set once by image_index).  Left to itself the compiler
+// hoists the unpacked (c, row, xl, LDS offset) of every element out of the caller's persistent tile loop — ~3 registers per
+// element for the whole kernel, which is what pushed these kernels into scratch; the opaque copy below keeps the (cheap) unpacking
+// inside the loop.
 template <int K>
 struct ImgRegs {
   static constexpr int TOT = 3 * Geo<K>::ROWS * Geo<K>::COLS;
   static constexpr int PER = (TOT + 255) / 256;
-  float v[PER];
+  int pk[PER];       // (c << 12) | (row << 6) | xl, or -1 past the end of the window
+  float v[PER];      // raw loads (from a clamped address when the element is outside the image)
+  unsigned inside;   // bit j: element j is inside the image; applied when the value LANDS — a select (or a branch merge) at the
+                     // request would make the compiler wait for the load right there, and nothing would travel under the MFMAs
 };
 
-template <int K, int PAD>
-__device__ __forceinline__ void image_request(ImgRegs<K>& r, const float* __restrict__ img, int n, int C, int cg, int H,
-                                              int W, int oy0, int ox0, bool valid) {
+template <int K>
+__device__ __forceinline__ void image_index(ImgRegs<K>& r) {
   constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS, TOT = ImgRegs<K>::TOT;
-  const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
 #pragma unroll
   for (int j = 0; j < ImgRegs<K>::PER; ++j) {
     const int idx = threadIdx.x + 256 * j;
     const int c = idx / (ROWS * COLS);
     const int rem = idx - c * (ROWS * COLS);
     const int row = rem / COLS, xl = rem - row * COLS;
-    const int iy = iy0 + row, ix = ix0 + xl;
-    r.v[j] = 0.f;
-    if (valid && idx < TOT && iy >= 0 && iy < H && ix >= 0 && ix < W)
-      r.v[j] = img[((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix];
+    r.pk[j] = idx < TOT ? ((c << 12) | (row << 6) | xl) : -1;
   }
 }
 
-template <int K>
-__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K>& r) {
-  constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS, TOT = ImgRegs<K>::TOT;
+// (channel, window row, window column) of element j; false past the end of the window.
+// HOIST: straight from the thread index — tile-independent, so the compiler keeps all of it in registers across the caller's tile
+// loop; otherwise unpacked from pk behind an opaque copy, i.e. recomputed at every use.
+template <int K, bool HOIST>
+__device__ __forceinline__ bool image_decode(const ImgRegs<K>& r, int j, int& c, int& row, int& xl) {
+  if (HOIST) {
+    constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS;
+    const int idx = threadIdx.x + 256 * j;
+    c = idx / (ROWS * COLS);
+    const int rem = idx - c * (ROWS * COLS);
+    row = rem / COLS; xl = rem - row * COLS;
+    return idx < ImgRegs<K>::TOT;
+  }
+  int pk = r.pk[j];
+  asm volatile("" : "+v"(pk));
+  c = pk >> 12; row = (pk >> 6) & 63; xl = pk & 63;
+  return pk >= 0;
+}
+
+// HOIST = true: the unpacked decomposition may live in registers for the whole kernel (no opaque copy): ~35 more registers, ~270
+// fewer VALU instructions per tile — worth it where the registers exist (conv1 forward: 1.10 vs 1.16 ms).
+template <int K, int PAD, bool HOIST = false>
+__device__ __forceinline__ void image_request(ImgRegs<K>& r, const float* __restrict__ img, int n, int C, int cg, int H,
+                                              int W, int oy0, int ox0, bool valid) {
+  const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
+  r.inside = 0;
 #pragma unroll
   for (int j = 0; j < ImgRegs<K>::PER; ++j) {
-    const int idx = threadIdx.x + 256 * j;
-    const int c = idx / (ROWS * COLS);
-    const int rem = idx - c * (ROWS * COLS);
-    const int row = rem / COLS, xl = rem - row * COLS;
-    if (idx < TOT) T[(c * 2 + (xl & 1)) * Geo<K>::PP + row * XP + (xl >> 1)] = r.v[j];
+    int c, row, xl;
+    const bool live = image_decode<K, HOIST>(r, j, c, row, xl);
+    const int iy = iy0 + row, ix = ix0 + xl;
+    const bool ok = valid && live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    r.v[j] = img[ok ? ((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix : (size_t)0];
+    r.inside |= (ok ? 1u : 0u) << j;
+  }
+}
+
+template <int K, bool HOIST = false>
+__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K>& r) {
+#pragma unroll
+  for (int j = 0; j < ImgRegs<K>::PER; ++j) {
+    int c, row, xl;
+    const bool live = image_decode<K, HOIST>(r, j, c, row, xl);
+    // (branch-free — elements past the end of the window go to a spare float of the first plane's padding: a wait inside a branch
+    // leaves the compiler unsure, at the join, whether the load has landed, and it then waits for EVERYTHING at the next re-use
+    // of the register, including the loads meant to stay in flight)
+    T[live ? (c * 2 + (xl & 1)) * Geo<K>::PP + row * XP + (xl >> 1) : Geo<K>::PP - 1] = ((r.inside >> j) & 1u) ? r.v[j] : 0.f;
   }
 }
 
@@ -121,7 +161,7 @@ __device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<
 // 256 threads, tile = 16x16 output pixels; wave w owns tile rows 4w..4w+3 (two 32-pixel M-tiles) x 64 channels.
 // Persistent over tiles; for C == 3 the 64 x KT weight matrix is staged in LDS once per workgroup.
 // ------------------------------------------------------------------------------------------------------------------
-template <int K, int PAD, bool BNBWD = false>
+template <int K, int PAD, bool BNBWD = false, bool MULTI = false>
 __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __restrict__ img,
                                                             const float* __restrict__ w_ref,
                                                             float* __restrict__ feat,
@@ -138,6 +178,14 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
   float* T = (float*)smem;                      // image window
   float* Wl = T + Geo<K>::TILE_FLOATS;          // [KS][2][64]
   float* red = Wl + KS * 128;                   // [4][128]
+  // PIPE (every use but the one that also prefetches y_raw, which has no registers to spare): the image window of the NEXT
+  // (tile, channel group) is requested into registers right after the barrier that publishes the current one, travels under
+  // the MFMA loop and lands in T after the barrier that ends it, so no HBM round trip sits between two barriers; the
+  // epilogue then transposes through its own 16 KB (E) instead of through T.
+  constexpr bool PIPE = !BNBWD;
+  constexpr bool HOIST = (K == 7) && !BNBWD;  // the LDS offsets of the landing are kept in registers (see image_decode); the request
+                                              // side (3 values per element) unpacks from pk — hoisting both spills
+  float* E = PIPE ? red + 512 : T;              // [4 waves][16 pixels][64 channels]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -153,13 +201,25 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
       Wl[idx] = v;
     }
   };
-  if (ncg == 1) stage_weights(0);
+  // MULTI (C = 6 / 9: more than one group of 3 image channels) re-stages the weights per group inside the tile loop; its own
+  // instantiation, because the staging loop's loads in the middle of the pipeline cost the single-group kernel a full
+  // "s_waitcnt vmcnt(0)" in front of every MFMA loop (the compiler merges the two paths conservatively)
+  if (!MULTI) stage_weights(0);
 
   const int tx = l31 & 15, tyl = l31 >> 4;
   const int pb0 = 2 * (wave * 4 + tyl) * XP + tx;        // M-tile 0: tile rows 4w, 4w+1
   const int pb1 = pb0 + 4 * XP;                          // M-tile 1: tile rows 4w+2, 4w+3
   const float* wl0 = Wl + h * 64 + l31;
 
+  ImgRegs<K> nx;
+  image_index<K>(nx);
+  if (PIPE && (int)blockIdx.x < ntiles) {  // the first window is staged the plain way
+    const int n = blockIdx.x / (tiles_y * tiles_x);
+    const int trem = blockIdx.x - n * (tiles_y * tiles_x);
+    image_request<K, PAD, false>(nx, img, n, C, 0, H, W, (trem / tiles_x) * 16, (trem % tiles_x) * 16, true);
+    image_land<K, HOIST>(T, nx);
+    if (MULTI) stage_weights(0);
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_y * tiles_x);
     const int trem = tile - n * (tiles_y * tiles_x);
@@ -180,20 +240,31 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
 
     for (int cg = 0; cg < ncg; ++cg) {
       __syncthreads();
-      stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
-      if (ncg > 1) stage_weights(cg);
-      if (BNBWD && cg == 0) {  // (after the image loads: they are waited for first, these stay in flight behind the MFMAs)
+      int cg2 = cg + 1;
+      if (PIPE) {
+        int tile2 = tile;
+        if (cg2 == ncg) { cg2 = 0; tile2 += gridDim.x; }
+        const int n2 = tile2 / (tiles_y * tiles_x);
+        const int trem2 = tile2 - n2 * (tiles_y * tiles_x);
+        image_request<K, PAD, false>(nx, img, n2, C, cg2, H, W, (trem2 / tiles_x) * 16, (trem2 % tiles_x) * 16, tile2 < ntiles);
+      } else {
+        image_request<K, PAD, false>(nx, img, n, C, cg, H, W, oy0, ox0, true);
+        image_land<K, HOIST>(T, nx);
+        if (MULTI) stage_weights(cg);
+      }
+      if (BNBWD && (!MULTI || cg == 0)) {  // (after the image loads: they are waited for first, these stay in flight behind the MFMAs)
 #pragma unroll
         for (int rowq = 0; rowq < 4; ++rowq)
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int oy = oy0 + wave * 4 + rowq, ox = ox0 + it * 4 + eg;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < HF && ox < WF) v = *(const f32x4*)(y_raw + ((size_t)(n * HF + oy) * WF + ox) * 64 + eslot * 4);
-            yv[BNBWD ? rowq * 4 + it : 0] = v;
+            // (branch-free: a pixel outside the feature map reads a clamped address; the epilogue never uses it)
+            const bool ok = oy < HF && ox < WF;
+            yv[BNBWD ? rowq * 4 + it : 0] = *(const f32x4*)(y_raw + (ok ? ((size_t)(n * HF + oy) * WF + ox) * 64 : (size_t)0) + eslot * 4);
           }
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the requests below the MFMA loop, next to their first use)
       }
-      __syncthreads();
+      if (!PIPE) __syncthreads();
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int ko = h ? koff<K>(KS + s) : koff<K>(s);
@@ -204,15 +275,25 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
+      if (PIPE) {
+        __syncthreads();  // every wave is done reading T (and Wl): the next window lands
+        image_land<K, HOIST>(T, nx);
+        if (MULTI) stage_weights(cg2);
+      }
     }
-    __syncthreads();  // every wave is done reading the image window: T becomes the transposition buffer (4 KB per wave)
-    float* Ew = T + wave * 1024;  // [16 pixels of one tile row][64 channels]
+    if (!PIPE) __syncthreads();  // every wave is done reading the image window: T becomes the transposition buffer (4 KB per wave)
+    float* Ew = E + wave * 1024;  // [16 pixels of one tile row][64 channels]
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     f32x4 bmean = s1, binv = s1, bsc = s1, bsh = s1;
     if (BNBWD) {
       const float* __restrict__ yb = y_bnp + (n / npg) * 256;
       bmean = *(const f32x4*)(yb + eslot * 4); binv = *(const f32x4*)(yb + 64 + eslot * 4);
       bsc = *(const f32x4*)(yb + 128 + eslot * 4); bsh = *(const f32x4*)(yb + 192 + eslot * 4);
+      // every load this epilogue consumes is waited for HERE, once: the stores below sit in branches, and at each join the compiler
+      // no longer knows which loads have landed — it would put "s_waitcnt vmcnt(0)" behind every store (one HBM round trip each)
+      asm volatile("" : "+v"(bmean), "+v"(binv), "+v"(bsc), "+v"(bsh));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(yv[BNBWD ? i : 0]));
     }
 #pragma unroll
     for (int rowq = 0; rowq < 4; ++rowq) {
@@ -225,7 +306,10 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
         Ew[il * 64 + 32 + l31] = acc[mt][1][8 * half + rr];
       }
       // (wave-private region: the compiler's lgkmcnt wait orders these writes before the reads below)
-      const int oy = oy0 + wave * 4 + rowq;
+      int oy = oy0 + wave * 4 + rowq;
+      // (opaque: the 16 store addresses are the ones y_raw was prefetched from before the MFMA loop; kept alive across the loop
+      // for re-use they cost 32 registers the BNBWD instantiation does not have)
+      if (BNBWD) asm volatile("" : "+v"(oy));
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int pl = it * 4 + eg, ox = ox0 + pl;
@@ -368,13 +452,14 @@ __global__ __launch_bounds__(256, 2) void conv1_dgrad_kernel(const float* __rest
 // address-path bound (measured 2 TB/s).  Wave w owns M-tile (w&1), ALL N-tiles and 64 of a half's 128 pixels.
 // Persistent over tiles; each (workgroup, w>>1) writes its own partial [64][NT*32] -> skinny_wgrad_reduce.
 // ------------------------------------------------------------------------------------------------------------------
-template <int K, int PAD>
+template <int K, int PAD, bool FUSED = false>
 __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __restrict__ img,
                                                              const float* __restrict__ feat,
                                                              float* __restrict__ partial, int N, int C, int H, int W,
                                                              int HF, int WF, int tiles_y, int tiles_x,
                                                              const float* __restrict__ feat_bnp, const PoolFuse pf, int npg,
                                                              int dephase) {
+  // FUSED (K = 7): the feature operand is rebuilt from (y, argmax, dpooled) by the BatchNorm + ReLU + MaxPool backward (PoolFuse)
   // dephase: the second resident workgroup of every CU (blocks >= gridDim.x / 2 of the persistent grid) starts `dephase`
   // x ~8k cycles late, so that its operand-staging phases fall into the other workgroup's MFMA phases instead of both
   // staging (and then both multiplying) at the same time
@@ -385,13 +470,16 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   constexpr int NT = (KT + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* T = (float*)smem;                  // image window
-  float* F = T + Geo<K>::TILE_FLOATS;       // [128 pixels][64 channels] feature rows of the current half tile
+  float* F = T + Geo<K>::TILE_FLOATS;       // [RPS*16 pixels][64 channels] feature rows of the current stage
+  // A tile is consumed in NSTAGE stages of RPS tile rows (8 = half a tile; 4 for FUSED, whose in-flight state per row is larger)
+  constexpr int RPS = FUSED ? 4 : 8, NSTAGE = 16 / RPS, NWR = RPS / 2 + 1;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int mt = wave & 1, sub = wave >> 1;
   const int cg = blockIdx.y;
   const int ntiles = N * tiles_y * tiles_x;
+  const int tpi = tiles_y * tiles_x;
 
   int kb[NT];  // per-lane LDS offset of this lane's tap in N-tile j (+h: the odd pixel of a k-step is one column on)
 #pragma unroll
@@ -408,152 +496,156 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int slot = tid & 15, prow = tid >> 4;  // feature staging: 16 lanes per pixel row (256 B), 16 pixels per pass
-  // feat_bnp != NULL: `feat` is a raw convolution output and the operand is relu(batchnorm(feat)) (fused, see conv64.hip)
+  // Per-group records, kept in registers and re-read when the tile sequence crosses into the next BatchNorm group:
+  //  * feat_bnp != NULL (K = 4): `feat` is a raw convolution output and the operand is relu(batchnorm(feat)): sc4 / sh4;
+  //  * FUSED: scale / shift of the forward BatchNorm (ReLU mask) and the two coefficients of its backward,
+  //    dy = scale*dz - (c0 + c1*y),  c1 = scale*invstd*S2/count,  c0 = scale*S1/count - c1*mean  (S1 = S2 = 0 in eval mode).
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-  int cur_grp = -1;  // group whose scale / shift sit in sc4 / sh4
-  // Plain (non pool-fused) feature staging is software-pipelined: the 8 rows a thread contributes to the NEXT half tile are
-  // requested before the current half's MFMA loop and written to LDS after it (pv / pmask carry them across).
-  // (K = 4 only: the 7x7 kernel's 160 accumulator registers leave no room for the 32 in-flight registers)
-  constexpr bool piped = (K == 4);
-  f32x4 pv[8];
+  f32x4 fc0 = {0.f, 0.f, 0.f, 0.f}, fc1 = {0.f, 0.f, 0.f, 0.f};
+  int cur_grp = -1;
+  // The staging of both operands is software-pipelined: what a thread contributes to the NEXT stage (RPS feature rows; FUSED:
+  // RPS rows of y plus the <= 2*NWR pooling windows that can have picked them) is REQUESTED into registers before the current
+  // stage's MFMA loop and RESOLVED into LDS after it, and the image window of the next tile travels under the last stage of this one.
+  f32x4 pv[RPS];
   unsigned pmask = 0;
+  f32x4 dpv[FUSED ? NWR : 1][2];
+  uint32_t am[FUSED ? NWR : 1][2];
+  unsigned wmask = 0;  // bit 2r+c: window (r, c) exists
   auto f_request = [&](int tile_, int half_) {
-    const int n_ = tile_ / (tiles_y * tiles_x);
-    const int trem_ = tile_ - n_ * (tiles_y * tiles_x);
+    const int n_ = tile_ / tpi;
+    const int trem_ = tile_ - n_ * tpi;
     const int oy0_ = (trem_ / tiles_x) * 16, ox0_ = (trem_ % tiles_x) * 16;
+    const bool live = tile_ < ntiles;
+    const float* __restrict__ fsrc = FUSED ? pf.y : feat;
     pmask = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {  // pixel p = 16*j + prow of the half: tile row 8*half + j, column prow
-      const int oy = oy0_ + 8 * half_ + j, ox = ox0_ + prow;
-      pv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (tile_ < ntiles && oy < HF && ox < WF) {
-        pv[j] = *(const f32x4*)(feat + ((size_t)(n_ * HF + oy) * WF + ox) * 64 + slot * 4);
-        pmask |= 1u << j;
+    for (int j = 0; j < RPS; ++j) {  // pixel p = 16*j + prow of the stage: tile row RPS*stage + j, column prow
+      const int oy = oy0_ + RPS * half_ + j, ox = ox0_ + prow;
+      const bool ok = live && oy < HF && ox < WF;  // (raw load from a clamped address; the mask is applied in f_resolve — see ImgRegs)
+      pv[j] = *(const f32x4*)(fsrc + (ok ? ((size_t)(n_ * HF + oy) * WF + ox) * 64 : (size_t)0) + slot * 4);
+      pmask |= (ok ? 1u : 0u) << j;
+    }
+    if constexpr (FUSED) {
+      // oyb is even, so the pooling windows (3x3, stride 2, pad 1) that can have picked one of the RPS rows oyb..oyb+RPS-1
+      // are the NWR window rows pb..pb+RPS/2 (pb = oyb/2): an even row r is only the centre (ky=1) of window r/2, an odd row is ky=0
+      // of window (r+1)/2 and ky=2 of window (r-1)/2; same along x with the parity of ox: window column c0 = (ox+1)>>1 seen
+      // through kx = (xodd ? 0 : 1), and c1 = (ox-1)>>1 through kx = 2 (odd ox only).
+      const int oyb = oy0_ + RPS * half_, ox = ox0_ + prow, pb = oyb >> 1;
+      const bool xin = live && ox < WF;
+      const int c0 = (ox + 1) >> 1, c1 = (ox - 1) >> 1;
+      const bool c0ok = xin && c0 < pf.WP, c1ok = xin && (ox & 1) && c1 < pf.WP;
+      wmask = 0;
+#pragma unroll
+      for (int r = 0; r < NWR; ++r) {
+        const bool rok = pb + r < pf.HP;
+        const size_t rowbase = (size_t)(n_ * pf.HP + pb + r) * pf.WP;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bool ok = rok && (c ? c1ok : c0ok);
+          const size_t pp = (ok ? (rowbase + (c ? c1 : c0)) * 64 : (size_t)0) + slot * 4;
+          am[r][c] = *(const uint32_t*)(pf.argmax + pp);
+          dpv[r][c] = *(const f32x4*)(pf.dpooled + pp);
+          wmask |= (ok ? 1u : 0u) << (2 * r + c);
+        }
       }
     }
   };
-  ImgRegs<piped ? K : 1> ir;  // K = 4: the image window of the next tile, requested during the second half of this one
+  auto f_resolve = [&](int ox0_) {  // the requested stage -> F
+    if constexpr (FUSED) {
+      const uint32_t kx0 = ((ox0_ + prow) & 1) ? 0u : 1u;
+#pragma unroll
+      for (int j = 0; j < RPS; ++j) {
+        f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+        // (window row, ky) pairs for row j: even j -> (j/2, 1); odd j -> ((j+1)/2, 0) and ((j-1)/2, 2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if ((j & 1) == 0 && t == 1) continue;
+          const int r = (j & 1) ? (t == 0 ? (j + 1) / 2 : (j - 1) / 2) : j / 2;
+          const uint32_t ky = (j & 1) ? (t == 0 ? 0u : 2u) : 1u;
+          const uint32_t me0 = ky * 3 + kx0, me1 = ky * 3 + 2;
+          const uint32_t a0 = ((wmask >> (2 * r)) & 1u) ? am[r][0] : 0xffffffffu;  // (0xff matches no window position)
+          const uint32_t a1 = ((wmask >> (2 * r + 1)) & 1u) ? am[r][1] : 0xffffffffu;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (((a0 >> (8 * e)) & 0xffu) == me0) dz[e] += dpv[r][0][e];
+            if (((a1 >> (8 * e)) & 0xffu) == me1) dz[e] += dpv[r][1][e];
+          }
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = pv[j][e] * sc4[e] + sh4[e];
+          const float d = z > 0.f ? dz[e] : 0.f;
+          o[e] = sc4[e] * d - (fc0[e] + fc1[e] * pv[j][e]);
+        }
+        if (!((pmask >> j) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = o;
+      }
+    } else {
+      if (K == 4 && feat_bnp) {  // a fused BatchNorm+ReLU is applied now, at consumption
+#pragma unroll
+        for (int j = 0; j < RPS; ++j) {
+          const bool ok = (pmask >> j) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float z = pv[j][e] * sc4[e] + sh4[e]; pv[j][e] = (ok && z > 0.f) ? z : 0.f; }
+        }
+      }
+      else {
+#pragma unroll
+        for (int j = 0; j < RPS; ++j)
+          if (!((pmask >> j) & 1u)) pv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < RPS; ++j) *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = pv[j];
+    }
+  };
+  ImgRegs<K> ir;  // the image window of the next tile, requested during the last stage of this one
+  image_index<K>(ir);
   auto i_request = [&](int tile_) {
-    if constexpr (piped) {
-      const int n_ = tile_ / (tiles_y * tiles_x);
-      const int trem_ = tile_ - n_ * (tiles_y * tiles_x);
-      image_request<K, PAD>(ir, img, n_, C, cg, H, W, (trem_ / tiles_x) * 16, (trem_ % tiles_x) * 16, tile_ < ntiles);
-    }
+    const int n_ = tile_ / tpi;
+    const int trem_ = tile_ - n_ * tpi;
+    image_request<K, PAD, K == 4>(ir, img, n_, C, cg, H, W, (trem_ / tiles_x) * 16, (trem_ % tiles_x) * 16, tile_ < ntiles);
   };
-  if (piped && (int)blockIdx.x < ntiles) { f_request(blockIdx.x, 0); i_request(blockIdx.x); }
+  if ((int)blockIdx.x < ntiles) { f_request(blockIdx.x, 0); i_request(blockIdx.x); }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int n = tile / (tiles_y * tiles_x);
-    const int trem = tile - n * (tiles_y * tiles_x);
-    const int oy0 = (trem / tiles_x) * 16, ox0 = (trem % tiles_x) * 16;
+    const int n = tile / tpi;
+    const int trem = tile - n * tpi;
+    const int ox0 = (trem % tiles_x) * 16;
     const int grp = n / npg;
-    if constexpr (K == 4) {  // (the 7x7 kernel has no registers to spare and never takes a fused forward operand)
-      if (feat_bnp && grp != cur_grp) {
-        sc4 = *(const f32x4*)(feat_bnp + grp * 256 + 128 + slot * 4);
-        sh4 = *(const f32x4*)(feat_bnp + grp * 256 + 192 + slot * 4);
-        cur_grp = grp;
-      }
-    }
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();
-      if (half == 0) {
-        if constexpr (piped) image_land<K>(T, ir);
-        else stage_image<K, PAD>(T, img, n, C, cg, H, W, oy0, ox0);
-      }
-      if (K == 7 && pf.y) {
-        // Fused BatchNorm + ReLU + MaxPool(3,2,pad=1) backward for this lane's column of 8 output rows (oy0 + 8*half + j,
-        // ox) x 4 channels.  oy0 is a multiple of 8, so the pooling windows that can have picked one of these rows are
-        // the 5 window rows pb..pb+4 (pb = first_row/2): an even row r is only the centre (ky=1) of window r/2, an odd
-        // row is ky=0 of window (r+1)/2 and ky=2 of window (r-1)/2; same along x with the parity of ox.  All <=10
-        // windows are loaded up front (independent loads), then the 8 rows are resolved from registers.
+    if (grp != cur_grp) {
+      cur_grp = grp;
+      if constexpr (FUSED) {
         const float* __restrict__ pbnp = pf.bnp + grp * 256;
         const float* __restrict__ psums = pf.sums + grp * 128;
         const f32x4 mean = *(const f32x4*)(pbnp + slot * 4), invstd = *(const f32x4*)(pbnp + 64 + slot * 4);
-        const f32x4 sc = *(const f32x4*)(pbnp + 128 + slot * 4), sh = *(const f32x4*)(pbnp + 192 + slot * 4);
+        sc4 = *(const f32x4*)(pbnp + 128 + slot * 4); sh4 = *(const f32x4*)(pbnp + 192 + slot * 4);
         f32x4 m1 = *(const f32x4*)(psums + slot * 4), m2 = *(const f32x4*)(psums + 64 + slot * 4);
         if (!pf.training) m1 = m2 = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int oyb = oy0 + 8 * half, ox = ox0 + prow, pb = oyb >> 1;
-        const bool xodd = ox & 1, xin = ox < WF;
-        // window columns: c0 = (ox+1)>>1 seen through kx = (xodd ? 0 : 1); c1 = (ox-1)>>1 through kx = 2 (odd ox only)
-        const int c0 = (ox + 1) >> 1, c1 = (ox - 1) >> 1;
-        const bool c0ok = xin && c0 < pf.WP, c1ok = xin && xodd && c1 < pf.WP;
-        const uint32_t kx0 = xodd ? 0u : 1u;
-        f32x4 yv[8], dpv[5][2];
-        uint32_t am[5][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          yv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (xin && oyb + j < HF) yv[j] = *(const f32x4*)(pf.y + ((size_t)(n * HF + oyb + j) * WF + ox) * 64 + slot * 4);
+        for (int e = 0; e < 4; ++e) {
+          fc1[e] = sc4[e] * invstd[e] * m2[e] * pf.inv_count;
+          fc0[e] = sc4[e] * m1[e] * pf.inv_count - fc1[e] * mean[e];
         }
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const bool rok = pb + r < pf.HP;
-          const size_t rowbase = (size_t)(n * pf.HP + pb + r) * pf.WP;
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const bool ok = rok && (c ? c1ok : c0ok);
-            am[r][c] = 0xffffffffu;  // matches no window position
-            dpv[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-              const size_t pp = (rowbase + (c ? c1 : c0)) * 64 + slot * 4;
-              am[r][c] = *(const uint32_t*)(pf.argmax + pp);
-              dpv[r][c] = *(const f32x4*)(pf.dpooled + pp);
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-          // (window row, ky) pairs for row j: even j -> (j/2, 1); odd j -> ((j+1)/2, 0) and ((j-1)/2, 2)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            if ((j & 1) == 0 && t == 1) continue;
-            const int r = (j & 1) ? (t == 0 ? (j + 1) / 2 : (j - 1) / 2) : j / 2;
-            const uint32_t ky = (j & 1) ? (t == 0 ? 0u : 2u) : 1u;
-            const uint32_t me0 = ky * 3 + kx0, me1 = ky * 3 + 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (((am[r][0] >> (8 * e)) & 0xffu) == me0) dz[e] += dpv[r][0][e];
-              if (((am[r][1] >> (8 * e)) & 0xffu) == me1) dz[e] += dpv[r][1][e];
-            }
-          }
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float z = yv[j][e] * sc[e] + sh[e];
-            const float d = z > 0.f ? dz[e] : 0.f;
-            o[e] = sc[e] * (d - m1[e] * pf.inv_count - (yv[j][e] - mean[e]) * invstd[e] * m2[e] * pf.inv_count);
-          }
-          if (!(xin && oyb + j < HF)) o = f32x4{0.f, 0.f, 0.f, 0.f};
-          *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = o;
-        }
-      } else {
-        // K = 4: the rows were requested one half tile ago (f_request); K = 7: request them here.
-        // A fused BatchNorm+ReLU is applied now, at consumption.
-        if (!piped) f_request(tile, half);
-        if (K == 4 && feat_bnp) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const bool ok = (pmask >> j) & 1u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float z = pv[j][e] * sc4[e] + sh4[e]; pv[j][e] = (ok && z > 0.f) ? z : 0.f; }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = pv[j];
+      } else if (K == 4 && feat_bnp) {
+        sc4 = *(const f32x4*)(feat_bnp + grp * 256 + 128 + slot * 4);
+        sh4 = *(const f32x4*)(feat_bnp + grp * 256 + 192 + slot * 4);
       }
+    }
+#pragma unroll 1
+    for (int half = 0; half < NSTAGE; ++half) {
       __syncthreads();
-      if (piped) {
-        if (half == 0) f_request(tile, 1);
-        else { f_request(tile + gridDim.x, 0); i_request(tile + gridDim.x); }
-      }
-      // 32 k-steps per wave: step s covers pixels (row 4*sub + (s>>3) of the half, column 2*(s&7) + h)
+      if (half == 0) image_land<K, K == 4>(T, ir);
+      f_resolve(ox0);
+      __syncthreads();
+      if (half + 1 < NSTAGE) f_request(tile, half + 1);
+      else { f_request(tile + gridDim.x, 0); i_request(tile + gridDim.x); }
+      // RPS*4 k-steps per wave: step s covers pixels (row (RPS/2)*sub + (s>>3) of the stage, column 2*(s&7) + h)
       const float* fcol = F + mt * 32 + l31;
 #pragma unroll 4
-      for (int s = 0; s < 32; ++s) {
-        const int lrow = 4 * sub + (s >> 3), tx = 2 * (s & 7);
+      for (int s = 0; s < RPS * 4; ++s) {
+        const int lrow = (RPS / 2) * sub + (s >> 3), tx = 2 * (s & 7);
         const float a = fcol[(lrow * 16 + tx + h) * 64];
-        const int base = 2 * (8 * half + lrow) * XP + tx;
+        const int base = 2 * (RPS * half + lrow) * XP + tx;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const float b = T[base + kb[j]];
@@ -645,42 +737,67 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
   for (int c = 0; c < 4; ++c) { fsc[c] = f32x4{1.f, 1.f, 1.f, 1.f}; fsh[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   int cur_grp = -1;
 
+  // A fragments are requested DEPTH M-tiles ahead of the MFMAs that consume them, across tile boundaries: the queue runs over this
+  // wave's (tile, M-tile) sequence, so the loads of the next tile are in flight during this tile's gather phase and barriers.
+  // Loads only — the BatchNorm+ReLU of a fused operand is applied when the fragment is CONSUMED (activate); otherwise the affine
+  // would wait for the load right at the request and nothing would stay in flight behind the MFMAs.
+  constexpr int DEPTH = 4;
+  const int tpi = tiles_y * tiles_x;
+  auto load_a = [&](int t, int mtile, f32x4 (&a)[4]) -> bool {
+    const int n = t / tpi;
+    const int trem = t - n * tpi;
+    const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
+    const int p = mtile * 16 + li;
+    const int ia = p / 17, ib = p - ia * 17;
+    const int fy = a0 - 1 + ia, fx = b0 - 1 + ib;
+    const bool ok = t < ntiles && p < 289 && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
+    const float* src = feat + (ok ? ((size_t)(n * HF + fy) * WF + fx) * 64 : (size_t)0) + 4 * kq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = *(const f32x4*)(src + 16 * c);  // raw (clamped address when !ok): masked in activate
+    return ok;
+  };
+  auto activate = [&](f32x4 (&a)[4], bool ok) {
+    if (!ok) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (feat_bnp) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float z = a[c][e] * fsc[c][e] + fsh[c][e]; a[c][e] = z > 0.f ? z : 0.f; }
+    }
+  };
+  f32x4 q[DEPTH][4];
+  bool qok[DEPTH];
+  int nt = blockIdx.x, nm = wave;  // the next (tile, M-tile) to request
+  auto advance = [&]() { nm += 4; if (nm >= 19) { nm = wave; nt += gridDim.x; } };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) { qok[d] = load_a(nt, nm, q[d]); advance(); }
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int n = tile / (tiles_y * tiles_x);
+    const int n = tile / tpi;
     if (feat_bnp && n / npg != cur_grp) {
       cur_grp = n / npg;
       const float* __restrict__ rec = feat_bnp + cur_grp * 256;
 #pragma unroll
       for (int c = 0; c < 4; ++c) { fsc[c] = *(const f32x4*)(rec + 128 + 16 * c + 4 * kq); fsh[c] = *(const f32x4*)(rec + 192 + 16 * c + 4 * kq); }
     }
-    const int trem = tile - n * (tiles_y * tiles_x);
+    const int trem = tile - n * tpi;
     const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
     __syncthreads();  // previous tile's gather is done with Tt
-    // loads only: the BatchNorm+ReLU of a fused operand is applied when the fragment is CONSUMED (activate), otherwise the
-    // affine would wait for the load right here and nothing would stay in flight behind the MFMAs
-    auto load_a = [&](int mtile, f32x4 (&a)[4]) -> bool {
-      const int p = mtile * 16 + li;
-      const int ia = p / 17, ib = p - ia * 17;
-      const int fy = a0 - 1 + ia, fx = b0 - 1 + ib;
-      const bool ok = (mtile < 19) && (p < 289) && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
-      const float* src = feat + ((size_t)(n * HF + (ok ? fy : 0)) * WF + (ok ? fx : 0)) * 64 + 4 * kq;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) a[c] = ok ? *(const f32x4*)(src + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      return ok;
-    };
-    auto activate = [&](f32x4 (&a)[4], bool ok) {
-      if (feat_bnp && ok) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float z = a[c][e] * fsc[c][e] + fsh[c][e]; a[c][e] = z > 0.f ? z : 0.f; }
-      }
-    };
-    f32x4 a[4], an[4], an2[4];
-    bool oka = load_a(wave, a);
-    bool okn = load_a(wave + 4, an);
     for (int mtile = wave; mtile < 19; mtile += 4) {
-      const bool okn2 = load_a(mtile + 8, an2);  // fragments travel two M-tiles ahead of the MFMAs that consume them
+      f32x4 a[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[c] = q[0][c];
+      const bool oka = qok[0];
+#pragma unroll
+      for (int d = 0; d + 1 < DEPTH; ++d) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[d][c] = q[d + 1][c];
+        qok[d] = qok[d + 1];
+      }
+      qok[DEPTH - 1] = load_a(nt, nm, q[DEPTH - 1]);
+      advance();
       activate(a, oka);
       f32x4 acc[3];
 #pragma unroll
@@ -697,9 +814,6 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
       for (int co = 0; co < 3; ++co)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Tt[(mtile * 16 + kq * 4 + r) * TP + co * 16 + li] = acc[co][r];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { a[c] = an[c]; an[c] = an2[c]; }
-      oka = okn; okn = okn2;
     }
     __syncthreads();
     const int oxl = tid & 31, rg = tid >> 5;
@@ -769,7 +883,7 @@ static int check_skinny(const srlz_skinny_desc* d) {
 }
 
 template <int K>
-static size_t conv_lds() { return (size_t)(Geo<K>::TILE_FLOATS + Geo<K>::KS * 128 + 512) * 4; }
+static size_t conv_lds(bool pipe) { return (size_t)(Geo<K>::TILE_FLOATS + Geo<K>::KS * 128 + 512 + (pipe ? 4096 : 0)) * 4; }
 
 static int images_per_group(const srlz_skinny_desc* d) { return d->n / (d->groups > 1 ? d->groups : 1); }
 
@@ -784,19 +898,24 @@ static int launch_conv(const float* img, const float* w, float* feat, float* sta
                        const float* y_raw = nullptr, const float* y_bnp = nullptr) {
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
-  const size_t lds = conv_lds<K>();
+  const bool multi = d->c > 3;
+  const dim3 grid(persistent_grid(ntiles)), block(256);
+#define SRLZ_CONV_LAUNCH(BN, MU, PIPED)                                                                                   \
+  do {                                                                                                                    \
+    const size_t lds = conv_lds<K>(PIPED);                                                                                \
+    SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, BN, MU>), lds);                                                              \
+    hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, BN, MU>), grid, block, lds, st, img, w, feat, stats, d->n, d->c,       \
+                       d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp, images_per_group(d));                        \
+  } while (0)
+  bool launched = false;
   if constexpr (K == 4) if (y_raw) {
-    SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, true>), lds);
-    hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, true>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
-                       d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp, images_per_group(d));
-    SRLZ_LAUNCHED();
-    return 0;
+    if (multi) SRLZ_CONV_LAUNCH(true, true, false); else SRLZ_CONV_LAUNCH(true, false, false);
+    launched = true;
   }
-  {
-    SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, false>), lds);
-    hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, false>), dim3(persistent_grid(ntiles)), dim3(256), lds, st, img, w, feat, stats,
-                       d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp, images_per_group(d));
+  if (!launched) {
+    if (multi) SRLZ_CONV_LAUNCH(false, true, true); else SRLZ_CONV_LAUNCH(false, false, true);
   }
+#undef SRLZ_CONV_LAUNCH
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -823,8 +942,15 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
   PoolFuse pf = {};
   if (pfuse) pf = *pfuse;
   static const int dephase = [] { const char* e = getenv("SRLZ_DEPHASE"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                     d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase);
+  bool launched = false;
+  if constexpr (K == 7) if (pf.y) {
+    hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD, true>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
+                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase);
+    launched = true;
+  }
+  if (!launched)
+    hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD, false>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
+                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
