@@ -37,18 +37,25 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
   C += (size_t)blockIdx.z * I * J;
   constexpr int U = BR * 64 / 256;  // elements of a 64 x BR tile per thread
   float va[U], vb[U];
+  unsigned ina = 0, inb = 0;  // bit u: element u is inside the matrix
+  // Requests are branch-free (an element outside the matrix reads element 0 and is zeroed when it is stashed): with a load inside
+  // a branch the compiler loses track of which loads have landed and falls back to "s_waitcnt vmcnt(0)" — here that made the
+  // prefetch synchronous and put a full wait between every two stores of the epilogue (tools/isa_audit.py).
   auto fetch = [&](int r0) {
+    ina = inb = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int e = tid + 256 * u;
       int i, r;
       if (sar == 1) { i = e / BR; r = e % BR; } else { r = e >> 6; i = e & 63; }
-      va[u] = 0.f;
-      if (i0 + i < I && r0 + r < rend) va[u] = A[(long long)(i0 + i) * sai + (long long)(r0 + r) * sar];
+      const bool oka = i0 + i < I && r0 + r < rend;
+      va[u] = A[oka ? (long long)(i0 + i) * sai + (long long)(r0 + r) * sar : 0LL];
+      ina |= (oka ? 1u : 0u) << u;
       int j, rb;
       if (sbr == 1) { j = e / BR; rb = e % BR; } else { rb = e >> 6; j = e & 63; }
-      vb[u] = 0.f;
-      if (j0 + j < J && r0 + rb < rend) vb[u] = B[(long long)(r0 + rb) * sbr + (long long)(j0 + j) * sbj];
+      const bool okb = j0 + j < J && r0 + rb < rend;
+      vb[u] = B[okb ? (long long)(r0 + rb) * sbr + (long long)(j0 + j) * sbj : 0LL];
+      inb |= (okb ? 1u : 0u) << u;
     }
   };
   auto stash = [&](int buf) {
@@ -57,10 +64,10 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
       const int e = tid + 256 * u;
       int i, r;
       if (sar == 1) { i = e / BR; r = e % BR; } else { r = e >> 6; i = e & 63; }
-      As[buf][r][i] = va[u];
+      As[buf][r][i] = ((ina >> u) & 1u) ? va[u] : 0.f;
       int j, rb;
       if (sbr == 1) { j = e / BR; rb = e % BR; } else { rb = e >> 6; j = e & 63; }
-      Bs[buf][rb][j] = vb[u];
+      Bs[buf][rb][j] = ((inb >> u) & 1u) ? vb[u] : 0.f;
     }
   };
   fetch(rbeg);
@@ -81,7 +88,8 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
     buf ^= 1;
   }
   const int j = j0 + wj * 32 + l31;
-  const float bj = (bias && j < J) ? bias[j] : 0.f;
+  float bj = bias ? bias[j < J ? j : 0] : 0.f;
+  asm volatile("" : "+v"(bj));  // waited for once, here, not behind every store of the loop below
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
