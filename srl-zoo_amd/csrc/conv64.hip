@@ -26,6 +26,12 @@
 
 namespace {
 
+#ifndef SRLZ_BATCH_FWD
+#define SRLZ_BATCH_FWD 16
+#endif
+#ifndef SRLZ_BATCH_BWD
+#define SRLZ_BATCH_BWD 12
+#endif
 constexpr int TM = 128;       // grid positions per forward tile
 constexpr int NTAPS = 9;
 
@@ -268,6 +274,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
                                                                     const ConvProg P, int ntiles, const OpFuse src_fuse_all) {
   constexpr int NT = NW * 64;      // threads
   constexpr int NACC = 8 / NW;     // 32-column tiles per wave
+  // rows (of 16 lanes) a thread requests per HBM round trip of the source staging: a stride-1 tile (244 rows = 15.25 passes) or a
+  // gather class (185 rows = 11.6 passes) in ONE batch instead of two
+  constexpr int BATCH_FWD = SRLZ_BATCH_FWD, BATCH_BWD = SRLZ_BATCH_BWD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* As = (float*)smem;                 // (TM + span) x 64, swizzled
   float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap, pre-swizzled in global
@@ -311,6 +320,47 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
 
   int cur_src = -1, cur_dst = -1;
 
+  // NW == 4: the accumulators leave through a 4 KB wave-private transposition buffer (this wave's part of the idle weight slab),
+  // 16 tile rows at a time, so that every global store is a 16-byte one — lane (g = lane >> 4, slot = lane & 15) stores channels
+  // [4*slot, 4*slot+4) of rows g, g+4, g+8, g+12 — instead of 32 dword-per-lane stores per flush (the dword path sustains ~5 B per
+  // cycle and CU, which bounds the scatter programs: a ConvTranspose forward tile writes 128 KB).  The BatchNorm partials are taken
+  // in the same layout (s4 / q4).  Rows 4..7 and 12..15 of the buffer hold their two 32-channel halves swapped, so that the lanes
+  // h = 0 / 1 of one ds_write_b32 (rows 4 apart, same column) hit different banks.
+  f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+  auto flush16 = [&](int d) {
+    if (P.dbg & 2) {
+      if (acc[0][0] + acc[NACC - 1][5] == 123.456f) dst[tid] = acc[0][1];
+      return;
+    }
+    const int dy = d >> 1, dx = d & 1;
+    float* S = Bs + wave * 1024;
+    const int eg = lane >> 4, eslot = lane & 15;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        const int swz = (rowl & 4) << 3;  // 32 for rows 4..7, 12..15
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) S[rowl * 64 + ((32 * j + l31) ^ swz)] = acc[j][8 * half + rr] + bcol[j];
+      }
+      // (wave-private: the compiler's lgkmcnt wait orders the writes above before the reads below)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rowl = eg + 4 * k;
+        const int row = wrow * 32 + 16 * half + rowl;
+        const f32x4 v = *(const f32x4*)(S + rowl * 64 + ((eslot ^ ((rowl & 4) << 1)) << 2));
+        const int n = rowinfo[row];
+        const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
+        if (n >= 0 && y < P.Hd && x < P.Wd) {
+          *(f32x4*)(dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 + eslot * 4) = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }
+        }
+      }
+    }
+  };
+
   auto flush = [&](int d) {
     if (P.dbg & 2) {  // ablation: keep the accumulators live, write nothing
       if (acc[0][0] + acc[NACC - 1][5] == 123.456f) dst[tid] = acc[0][1];
@@ -336,19 +386,22 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
 
   // The weight slab of tap t+1 is fetched into registers while tap t's MFMAs run, and written to LDS between the two
   // barriers of the next iteration: the L2 latency of the slab never sits between barriers.
+  // Wave w moves the contiguous part [w, w+1) * 16 KB / NW of the slab (and nobody else's): between the barrier that ends a tap and
+  // its own slab write a wave may therefore use that part of Bs as private scratch (flush16).
   constexpr int BV = 1024 / NT;  // 16-byte vectors of the 16 KB slab per thread
+  const int bslot = wave * (BV * 64) + lane;
   f32x4 breg[BV];
   {
     const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[0] * 4096);
 #pragma unroll
-    for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
+    for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
   }
 #pragma unroll
   for (int ti = 0; ti < NTAPS; ++ti) {
     const int tsrc = P.tsrc[ti], tdst = P.tdst[ti];
     __syncthreads();  // all waves are done with the previous tap's Bs (and with As if it is about to be replaced)
     if (tdst != cur_dst) {
-      if (cur_dst >= 0) flush(cur_dst);
+      if (cur_dst >= 0) { if constexpr (NW == 4) flush16(cur_dst); else flush(cur_dst); }
 #pragma unroll
       for (int j = 0; j < NACC; ++j)
 #pragma unroll
@@ -358,10 +411,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
     if (tsrc != cur_src) {
       if (!(P.dbg & 1)) {
         if (BWD)
-          stage_rows<true, (NW == 4 ? 8 : 2), NT, true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q,
+          stage_rows<true, (NW == 4 ? BATCH_BWD : 2), NT, true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q,
                                                         q0 + P.min_off, TM + P.span, src_fuse, -P.min_off, TM);
         else
-          stage_rows<true, (NW == 4 ? 8 : 4), NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off,
+          stage_rows<true, (NW == 4 ? BATCH_FWD : 4), NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off,
                                                   TM + P.span, src_fuse);
       }
       cur_src = tsrc;
@@ -369,13 +422,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
     {
       f32x4* wdst = (f32x4*)Bs;
 #pragma unroll
-      for (int i = 0; i < BV; ++i) wdst[i * NT + tid] = breg[i];
+      for (int i = 0; i < BV; ++i) wdst[bslot + i * 64] = breg[i];
     }
     __syncthreads();
     if (ti + 1 < NTAPS) {  // (compile-time condition: a run-time one turns the requests into a branch the MFMAs get hoisted above)
       const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[ti + 1] * 4096);
 #pragma unroll
-      for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
+      for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
     }
     __builtin_amdgcn_sched_barrier(0);  // the slab requests go out HERE, ahead of the tap's MFMAs (the scheduler sinks them otherwise)
     const int R = wrow * 32 + l31 + P.toff[ti] - P.min_off;
@@ -408,19 +461,37 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
       for (int j = 0; j < NACC; ++j) b[j] = bn[j];
     }
   }
-  flush(cur_dst);
+  if constexpr (NW == 4) {
+    __syncthreads();  // every wave is done with the last tap's slab: Bs becomes scratch
+    flush16(cur_dst);
+  } else {
+    flush(cur_dst);
+  }
 
   if (stats_partial && !(P.dbg & 2)) {
-    // lanes l and l+32 hold the same columns; then the 4 row groups are combined through LDS
+    // the lane groups (NW == 4: the 4 row groups g; else lanes l and l+32) hold the same columns; then the 4 row groups of
+    // waves are combined through LDS
     __syncthreads();
     float* red = Bs;  // [4 row groups][128]
+    if constexpr (NW == 4) {
 #pragma unroll
-    for (int j = 0; j < NACC; ++j) {
-      sum[j] += __shfl_xor(sum[j], 32, 64);
-      sq[j] += __shfl_xor(sq[j], 32, 64);
-      if (h == 0) {
-        red[wrow * 128 + (wcol * NACC + j) * 32 + l31] = sum[j];
-        red[wrow * 128 + 64 + (wcol * NACC + j) * 32 + l31] = sq[j];
+      for (int e = 0; e < 4; ++e) {
+        s4[e] += __shfl_xor(s4[e], 16, 64); s4[e] += __shfl_xor(s4[e], 32, 64);
+        q4[e] += __shfl_xor(q4[e], 16, 64); q4[e] += __shfl_xor(q4[e], 32, 64);
+      }
+      if (lane < 16) {
+        *(f32x4*)(red + wrow * 128 + lane * 4) = s4;
+        *(f32x4*)(red + wrow * 128 + 64 + lane * 4) = q4;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        sum[j] += __shfl_xor(sum[j], 32, 64);
+        sq[j] += __shfl_xor(sq[j], 32, 64);
+        if (h == 0) {
+          red[wrow * 128 + (wcol * NACC + j) * 32 + l31] = sum[j];
+          red[wrow * 128 + 64 + (wcol * NACC + j) * 32 + l31] = sq[j];
+        }
       }
     }
     __syncthreads();
