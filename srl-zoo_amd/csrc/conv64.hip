@@ -607,12 +607,25 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
 //  * the new source rows and the next gradient rows are requested into registers BEFORE the chunk's MFMA loop and
 //    written to LDS after it: their latency sits behind the matrix work (two barriers per group remain).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int RING = 256;  // rows; >= TK + span + (prefetched TK rows are written only after the readers' barrier)
+// The source ring of conv64_wgrad_ring_kernel: row q of the virtual grid lives at slot q mod RING_ROWS; the first RING_MIRROR
+// slots are kept a second time behind the ring (slots RING_ROWS .. RING_ROWS + RING_MIRROR), so that a reader that starts at
+// any slot can go on for RING_MIRROR rows without wrapping — the MFMA loop wraps ONE wave-uniform (scalar) row index per tap
+// and 4 k-steps and reaches its 4 rows through the immediate offsets of two ds_read2st64_b32.  (The previous layout — 256
+// slots, "& 255" on every address — cost three VALU instructions and one ds_read_b32 per MFMA, and that instruction stream,
+// not the matrix pipe, bounded the loop: 113 TF with every load and barrier removed.)
+// RING_ROWS >= TK + span + TK (the prefetched TK rows are written only after the readers' barrier).
+template <int V> struct IntC { static constexpr int value = V; };
+constexpr int RING_ROWS = 248, RING_MIRROR = 8, RING = RING_ROWS + RING_MIRROR;
+__device__ __forceinline__ int ring_slot(int q) { return (q + 4 * RING_ROWS) % RING_ROWS; }  // q >= -4 * RING_ROWS
 
-// rows [qstart, qstart+64) of class `cls`: 4 rows per thread (16 apart) into registers; okmask bit j = row j in bounds
-__device__ __forceinline__ void rows64_load(f32x4 (&v)[4], unsigned& okmask, const float* __restrict__ src, int H, int W,
+// rows [qstart, qstart+64) of class `cls`: 4 rows per thread (16 apart) into registers; okmask bit j = row j in bounds.
+// <J0, NJ>: only this thread's rows J0 .. J0+NJ-1 (v[j - J0]); the other bits of okmask are left alone.
+template <int J0 = 0, int NJ = 4>
+__device__ __forceinline__ void rows64_load(f32x4 (&v)[NJ], unsigned& okmask, const float* __restrict__ src, int H, int W,
                                             int stride, int cls, int PW, int PH, int total_q, int qstart) {
-  const int t = threadIdx.x, slot = t & 15;
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));  // opaque: nothing derived from the thread index here is worth a register across the caller's loops
+  const int slot = t & 15;
   const int cy = cls >> 1, cx = cls & 1;
   const int PHW = PH * PW;
   const int sa = 16 / PW, sb = 16 - sa * PW;
@@ -622,35 +635,42 @@ __device__ __forceinline__ void rows64_load(f32x4 (&v)[4], unsigned& okmask, con
   int a = rem / PW;
   int b = rem - a * PW;
   const int N1max = total_q / PHW;
-  okmask = 0;
+  if (J0 == 0) okmask = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int y = a * stride + cy, x = b * stride + cx;
-    const bool ok = n1 >= 1 && n1 <= N1max && y < H && x < W;
-    okmask |= (ok ? 1u : 0u) << j;
-    if (ok) v[j] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
+  for (int j = 0; j < J0 + NJ; ++j) {
+    if (j >= J0) {
+      v[j - J0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int y = a * stride + cy, x = b * stride + cx;
+      const bool ok = n1 >= 1 && n1 <= N1max && y < H && x < W;
+      okmask |= (ok ? 1u : 0u) << j;
+      if (ok) v[j - J0] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
+    }
     b += sb; a += sa;
     if (b >= PW) { b -= PW; ++a; }
     if (a >= PH) { a -= PH; ++n1; }
   }
 }
 
-// registers -> LDS rows (row index of this thread's j-th row = rbase + 16*j, masked with `mask` for the ring);
+// registers -> LDS rows (row index of this thread's j-th row = rbase + 16*j; RINGED: its ring slot, plus the mirror copy);
 // bnp != NULL: relu(batchnorm(.)) applied to in-bounds rows on the way (OpFuse forward fusion)
-__device__ __forceinline__ void rows64_store(float* __restrict__ lds, int rbase, int mask, f32x4 (&v)[4], unsigned okmask,
+template <bool RINGED, int J0 = 0, int NJ = 4>
+__device__ __forceinline__ void rows64_store(float* __restrict__ lds, int rbase, f32x4 (&v)[NJ], unsigned okmask,
                                              const float* __restrict__ bnp) {
-  const int t = threadIdx.x, slot = t & 15;
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));  // (see rows64_load)
+  const int slot = t & 15;
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = J0; j < J0 + NJ; ++j) {
     if (bnp && ((okmask >> j) & 1u)) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = z > 0.f ? z : 0.f; }
+      for (int e = 0; e < 4; ++e) { const float z = v[j - J0][e] * sc4[e] + sh4[e]; v[j - J0][e] = z > 0.f ? z : 0.f; }
     }
-    const int R = (rbase + (t >> 4) + 16 * j) & mask;
-    *(f32x4*)(lds + R * 64 + slot * 4) = v[j];
+    int R = rbase + (t >> 4) + 16 * j;
+    if (RINGED) R = ring_slot(R);
+    *(f32x4*)(lds + R * 64 + slot * 4) = v[j - J0];
+    if (RINGED && R < RING_MIRROR) *(f32x4*)(lds + (R + RING_ROWS) * 64 + slot * 4) = v[j - J0];
   }
 }
 
@@ -695,56 +715,77 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
     unsigned ok;
     for (int r0 = 0; r0 < TK + P.span; r0 += 64) {
       rows64_load(v, ok, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0);
-      rows64_store(Ss, q0 + P.min_off + r0, RING - 1, v, ok, x_bnp);
+      rows64_store<true>(Ss, q0 + P.min_off + r0, v, ok, x_bnp);
     }
     rows64_load(v, ok, g, P.Hd, P.Wd, P.ds, P.tdst[0], P.PW, P.PH, P.total_q, q0);
-    rows64_store(Gs, 0, 0xffff, v, ok, nullptr);
+    rows64_store<false>(Gs, 0, v, ok, nullptr);
   }
   __syncthreads();
 
+  unsigned oks = 0;
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int q0 = chunk * TK;
     const bool last_chunk = chunk + 1 >= c_end;
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-      const int t0 = GSTART[gi], t1 = GSTART[gi + 1];
-      const bool last_group = gi == NG - 1;
+    auto group = [&](auto GI) {
+      constexpr int gi = decltype(GI)::value;
+      constexpr int t0 = GSTART[gi], t1 = GSTART[gi + 1];
+      constexpr bool last_group = gi == NG - 1;
       // ---- requests for what the NEXT step needs: the next class's gradient rows; at the last group of a chunk also the
       //      64 new source rows of the next chunk (they overwrite ring slots nobody reads after this chunk)
-      f32x4 pg[4], ps[4];
-      unsigned okg = 0, oks = 0;
+      // (stride 2: the 64 new source rows come in two halves, during the two 2-tap groups — with the next class's gradient rows
+      //  also in flight, a full set of both does not fit in the registers the 144 accumulators leave.  New source rows may land at
+      //  any point of the chunk: RING_ROWS >= TK + span + TK keeps their slots outside the window the chunk still reads.)
+      constexpr int SJ0 = S2 ? (gi == 2 ? 2 : 0) : 0, SNJ = S2 ? 2 : 4;
+      f32x4 pg[4], ps[SNJ];
+      unsigned okg = 0;
       const bool want_g = !(last_group && last_chunk);
-      const bool want_s = last_group && !last_chunk;
+      const bool want_s = (S2 ? (gi == 1 || gi == 2) : last_group) && !last_chunk;
       if (want_g) {
         const int nq0 = last_group ? q0 + TK : q0;
-        const int ncls = last_group ? P.tdst[0] : P.tdst[GSTART[gi + 1]];
+        constexpr int ntap = last_group ? 0 : GSTART[gi + 1];  // first tap of the next class
+        const int ncls = P.tdst[ntap];
         rows64_load(pg, okg, g, P.Hd, P.Wd, P.ds, ncls, P.PW, P.PH, P.total_q, nq0);
       }
-      if (want_s) rows64_load(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span);
+      if (want_s) rows64_load<SJ0, SNJ>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span);
       // ---- this group's work
       {
         const int col = tid & 63, part = tid >> 6;
 #pragma unroll
         for (int r = 0; r < TK / 4; ++r) bsum += Gs[(part * (TK / 4) + r) * 64 + col];
       }
-      const float* gcol = Gs + nj * 32 + l31;
-      const float* scol = Ss + mi * 32 + l31;
-#pragma unroll 4
-      for (int ks = 0; ks < TK / 2; ++ks) {
-        const int row = 2 * ks + h;
-        const float bfrag = gcol[row * 64];
+      // 8 blocks of 4 k-steps; k-step i of block b multiplies grid rows q0 + 8b + 2i + h.  Per tap the ring slot of row
+      // q0 + toff + 8b is wave-uniform (u[t], wrapped with scalar instructions); the 4 rows of a lane are u + h + {0,2,4,6}
+      // — never past the mirror — i.e. one address and two ds_read2st64_b32 per tap and block.
+      const float* gcol = Gs + (h * 64 + nj * 32 + l31);
+      const float* scol = Ss + (h * 64 + mi * 32 + l31);
+      int u[NTAPS];
+#pragma unroll
+      for (int t = t0; t < t1; ++t) u[t] = ring_slot(q0 + P.toff[t]);
+#pragma unroll 1
+      for (int b = 0; b < TK / 8; ++b) {
+        float bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = gcol[(8 * b + 2 * i) * 64];
 #pragma unroll
         for (int t = t0; t < t1; ++t) {
-          const float afrag = scol[((q0 + row + P.toff[t]) & (RING - 1)) * 64];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[t], 0, 0, 0);
+          const float* ap = scol + u[t] * 64;
+          float af[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i] = ap[2 * i * 64];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc[t], 0, 0, 0);
+          u[t] += 8;
+          if (u[t] >= RING_ROWS) u[t] -= RING_ROWS;
         }
       }
       // ---- land the prefetched rows
       __syncthreads();
-      if (want_g) rows64_store(Gs, 0, 0xffff, pg, okg, nullptr);
-      if (want_s) rows64_store(Ss, q0 + P.min_off + TK + P.span, RING - 1, ps, oks, x_bnp);
+      if (want_g) rows64_store<false>(Gs, 0, pg, okg, nullptr);
+      if (want_s) rows64_store<true, SJ0, SNJ>(Ss, q0 + P.min_off + TK + P.span, ps, oks, x_bnp);
       __syncthreads();
-    }
+    };
+    group(IntC<0>{});
+    if constexpr (NG > 1) { group(IntC<1>{}); group(IntC<2>{}); group(IntC<3>{}); }
   }
   // partial[wg][9 (reference tap index)][64 ci][64 co] + [wg][64] bias sums after all workgroups' tap blocks
   float* out = partial + (size_t)blockIdx.x * (NTAPS * 4096);
@@ -1179,7 +1220,7 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   for (int t = 1; t < NTAPS; ++t) single_src = single_src && P.tsrc[t] == P.tsrc[0];
   static const int use_ring = [] { const char* e = getenv("SRLZ_WGRAD_RING"); return e ? atoi(e) : 1; }();
   int launched_grid = grid;
-  if (use_ring && single_src && gf.y == nullptr && tk + P.span <= RING - 64 + 64 && tk == 64) {
+  if (use_ring && single_src && gf.y == nullptr && tk + P.span + tk <= RING_ROWS && tk == 64) {
     // contiguous chunk ranges per workgroup (ring re-use of the source rows), group by group
     const int gpg = grid / P.G;
     const int cpw = (nchunks + gpg - 1) / gpg;
