@@ -696,7 +696,9 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float bsum = 0.f;
+  // bias gradient (column sums of the gradient rows): every gradient row passes through exactly one thread's registers on its
+  // way into Gs, so the sums are taken there (channels [4*slot, 4*slot+4) of this thread's rows) instead of re-reading Gs
+  f32x4 bs4 = {0.f, 0.f, 0.f, 0.f};
 
   constexpr int NG = S2 ? 4 : 1;
   constexpr int GSTART[5] = {0, S2 ? 4 : 9, 6, 8, 9};
@@ -719,6 +721,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
     }
     rows64_load(v, ok, g, P.Hd, P.Wd, P.ds, P.tdst[0], P.PW, P.PH, P.total_q, q0);
     rows64_store<false>(Gs, 0, v, ok, nullptr);
+    bs4 += (v[0] + v[1]) + (v[2] + v[3]);  // (rows outside the tensor are zero)
   }
   __syncthreads();
 
@@ -748,11 +751,6 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
       }
       if (want_s) rows64_load<SJ0, SNJ>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span);
       // ---- this group's work
-      {
-        const int col = tid & 63, part = tid >> 6;
-#pragma unroll
-        for (int r = 0; r < TK / 4; ++r) bsum += Gs[(part * (TK / 4) + r) * 64 + col];
-      }
       // 8 blocks of 4 k-steps; k-step i of block b multiplies grid rows q0 + 8b + 2i + h.  Per tap the ring slot of row
       // q0 + toff + 8b is wave-uniform (u[t], wrapped with scalar instructions); the 4 rows of a lane are u + h + {0,2,4,6}
       // — never past the mirror — i.e. one address and two ds_read2st64_b32 per tap and block.
@@ -764,8 +762,12 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
 #pragma unroll 1
       for (int b = 0; b < TK / 8; ++b) {
         float bf[4];
+        int go = b * (8 * 64);
+        asm volatile("" : "+v"(go));  // one address; the 4 rows are immediate offsets (Gs sits 64 KB into LDS: left to fold that
+                                      // constant itself, the compiler needs one add and one ds_read_b32 per row).  The opaque value
+                                      // is the OFFSET: laundering the pointer would lose the LDS address space (flat loads).
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bf[i] = gcol[(8 * b + 2 * i) * 64];
+        for (int i = 0; i < 4; ++i) bf[i] = gcol[go + 2 * i * 64];
 #pragma unroll
         for (int t = t0; t < t1; ++t) {
           const float* ap = scol + u[t] * 64;
@@ -780,7 +782,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
       }
       // ---- land the prefetched rows
       __syncthreads();
-      if (want_g) rows64_store<false>(Gs, 0, pg, okg, nullptr);
+      if (want_g) {
+        rows64_store<false>(Gs, 0, pg, okg, nullptr);
+        bs4 += (pg[0] + pg[1]) + (pg[2] + pg[3]);
+      }
       if (want_s) rows64_store<true, SJ0, SNJ>(Ss, q0 + P.min_off + TK + P.span, ps, oks, x_bnp);
       __syncthreads();
     };
@@ -798,14 +803,19 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
       o[row * 64 + nj * 32 + l31] = acc[t][r];
     }
   }
-  float* red = Ss;
-  red[tid] = bsum;
+  __syncthreads();  // (every wave is done with the ring)
+  float* red = Ss;  // [16 row groups][64 channels]
+  *(f32x4*)(red + (tid >> 4) * 64 + (tid & 15) * 4) = bs4;
   __syncthreads();
   if (tid < 64) {
     float* bout = partial + (size_t)gridDim.x * (NTAPS * 4096) + (size_t)blockIdx.x * 64;
-    bout[tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r * 64 + tid];
+    bout[tid] = t;
   }
 }
+
 
 // dw_ref[...] = sum over workgroups (fixed order); layout: conv [co][ci][3][3], convT [ci][co][3][3].
 // 1024 threads per block: 256 outputs x 4 slices of the workgroup range, 4 loads in flight per thread, fp64 combine.

@@ -494,6 +494,10 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const float* tb[NT];  // this lane's image-operand column of N-tile j (tap offset and the odd-pixel shift h folded in)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) tb[j] = T + kb[j];
+  const float* fcol = F + h * 64 + mt * 32 + l31;  // this lane's feature-operand column (h: the odd pixel of a k-step is one row on)
 
   const int slot = tid & 15, prow = tid >> 4;  // feature staging: 16 lanes per pixel row (256 B), 16 pixels per pass
   // Per-group records, kept in registers and re-read when the tile sequence crosses into the next BatchNorm group:
@@ -639,18 +643,27 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
       __syncthreads();
       if (half + 1 < NSTAGE) f_request(tile, half + 1);
       else { f_request(tile + gridDim.x, 0); i_request(tile + gridDim.x); }
-      // RPS*4 k-steps per wave: step s covers pixels (row (RPS/2)*sub + (s>>3) of the stage, column 2*(s&7) + h)
-      const float* fcol = F + mt * 32 + l31;
-#pragma unroll 4
-      for (int s = 0; s < RPS * 4; ++s) {
-        const int lrow = (RPS / 2) * sub + (s >> 3), tx = 2 * (s & 7);
-        const float a = fcol[(lrow * 16 + tx + h) * 64];
-        const int base = 2 * (RPS * half + lrow) * XP + tx;
+      // RPS*4 k-steps per wave, in blocks of 4: step i of block blk covers pixel (row (RPS/2)*sub + (blk>>1) of the stage, column
+      // 8*(blk&1) + 2i + h).  Everything that varies inside a block is an immediate offset of a ds_read2 (columns 0,2 / 4,6) and
+      // everything that varies between blocks is wave-uniform, so a block costs one address per operand column (1 + NT VALU adds)
+      // for its 4*NT MFMAs — the instruction stream, not the matrix pipe, is what bounds these loops.
+      const int subu = __builtin_amdgcn_readfirstlane(sub);
+#pragma unroll 2
+      for (int blk = 0; blk < RPS; ++blk) {
+        const int lrow = (RPS / 2) * subu + (blk >> 1), tx0 = 8 * (blk & 1);
+        const float* fa = fcol + (lrow * 16 + tx0) * 64;
+        const int boff = 2 * (RPS * half + lrow) * XP + tx0;
+        float a[4], b[NT][4];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float b = T[base + kb[j]];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) a[i] = fa[2 * i * 64];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) b[j][i] = tb[j][boff + 2 * i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j][i], acc[j], 0, 0, 0);
       }
     }
   }
