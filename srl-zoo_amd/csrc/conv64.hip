@@ -42,6 +42,8 @@ struct ConvProg {
   int ss, Hs, Ws;  // source: stride, image dims
   int ds, Hd, Wd;  // dest
   int tsrc[NTAPS], tdst[NTAPS], toff[NTAPS], tw[NTAPS];
+  int tp[NTAPS + 2];  // the same per tap in one word: toff (low 16 bits, signed) | tw << 16 | tsrc << 20 | tdst << 22; two zero words
+                      // behind the last tap (conv64_fwd_kernel fetches two taps ahead)
   int min_off, span;
   int s2;          // 1 if taps are grouped {4,2,2,1} by class, 0 if a single group of 9
   int dbg;         // ablation switches for tools/kbench.py (env SRLZ_ABLATE): 1 skip A staging, 2 skip epilogue
@@ -127,6 +129,11 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
     }
   }
   if (nt != NTAPS) return -1;
+  for (int t = 0; t < NTAPS; ++t) {
+    if (P->toff[t] < -32768 || P->toff[t] > 32767) return -1;
+    P->tp[t] = (P->toff[t] & 0xffff) | (P->tw[t] << 16) | (P->tsrc[t] << 20) | (P->tdst[t] << 22);
+  }
+  P->tp[NTAPS] = P->tp[NTAPS + 1] = 0;
   P->span = max_off - P->min_off;
   P->s2 = (stride == 2);
   { const char* e = getenv("SRLZ_ABLATE"); P->dbg = e ? atoi(e) : 0; }
@@ -396,9 +403,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
 #pragma unroll
     for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
   }
+  // The per-tap program words travel two taps ahead of their use (w0 = this tap, w1 = the next one, whose slab is requested
+  // right after this tap's second barrier): fetched at their point of use, each costs a scalar-memory round trip in front of the
+  // slab requests / the first LDS reads of every tap.
+  int w0 = P.tp[0], w1 = P.tp[1];
 #pragma unroll
   for (int ti = 0; ti < NTAPS; ++ti) {
-    const int tsrc = P.tsrc[ti], tdst = P.tdst[ti];
+    const int w2 = P.tp[ti + 2];
+    const int tsrc = (w0 >> 20) & 3, tdst = (w0 >> 22) & 3;
     __syncthreads();  // all waves are done with the previous tap's Bs (and with As if it is about to be replaced)
     if (tdst != cur_dst) {
       if (cur_dst >= 0) { if constexpr (NW == 4) flush16(cur_dst); else flush(cur_dst); }
@@ -426,12 +438,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
     }
     __syncthreads();
     if (ti + 1 < NTAPS) {  // (compile-time condition: a run-time one turns the requests into a branch the MFMAs get hoisted above)
-      const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[ti + 1] * 4096);
+      const f32x4* wsrc = (const f32x4*)(wpack + (size_t)((w1 >> 16) & 15) * 4096);
 #pragma unroll
       for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
     }
     __builtin_amdgcn_sched_barrier(0);  // the slab requests go out HERE, ahead of the tap's MFMAs (the scheduler sinks them otherwise)
-    const int R = wrow * 32 + l31 + P.toff[ti] - P.min_off;
+    const int R = wrow * 32 + l31 + (int)(short)(w0 & 0xffff) - P.min_off;
     const float* arow = As + R * 64;
     const int akey = R & 15;
     const float* brow = Bs + (wcol * NACC * 32 + l31) * 64;  // column tile j is 32 rows (2048 floats) further
@@ -460,6 +472,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
 #pragma unroll
       for (int j = 0; j < NACC; ++j) b[j] = bn[j];
     }
+    w0 = w1; w1 = w2;
   }
   if constexpr (NW == 4) {
     __syncthreads();  // every wave is done with the last tap's slab: Bs becomes scratch
