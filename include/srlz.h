@@ -177,6 +177,17 @@ int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* 
                               const float* x_bnp, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
                               srlz_stream_t stream);
 
+/* kind 1 data gradient + BatchNorm-backward partials + weight gradient + bias gradient in ONE pass over dy and x_raw (C == 3, the
+ * layer input was relu(batchnorm(x_raw)): the autograd backward of nn.ConvTranspose2d(64, 3, 4, stride=2), models/models.py:82,
+ * as srlz_convT_out_bwd_data(x_raw, x_bnp, bn_bwd_partial) followed by srlz_convT_out_bwd_weight(x_bnp) would compute it, with
+ * x_raw (1.6 GB at 512 images) and dy crossing HBM once instead of twice.  Tiles are 8 x 16 feature positions:
+ * bn_bwd_partial has srlz_convT_out_bwd_fused_tiles(d) rows of 128 floats; ws >= srlz_convT_out_bwd_fused_workspace(d) bytes. */
+int srlz_convT_out_bwd_fused_tiles(const srlz_skinny_desc* d);
+size_t srlz_convT_out_bwd_fused_workspace(const srlz_skinny_desc* d);
+int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw, const float* x_bnp,
+                             float* bn_bwd_partial, float* dw_ref, float* dbias /* may be NULL */, void* ws, size_t ws_bytes,
+                             const srlz_skinny_desc* d, srlz_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * BatchNorm2d(64) (+ ReLU (+ MaxPool 3x3 s2)) — nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d,
  * models/models.py:50-52,55-57,60-62 (encoder) and 67-68,71-72,75-76,79-80 (decoder).

@@ -16,9 +16,9 @@ namespace {
 
 constexpr int XP = 24;  // LDS row pitch (floats) of one half-row; 2*XP % 32 == 16 -> two tile rows never collide
 
-template <int K>
+template <int K, int TR = 16>
 struct Geo {
-  static constexpr int ROWS = 30 + K;              // image rows/cols feeding a 16x16 output tile
+  static constexpr int ROWS = 2 * (TR - 1) + K;    // image rows/cols feeding a TR x 16 output tile
   static constexpr int COLS = 30 + K;
   static constexpr int KT = 3 * K * K;             // taps per channel group
   static constexpr int KS = (KT + 1) / 2;          // MFMA k-steps (2 taps per step)
@@ -42,12 +42,12 @@ struct PoolFuse {
   float inv_count;
 };
 
-template <int K>
+template <int K, int TR = 16>
 __host__ __device__ constexpr int koff(int k) {
   // LDS offset of tap k = (c,ky,kx) relative to the pixel base (2*ty*XP + tx)
-  const int kk = (k < Geo<K>::KT) ? k : 0;
+  const int kk = (k < Geo<K, TR>::KT) ? k : 0;
   const int c = kk / (K * K), ky = (kk / K) % K, kx = kk % K;
-  return (c * 2 + (kx & 1)) * Geo<K>::PP + ky * XP + (kx >> 1);
+  return (c * 2 + (kx & 1)) * Geo<K, TR>::PP + ky * XP + (kx >> 1);
 }
 
 // Stage channels [3cg, 3cg+3) of the image window of output tile (oy0, ox0) into LDS.
@@ -83,9 +83,9 @@ __device__ __forceinline__ void stage_image(float* __restrict__ T, const float* 
 // hoists the unpacked (c, row, xl, LDS offset) of every element out of the caller's persistent tile loop — ~3 registers per
 // element for the whole kernel, which is what pushed these kernels into scratch; the opaque copy below keeps the (cheap) unpacking
 // inside the loop.
-template <int K>
+template <int K, int TR = 16>
 struct ImgRegs {
-  static constexpr int TOT = 3 * Geo<K>::ROWS * Geo<K>::COLS;
+  static constexpr int TOT = 3 * Geo<K, TR>::ROWS * Geo<K, TR>::COLS;
   static constexpr int PER = (TOT + 255) / 256;
   int pk[PER];       // (c << 12) | (row << 6) | xl, or -1 past the end of the window
   float v[PER];      // raw loads (from a clamped address when the element is outside the image)
@@ -93,11 +93,11 @@ struct ImgRegs {
                      // request would make the compiler wait for the load right there, and nothing would travel under the MFMAs
 };
 
-template <int K>
-__device__ __forceinline__ void image_index(ImgRegs<K>& r) {
-  constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS, TOT = ImgRegs<K>::TOT;
+template <int K, int TR = 16>
+__device__ __forceinline__ void image_index(ImgRegs<K, TR>& r) {
+  constexpr int ROWS = Geo<K, TR>::ROWS, COLS = Geo<K, TR>::COLS, TOT = ImgRegs<K, TR>::TOT;
 #pragma unroll
-  for (int j = 0; j < ImgRegs<K>::PER; ++j) {
+  for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) {
     const int idx = threadIdx.x + 256 * j;
     const int c = idx / (ROWS * COLS);
     const int rem = idx - c * (ROWS * COLS);
@@ -109,15 +109,15 @@ __device__ __forceinline__ void image_index(ImgRegs<K>& r) {
 // (channel, window row, window column) of element j; false past the end of the window.
 // HOIST: straight from the thread index — tile-independent, so the compiler keeps all of it in registers across the caller's tile
 // loop; otherwise unpacked from pk behind an opaque copy, i.e. recomputed at every use.
-template <int K, bool HOIST>
-__device__ __forceinline__ bool image_decode(const ImgRegs<K>& r, int j, int& c, int& row, int& xl) {
+template <int K, bool HOIST, int TR = 16>
+__device__ __forceinline__ bool image_decode(const ImgRegs<K, TR>& r, int j, int& c, int& row, int& xl) {
   if (HOIST) {
-    constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS;
+    constexpr int ROWS = Geo<K, TR>::ROWS, COLS = Geo<K, TR>::COLS;
     const int idx = threadIdx.x + 256 * j;
     c = idx / (ROWS * COLS);
     const int rem = idx - c * (ROWS * COLS);
     row = rem / COLS; xl = rem - row * COLS;
-    return idx < ImgRegs<K>::TOT;
+    return idx < ImgRegs<K, TR>::TOT;
   }
   int pk = r.pk[j];
   asm volatile("" : "+v"(pk));
@@ -127,15 +127,15 @@ __device__ __forceinline__ bool image_decode(const ImgRegs<K>& r, int j, int& c,
 
 // HOIST = true: the unpacked decomposition may live in registers for the whole kernel (no opaque copy): ~35 more registers, ~270
 // fewer VALU instructions per tile — worth it where the registers exist (conv1 forward: 1.10 vs 1.16 ms).
-template <int K, int PAD, bool HOIST = false>
-__device__ __forceinline__ void image_request(ImgRegs<K>& r, const float* __restrict__ img, int n, int C, int cg, int H,
+template <int K, int PAD, bool HOIST = false, int TR = 16>
+__device__ __forceinline__ void image_request(ImgRegs<K, TR>& r, const float* __restrict__ img, int n, int C, int cg, int H,
                                               int W, int oy0, int ox0, bool valid) {
   const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
   r.inside = 0;
 #pragma unroll
-  for (int j = 0; j < ImgRegs<K>::PER; ++j) {
+  for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) {
     int c, row, xl;
-    const bool live = image_decode<K, HOIST>(r, j, c, row, xl);
+    const bool live = image_decode<K, HOIST, TR>(r, j, c, row, xl);
     const int iy = iy0 + row, ix = ix0 + xl;
     const bool ok = valid && live && iy >= 0 && iy < H && ix >= 0 && ix < W;
     r.v[j] = img[ok ? ((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix : (size_t)0];
@@ -143,16 +143,16 @@ __device__ __forceinline__ void image_request(ImgRegs<K>& r, const float* __rest
   }
 }
 
-template <int K, bool HOIST = false>
-__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K>& r) {
+template <int K, bool HOIST = false, int TR = 16>
+__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K, TR>& r) {
 #pragma unroll
-  for (int j = 0; j < ImgRegs<K>::PER; ++j) {
+  for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) {
     int c, row, xl;
-    const bool live = image_decode<K, HOIST>(r, j, c, row, xl);
+    const bool live = image_decode<K, HOIST, TR>(r, j, c, row, xl);
     // (branch-free — elements past the end of the window go to a spare float of the first plane's padding: a wait inside a branch
     // leaves the compiler unsure, at the join, whether the load has landed, and it then waits for EVERYTHING at the next re-use
     // of the register, including the loads meant to stay in flight)
-    T[live ? (c * 2 + (xl & 1)) * Geo<K>::PP + row * XP + (xl >> 1) : Geo<K>::PP - 1] = ((r.inside >> j) & 1u) ? r.v[j] : 0.f;
+    T[live ? (c * 2 + (xl & 1)) * Geo<K, TR>::PP + row * XP + (xl >> 1) : Geo<K, TR>::PP - 1] = ((r.inside >> j) & 1u) ? r.v[j] : 0.f;
   }
 }
 
@@ -711,6 +711,200 @@ __global__ __launch_bounds__(1024) void skinny_wgrad_reduce(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(64, 3, 4, stride 2) BACKWARD in one pass (C == 3, BatchNorm backward deferred into the producer: the
+// product path).  Per tile of 8 x 16 feature positions:
+//   dA   = the data gradient w.r.t. relu(bn(y))          [skinny_conv_kernel<4,0,true>: im2col(dy) . W]
+//   the two BatchNorm-backward sums of that tile          [its epilogue, from the prefetched y]
+//   dW  += relu(bn(y)) (x) im2col(dy)                     [skinny_wgrad_kernel<4,0> with the fused forward operand]
+// The two contractions consume the same two operands — the image window of dy (staged once in T) and the 8x16x64 tile of y
+// (read once into registers) — so y (1.6 GB at N = 512) and dy cross HBM once instead of twice; what is left is the
+// unavoidable 3.6 GB (y in, dA out, dy in).
+// Waves: data gradient — wave w owns tile rows 2w, 2w+1 (one 32-pixel M-tile) x 64 channels; weight gradient — wave
+// (mt = w & 1, sub = w >> 1) owns channels [32mt, 32mt+32) x 48 taps over tile rows [4 sub, 4 sub + 4).
+// The accumulators of the data gradient leave through a wave-private transposition buffer that is the wave's own 32 rows of
+// F; each lane then overwrites the 16 bytes it has just read with relu(bn(y)) — the weight gradient's feature operand.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FTR = 8;  // tile rows of the fused kernel
+__global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w_ref,
+                                                              float* __restrict__ feat, float* __restrict__ stats_partial,
+                                                              float* __restrict__ wpartial, int N, int H, int W, int HF,
+                                                              int WF, int tiles_y, int tiles_x,
+                                                              const float* __restrict__ y_raw,
+                                                              const float* __restrict__ y_bnp, int npg) {
+  constexpr int K = 4, PAD = 0, C = 3, TR = FTR;
+  using G = Geo<K, TR>;
+  constexpr int KT = G::KT, KS = G::KS, NT = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* T = (float*)smem;               // image window of dy
+  float* Wl = T + G::TILE_FLOATS;        // [KS][2][64] data-gradient weights
+  float* red = Wl + KS * 128;            // [4][128]
+  float* F = red + 512;                  // [TR*16 pixels][64 channels]: transposition buffer, then relu(bn(y))
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ntiles = N * tiles_y * tiles_x, tpi = tiles_y * tiles_x;
+
+  for (int idx = tid; idx < KS * 128; idx += 256) {
+    const int co = idx & 63, sh = idx >> 6;
+    const int k = (sh & 1) * KS + (sh >> 1);
+    Wl[idx] = (k < KT) ? w_ref[(size_t)co * C * (K * K) + k] : 0.f;  // [ci = co][c][ky][kx], k = (c*K+ky)*K+kx
+  }
+  // data gradient: this lane's pixel of the wave's M-tile and its weight column (keeping the 48 weights of a lane in registers
+  // instead was measured: same time, 50 more registers)
+  const int pb = 2 * (wave * 2 + (l31 >> 4)) * XP + (l31 & 15);
+  const float* wl0 = Wl + h * 64 + l31;
+  // weight gradient: operand columns (see skinny_wgrad_kernel)
+  const int mt = wave & 1, sub = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const float* tb[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int k = j * 32 + l31;
+    const int kk = (k < KT) ? k : 0;
+    const int c = kk / (K * K), ky = (kk / K) % K, kx = kk % K;
+    tb[j] = T + ((c * 2 + (kx & 1)) * G::PP + ky * XP + (kx >> 1) + h);
+  }
+  // (taps 48..63 of N-tile 1 do not exist: they alias tap 0 and are dropped by skinny_wgrad_reduce, which reads KT columns)
+  const float* fcol = F + h * 64 + mt * 32 + l31;
+  f32x16 accw[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+
+  const int eg = lane >> 4, eslot = lane & 15;
+  f32x4 bmean = {0.f, 0.f, 0.f, 0.f}, binv = bmean, bsc = bmean, bsh = bmean;
+  int cur_grp = -1;
+
+  // this lane's 8 x float4 of y: pixel eg + 4k of the wave's 32 (tile row 2w + (pix >> 4), column pix & 15), channels 4*eslot..
+  // Requested one tile ahead — right after the epilogue has consumed the previous set, so the same 32 registers carry them —
+  // and in flight during the weight-gradient pass, the barriers and the next tile's data-gradient MFMAs.
+  f32x4 yv[8];
+  unsigned yin = 0, yin_next = 0;
+  auto y_request = [&](int tile_) {
+    const int n_ = tile_ / tpi, trem_ = tile_ - n_ * tpi;
+    const int oy0_ = (trem_ / tiles_x) * TR, ox0_ = (trem_ % tiles_x) * 16;
+    yin_next = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pix = eg + 4 * k;
+      const int oy = oy0_ + wave * 2 + (pix >> 4), ox = ox0_ + (pix & 15);
+      const bool ok = tile_ < ntiles && oy < HF && ox < WF;
+      yv[k] = *(const f32x4*)(y_raw + (ok ? ((size_t)(n_ * HF + oy) * WF + ox) * 64 : (size_t)0) + eslot * 4);
+      yin_next |= (ok ? 1u : 0u) << k;
+    }
+  };
+  ImgRegs<K, TR> nx;
+  image_index<K, TR>(nx);
+  y_request(blockIdx.x);
+  if ((int)blockIdx.x < ntiles) {
+    const int n = blockIdx.x / tpi, trem = blockIdx.x - n * tpi;
+    image_request<K, PAD, true, TR>(nx, img, n, C, 0, H, W, (trem / tiles_x) * TR, (trem % tiles_x) * 16, true);
+    image_land<K, true, TR>(T, nx);
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tpi, trem = tile - n * tpi;
+    const int oy0 = (trem / tiles_x) * TR, ox0 = (trem % tiles_x) * 16;
+    if (n / npg != cur_grp) {
+      cur_grp = n / npg;
+      const float* __restrict__ yb = y_bnp + cur_grp * 256;
+      bmean = *(const f32x4*)(yb + eslot * 4); binv = *(const f32x4*)(yb + 64 + eslot * 4);
+      bsc = *(const f32x4*)(yb + 128 + eslot * 4); bsh = *(const f32x4*)(yb + 192 + eslot * 4);
+      asm volatile("" : "+v"(bmean), "+v"(binv), "+v"(bsc), "+v"(bsh));  // (waited for here)
+    }
+    yin = yin_next;
+    __syncthreads();  // T of this tile has landed; the previous tile's weight-gradient pass is done with T and F
+    {
+      const int tile2 = tile + gridDim.x;
+      const int n2 = tile2 / tpi, trem2 = tile2 - n2 * tpi;
+      image_request<K, PAD, true, TR>(nx, img, n2, C, 0, H, W, (trem2 / tiles_x) * TR, (trem2 % tiles_x) * 16, tile2 < ntiles);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- data gradient: 32 pixels x 64 channels per wave, K = 48 taps
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const int ko = h ? koff<K, TR>(KS + s2) : koff<K, TR>(s2);
+      const float a = T[pb + ko];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl0[s2 * 128], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl0[s2 * 128 + 32], acc[1], 0, 0, 0);
+    }
+    // ---- epilogue: transpose, store dA, BatchNorm-backward partials, leave relu(bn(y)) behind
+    float* Ew = F + wave * 2048;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pix = (r & 3) + 8 * (r >> 2) + 4 * h;
+      Ew[pix * 64 + l31] = acc[0][r];
+      Ew[pix * 64 + 32 + l31] = acc[1][r];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(yv[k]));  // all y loads waited for once, outside the branches below
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pix = eg + 4 * k;
+      float* cell = Ew + pix * 64 + eslot * 4;
+      const f32x4 v = *(const f32x4*)cell;
+      const f32x4 yy = yv[k];
+      f32x4 act = {0.f, 0.f, 0.f, 0.f};
+      if ((yin >> k) & 1u) {
+        const int oy = oy0 + wave * 2 + (pix >> 4), ox = ox0 + (pix & 15);
+        *(f32x4*)(feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + eslot * 4) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = yy[e] * bsc[e] + bsh[e];
+          if (z > 0.f) { act[e] = z; s1[e] += v[e]; s2v[e] += v[e] * ((yy[e] - bmean[e]) * binv[e]); }
+        }
+      }
+      *(f32x4*)cell = act;
+    }
+    y_request(tile + gridDim.x);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1[e] += __shfl_xor(s1[e], 16, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
+      s2v[e] += __shfl_xor(s2v[e], 16, 64); s2v[e] += __shfl_xor(s2v[e], 32, 64);
+    }
+    if (eg == 0) {
+      *(f32x4*)(red + wave * 128 + eslot * 4) = s1;
+      *(f32x4*)(red + wave * 128 + 64 + eslot * 4) = s2v;
+    }
+    __syncthreads();  // F = relu(bn(y)) of the whole tile; red complete
+    if (tid < 128) stats_partial[(size_t)tile * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+    // ---- weight gradient: 64 pixels (tile rows 4 sub .. 4 sub + 3) per wave in 8 blocks of 4 k-steps
+#pragma unroll 2
+    for (int blk = 0; blk < TR; ++blk) {
+      const int lrow = (TR / 2) * sub + (blk >> 1), tx0 = 8 * (blk & 1);
+      const float* fa = fcol + (lrow * 16 + tx0) * 64;
+      const int boff = 2 * lrow * XP + tx0;
+      float a[4], b[NT][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = fa[2 * i * 64];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[j][i] = tb[j][boff + 2 * i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j][i], accw[j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with T and F: the next window lands
+    image_land<K, true, TR>(T, nx);
+  }
+  float* out = wpartial + ((size_t)blockIdx.x * 2 + sub) * (64 * NT * 32);
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[row * (NT * 32) + j * 32 + l31] = accw[j][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // kind 1 forward: img[n,co,oy,ox] = bias[co] + sum_{ci,ky,kx: oy=2iy+ky, ox=2ix+kx} feat[n,iy,ix,ci]*w_ref[ci,co,ky,kx]
 // Tile: 16x16 positions of the (a,b) = (oy>>1, ox>>1) grid -> 32x32 output pixels x 3 channels; needs the 17x17 feature
 // pixels (a0-1.., b0-1..).  Step 1: Tt[p][co*16+tap] = feat[p][:] . W (M = 289 px in 19 M-tiles of 16, N = 48, K = 64)
@@ -1057,6 +1251,52 @@ extern "C" int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref,
                "convT_out_bwd_data: x_raw, x_bnp and bn_bwd_partial go together");
   // dx[n,iy,ix,ci] = sum_{co,ky,kx} dy[n,co,2iy+ky,2ix+kx] * w_ref[ci,co,ky,kx]  == a 4x4 s2 p0 "conv" of dy
   return launch_conv<4, 0>(dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, d, as_stream(stream), x_raw, x_bnp);
+}
+
+static size_t fused_bwd_lds() { return (size_t)(Geo<4, FTR>::TILE_FLOATS + Geo<4, FTR>::KS * 128 + 512 + FTR * 16 * 64) * 4; }
+
+extern "C" int srlz_convT_out_bwd_fused_tiles(const srlz_skinny_desc* d) {
+  if (check_skinny(d)) return -1;
+  return d->n * ((d->hf + FTR - 1) / FTR) * ((d->wf + 15) / 16);
+}
+
+extern "C" size_t srlz_convT_out_bwd_fused_workspace(const srlz_skinny_desc* d) {
+  if (check_skinny(d)) return 0;
+  const int g = persistent_grid(srlz_convT_out_bwd_fused_tiles(d));
+  return (size_t)g * 2 * 64 * 64 * sizeof(float) + (size_t)d->n * d->c * sizeof(double);
+}
+
+extern "C" int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,
+                                        const float* x_bnp, float* bn_bwd_partial, float* dw_ref, float* dbias, void* ws,
+                                        size_t ws_bytes, const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 1 && d->c == 3, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: kind 1, 3 image channels");
+  SRLZ_REQUIRE(dy_nchw && w_ref && dx_nhwc && x_raw && x_bnp && bn_bwd_partial && dw_ref && ws, SRLZ_ERR_NULL,
+               "convT_out_bwd_fused: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= srlz_convT_out_bwd_fused_workspace(d), SRLZ_ERR_WORKSPACE,
+               "convT_out_bwd_fused: workspace too small (%zu)", ws_bytes);
+  hipStream_t st = as_stream(stream);
+  const int ty = (d->hf + FTR - 1) / FTR, tx = (d->wf + 15) / 16;
+  const int ntiles = d->n * ty * tx;
+  const int g = persistent_grid(ntiles);
+  const size_t lds = fused_bwd_lds();
+  float* partial = (float*)ws;
+  SRLZ_MAX_LDS(convT_out_bwd_kernel, lds);
+  hipLaunchKernelGGL(convT_out_bwd_kernel, dim3(g), dim3(256), lds, st, dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, partial, d->n,
+                     d->himg, d->wimg, d->hf, d->wf, ty, tx, x_raw, x_bnp, images_per_group(d));
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((64 * 48 + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, 16, 48, 64, dw_ref);
+  SRLZ_LAUNCHED();
+  if (dbias) {
+    double* part = (double*)((char*)ws + (size_t)g * 2 * 64 * 64 * sizeof(float));
+    SRLZ_REQUIRE((((uintptr_t)part) & 7) == 0 && ((d->himg * d->wimg) & 3) == 0, SRLZ_ERR_BAD_DESC,
+                 "convT_out_bwd_fused: unaligned workspace / image plane");
+    hipLaunchKernelGGL(nchw_chan_sum_partial, dim3(d->n * d->c), dim3(256), 0, st, dy_nchw, d->c, d->himg * d->wimg, part, d->n);
+    SRLZ_LAUNCHED();
+    hipLaunchKernelGGL(nchw_chan_sum_final, dim3(d->c), dim3(64), 0, st, part, d->n, dbias);
+    SRLZ_LAUNCHED();
+  }
+  return 0;
 }
 
 extern "C" int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias,

@@ -87,6 +87,9 @@ _PROTOS = {
     "srlz_convT_out_bwd_data": (c_int, [P, P, P, P, P, P, _SK, P]),
     "srlz_bn_bwd_finalize_partials": (c_int, [P, c_int, c_int, P, P, P, P, c_size_t, P]),
     "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _SK, P]),
+    "srlz_convT_out_bwd_fused_tiles": (c_int, [_SK]),
+    "srlz_convT_out_bwd_fused_workspace": (c_size_t, [_SK]),
+    "srlz_convT_out_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, _SK, P]),
     "srlz_bn_finalize": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),
     "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),
@@ -133,6 +136,7 @@ _PROTOS = {
 
 # entry points whose int return value is data, not a status
 _NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
+               "srlz_convT_out_bwd_fused_tiles",
                "srlz_conv64_debug_program", "srlz_comm_world"}
 
 EXPORTED = sorted(_PROTOS.keys())

@@ -575,6 +575,10 @@ class DecBlockFn(Function):
         return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(wp, dw), _give(cp, db), None, None, None
 
 
+# A/B switch: the last ConvTranspose's backward as one fused launch (0: data gradient and weight gradient as two launches)
+_FUSED_OUT_BWD = _os.environ.get("SRLZ_FUSED_OUT_BWD", "1") != "0"
+
+
 class DecOutFn(Function):
     """(y_prev raw, stats, BN params) -> ConvTranspose2d(64, C, 4, 2)(relu(bn(y_prev))), NCHW (models/models.py:79-82)."""
 
@@ -599,6 +603,17 @@ class DecOutFn(Function):
         dy = _check(dy, "decoder output dy")
         dw = _gbuf(w)
         db = _gbuf(ctx.params[2], d.c, dy.device)
+        if ctx.in_link is not None and d.c == 3 and _FUSED_OUT_BWD:
+            # data gradient, its BatchNorm-backward partials and the weight / bias gradients in one pass over (dy, y_prev)
+            da = torch.empty_like(y_prev)
+            partial = torch.empty((C.convT_out_bwd_fused_tiles(d), 128), dtype=torch.float32, device=dy.device)
+            nbytes = C.convT_out_bwd_fused_workspace(d)
+            ws = _ws(nbytes, dy.device, slot=1)
+            C.convT_out_bwd_fused(ptr(dy), ptr(w), ptr(da), ptr(y_prev), ptr(bnp), ptr(partial), ptr(dw), ptr(db), ptr(ws), nbytes, d,
+                                  stream())
+            dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial, gb=ctx.params[:2])
+            gp, bp, cp = ctx.params
+            return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(w, dw), _give(cp, db), None
         nbytes = C.skinny_bwd_weight_workspace(d)
         ws = _ws(nbytes, dy.device, slot=1)
         with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:

@@ -632,6 +632,55 @@ def test_convT_out_bwd_data_emits_bn_backward_sums(C, n, c, hf):
         assert rel_err(b, a) < 2e-5
 
 
+@pytest.mark.parametrize("n,hf,groups", [(2, 111, 1), (4, 37, 2), (3, 21, 1)])
+def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
+    """srlz_convT_out_bwd_fused (one pass over dy and x_raw) == srlz_convT_out_bwd_data(x_raw, bnp, partial) followed by
+    srlz_convT_out_bwd_weight(bnp): identical dA (same contraction order), BatchNorm-backward sums / dgamma / dbeta from the
+    8x16 tiles, weight and bias gradients to rounding (different summation order)."""
+    g = torch.Generator().manual_seed(71 + hf)
+    himg = (hf - 1) * 2 + 4
+    x_raw = (torch.randn(n, hf, hf, 64, generator=g) * 1.3 + 0.2).to(DEV)
+    w = (torch.randn(64, 3, 4, 4, generator=g) * 0.1).to(DEV)
+    dimg = torch.randn(n, 3, himg, himg, generator=g).to(DEV)
+    recs = []
+    for gi in range(groups):
+        xg = x_raw[gi * (n // groups):(gi + 1) * (n // groups)].double()
+        gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+        mean, var = xg.mean((0, 1, 2)).cpu(), xg.var((0, 1, 2), unbiased=False).cpu()
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        recs.append(torch.cat((mean, invstd, gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd)).float())
+    bnp = torch.cat(recs).to(DEV)
+    d = C.SkinnyDesc(n, 3, himg, himg, hf, hf, 1, groups)
+    st = C.stream()
+    nb = C.bn_bwd_workspace(0)
+    wsb = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    # reference: the two launches
+    da0 = torch.empty(n, hf, hf, 64, device=DEV)
+    p0 = torch.empty((C.skinny_tiles(d), 128), device=DEV)
+    C.convT_out_bwd_data(C.ptr(dimg), C.ptr(w), C.ptr(da0), C.ptr(x_raw), C.ptr(bnp), C.ptr(p0), d, st)
+    n0 = C.skinny_bwd_weight_workspace(d)
+    ws0 = torch.empty(n0, dtype=torch.uint8, device=DEV)
+    dw0, db0 = torch.empty(64, 3, 4, 4, device=DEV), torch.empty(3, device=DEV)
+    C.convT_out_bwd_weight(C.ptr(x_raw), C.ptr(dimg), C.ptr(dw0), C.ptr(db0), C.ptr(bnp), C.ptr(ws0), n0, d, st)
+    # fused
+    da1 = torch.full((n, hf, hf, 64), float("nan"), device=DEV)
+    p1 = torch.full((C.convT_out_bwd_fused_tiles(d), 128), float("nan"), device=DEV)
+    n1 = C.convT_out_bwd_fused_workspace(d)
+    ws1 = torch.empty(n1, dtype=torch.uint8, device=DEV)
+    dw1, db1 = torch.full((64, 3, 4, 4), float("nan"), device=DEV), torch.full((3,), float("nan"), device=DEV)
+    C.convT_out_bwd_fused(C.ptr(dimg), C.ptr(w), C.ptr(da1), C.ptr(x_raw), C.ptr(bnp), C.ptr(p1), C.ptr(dw1), C.ptr(db1), C.ptr(ws1),
+                          n1, d, st)
+    out = [[torch.empty(k, device=DEV) for k in (128 * groups, 64, 64)] for _ in range(2)]
+    for p, o in ((p0, out[0]), (p1, out[1])):
+        C.bn_bwd_finalize_partials(C.ptr(p), p.shape[0], groups, C.ptr(o[0]), C.ptr(o[1]), C.ptr(o[2]), C.ptr(wsb), nb, st)
+    torch.cuda.synchronize()
+    assert torch.equal(da0, da1)
+    for a, b in zip(out[0], out[1]):
+        assert rel_err(b, a) < 2e-5
+    assert rel_err(dw1, dw0) < 2e-5
+    assert torch.equal(db1, db0)
+
+
 @pytest.mark.parametrize("n,c,h", [(2, 3, 224), (1, 6, 64), (2, 3, 50)])
 def test_conv1_bwd_data(C, n, c, h):
     """srlz_conv1_bwd_data: d(loss)/d(image) of Conv2d(C,64,7,2,3) (two-phase pixel-GEMM + gather) against fp64 autograd."""
