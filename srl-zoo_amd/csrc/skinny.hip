@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   float* T = (float*)smem;                  // image window
   float* F = T + Geo<K>::TILE_FLOATS;       // [RPS*16 pixels][64 channels] feature rows of the current stage
   // A tile is consumed in NSTAGE stages of RPS tile rows (8 = half a tile; 4 for FUSED, whose in-flight state per row is larger)
-  constexpr int RPS = FUSED ? 4 : 8, NSTAGE = 16 / RPS, NWR = RPS / 2 + 1;
+  constexpr int RPS = FUSED ? 4 : 8, NSTAGE = 16 / RPS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -512,9 +512,14 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   // stage's MFMA loop and RESOLVED into LDS after it, and the image window of the next tile travels under the last stage of this one.
   f32x4 pv[RPS];
   unsigned pmask = 0;
-  f32x4 dpv[FUSED ? NWR : 1][2];
-  uint32_t am[FUSED ? NWR : 1][2];
-  unsigned wmask = 0;  // bit 2r+c: window (r, c) exists
+  f32x4 dpv[FUSED ? 2 : 1][2];
+  uint32_t am[FUSED ? 2 : 1][2];
+  unsigned wmask = 0;  // bit 2wy+wx: window (wy, wx) exists
+  // FUSED thread mapping: a thread owns a 2x2 block of pixels of the 4x16 stage — rows 2*brow + i, columns 2*bcol + j — and the
+  // 2x2 pooling windows that can have picked them (3x3, stride 2, pad 1: window (R + wy, Cx + wx) sees pixel (2R + i, 2Cx + j) at
+  // ky = i - 2wy + 1, kx = j - 2wx + 1), i.e. 9 membership tests with compile-time codes for 4 pixels on EVERY lane.  (One column
+  // of 4 rows per thread needs 6 tests on even and 12 on odd columns, and a wave then pays 12 everywhere.)
+  const int brow = (tid >> 4) >> 3, bcol = (tid >> 4) & 7;
   auto f_request = [&](int tile_, int half_) {
     const int n_ = tile_ / tpi;
     const int trem_ = tile_ - n_ * tpi;
@@ -522,69 +527,71 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
     const bool live = tile_ < ntiles;
     const float* __restrict__ fsrc = FUSED ? pf.y : feat;
     pmask = 0;
-#pragma unroll
-    for (int j = 0; j < RPS; ++j) {  // pixel p = 16*j + prow of the stage: tile row RPS*stage + j, column prow
-      const int oy = oy0_ + RPS * half_ + j, ox = ox0_ + prow;
-      const bool ok = live && oy < HF && ox < WF;  // (raw load from a clamped address; the mask is applied in f_resolve — see ImgRegs)
-      pv[j] = *(const f32x4*)(fsrc + (ok ? ((size_t)(n_ * HF + oy) * WF + ox) * 64 : (size_t)0) + slot * 4);
-      pmask |= (ok ? 1u : 0u) << j;
-    }
     if constexpr (FUSED) {
-      // oyb is even, so the pooling windows (3x3, stride 2, pad 1) that can have picked one of the RPS rows oyb..oyb+RPS-1
-      // are the NWR window rows pb..pb+RPS/2 (pb = oyb/2): an even row r is only the centre (ky=1) of window r/2, an odd row is ky=0
-      // of window (r+1)/2 and ky=2 of window (r-1)/2; same along x with the parity of ox: window column c0 = (ox+1)>>1 seen
-      // through kx = (xodd ? 0 : 1), and c1 = (ox-1)>>1 through kx = 2 (odd ox only).
-      const int oyb = oy0_ + RPS * half_, ox = ox0_ + prow, pb = oyb >> 1;
-      const bool xin = live && ox < WF;
-      const int c0 = (ox + 1) >> 1, c1 = (ox - 1) >> 1;
-      const bool c0ok = xin && c0 < pf.WP, c1ok = xin && (ox & 1) && c1 < pf.WP;
+      const int oyb = oy0_ + RPS * half_ + 2 * brow, oxb = ox0_ + 2 * bcol;  // both even
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int oy = oyb + i, ox = oxb + j;
+          const bool ok = live && oy < HF && ox < WF;  // (raw load from a clamped address; the mask is applied in f_resolve)
+          pv[2 * i + j] = *(const f32x4*)(fsrc + (ok ? ((size_t)(n_ * HF + oy) * WF + ox) * 64 : (size_t)0) + slot * 4);
+          pmask |= (ok ? 1u : 0u) << (2 * i + j);
+        }
       wmask = 0;
 #pragma unroll
-      for (int r = 0; r < NWR; ++r) {
-        const bool rok = pb + r < pf.HP;
-        const size_t rowbase = (size_t)(n_ * pf.HP + pb + r) * pf.WP;
+      for (int wy = 0; wy < 2; ++wy)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const bool ok = rok && (c ? c1ok : c0ok);
-          const size_t pp = (ok ? (rowbase + (c ? c1 : c0)) * 64 : (size_t)0) + slot * 4;
-          am[r][c] = *(const uint32_t*)(pf.argmax + pp);
-          dpv[r][c] = *(const f32x4*)(pf.dpooled + pp);
-          wmask |= (ok ? 1u : 0u) << (2 * r + c);
+        for (int wx = 0; wx < 2; ++wx) {
+          const int py = (oyb >> 1) + wy, px = (oxb >> 1) + wx;
+          const bool ok = live && py < pf.HP && px < pf.WP;
+          const size_t pp = (ok ? ((size_t)(n_ * pf.HP + py) * pf.WP + px) * 64 : (size_t)0) + slot * 4;
+          am[wy][wx] = *(const uint32_t*)(pf.argmax + pp);
+          dpv[wy][wx] = *(const f32x4*)(pf.dpooled + pp);
+          wmask |= (ok ? 1u : 0u) << (2 * wy + wx);
         }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RPS; ++j) {  // pixel p = 16*j + prow of the stage: tile row RPS*stage + j, column prow
+        const int oy = oy0_ + RPS * half_ + j, ox = ox0_ + prow;
+        const bool ok = live && oy < HF && ox < WF;  // (raw load from a clamped address; the mask is applied in f_resolve — see ImgRegs)
+        pv[j] = *(const f32x4*)(fsrc + (ok ? ((size_t)(n_ * HF + oy) * WF + ox) * 64 : (size_t)0) + slot * 4);
+        pmask |= (ok ? 1u : 0u) << j;
       }
     }
   };
-  auto f_resolve = [&](int ox0_) {  // the requested stage -> F
+  auto f_resolve = [&]() {  // the requested stage -> F
     if constexpr (FUSED) {
-      const uint32_t kx0 = ((ox0_ + prow) & 1) ? 0u : 1u;
+      uint32_t a[2][2];
 #pragma unroll
-      for (int j = 0; j < RPS; ++j) {
-        f32x4 dz = {0.f, 0.f, 0.f, 0.f};
-        // (window row, ky) pairs for row j: even j -> (j/2, 1); odd j -> ((j+1)/2, 0) and ((j-1)/2, 2)
+      for (int wy = 0; wy < 2; ++wy)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          if ((j & 1) == 0 && t == 1) continue;
-          const int r = (j & 1) ? (t == 0 ? (j + 1) / 2 : (j - 1) / 2) : j / 2;
-          const uint32_t ky = (j & 1) ? (t == 0 ? 0u : 2u) : 1u;
-          const uint32_t me0 = ky * 3 + kx0, me1 = ky * 3 + 2;
-          const uint32_t a0 = ((wmask >> (2 * r)) & 1u) ? am[r][0] : 0xffffffffu;  // (0xff matches no window position)
-          const uint32_t a1 = ((wmask >> (2 * r + 1)) & 1u) ? am[r][1] : 0xffffffffu;
+        for (int wx = 0; wx < 2; ++wx) a[wy][wx] = ((wmask >> (2 * wy + wx)) & 1u) ? am[wy][wx] : 0xffffffffu;  // 0xff matches nothing
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int wy = 0; wy <= i; ++wy)
+#pragma unroll
+            for (int wx = 0; wx <= j; ++wx) {
+              const uint32_t code = (uint32_t)((i - 2 * wy + 1) * 3 + (j - 2 * wx + 1));
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (((a[wy][wx] >> (8 * e)) & 0xffu) == code) dz[e] += dpv[wy][wx][e];
+            }
+          const f32x4 yy = pv[2 * i + j];
+          f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (((a0 >> (8 * e)) & 0xffu) == me0) dz[e] += dpv[r][0][e];
-            if (((a1 >> (8 * e)) & 0xffu) == me1) dz[e] += dpv[r][1][e];
+            const float z = yy[e] * sc4[e] + sh4[e];
+            const float d = z > 0.f ? dz[e] : 0.f;
+            o[e] = sc4[e] * d - (fc0[e] + fc1[e] * yy[e]);
           }
+          if (!((pmask >> (2 * i + j)) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)(F + (16 * (2 * brow + i) + 2 * bcol + j) * 64 + slot * 4) = o;
         }
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = pv[j][e] * sc4[e] + sh4[e];
-          const float d = z > 0.f ? dz[e] : 0.f;
-          o[e] = sc4[e] * d - (fc0[e] + fc1[e] * pv[j][e]);
-        }
-        if (!((pmask >> j) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
-        *(f32x4*)(F + (16 * j + prow) * 64 + slot * 4) = o;
-      }
     } else {
       if (K == 4 && feat_bnp) {  // a fused BatchNorm+ReLU is applied now, at consumption
 #pragma unroll
@@ -613,8 +620,6 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   if ((int)blockIdx.x < ntiles) { f_request(blockIdx.x, 0); i_request(blockIdx.x); }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / tpi;
-    const int trem = tile - n * tpi;
-    const int ox0 = (trem % tiles_x) * 16;
     const int grp = n / npg;
     if (grp != cur_grp) {
       cur_grp = grp;
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
     for (int half = 0; half < NSTAGE; ++half) {
       __syncthreads();
       if (half == 0) image_land<K, K == 4>(T, ir);
-      f_resolve(ox0);
+      f_resolve();
       __syncthreads();
       if (half + 1 < NSTAGE) f_request(tile, half + 1);
       else { f_request(tile + gridDim.x, 0); i_request(tile + gridDim.x); }
