@@ -629,7 +629,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
 // RING_ROWS >= TK + span + TK (the prefetched TK rows are written only after the readers' barrier).
 template <int V> struct IntC { static constexpr int value = V; };
 constexpr int RING_ROWS = 248, RING_MIRROR = 8, RING = RING_ROWS + RING_MIRROR;
-__device__ __forceinline__ int ring_slot(int q) { return (q + 4 * RING_ROWS) % RING_ROWS; }  // q >= -4 * RING_ROWS
+// the stride-2 (ConvTranspose) kernel walks 32-position chunks: RING_ROWS_S2 >= 32 + span + 32, and 4 x 32 gradient rows next to it
+constexpr int RING_ROWS_S2 = 184, RING_S2 = RING_ROWS_S2 + RING_MIRROR;
+template <int ROWS = RING_ROWS>
+__device__ __forceinline__ int ring_slot(int q) { return (q + 4 * ROWS) % ROWS; }  // q >= -4 * ROWS
 
 // rows [qstart, qstart+64) of class `cls`: 4 rows per thread (16 apart) into registers; okmask bit j = row j in bounds.
 // <J0, NJ>: only this thread's rows J0 .. J0+NJ-1 (v[j - J0]); the other bits of okmask are left alone.
@@ -666,7 +669,7 @@ __device__ __forceinline__ void rows64_load(f32x4 (&v)[NJ], unsigned& okmask, co
 
 // registers -> LDS rows (row index of this thread's j-th row = rbase + 16*j; RINGED: its ring slot, plus the mirror copy);
 // bnp != NULL: relu(batchnorm(.)) applied to in-bounds rows on the way (OpFuse forward fusion)
-template <bool RINGED, int J0 = 0, int NJ = 4>
+template <bool RINGED, int J0 = 0, int NJ = 4, int ROWS = RING_ROWS>
 __device__ __forceinline__ void rows64_store(float* __restrict__ lds, int rbase, f32x4 (&v)[NJ], unsigned okmask,
                                              const float* __restrict__ bnp) {
   int t = threadIdx.x;
@@ -681,9 +684,9 @@ __device__ __forceinline__ void rows64_store(float* __restrict__ lds, int rbase,
       for (int e = 0; e < 4; ++e) { const float z = v[j - J0][e] * sc4[e] + sh4[e]; v[j - J0][e] = z > 0.f ? z : 0.f; }
     }
     int R = rbase + (t >> 4) + 16 * j;
-    if (RINGED) R = ring_slot(R);
+    if (RINGED) R = ring_slot<ROWS>(R);
     *(f32x4*)(lds + R * 64 + slot * 4) = v[j - J0];
-    if (RINGED && R < RING_MIRROR) *(f32x4*)(lds + (R + RING_ROWS) * 64 + slot * 4) = v[j - J0];
+    if (RINGED && R < RING_MIRROR) *(f32x4*)(lds + (R + ROWS) * 64 + slot * 4) = v[j - J0];
   }
 }
 
@@ -829,6 +832,132 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same for stride-2 scatter programs (ConvTranspose weight gradients: one source class, four destination classes with
+// 4 / 2 / 2 / 1 taps).  conv64_wgrad_ring_kernel<true> walks a 64-position chunk class by class — four barrier pairs per chunk,
+// the last of them around 32 MFMAs per wave.  Here a chunk is 32 positions and carries the gradient rows of ALL four classes
+// (4 x 8 KB) next to a 184 + 8 row source ring (48 KB): one barrier pair per 144 MFMAs, every tap of a k-block shares the block's
+// loads, and the prefetch (8 gradient + 2 source float4 per thread) travels under a whole chunk.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                     float* __restrict__ partial, const ConvProg P, int nchunks,
+                                                                     int chunks_per_wg, int wgs_per_group,
+                                                                     const float* __restrict__ x_bnp) {
+  constexpr int TK = 32;
+  constexpr int GRP[NTAPS] = {0, 0, 0, 0, 1, 1, 2, 2, 3};  // destination-class group of tap t (taps are sorted 4/2/2/1)
+  constexpr int GFIRST[4] = {0, 4, 6, 8};
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Ss = (float*)smem;          // ring: source row q at slot q mod RING_ROWS_S2 (+ mirror)
+  float* Gs = Ss + RING_S2 * 64;     // [4 classes][TK rows][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mi = wave & 1, nj = wave >> 1;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  f32x4 bs4 = {0.f, 0.f, 0.f, 0.f};
+
+  const int cs = P.tsrc[0];
+  const int grp = (P.G > 1) ? blockIdx.x / wgs_per_group : 0;
+  x += grp * P.src_gstride;
+  g += grp * P.dst_gstride;
+  if (x_bnp) x_bnp += grp * 256;
+  const int c_begin = (blockIdx.x - grp * wgs_per_group) * chunks_per_wg;
+  const int c_end = (c_begin + chunks_per_wg < nchunks) ? c_begin + chunks_per_wg : nchunks;
+
+  f32x4 pg[4][2], ps[2];
+  unsigned okg[4] = {0, 0, 0, 0}, oks = 0;
+  auto g_request = [&](int q0_) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      rows64_load<0, 2>(pg[c], okg[c], g, P.Hd, P.Wd, P.ds, P.tdst[GFIRST[c]], P.PW, P.PH, P.total_q, q0_);
+  };
+  auto g_land = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      rows64_store<false, 0, 2>(Gs + c * TK * 64, 0, pg[c], okg[c], nullptr);
+      bs4 += pg[c][0] + pg[c][1];  // (rows outside the tensor are zero)
+    }
+  };
+  if (c_begin < c_end) {
+    const int q0 = c_begin * TK;
+    for (int r0 = 0; r0 < TK + P.span; r0 += 32) {
+      rows64_load<0, 2>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0);
+      rows64_store<true, 0, 2, RING_ROWS_S2>(Ss, q0 + P.min_off + r0, ps, oks, x_bnp);
+    }
+    g_request(q0);
+    g_land();
+  }
+  __syncthreads();
+
+  const float* gcol = Gs + (h * 64 + nj * 32 + l31);
+  const float* scol = Ss + (h * 64 + mi * 32 + l31);
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const int q0 = chunk * TK;
+    const bool more = chunk + 1 < c_end;
+    if (more) {
+      g_request(q0 + TK);
+      rows64_load<0, 2>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span);
+    }
+    int u[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) u[t] = ring_slot<RING_ROWS_S2>(q0 + P.toff[t]);
+#pragma unroll 1
+    for (int b = 0; b < TK / 8; ++b) {
+      int go = b * (8 * 64);
+      asm volatile("" : "+v"(go));  // (one address per class; see conv64_wgrad_ring_kernel)
+      float bf[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[c][i] = gcol[c * TK * 64 + go + 2 * i * 64];
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {
+        const float* ap = scol + u[t] * 64;
+        float af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = ap[2 * i * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[GRP[t]][i], acc[t], 0, 0, 0);
+        u[t] += 8;
+        if (u[t] >= RING_ROWS_S2) u[t] -= RING_ROWS_S2;
+      }
+    }
+    __syncthreads();  // every wave is done with this chunk's gradient rows (and with the ring slots the new rows replace)
+    if (more) {
+      g_land();
+      rows64_store<true, 0, 2, RING_ROWS_S2>(Ss, q0 + P.min_off + TK + P.span, ps, oks, x_bnp);
+    }
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.x * (NTAPS * 4096);
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t) {
+    float* o = out + (size_t)P.tw[t] * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      o[row * 64 + nj * 32 + l31] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  float* red = Ss;  // [16 row groups][64 channels]
+  *(f32x4*)(red + (tid >> 4) * 64 + (tid & 15) * 4) = bs4;
+  __syncthreads();
+  if (tid < 64) {
+    float* bout = partial + (size_t)gridDim.x * (NTAPS * 4096) + (size_t)blockIdx.x * 64;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r * 64 + tid];
+    bout[tid] = t;
+  }
+}
 
 // dw_ref[...] = sum over workgroups (fixed order); layout: conv [co][ci][3][3], convT [ci][co][3][3].
 // 1024 threads per block: 256 outputs x 4 slices of the workgroup range, 4 loads in flight per thread, fp64 combine.
@@ -1243,7 +1372,18 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   for (int t = 1; t < NTAPS; ++t) single_src = single_src && P.tsrc[t] == P.tsrc[0];
   static const int use_ring = [] { const char* e = getenv("SRLZ_WGRAD_RING"); return e ? atoi(e) : 1; }();
   int launched_grid = grid;
-  if (use_ring && single_src && gf.y == nullptr && tk + P.span + tk <= RING_ROWS && tk == 64) {
+  static const int s2_tk32 = [] { const char* e = getenv("SRLZ_WGRAD_S2_TK32"); return e ? atoi(e) : 1; }();
+  if (use_ring && s2_tk32 && single_src && gf.y == nullptr && P.s2 && 32 + P.span + 32 <= RING_ROWS_S2) {
+    // 32-position chunks carrying all four destination classes (conv64_wgrad_ring_s2_kernel)
+    const int nch = (P.total_q + 31) / 32;
+    const int gpg = grid / P.G;
+    const int cpw = (nch + gpg - 1) / gpg;
+    const int wpg = (nch + cpw - 1) / cpw;
+    launched_grid = wpg * P.G;
+    const size_t lds = (size_t)(RING_S2 + 4 * 32) * 256;
+    SRLZ_MAX_LDS(conv64_wgrad_ring_s2_kernel, lds);
+    hipLaunchKernelGGL(conv64_wgrad_ring_s2_kernel, dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nch, cpw, wpg, x_bnp);
+  } else if (use_ring && single_src && gf.y == nullptr && tk + P.span + tk <= RING_ROWS && tk == 64) {
     // contiguous chunk ranges per workgroup (ring re-use of the source rows), group by group
     const int gpg = grid / P.G;
     const int cpw = (nchunks + gpg - 1) / gpg;
