@@ -576,16 +576,22 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < TK / 4; ++r) bsum += Gs[(part * (TK / 4) + r) * 64 + col];
       }
-      const float* gcol = Gs + nj * 32 + l31;
-      const float* scol = Ss + mi * 32 + l31;
-#pragma unroll 4
-      for (int ks = 0; ks < TK / 2; ++ks) {
-        const int row = 2 * ks + h;
-        const float bfrag = gcol[row * 64];
+      // blocks of 4 k-steps (rows 8b + 2i + h): one address per operand column and block, the 4 rows as immediate offsets
+      const float* gcol = Gs + h * 64 + nj * 32 + l31;
+      const float* scol = Ss + h * 64 + mi * 32 + l31;
+#pragma unroll 2
+      for (int b = 0; b < TK / 8; ++b) {
+        float bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = gcol[(8 * b + 2 * i) * 64];
 #pragma unroll
         for (int t = t0; t < t1; ++t) {
-          const float afrag = scol[(row + P.toff[t] - P.min_off) * 64];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[t], 0, 0, 0);
+          const float* ap = scol + (8 * b + P.toff[t] - P.min_off) * 64;
+          float af[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i] = ap[2 * i * 64];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc[t], 0, 0, 0);
         }
       }
     }
