@@ -1,0 +1,36 @@
+"""Static guard for the compiler-level pathologies of DESIGN.md 5.2, on the ISA hipcc generates for gfx950 (no GPU needed):
+no kernel may serialise its global stores behind full memory waits, and the hot kernels must not spill (a spill reload is a
+vector-memory load: waiting for it drains every store issued before it)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+import isa_audit  # noqa: E402
+
+HOT = ("conv64_fwd_kernel<4, false>", "conv64_fwd_kernel<4, true>", "conv64_wgrad_ring_kernel<false>",
+       "conv64_wgrad_ring_s2_kernel", "skinny_conv_kernel<7, 3, false, false>", "skinny_conv_kernel<4, 0, true, false>",
+       "skinny_wgrad_kernel<7, 3, true>", "skinny_wgrad_kernel<4, 0, false>", "convT_out_kernel", "convT_out_bwd_kernel")
+
+
+@pytest.mark.skipif(not os.path.exists(isa_audit.HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc")
+@pytest.mark.parametrize("source", ["conv64.hip", "skinny.hip", "linear.hip"])
+def test_no_serialised_stores_and_no_spills_in_hot_kernels(source):
+    ks = list(isa_audit.kernels(isa_audit.disassemble(os.path.join(isa_audit.CSRC, source))))
+    names = isa_audit.demangle([k for k, _ in ks])
+    assert ks, "no kernels found in " + source
+    seen = set()
+    for (_, body), name in zip(ks, names):
+        a = isa_audit.audit(body)
+        assert a["store_wait_chain"] < 2, "%s: %d stores each wait for the previous one (s_waitcnt vmcnt(0) between them)" % (
+            name, a["store_wait_chain"] + 1)
+        for hot in HOT:
+            if name.startswith(hot):
+                seen.add(hot)
+                assert a["scratch_reloads"] == 0, "%s spills (%d scratch reloads)" % (name, a["scratch_reloads"])
+    if source != "linear.hip":
+        expected = [h for h in HOT if (h.startswith("conv64") == (source == "conv64.hip"))]
+        assert set(expected) <= seen, "kernels renamed? missing %s" % sorted(set(expected) - seen)
