@@ -179,7 +179,10 @@ template <bool SWZ, int BATCH = 8, int NTHREADS = 256, bool BWD = false>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
                                            int stride, int cls, int PW, int PH, int total_q, int qstart,
                                            int nrows, const OpFuse f = SRLZ_NO_FUSE, int core_lo = 0, int core_n = 0,
-                                           int cstride = 64, int coff = 0) {
+                                           int cstride = 64, int coff = 0, const float* __restrict__ lrec = nullptr) {
+  // lrec != NULL: the per-channel coefficients of the fused operand (scale, shift, c0, c1: 4 x 64 floats) have been put in LDS by
+  // the caller, once per workgroup — read from the global records at every call they cost two to three dependent L2 round trips in
+  // front of each staging (four stagings per tile for the stride-2 gather programs)
   // cstride / coff: the tensor has `cstride` channels per pixel and this call stages channels [coff, coff + 64) (convN_*)
   const float* __restrict__ bnp = f.bnp;
   // Loads are issued in batches of 8 rows per thread before any LDS store, so the HBM/L2 latency is paid once per
@@ -200,8 +203,11 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
   const int N1max = total_q / PHW;  // images
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-  if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
-  if (BWD && f.training) {
+  if (lrec) {
+    sc4 = *(const f32x4*)(lrec + slot * 4); sh4 = *(const f32x4*)(lrec + 64 + slot * 4);
+    if (BWD) { c0 = *(const f32x4*)(lrec + 128 + slot * 4); c1 = *(const f32x4*)(lrec + 192 + slot * 4); }
+  } else if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
+  if (!lrec && BWD && f.training) {
     const f32x4 mean = *(const f32x4*)(bnp + slot * 4), invstd = *(const f32x4*)(bnp + 64 + slot * 4);
     const f32x4 m1 = *(const f32x4*)(f.sums + slot * 4), m2 = *(const f32x4*)(f.sums + 64 + slot * 4);
 #pragma unroll
@@ -212,7 +218,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
   }
   for (int base = t >> 4; base < nrows; base += RP * BATCH) {
     f32x4 v[BATCH], yv[BWD ? BATCH : 1];
-    size_t offs[BWD ? BATCH : 1];
+    unsigned offs[BWD ? BATCH : 1];  // float offsets of the rows (a group's tensor has < 2^32 floats: checked by the host)
     unsigned okmask = 0;
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
@@ -225,7 +231,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
       // next weight slab was waited for before the MFMAs it is meant to hide behind.
       const size_t off = (ok ? ((size_t)((n1 - 1) * H + y) * W + x) * cstride : (size_t)0) + coff + slot * 4;
       v[j] = *(const f32x4*)(src + off);
-      if (BWD) { yv[j] = *(const f32x4*)(f.y + off); offs[j] = off; }
+      if (BWD) { yv[j] = *(const f32x4*)(f.y + off); offs[j] = (unsigned)off; }
       b += sb; a += sa;
       if (b >= PW) { b -= PW; ++a; }
       if (a >= PH) { a -= PH; ++n1; }
@@ -252,7 +258,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
               const float dz = z > 0.f ? v[j][e] : 0.f;
               v[j][e] = sc4[e] * dz - (c0[e] + c1[e] * yv[j][e]);
             }
-            if (f.dy_out && (unsigned)(R - core_lo) < (unsigned)core_n) *(f32x4*)(f.dy_out + offs[j]) = v[j];
+            if (f.dy_out && (unsigned)(R - core_lo) < (unsigned)core_n) *(f32x4*)(f.dy_out + (size_t)offs[j]) = v[j];
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float z = v[j][e] * sc4[e] + sh4[e]; v[j][e] = z > 0.f ? z : 0.f; }
@@ -315,6 +321,19 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
     }
     rowinfo[tid] = n; rowinfo[TM + tid] = ya; rowinfo[2 * TM + tid] = xb;
   }
+  // coefficients of a fused operand, once per workgroup (visible after the first tap's barrier, which precedes the first staging)
+  float* frec = (float*)(rowinfo + 3 * TM);  // [4][64]: scale, shift, c0, c1
+  if (src_fuse.bnp && tid >= NT - 64) {
+    const int c = tid - (NT - 64);
+    const float sc = src_fuse.bnp[128 + c], sh = src_fuse.bnp[192 + c];
+    float c0 = 0.f, c1 = 0.f;
+    if (BWD && src_fuse.training) {
+      c1 = sc * src_fuse.bnp[64 + c] * src_fuse.sums[64 + c] * src_fuse.inv_count;
+      c0 = sc * src_fuse.sums[c] * src_fuse.inv_count - c1 * src_fuse.bnp[c];
+    }
+    frec[c] = sc; frec[64 + c] = sh; frec[128 + c] = c0; frec[192 + c] = c1;
+  }
+  const float* lrec = src_fuse.bnp ? frec : nullptr;
 
   f32x16 acc[NACC];
   float sum[NACC], sq[NACC];  // BatchNorm partials of this lane's columns
@@ -424,10 +443,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
       if (!(P.dbg & 1)) {
         if (BWD)
           stage_rows<true, (NW == 4 ? BATCH_BWD : 2), NT, true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q,
-                                                        q0 + P.min_off, TM + P.span, src_fuse, -P.min_off, TM);
+                                                        q0 + P.min_off, TM + P.span, src_fuse, -P.min_off, TM, 64, 0, lrec);
         else
           stage_rows<true, (NW == 4 ? BATCH_FWD : 4), NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off,
-                                                  TM + P.span, src_fuse);
+                                                  TM + P.span, src_fuse, 0, 0, 64, 0, lrec);
       }
       cur_src = tsrc;
     }
@@ -1047,7 +1066,7 @@ static int program_for(ConvProg* P, const srlz_conv64_desc* d, int backward_data
   return 0;
 }
 
-static size_t fwd_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) * 256 + 16384 + 3 * TM * 4; }
+static size_t fwd_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) * 256 + 16384 + 3 * TM * 4 + 256 * 4; }
 static size_t wgrad_lds_bytes(const ConvProg& P, int tk) { return (size_t)(tk + P.span + tk) * 256; }
 static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried: the extra staging registers spill
 
@@ -1067,6 +1086,8 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
                        P, ntiles, src_fuse);                                                                               \
   } while (0)
   if (src_fuse.y) {
+    SRLZ_REQUIRE((long long)P.N * P.Hs * P.Ws * 64 < (1LL << 32), SRLZ_ERR_BAD_DESC,
+                 "conv64: a group's operand has %lld floats (the fused staging keeps 32-bit row offsets)", (long long)P.N * P.Hs * P.Ws * 64);
     if (nw_bwd == 8) SRLZ_FWD_LAUNCH(8, true);
     else SRLZ_FWD_LAUNCH(4, true);
   } else {
