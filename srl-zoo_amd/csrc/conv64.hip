@@ -694,14 +694,24 @@ __device__ __forceinline__ void rows64_load(f32x4 (&v)[NJ], unsigned& okmask, co
 
 // registers -> LDS rows (row index of this thread's j-th row = rbase + 16*j; RINGED: its ring slot, plus the mirror copy);
 // bnp != NULL: relu(batchnorm(.)) applied to in-bounds rows on the way (OpFuse forward fusion)
+// The scale / shift of a fused operand for this thread's four channels (identity when bnp == NULL): loaded ONCE by the caller — at
+// every landing they would be an L2 round trip in front of the LDS writes, once per 32- or 64-position chunk.
+struct BnQuad { f32x4 sc, sh; bool on; };
+__device__ __forceinline__ BnQuad bn_quad(const float* __restrict__ bnp) {
+  BnQuad q = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{0.f, 0.f, 0.f, 0.f}, bnp != nullptr};
+  const int slot = threadIdx.x & 15;
+  if (bnp) { q.sc = *(const f32x4*)(bnp + 128 + slot * 4); q.sh = *(const f32x4*)(bnp + 192 + slot * 4); }
+  return q;
+}
+
 template <bool RINGED, int J0 = 0, int NJ = 4, int ROWS = RING_ROWS>
 __device__ __forceinline__ void rows64_store(float* __restrict__ lds, int rbase, f32x4 (&v)[NJ], unsigned okmask,
-                                             const float* __restrict__ bnp) {
+                                             const BnQuad& bq) {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));  // (see rows64_load)
   const int slot = t & 15;
-  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-  if (bnp) { sc4 = *(const f32x4*)(bnp + 128 + slot * 4); sh4 = *(const f32x4*)(bnp + 192 + slot * 4); }
+  const f32x4 sc4 = bq.sc, sh4 = bq.sh;
+  const bool bnp = bq.on;
 #pragma unroll
   for (int j = J0; j < J0 + NJ; ++j) {
     if (bnp && ((okmask >> j) & 1u)) {
@@ -749,6 +759,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   x += grp * P.src_gstride;
   g += grp * P.dst_gstride;
   if (x_bnp) x_bnp += grp * 256;
+  const BnQuad xq = bn_quad(x_bnp), noq = bn_quad(nullptr);
   const int c_begin = (blockIdx.x - grp * wgs_per_group) * chunks_per_wg;
   const int c_end = (c_begin + chunks_per_wg < nchunks) ? c_begin + chunks_per_wg : nchunks;
   if (c_begin < c_end) {
@@ -758,10 +769,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
     unsigned ok;
     for (int r0 = 0; r0 < TK + P.span; r0 += 64) {
       rows64_load(v, ok, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0);
-      rows64_store<true>(Ss, q0 + P.min_off + r0, v, ok, x_bnp);
+      rows64_store<true>(Ss, q0 + P.min_off + r0, v, ok, xq);
     }
     rows64_load(v, ok, g, P.Hd, P.Wd, P.ds, P.tdst[0], P.PW, P.PH, P.total_q, q0);
-    rows64_store<false>(Gs, 0, v, ok, nullptr);
+    rows64_store<false>(Gs, 0, v, ok, noq);
     bs4 += (v[0] + v[1]) + (v[2] + v[3]);  // (rows outside the tensor are zero)
   }
   __syncthreads();
@@ -824,10 +835,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
       // ---- land the prefetched rows
       __syncthreads();
       if (want_g) {
-        rows64_store<false>(Gs, 0, pg, okg, nullptr);
+        rows64_store<false>(Gs, 0, pg, okg, noq);
         bs4 += (pg[0] + pg[1]) + (pg[2] + pg[3]);
       }
-      if (want_s) rows64_store<true, SJ0, SNJ>(Ss, q0 + P.min_off + TK + P.span, ps, oks, x_bnp);
+      if (want_s) rows64_store<true, SJ0, SNJ>(Ss, q0 + P.min_off + TK + P.span, ps, oks, xq);
       __syncthreads();
     };
     group(IntC<0>{});
@@ -893,6 +904,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const floa
   x += grp * P.src_gstride;
   g += grp * P.dst_gstride;
   if (x_bnp) x_bnp += grp * 256;
+  const BnQuad xq = bn_quad(x_bnp), noq = bn_quad(nullptr);
   const int c_begin = (blockIdx.x - grp * wgs_per_group) * chunks_per_wg;
   const int c_end = (c_begin + chunks_per_wg < nchunks) ? c_begin + chunks_per_wg : nchunks;
 
@@ -906,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const floa
   auto g_land = [&]() {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      rows64_store<false, 0, 2>(Gs + c * TK * 64, 0, pg[c], okg[c], nullptr);
+      rows64_store<false, 0, 2>(Gs + c * TK * 64, 0, pg[c], okg[c], noq);
       bs4 += pg[c][0] + pg[c][1];  // (rows outside the tensor are zero)
     }
   };
@@ -914,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const floa
     const int q0 = c_begin * TK;
     for (int r0 = 0; r0 < TK + P.span; r0 += 32) {
       rows64_load<0, 2>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0);
-      rows64_store<true, 0, 2, RING_ROWS_S2>(Ss, q0 + P.min_off + r0, ps, oks, x_bnp);
+      rows64_store<true, 0, 2, RING_ROWS_S2>(Ss, q0 + P.min_off + r0, ps, oks, xq);
     }
     g_request(q0);
     g_land();
@@ -957,7 +969,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const floa
     __syncthreads();  // every wave is done with this chunk's gradient rows (and with the ring slots the new rows replace)
     if (more) {
       g_land();
-      rows64_store<true, 0, 2, RING_ROWS_S2>(Ss, q0 + P.min_off + TK + P.span, ps, oks, x_bnp);
+      rows64_store<true, 0, 2, RING_ROWS_S2>(Ss, q0 + P.min_off + TK + P.span, ps, oks, xq);
     }
     __syncthreads();
   }
