@@ -131,21 +131,28 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
     const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
     f32x4 best = {-1.f, -1.f, -1.f, -1.f};  // relu output is >= 0, so -1 marks "nothing seen yet"
     int bi[4] = {0, 0, 0, 0};
+    // the nine window loads go out together, branch-free (a position outside the image reads a clamped address and is skipped
+    // below): with the loads inside the bounds branches the compiler waits for each one before it issues the next
+    f32x4 win[9];
+    unsigned inside = 0;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = py * 2 - pad + ky;
-      if (iy < 0 || iy >= H) continue;
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int ix = px * 2 - pad + kx;
-        if (ix < 0 || ix >= W) continue;
-        const f32x4 v = *(const f32x4*)(y + ((size_t)(n * H + iy) * W + ix) * 64 + c4 * 4);
+        const int iy = py * 2 - pad + ky, ix = px * 2 - pad + kx;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        win[ky * 3 + kx] = *(const f32x4*)(y + (ok ? ((size_t)(n * H + iy) * W + ix) * 64 : (size_t)0) + c4 * 4);
+        inside |= (ok ? 1u : 0u) << (ky * 3 + kx);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float z = v[j] * sc[j] + sh[j];
-          z = z > 0.f ? z : 0.f;
-          if (z > best[j]) { best[j] = z; bi[j] = ky * 3 + kx; }
-        }
+    for (int k = 0; k < 9; ++k) {
+      const f32x4 v = win[k];
+      const bool ok = (inside >> k) & 1u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float z = v[j] * sc[j] + sh[j];
+        z = z > 0.f ? z : 0.f;
+        if (ok && z > best[j]) { best[j] = z; bi[j] = k; }
       }
     }
     if (out_nchw) {
