@@ -302,37 +302,59 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply(const float* __res
     const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
     const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
     const f32x4 sh = *(const f32x4*)(bnp + 192 + c4 * 4);
+    // Every load of the thread goes out up front, branch-free (clamped address + mask), and is waited for once before the first
+    // store: with loads inside the bounds branches the compiler serialises them, and a load consumed after a conditional store
+    // waits for that store.
+    f32x4 m1 = {0.f, 0.f, 0.f, 0.f}, m2 = m1;
+    if (training) { m1 = *(const f32x4*)(sums + c4 * 4); m2 = *(const f32x4*)(sums + 64 + c4 * 4); }
     // the four windows (wy, wx) in {by-1, by} x {bx-1, bx}
     uint32_t am[2][2];
     f32x4 dp[2][2];
+    unsigned wok = 0;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int py = by - 1 + a, px = bx - 1 + b;
-        am[a][b] = 0xffffffffu;  // matches no window index
-        dp[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (py >= 0 && py < HP && px >= 0 && px < WP) {
-          const size_t pp = ((size_t)(n * HP + py) * WP + px);
-          am[a][b] = *(const uint32_t*)(argmax + pp * 64 + c4 * 4);
-          if (dp_nchw) {
+        const bool ok = py >= 0 && py < HP && px >= 0 && px < WP;
+        const size_t pp = ok ? ((size_t)(n * HP + py) * WP + px) : (size_t)0;
+        am[a][b] = *(const uint32_t*)(argmax + pp * 64 + c4 * 4);
+        if (dp_nchw) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dp[a][b][j] = dpooled[((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px];
-          } else {
-            dp[a][b] = *(const f32x4*)(dpooled + pp * 64 + c4 * 4);
-          }
+          for (int j = 0; j < 4; ++j)
+            dp[a][b][j] = dpooled[ok ? ((size_t)(n * 64 + c4 * 4 + j) * HP + py) * WP + px : (size_t)0];
+        } else {
+          dp[a][b] = *(const f32x4*)(dpooled + pp * 64 + c4 * 4);
         }
+        wok |= (ok ? 1u : 0u) << (2 * a + b);
+      }
+    f32x4 yv[2][2];
+    unsigned yok = 0;
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+      for (int rx = 0; rx < 2; ++rx) {
+        const int iy = 2 * by - pad + ry, ix = 2 * bx - pad + rx;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        yv[ry][rx] = *(const f32x4*)(y + (ok ? ((size_t)(n * H + iy) * W + ix) * 64 : (size_t)0) + c4 * 4);
+        yok |= (ok ? 1u : 0u) << (2 * ry + rx);
+      }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        asm volatile("" : "+v"(am[a][b]), "+v"(dp[a][b]), "+v"(yv[a][b]));
+        if (!((wok >> (2 * a + b)) & 1u)) am[a][b] = 0xffffffffu;  // matches no window index
       }
 #pragma unroll
     for (int ry = 0; ry < 2; ++ry) {
       const int iy = 2 * by - pad + ry;
-      if (iy < 0 || iy >= H) continue;
 #pragma unroll
       for (int rx = 0; rx < 2; ++rx) {
         const int ix = 2 * bx - pad + rx;
-        if (ix < 0 || ix >= W) continue;
+        if (!((yok >> (2 * ry + rx)) & 1u)) continue;
         const size_t pix = ((size_t)(n * H + iy) * W + ix);
-        const f32x4 v = *(const f32x4*)(y + pix * 64 + c4 * 4);
+        const f32x4 v = yv[ry][rx];
         f32x4 dz = {0.f, 0.f, 0.f, 0.f};
         // row ry = 0: windows by-1 (ky = 2) and by (ky = 0); ry = 1: window by only (ky = 1)
 #pragma unroll
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply(const float* __res
           const float d = z > 0.f ? dz[j] : 0.f;
           if (training) {
             const float xh = (v[j] - mean[j]) * invstd[j];
-            o[j] = sc[j] * (d - sums[c4 * 4 + j] * inv_count - xh * sums[64 + c4 * 4 + j] * inv_count);
+            o[j] = sc[j] * (d - m1[j] * inv_count - xh * m2[j] * inv_count);
           } else {
             o[j] = sc[j] * d;
           }
