@@ -36,6 +36,7 @@ namespace {
 #define SRLZ_BATCH_BWD 12
 #endif
 constexpr int TM = 128;       // grid positions per forward tile
+constexpr int BATCH_FWD = SRLZ_BATCH_FWD;  // rows (of 16 lanes) a thread requests per round trip of a plain / forward-fused staging
 constexpr int NTAPS = 9;
 
 struct ConvProg {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
   constexpr int NACC = 8 / NW;     // 32-column tiles per wave
   // rows (of 16 lanes) a thread requests per HBM round trip of the source staging: a stride-1 tile (244 rows = 15.25 passes) or a
   // gather class (185 rows = 11.6 passes) in ONE batch instead of two
-  constexpr int BATCH_FWD = SRLZ_BATCH_FWD, BATCH_BWD = SRLZ_BATCH_BWD;
+  constexpr int BATCH_BWD = SRLZ_BATCH_BWD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* As = (float*)smem;                 // (TM + span) x 64, swizzled
   float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap, pre-swizzled in global
@@ -1199,7 +1200,7 @@ __global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restri
       const int tsrc = P.tsrc[ti];
       __syncthreads();
       if (tsrc != cur_src) {
-        stage_rows<true, 8, NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span, fuse, 0, 0,
+        stage_rows<true, BATCH_FWD, NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span, fuse, 0, 0,
                                 cin, ci * 64);
         cur_src = tsrc;
       }
