@@ -50,34 +50,8 @@ __host__ __device__ constexpr int koff(int k) {
   return (c * 2 + (kx & 1)) * Geo<K, TR>::PP + ky * XP + (kx >> 1);
 }
 
-// Stage channels [3cg, 3cg+3) of the image window of output tile (oy0, ox0) into LDS.
-template <int K, int PAD>
-__device__ __forceinline__ void stage_image(float* __restrict__ T, const float* __restrict__ img, int n, int C,
-                                            int cg, int H, int W, int oy0, int ox0) {
-  constexpr int ROWS = Geo<K>::ROWS, COLS = Geo<K>::COLS, TOT = 3 * ROWS * COLS;
-  constexpr int BATCH = 9;  // loads in flight per thread before the first LDS store
-  const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
-  for (int base = threadIdx.x; base < TOT; base += 256 * BATCH) {
-    float v[BATCH];
-    int dst[BATCH];
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) {
-      const int idx = base + 256 * j;
-      const int c = idx / (ROWS * COLS);
-      const int rem = idx - c * (ROWS * COLS);
-      const int r = rem / COLS, xl = rem - r * COLS;
-      const int iy = iy0 + r, ix = ix0 + xl;
-      v[j] = 0.f;
-      if (idx < TOT && iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = img[((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix];
-      dst[j] = (c * 2 + (xl & 1)) * Geo<K>::PP + r * XP + (xl >> 1);
-    }
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j)
-      if (base + 256 * j < TOT) T[dst[j]] = v[j];
-  }
-}
-
-// The same staging split in two (request into registers / land in LDS) for software-pipelined callers.
+// Staging of the image window of an output tile, split in two (request into registers / land in LDS) so that callers can
+// software-pipeline it; a synchronous staging is a request followed by a land.
 // Element j of a thread is window element idx = tid + 256*j = (channel c, window row, window column xl); its decomposition is
 // tile-independent and is kept PACKED in one register per element (pk, set once by image_index).  Left to itself the compiler
 // hoists the unpacked (c, row, xl, LDS offset) of every element out of the caller's persistent tile loop — ~3 registers per
