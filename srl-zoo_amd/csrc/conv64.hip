@@ -467,11 +467,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
     }
     __builtin_amdgcn_sched_barrier(0);  // the slab requests go out HERE, ahead of the tap's MFMAs (the scheduler sinks them otherwise)
     const int R = wrow * 32 + l31 + (int)(short)(w0 & 0xffff) - P.min_off;
-    const float* arow = As + R * 64;
-    const int akey = R & 15;
+    // offset of this lane's first 16-byte slot of row R; slot (2kc + h) ^ (R & 15) of the swizzled row is that offset XOR
+    // (kc << 5) bytes — R*256 has no bits below 8, 2kc + h = 2kc ^ h — so each k-chunk costs ONE v_xor with a literal
+    int abase = (R * 64 + ((h ^ (R & 15)) << 2)) * 4;  // in BYTES (the XOR then is the whole address computation)
+    asm volatile("" : "+v"(abase));                     // one opaque value: the compiler otherwise re-splits it into its parts
     const float* brow = Bs + (wcol * NACC * 32 + l31) * 64;  // column tile j is 32 rows (2048 floats) further
     const int bkey = lane & 15;
-    f32x4 a = *(const f32x4*)(arow + ((h ^ akey) << 2));
+    f32x4 a = *(const f32x4*)((const char*)As + abase);
     f32x4 b[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; ++j) b[j] = *(const f32x4*)(brow + j * 2048 + ((h ^ bkey) << 2));
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
       for (int j = 0; j < NACC; ++j) bn[j] = b[j];
       if (kc < 7) {
         const int slot = (kc + 1) * 2 + h;
-        an = *(const f32x4*)(arow + ((slot ^ akey) << 2));
+        an = *(const f32x4*)((const char*)As + (abase ^ ((kc + 1) << 5)));
 #pragma unroll
         for (int j = 0; j < NACC; ++j) bn[j] = *(const f32x4*)(brow + j * 2048 + ((slot ^ bkey) << 2));
       }
