@@ -307,6 +307,15 @@ int srlz_sqdiff_pair_loss(const float* a, const float* b, long long n_per_group,
                           void* ws, size_t ws_bytes, srlz_stream_t stream);
 /* out = [a ; b] (n_each floats each) — joins the halves of a batched pair (th.cat of learner.py's obs / next_obs) */
 int srlz_join2(const float* a, const float* b, float* out, long long n_each, srlz_stream_t stream);
+
+/* LossManager.computeTotalLoss (losses/losses.py:55-56): total = sum_i w_i * l_i over n <= SRLZ_MAX_LOSS_TERMS device scalars, in
+ * Python's left-to-right fp32 order with separately rounded products.  `scalars` and `weights` are HOST arrays (of device pointers /
+ * of floats).  tail != NULL: also tail[0] = total, tail[1 + i] = l_i (the step's scalars in the gradient bucket's tail,
+ * models/learner.py:485,501-522).  _bwd: g[i] = dout * w_i. */
+#define SRLZ_MAX_LOSS_TERMS 15
+int srlz_weighted_total(const float* const* scalars, const float* weights, int n, float* total, float* tail,
+                        srlz_stream_t stream);
+int srlz_weighted_total_bwd(const float* dout, const float* weights, int n, float* g, srlz_stream_t stream);
 /* out[0] = -0.5*sum(1 + logvar - mu^2 - exp(logvar))      kullbackLeiblerLoss 239-256 */
 int srlz_kl_sum(const float* mu, const float* logvar, long long n, float* out, void* ws, size_t ws_bytes,
                 srlz_stream_t stream);

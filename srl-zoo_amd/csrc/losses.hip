@@ -368,7 +368,57 @@ __global__ __launch_bounds__(256) void join2_kernel(const float* __restrict__ a,
   for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// total = (((0 + w0*l0) + w1*l1) + ...) in fp32 with separately rounded products — exactly Python's sum([w_i * l_i]) over 0-dim
+// fp32 tensors (reference losses/losses.py:55-56) — plus the step's scalars into the gradient bucket's tail: [total, l_0, l_1, ...]
+struct ScalarList {
+  const float* p[SRLZ_MAX_LOSS_TERMS];
+  float w[SRLZ_MAX_LOSS_TERMS];
+  int n;
+};
+__global__ void weighted_total_kernel(const ScalarList L, float* __restrict__ total, float* __restrict__ tail) {
+  if (threadIdx.x != 0) return;
+  float t = 0.f;
+  for (int i = 0; i < L.n; ++i) {
+    const float l = *L.p[i];
+    t = __fadd_rn(t, __fmul_rn(L.w[i], l));
+    if (tail) tail[1 + i] = l;
+  }
+  *total = t;
+  if (tail) tail[0] = t;
+}
+// g[i] = dout * w_i (autograd of the same expression)
+__global__ void weighted_total_bwd_kernel(const ScalarList L, const float* __restrict__ dout, float* __restrict__ g) {
+  const int i = threadIdx.x;
+  if (i < L.n) g[i] = __fmul_rn(*dout, L.w[i]);
+}
+
 }  // namespace
+
+extern "C" int srlz_weighted_total(const float* const* scalars, const float* weights, int n, float* total, float* tail,
+                                   srlz_stream_t stream) {
+  SRLZ_REQUIRE(scalars && weights && total, SRLZ_ERR_NULL, "weighted_total: null pointer");
+  SRLZ_REQUIRE(n >= 1 && n <= SRLZ_MAX_LOSS_TERMS, SRLZ_ERR_BAD_DESC, "weighted_total: %d terms (1..%d)", n, SRLZ_MAX_LOSS_TERMS);
+  ScalarList L;
+  for (int i = 0; i < n; ++i) {
+    SRLZ_REQUIRE(scalars[i], SRLZ_ERR_NULL, "weighted_total: null term %d", i);
+    L.p[i] = scalars[i]; L.w[i] = weights[i];
+  }
+  L.n = n;
+  hipLaunchKernelGGL(weighted_total_kernel, dim3(1), dim3(64), 0, as_stream(stream), L, total, tail);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_weighted_total_bwd(const float* dout, const float* weights, int n, float* g, srlz_stream_t stream) {
+  SRLZ_REQUIRE(dout && weights && g, SRLZ_ERR_NULL, "weighted_total_bwd: null pointer");
+  SRLZ_REQUIRE(n >= 1 && n <= SRLZ_MAX_LOSS_TERMS, SRLZ_ERR_BAD_DESC, "weighted_total_bwd: %d terms (1..%d)", n, SRLZ_MAX_LOSS_TERMS);
+  ScalarList L;
+  for (int i = 0; i < n; ++i) { L.p[i] = nullptr; L.w[i] = weights[i]; }
+  L.n = n;
+  hipLaunchKernelGGL(weighted_total_bwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), L, dout, g);
+  SRLZ_LAUNCHED();
+  return 0;
+}
 
 extern "C" size_t srlz_reduce_workspace(long long n) {
   (void)n;

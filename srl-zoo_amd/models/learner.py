@@ -51,6 +51,10 @@ def _requireGpu(cuda):
                            % (cuda, th.cuda.is_available()))
 
 
+# A/B switch: total loss + scalar tail as one launch (0: LossManager.computeTotalLoss() on 0-dim tensors + torch.stack)
+_FUSED_TOTAL = os.environ.get("SRLZ_FUSED_TOTAL", "1") != "0"
+
+
 class _DeviceFeed(object):
     """One-minibatch look-ahead between the loader process and the GPU: the H2D copy of minibatch i+1 is issued on a copy
     stream right after step i has been enqueued (advance()), i.e. BEFORE the host blocks on step i's loss scalars, so it
@@ -469,11 +473,17 @@ class SRL4robotics(BaseLearner):
         if self.use_triplets:
             tripletLoss(states, positive_states, negative_states, weight=w['triplet'], loss_manager=loss_manager, alpha=0.2)
 
-        loss = loss_manager.computeTotalLoss()
-        loss.backward()  # the reference backpropagates on validation minibatches too (learner.py:487-489)
-        # the step's scalars ride in the tail of the gradient bucket: with several GPUs every rank reads the SAME (mean)
-        # losses back, so the NaN exit and the best-model decision are taken by all ranks together
-        self.flat_params.put_scalars([loss] + list(loss_manager.losses))
+        # LossManager.computeTotalLoss() as one launch, which also drops the step's scalars [total, l_0, l_1, ...] into the tail
+        # of the gradient bucket: with several GPUs every rank reads the SAME (mean) losses back, so the NaN exit and the
+        # best-model decision are taken by all ranks together
+        from srlz import ops
+        if _FUSED_TOTAL and 1 <= len(loss_manager.losses) < self.flat_params.TAIL:
+            loss = ops.TotalLossFn.apply(tuple(loss_manager.weights), self.flat_params.tail, *loss_manager.losses)
+            loss.backward()  # the reference backpropagates on validation minibatches too (learner.py:487-489)
+        else:
+            loss = loss_manager.computeTotalLoss()
+            loss.backward()
+            self.flat_params.put_scalars([loss] + list(loss_manager.losses))
         if not validation_mode:
             grad_scale = optim.allreduce_gradients(self.flat_params)
             self.optimizer.step(grad_scale)

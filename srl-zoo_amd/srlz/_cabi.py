@@ -113,6 +113,8 @@ _PROTOS = {
     "srlz_sqdiff_grad_groups": (c_int, [P, P, P, c_int, c_float, c_float, P, c_longlong, c_int, P]),
     "srlz_sqdiff_pair_loss": (c_int, [P, P, c_longlong, c_int, P, P, P, c_size_t, P]),
     "srlz_join2": (c_int, [P, P, P, c_longlong, P]),
+    "srlz_weighted_total": (c_int, [P, P, c_int, P, P, P]),
+    "srlz_weighted_total_bwd": (c_int, [P, P, c_int, P, P]),
     "srlz_kl_sum": (c_int, [P, P, c_longlong, P, P, c_size_t, P]),
     "srlz_kl_grad": (c_int, [P, P, P, c_float, P, P, c_longlong, P]),
     "srlz_reparam_fwd": (c_int, [P, P, P, P, c_longlong, P]),

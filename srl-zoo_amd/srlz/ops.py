@@ -678,6 +678,31 @@ class LinearFn(Function):
         return dx, _give(w, dw), _give(ctx.params[0], db), None
 
 
+class TotalLossFn(Function):
+    """total = sum_i w_i * l_i over 0-dim device scalars, as LossManager.computeTotalLoss forms it (reference losses/losses.py:55-56:
+    Python's left-to-right sum of separately rounded fp32 products), in ONE launch that also drops [total, l_0, l_1, ...] into
+    `tail` (the gradient bucket's scalar tail) when given; backward: d l_i = w_i * d total, one launch."""
+
+    @staticmethod
+    def forward(ctx, weights, tail, *losses):
+        import ctypes
+        n = len(losses)
+        losses = [_check(l, "loss term").reshape(()) for l in losses]
+        ptrs = (ctypes.c_void_p * n)(*[l.data_ptr() for l in losses])
+        w = (ctypes.c_float * n)(*[float(x) for x in weights])
+        total = torch.empty((), dtype=torch.float32, device=losses[0].device)
+        C.weighted_total(ptrs, w, n, ptr(total), ptr(tail), stream())
+        ctx.weights, ctx.n = w, n
+        ctx.keep = losses  # (the kernel is asynchronous: the terms must outlive it)
+        return total
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = torch.empty(ctx.n, dtype=torch.float32, device=dout.device)
+        C.weighted_total_bwd(ptr(dout.contiguous()), ctx.weights, ctx.n, ptr(g), stream())
+        return (None, None) + tuple(g[i] for i in range(ctx.n))
+
+
 class MaskColumnsFn(Function):
     """x with every column outside [lo, hi) zeroed — SRLModulesSplit.detachSplit (reference models/modules.py:191-236)
     rebuilds the state from th.zeros_like blocks and one kept slice, i.e. applies this mask; gradient = same mask."""

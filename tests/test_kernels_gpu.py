@@ -723,3 +723,24 @@ def test_native_comm_single_rank(C):
     finally:
         C.comm_destroy()
     assert C.comm_world() == 0
+
+
+def test_total_loss_is_pythons_left_to_right_fp32_sum(C):
+    """ops.TotalLossFn == LossManager.computeTotalLoss()'s expression sum([w_i * l_i]) on 0-dim fp32 tensors, bit for bit (value,
+    scalar tail, gradients)."""
+    from srlz import ops
+    g = torch.Generator().manual_seed(5)
+    vals = [(torch.randn((), generator=g) * s).to(DEV).requires_grad_() for s in (5.0, 3e6, 1e3, 0.7, 1e-3)]
+    weights = (1.0, 0.5e-6, 2.0, 1.0, 0.3)
+    ref_terms = [v.detach().clone().requires_grad_() for v in vals]
+    ref = sum([weights[i] * ref_terms[i] for i in range(len(weights))])
+    (ref * 1.5).backward()
+    tail = torch.full((16,), float("nan"), device=DEV)
+    tot = ops.TotalLossFn.apply(weights, tail, *vals)
+    (tot * 1.5).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(tot.detach(), ref.detach())
+    assert torch.equal(tail[0], ref.detach()) and all(torch.equal(tail[1 + i], vals[i].detach()) for i in range(len(vals)))
+    for a, b in zip(vals, ref_terms):
+        assert torch.equal(a.grad, b.grad)
+
