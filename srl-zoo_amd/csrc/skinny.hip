@@ -709,7 +709,8 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
                                                               float* __restrict__ wpartial, int N, int H, int W, int HF,
                                                               int WF, int tiles_y, int tiles_x,
                                                               const float* __restrict__ y_raw,
-                                                              const float* __restrict__ y_bnp, int npg) {
+                                                              const float* __restrict__ y_bnp, int npg,
+                                                              double* __restrict__ bias_partial) {
   constexpr int K = 4, PAD = 0, C = 3, TR = FTR;
   using G = Geo<K, TR>;
   constexpr int KT = G::KT, KS = G::KS, NT = 2;
@@ -774,11 +775,34 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
   };
   ImgRegs<K, TR> nx;
   image_index<K, TR>(nx);
+  // Bias gradient (the per-channel sum of dy) from the windows this kernel stages anyway — a separate pass would read dy a second
+  // time.  A tile OWNS rows [0, 2 TR) x columns [0, 32) of its (2 TR + 2) x 34 window, the last tile row / column also the tail,
+  // so every image pixel is counted exactly once; element j of a thread always belongs to the same channel, so one fp32
+  // accumulator per element suffices (<= ntiles / gridDim.x additions each) and the channels are only told apart at the end.
+  constexpr int PER = ImgRegs<K, TR>::PER;
+  float bsum[PER];
+  unsigned mrow = 0, mcol = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    int c, row, xl;
+    const bool live = image_decode<K, true, TR>(nx, j, c, row, xl);
+    bsum[j] = 0.f;
+    mrow |= (live && row < 2 * TR ? 1u : 0u) << j;
+    mcol |= (live && xl < 32 ? 1u : 0u) << j;
+  }
+  auto bias_accumulate = [&](int trem_) {
+    const bool last_y = trem_ / tiles_x == tiles_y - 1, last_x = trem_ % tiles_x == tiles_x - 1;
+    const unsigned own = nx.inside & (last_y ? ~0u : mrow) & (last_x ? ~0u : mcol);
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      bsum[j] += __builtin_bit_cast(float, __builtin_bit_cast(unsigned, nx.v[j]) & (unsigned)(-(int)((own >> j) & 1u)));
+  };
   y_request(blockIdx.x);
   if ((int)blockIdx.x < ntiles) {
     const int n = blockIdx.x / tpi, trem = blockIdx.x - n * tpi;
     image_request<K, PAD, true, TR>(nx, img, n, C, 0, H, W, (trem / tiles_x) * TR, (trem % tiles_x) * 16, true);
     image_land<K, true, TR>(T, nx);
+    bias_accumulate(trem);
   }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / tpi, trem = tile - n * tpi;
@@ -872,6 +896,26 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
     }
     __syncthreads();  // every wave is done with T and F: the next window lands
     image_land<K, true, TR>(T, nx);
+    bias_accumulate((tile + (int)gridDim.x) % tpi);  // (past the last tile nothing is inside: adds zeros)
+  }
+  if (bias_partial) {  // [3][gridDim.x] fp64, summed over workgroups in a fixed order by nchw_chan_sum_final
+    float cs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      int c, row, xl;
+      image_decode<K, true, TR>(nx, j, c, row, xl);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) cs[cc] += (c == cc) ? bsum[j] : 0.f;
+    }
+    __syncthreads();
+    double* bred = (double*)red;  // [3][4 waves]
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const double dsum = wave_sum_d((double)cs[cc]);
+      if (lane == 0) bred[cc * 4 + wave] = dsum;
+    }
+    __syncthreads();
+    if (tid < 3) bias_partial[(size_t)tid * gridDim.x + blockIdx.x] = (bred[tid * 4] + bred[tid * 4 + 1]) + (bred[tid * 4 + 2] + bred[tid * 4 + 3]);
   }
   float* out = wpartial + ((size_t)blockIdx.x * 2 + sub) * (64 * NT * 32);
 #pragma unroll
@@ -1242,7 +1286,7 @@ extern "C" int srlz_convT_out_bwd_fused_tiles(const srlz_skinny_desc* d) {
 extern "C" size_t srlz_convT_out_bwd_fused_workspace(const srlz_skinny_desc* d) {
   if (check_skinny(d)) return 0;
   const int g = persistent_grid(srlz_convT_out_bwd_fused_tiles(d));
-  return (size_t)g * 2 * 64 * 64 * sizeof(float) + (size_t)d->n * d->c * sizeof(double);
+  return (size_t)g * 2 * 64 * 64 * sizeof(float) + (size_t)g * 3 * sizeof(double);
 }
 
 extern "C" int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,
@@ -1260,19 +1304,16 @@ extern "C" int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref
   const int g = persistent_grid(ntiles);
   const size_t lds = fused_bwd_lds();
   float* partial = (float*)ws;
+  double* bias_part = dbias ? (double*)((char*)ws + (size_t)g * 2 * 64 * 64 * sizeof(float)) : nullptr;  // [3][g]
+  SRLZ_REQUIRE((((uintptr_t)bias_part) & 7) == 0, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: unaligned workspace");
   SRLZ_MAX_LDS(convT_out_bwd_kernel, lds);
   hipLaunchKernelGGL(convT_out_bwd_kernel, dim3(g), dim3(256), lds, st, dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, partial, d->n,
-                     d->himg, d->wimg, d->hf, d->wf, ty, tx, x_raw, x_bnp, images_per_group(d));
+                     d->himg, d->wimg, d->hf, d->wf, ty, tx, x_raw, x_bnp, images_per_group(d), bias_part);
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((64 * 48 + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, 16, 48, 64, dw_ref);
   SRLZ_LAUNCHED();
   if (dbias) {
-    double* part = (double*)((char*)ws + (size_t)g * 2 * 64 * 64 * sizeof(float));
-    SRLZ_REQUIRE((((uintptr_t)part) & 7) == 0 && ((d->himg * d->wimg) & 3) == 0, SRLZ_ERR_BAD_DESC,
-                 "convT_out_bwd_fused: unaligned workspace / image plane");
-    hipLaunchKernelGGL(nchw_chan_sum_partial, dim3(d->n * d->c), dim3(256), 0, st, dy_nchw, d->c, d->himg * d->wimg, part, d->n);
-    SRLZ_LAUNCHED();
-    hipLaunchKernelGGL(nchw_chan_sum_final, dim3(d->c), dim3(64), 0, st, part, d->n, dbias);
+    hipLaunchKernelGGL(nchw_chan_sum_final, dim3(d->c), dim3(64), 0, st, bias_part, g, dbias);
     SRLZ_LAUNCHED();
   }
   return 0;

@@ -636,7 +636,8 @@ def test_convT_out_bwd_data_emits_bn_backward_sums(C, n, c, hf):
 def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
     """srlz_convT_out_bwd_fused (one pass over dy and x_raw) == srlz_convT_out_bwd_data(x_raw, bnp, partial) followed by
     srlz_convT_out_bwd_weight(bnp): identical dA (same contraction order), BatchNorm-backward sums / dgamma / dbeta from the
-    8x16 tiles, weight and bias gradients to rounding (different summation order)."""
+    8x16 tiles, weight and bias gradients to rounding (different summation order; the bias gradient comes from the staged
+    windows of the fused kernel: every image pixel owned by exactly one tile)."""
     g = torch.Generator().manual_seed(71 + hf)
     himg = (hf - 1) * 2 + 4
     x_raw = (torch.randn(n, hf, hf, 64, generator=g) * 1.3 + 0.2).to(DEV)
@@ -678,7 +679,10 @@ def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
     for a, b in zip(out[0], out[1]):
         assert rel_err(b, a) < 2e-5
     assert rel_err(dw1, dw0) < 2e-5
-    assert torch.equal(db1, db0)
+    ref = dimg.double().sum((0, 2, 3))
+    tol = 3e-6 * (n * himg * himg) ** 0.5  # unit-variance data: a few fp32 ulps of the typical |sum|
+    assert float((db0.double() - ref).abs().max()) <= tol
+    assert float((db1.double() - ref).abs().max()) <= tol
 
 
 @pytest.mark.parametrize("n,c,h", [(2, 3, 224), (1, 6, 64), (2, 3, 50)])
