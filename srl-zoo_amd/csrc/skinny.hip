@@ -657,12 +657,14 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   }
 }
 
-// dw_ref[ch][cg*3+c][ky][kx] = sum over workgroups of partial[cg][wg][ch][k]; 256 outputs x 4 slices of the
-// workgroup range per 1024-thread block, fp64, fixed order.
+// dw_ref[ch][cg*3+c][ky][kx] = sum over workgroups of partial[cg][wg][ch][k]; 64 outputs x 16 slices of the
+// workgroup range per 1024-thread block, fp64, fixed order.  (With 256 outputs x 4 slices the launch had 12 blocks for the
+// ConvTranspose layer — twelve CUs streaming 33 MB: 37 us; the slices are what spreads it over the chip.)
+constexpr int WRED_OUTS = 64, WRED_PARTS = 16;
 __global__ __launch_bounds__(1024) void skinny_wgrad_reduce(const float* __restrict__ partial, int nwg, int C, int KK, int KT,
                                                            int NTW, float* __restrict__ dw_ref) {
-  const int o = threadIdx.x & 255, part = threadIdx.x >> 8;
-  const int id = blockIdx.x * 256 + o;
+  const int o = threadIdx.x & (WRED_OUTS - 1), part = threadIdx.x / WRED_OUTS;
+  const int id = blockIdx.x * WRED_OUTS + o;
   const int ncg = C / 3;
   const bool live = id < ncg * 64 * KT;
   int cg = 0, ch = 0, k = 0;
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(1024) void skinny_wgrad_reduce(const float* __restr
     const int rem = id - cg * 64 * KT;
     ch = rem / KT; k = rem - ch * KT;
     const float* base = partial + (size_t)cg * nwg * (64 * NTW) + ch * NTW + k;
-    const int per = (nwg + 3) / 4;
+    const int per = (nwg + WRED_PARTS - 1) / WRED_PARTS;
     const int w0 = part * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
     int w = w0;
     for (; w + 3 < w1; w += 4) {
@@ -683,10 +685,15 @@ __global__ __launch_bounds__(1024) void skinny_wgrad_reduce(const float* __restr
     }
     for (; w < w1; ++w) s0 += (double)base[(size_t)w * (64 * NTW)];
   }
-  __shared__ double sm[4][256];
+  __shared__ double sm[WRED_PARTS][WRED_OUTS];
   sm[part][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (part == 0 && live) dw_ref[((size_t)ch * C + cg * 3) * KK + k] = (float)((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
+  if (part == 0 && live) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < WRED_PARTS; ++q) t += sm[q][o];
+    dw_ref[((size_t)ch * C + cg * 3) * KK + k] = (float)t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1183,7 +1190,7 @@ static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws
                        d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
-  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
+  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + WRED_OUTS - 1) / WRED_OUTS), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
                      NT * 32, dw);
   SRLZ_LAUNCHED();
   return 0;
@@ -1310,7 +1317,7 @@ extern "C" int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref
   hipLaunchKernelGGL(convT_out_bwd_kernel, dim3(g), dim3(256), lds, st, dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, partial, d->n,
                      d->himg, d->wimg, d->hf, d->wf, ty, tx, x_raw, x_bnp, images_per_group(d), bias_part);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((64 * 48 + 255) / 256), dim3(1024), 0, st, partial, 2 * g, d->c, 16, 48, 64, dw_ref);
+  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3(64 * 48 / WRED_OUTS), dim3(1024), 0, st, partial, 2 * g, d->c, 16, 48, 64, dw_ref);
   SRLZ_LAUNCHED();
   if (dbias) {
     hipLaunchKernelGGL(nchw_chan_sum_final, dim3(d->c), dim3(64), 0, st, bias_part, g, dbias);
