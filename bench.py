@@ -7,12 +7,18 @@ is already resident in HBM: forward of obs and next_obs through the conv auto-en
 BASELINE.json configs[1]: synthetic 224x224x3 observations, --losses autoencoder, custom_cnn, state-dim 200, bs=256.
 `--losses vae` / `--losses autoencoder inverse forward` select configs[2] / configs[3]'s per-GPU workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 runs one process per GPU over RCCL.  Either a launcher provides the ranks (python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment), or — when
+WORLD_SIZE is not set — bench.py starts the N ranks itself (self_launch) and rank 0 prints the line.
 
 Prints ONE JSON line (rank 0).  value = 2*B*N*K / t  (both frames of a sample go through forward+backward), with t the
 max over ranks of the wall time of exactly K steps bracketed by barrier + synchronize.
-"roofline" is measured live with HIP events on the stream the kernels are launched on, over the timed region, for the
-MFMA implicit-GEMM convolution kernel (conv64_fwd_kernel); "cpu_baseline" times the CPU oracle (plain torch fp32 twin
+"roofline" is measured live with HIP events on the stream the kernels are launched on, for the MFMA implicit-GEMM convolution
+kernel (conv64_fwd_kernel), in a short instrumented pass of the same steps RIGHT AFTER the timed region (two events per launch
+inside the timed region cost ~0.5 % of the headline, VERDICT r2 item 11 — the timed region carries no instrumentation);
+"cpu_baseline" times the CPU oracle (plain torch fp32 twin
 of the reference path) on the host cores for a bounded sample — a reported baseline, not a target.
 """
 import argparse
@@ -55,13 +61,15 @@ def host_cores():
     return n
 
 
-def cpu_baseline(losses):
+def cpu_baseline(losses, full=False):
     """The CPU oracle (oracle/torch_twin.py: the reference's own torch CPU ops, fp32, pinned to the reference by the golden
-    fixtures) timed on this box's host cores, SURVEY.md 8(d) protocol scaled to a bounded sample (~30 s of CPU work):
-    the same train step (forward x2, losses, backward, Adam) at the reference's default minibatch (bs = 32, BASELINE.json
-    configs[0]) with all usable cores and with 8 threads, and at bs = 64 with all cores; median step time after one warm-up.
-    `value` is the bs = 32 / all-cores figure.  kind = "port": a restatement of the reference path, not the reference's own
-    files (those cannot travel to the GPU box)."""
+    fixtures) timed on this box's host cores with BASELINE.md section 3's protocol: the same train step (forward x2, losses,
+    backward, Adam); bs = 32 (BASELINE.json configs[0]'s minibatch) with all usable cores, 3 warm-up + 10 timed steps, median —
+    that is `value`; plus a bs = 256 leg (configs[1]'s minibatch).  Default run: the bs = 256 leg is BOUNDED to 1 warm-up + 2
+    timed steps (a step takes seconds; the whole leg stays within ~40 s of CPU work) and the 8-thread comparability leg is
+    skipped; `--cpu-baseline-full` runs every leg of the protocol (3 + 10 steps at bs = 32 with all cores and with 8 threads,
+    3 + 10 at bs = 256: minutes).  kind = "port": a restatement of the reference path, not the reference's own files (those
+    cannot travel to the GPU box)."""
     from oracle import torch_twin as T
     import preprocessing.preprocess as pre
     from models.modules import SRLModules
@@ -69,7 +77,7 @@ def cpu_baseline(losses):
     cores = host_cores()
     pre.N_CHANNELS = 3
 
-    def run(bs, threads, steps):
+    def run(bs, threads, warm, steps):
         torch.set_num_threads(threads)
         np.random.seed(1)
         torch.manual_seed(1)
@@ -81,22 +89,29 @@ def cpu_baseline(losses):
         actions = torch.randint(0, 6, (bs,))
         eps = [torch.randn(bs, 200), torch.randn(bs, 200)] if "vae" in losses else [None, None]
         times = []
-        for i in range(steps + 1):
+        for i in range(warm + steps):
             t0 = time.time()
             T.train_step(sd, losses, obs, next_obs, actions, eps=eps[0], next_eps=eps[1])
             opt.step(sd)
-            if i > 0:  # first step = warm-up
+            if i >= warm:
                 times.append(time.time() - t0)
         med = float(np.median(times))
-        return {"bs": bs, "threads": threads, "steps": steps, "s_per_step": round(med, 3), "images_per_s": round(2 * bs / med, 2)}
+        return {"bs": bs, "threads": threads, "warmup": warm, "steps": steps, "s_per_step": round(med, 3),
+                "images_per_s": round(2 * bs / med, 2), "samples_per_s": round(bs / med, 2)}
 
-    runs = [run(32, cores, 5), run(32, min(8, cores), 3), run(64, cores, 3)]
+    runs = [run(32, cores, 3, 10)]
+    if full:
+        runs += [run(32, min(8, cores), 3, 10), run(256, cores, 3, 10)]
+    else:
+        runs += [run(256, cores, 1, 2)]
     torch.set_num_threads(cores)
     head = runs[0]
     return {"value": head["images_per_s"], "unit": "images/s", "cores": head["threads"], "kind": "port",
-            "sample": "median of %d train steps (fwd x2, losses, bwd, Adam) at bs=32 (64 images each) after 1 warm-up; torch %s CPU "
-                      "fp32, %d threads = all usable cores; %.2f s/step" % (head["steps"], torch.__version__, head["threads"],
-                                                                            head["s_per_step"]),
+            "protocol": "BASELINE.md section 3" + ("" if full else " (bs=256 leg bounded to 1+2 steps, 8-thread leg skipped: "
+                                                              "--cpu-baseline-full runs them)"),
+            "sample": "median of %d train steps (fwd x2, losses, bwd, Adam) at bs=32 (64 images each) after %d warm-ups; torch %s CPU "
+                      "fp32, %d threads = all usable cores; %.2f s/step" % (head["steps"], head["warmup"], torch.__version__,
+                                                                            head["threads"], head["s_per_step"]),
             "runs": runs}
 
 
@@ -109,36 +124,90 @@ def conv64_algorithmic_bytes(layer_key):
     return 4.0 * 64 * n * (hi * wi + ho * wo) + 4.0 * 9 * 64 * 64
 
 
-def committed_pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest profiles/*_pmc_traffic.json (rocprofv3 PMC passes of this same
-    command, collected by tools/profile_round.sh and committed; counters cannot be read from inside the process)."""
+def csrc_sha16():
+    """Fingerprint of the kernel sources (csrc/*.hip, *.cpp, *.h): profiles/*_pmc_*.json carry the value they were recorded at."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(REPO, "srl-zoo_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.cpp")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _newest_profile(suffix):
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*" + suffix)))
     if not files:
         return None, None
     try:
-        rec = json.load(open(files[-1]))["kernels"].get(kernel)
-    except (OSError, ValueError, KeyError):
+        return json.load(open(files[-1])), "profiles/" + os.path.basename(files[-1])
+    except (OSError, ValueError):
         return None, None
+
+
+def committed_pmc_traffic(kernel):
+    """(HBM bytes per launch of `kernel`, source file, stale) from the newest profiles/*_pmc_traffic.json (rocprofv3 PMC passes
+    of this same command, collected by tools/profile_round.sh and committed; counters cannot be read from inside the process).
+    stale = the file was recorded at other kernel sources than the ones this run was built from (or carries no fingerprint)."""
+    doc, src = _newest_profile("_pmc_traffic.json")
+    rec = (doc or {}).get("kernels", {}).get(kernel)
     if not rec:
-        return None, None
-    return rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
+        return None, None, None
+    return rec["hbm_bytes_per_launch"], src, doc.get("csrc_sha16") != csrc_sha16()
 
 
 def committed_pmc_mfma(kernel):
-    """Matrix-pipe busy fraction and measured clock of `kernel` from the newest profiles/*_pmc_mfma.json (rocprofv3 PMC pass
-    of this same command, tools/profile_round.sh)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_mfma.json")))
-    if not files:
-        return None, None, None
-    try:
-        rec = json.load(open(files[-1]))["kernels"].get(kernel)
-    except (OSError, ValueError, KeyError):
-        return None, None, None
+    """(matrix-pipe busy fraction, measured clock, source file, stale) of `kernel` from the newest profiles/*_pmc_mfma.json."""
+    doc, src = _newest_profile("_pmc_mfma.json")
+    rec = (doc or {}).get("kernels", {}).get(kernel)
     if not rec:
-        return None, None, None
-    return rec["mfma_busy_frac"], rec["clock_ghz"], "profiles/" + os.path.basename(files[-1])
+        return None, None, None, None
+    return rec["mfma_busy_frac"], rec["clock_ghz"], src, doc.get("csrc_sha16") != csrc_sha16()
+
+
+def rank_environments(n, port, base=None):
+    """Environment of each of the n ranks bench.py starts itself (one process per GPU, rendezvous on 127.0.0.1) — the same
+    variables torch.distributed.run would set."""
+    base = dict(os.environ if base is None else base)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    envs = []
+    for r in range(n):
+        e = dict(base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port))
+        envs.append(e)
+    return envs
+
+
+def self_launch(n, argv, script=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (this same command line, one process per GPU), let
+    rank 0 own stdout (the ONE JSON line), wait for all; a failing rank takes the others down.  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r, env in enumerate(rank_environments(n, port)):
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:  # the others would hang in their next collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -153,6 +222,10 @@ def main():
                     help="input channels: 6 = --multi-view (two stacked cameras, BASELINE.json configs[4] `vae` half); "
                          "`--losses triplet` forces 9 (anchor / positive / negative views, configs[4] `triplet` half)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="every leg of BASELINE.md section 3's CPU protocol (minutes) instead of the bounded default")
+    ap.add_argument("--timer-steps", type=int, default=5,
+                    help="instrumented steps (HIP events around every MFMA launch) run AFTER the timed region for the roofline object")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--host-input", action="store_true",
                     help="NOT the contract's metric: every step starts from uint8 frames in pinned HOST memory (H2D copy + "
@@ -162,21 +235,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..."
-                         % (args.gpus, args.gpus, args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))  # no launcher: start the ranks ourselves
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    from srlz import optim as _optim
+    local_dev = _optim.local_device_index() if world > 1 else local_rank
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl")  # RCCL over xGMI
+        torch.distributed.init_process_group(backend=_optim.dist_backend())  # "nccl" = RCCL over xGMI
         # communicator set-up (seconds) must never land in the timed region, whatever --warmup says
         warm = torch.zeros(1 << 20, device=device)
-        torch.distributed.all_reduce(warm)
+        _optim._sum_across_ranks(warm)
         torch.cuda.synchronize()
-        from srlz import optim as _optim
         if _optim.native_comm_requested():  # SRLZ_COMM=rccl: the library's own RCCL communicator (include/srlz.h)
             _optim.init_native_comm()
             _optim._sum_across_ranks(warm)
@@ -248,19 +322,26 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    if not args.no_kernel_timers:
-        ops.timers_enable(True)
     t0 = time.time()
     for _ in range(args.steps):
         totals.append(step().detach())
     sync()
     dt = time.time() - t0
-    ops.timers_enable(False)
     last_losses = torch.stack(totals).tolist()
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)
+        if torch.distributed.get_backend() != "gloo":
+            t = t.to(device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # the roofline's per-launch HIP-event times: the SAME steps, instrumented, after the clock has stopped
+    timer_steps = 0 if args.no_kernel_timers or rank != 0 else max(0, args.timer_steps)
+    if timer_steps:
+        ops.timers_enable(True)
+    for _ in range(args.timer_steps if not args.no_kernel_timers else 0):  # (every rank runs them: the steps hold collectives)
+        step()
+    sync()
+    ops.timers_enable(False)
 
     if rank == 0:
         images = 2 * B * world * args.steps
@@ -302,8 +383,8 @@ def main():
             for key, v in layers.items():
                 alg_bytes += v["launches"] * conv64_algorithmic_bytes(key)
             alg_bytes /= max(1, k["launches"])
-            traffic, traffic_src = committed_pmc_traffic("conv64_fwd_kernel<4, false>")
-            busy, clock, busy_src = committed_pmc_mfma("conv64_fwd_kernel<4, false>")
+            traffic, traffic_src, traffic_stale = committed_pmc_traffic("conv64_fwd_kernel<4, false>")
+            busy, clock, busy_src, busy_stale = committed_pmc_mfma("conv64_fwd_kernel<4, false>")
             out["roofline"] = {"kernel": "conv64_fwd_kernel<4,false> (3x3 64->64 conv / convT forward and data-gradient, all "
                                          "layers; the <4,true> instantiation = data-gradient with the BatchNorm backward "
                                          "fused into its operand load is listed under fused_dgrad_layers)",
@@ -312,13 +393,18 @@ def main():
                                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": round(alg_bytes),
                                "mfma_busy_frac": busy, "clock_ghz": clock, "mfma_pmc_source": busy_src,
+                               "stale": bool(traffic_stale or busy_stale), "csrc_sha16": csrc_sha16(),
+                               "stale_note": "traffic / mfma_busy_frac / clock_ghz come from committed rocprofv3 PMC passes; stale = "
+                                             "those passes were recorded at other kernel sources than this build's",
+                               "timing": "%d instrumented steps after the timed region (HIP events on the launch stream)" % timer_steps,
                                "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),
                                "layers": layers, "fused_dgrad_layers": fused}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(list(args.losses))
+            out["cpu_baseline"] = cpu_baseline(list(args.losses), full=args.cpu_baseline_full)
         print(json.dumps(out))
     if world > 1:
+        _optim.destroy_native_comm()
         torch.distributed.destroy_process_group()
 
 

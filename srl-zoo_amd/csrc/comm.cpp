@@ -4,13 +4,24 @@
 // process (one process per GPU), created from a 128-byte unique id that rank 0 generates and the host shares by whatever
 // rendezvous it has (the Python side uses torch.distributed's store).
 // RCCL is resolved at srlz_comm_init() time with dlopen — the copy already loaded into the process (PyTorch ships one) is
-// preferred, so the two never coexist — and the library keeps loading where RCCL is absent.
+// preferred, so the two never coexist — and the library keeps BUILDING and loading where RCCL (headers or library) is
+// absent: the handful of NCCL-ABI types this file needs are declared here instead of including <rccl/rccl.h>.
 #include "common.h"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
 
 namespace {
+
+// ---- the slice of the NCCL / RCCL C ABI used below (stable since NCCL 2.0; values as in rccl.h) ----
+struct ncclComm;
+typedef ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+typedef int ncclResult_t;      // enum in the header; ncclSuccess == 0
+typedef int ncclDataType_t;    // enum in the header
+typedef int ncclRedOp_t;       // enum in the header
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclFloat32 = 7;
+constexpr ncclRedOp_t ncclSum = 0;
 
 struct Api {
   void* handle = nullptr;

@@ -532,9 +532,16 @@ class SRL4robotics(BaseLearner):
         if (self.use_inverse_loss or self.use_forward_loss) and (n_actions > self.dim_action or int(np.min(actions)) < 0):
             raise ValueError("actions must lie in [0, {}) (n_actions of the model), found [{}, {}]".format(
                 self.dim_action, int(np.min(actions)), int(np.max(actions))))
-        if self.use_reward_loss and not set(np.unique(rewards).tolist()) <= {-1, 0, 1}:
-            raise ValueError("the reward head has two classes: rewards must be -1 / 0 / 1 (-1 is mapped to 0), found {}".format(
-                sorted(set(np.unique(rewards).tolist()))))
+        if self.use_reward_loss:
+            # validated AFTER the reference's own transformation (learner.py:444-449: -1 -> 0, then .long() truncates, so
+            # fractional rewards such as 0.5 / -0.5 are legal there): the class index must lie in [0, 2)
+            classes = np.array(rewards).copy()
+            classes[classes == -1] = 0
+            classes = th.from_numpy(np.ascontiguousarray(classes)).long().numpy()
+            if classes.size and (classes.min() < 0 or classes.max() > 1):
+                raise ValueError("the reward head has two classes: after mapping -1 to 0 and truncating to int64 (reference "
+                                 "learner.py:444-449) rewards must fall in [0, 2), found classes {}".format(
+                                     sorted(set(classes.tolist()))))
         print("{} unique actions / {} actions".format(len(set(actions)), n_actions))
         print("Number of observations per action")
         print(np.array([np.sum(actions == i) for i in range(n_actions)], dtype=np.int64))

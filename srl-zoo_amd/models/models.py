@@ -140,12 +140,18 @@ class BaseModelVAE(BaseModelAutoEncoder):
         the reference would), and they pin two input batches."""
         self._recent, self._recent_versions = [], []
 
-    def rememberPair(self, x, next_x, mu, next_mu):
+    def rememberPair(self, x, next_x, mu=None, next_mu=None):
         """After a batched forward over [x ; next_x]: make the learner's getStates(x) / getStates(next_x) (the quirk above)
-        find the halves — group 0 / group 1 of the statistics the batched pass recorded."""
-        _, _, stats, _ = self._recent.pop()
+        find the halves — group 0 / group 1 of the statistics the batched pass recorded.  What getStates returns is
+        encode()[0], the FULL mu (reference models.py:131-139): the halves are taken from the batched mu that the forward
+        remembered, never from what a wrapper returned as its second output (SRLModulesSplit.forwardVAE hands out the mu
+        masked to the 'vae' split).  `mu` / `next_mu` are re-used only when they are the halves of exactly that tensor."""
+        _, mu_full, stats, _ = self._recent.pop()
         self._recent_versions.pop()
         self._recent, self._recent_versions = [], []
+        pair = getattr(mu, "_srlz_pair", None) if mu is not None else None
+        if pair is None or pair[0] is not mu_full or next_mu is None:
+            mu, next_mu = ops.pair_split(mu_full)
         self._remember(x, mu, stats, 0)
         self._remember(next_x, next_mu, stats, 1)
 
@@ -153,7 +159,11 @@ class BaseModelVAE(BaseModelAutoEncoder):
         """z = eps * exp(0.5 logvar) + mu in training (eps from torch's generator, as the reference does), mu in eval."""
         if self.training:
             if self.eps_fn is None:
-                eps = th.empty_like(mu).normal_()
+                # one draw per MODEL CALL, in call order (reference models.py:161 runs once per self.model(...)): a batched pair
+                # consumes the generator exactly like the two calls it stands for
+                eps = th.empty_like(mu)
+                for part in eps.chunk(ops.cur_groups(True)):
+                    part.normal_()
             elif ops.cur_groups(True) > 1:  # (test hook) a batched pair: one draw per model call, in call order
                 eps = th.cat([self.eps_fn(part) for part in mu.chunk(ops.cur_groups(True))], 0)
             else:

@@ -5,6 +5,8 @@ The reference relies on ``loss.backward()`` (models/learner.py:489); here each f
 used for storage only: no torch compute op touches an activation.  Activations are NHWC between the first conv and the
 last transposed conv; images and everything the caller sees stay in the reference's NCHW layout.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -895,15 +897,17 @@ class SplitFn(Function):
 def pair_split(t):
     """The two halves of a batched tensor, remembered as a pair so that pair-aware consumers can find the whole."""
     a, b = SplitFn.apply(t)
-    a._srlz_pair = (t, 0, b)
-    b._srlz_pair = (t, 1, a)
+    # (weak references to the sibling: a <-> b would otherwise be a cycle that keeps the batched tensor — 300 MB for the
+    # reconstructions at bs = 256 — alive until Python's cyclic collector runs)
+    a._srlz_pair = (t, 0, weakref.ref(b))
+    b._srlz_pair = (t, 1, weakref.ref(a))
     return a, b
 
 
 def pair_of(a, b):
     """The batched tensor whose halves are exactly (a, b) — or None."""
     ra = getattr(a, "_srlz_pair", None)
-    if ra is not None and ra[1] == 0 and ra[2] is b:
+    if ra is not None and ra[1] == 0 and ra[2]() is b:
         return ra[0]
     if torch.is_tensor(a) and torch.is_tensor(b) and not (a.requires_grad or b.requires_grad) and a.is_cuda and b.is_cuda \
             and a.dtype == torch.float32 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous() \

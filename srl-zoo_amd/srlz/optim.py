@@ -179,10 +179,34 @@ def destroy_native_comm():
         _native_ready = False
 
 
+def dist_backend():
+    """Backend of the process group the ranks are launched with: "nccl" (= RCCL over xGMI, one GPU per rank — the product
+    configuration) unless SRLZ_DIST_BACKEND says otherwise.  "gloo" exists for ONE purpose: several ranks sharing a GPU on a
+    box with fewer GPUs than ranks (RCCL refuses two ranks on one device), so that the whole multi-rank control flow of
+    learn() / train.py / bench.py can be exercised on a 1-GPU machine; the bucket then bounces through host memory."""
+    import os
+    return os.environ.get("SRLZ_DIST_BACKEND", "nccl").lower()
+
+
+def local_device_index():
+    """GPU of this rank: LOCAL_RANK, wrapped around the visible devices (ranks share GPUs only in the gloo debug topology)."""
+    import os
+    n = max(torch.cuda.device_count(), 1)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank >= n and dist_backend() == "nccl":
+        raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible: RCCL needs one GPU per rank (SRLZ_DIST_BACKEND=gloo "
+                           "lets ranks share a GPU for functional tests)" % (local_rank, n))
+    return local_rank % n
+
+
 def _sum_across_ranks(t):
     if _native_ready:
         from . import _cabi as C
         C.comm_allreduce_f32(C.ptr(t), t.numel(), C.stream())
+    elif t.is_cuda and dist.get_backend() == "gloo":
+        host = t.detach().cpu()  # (debug topology only, see dist_backend)
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
@@ -222,7 +246,12 @@ def average_running_stats(state_dict):
     if size == 1 or not keys:
         return state_dict
     flat = torch.cat([state_dict[k].reshape(-1).float() for k in keys])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        flat = flat.cpu()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat = flat.to(state_dict[keys[0]].device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= size
     off = 0
     for k in keys:

@@ -93,9 +93,9 @@ def initDistributed():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size == 1:
         return 0, 1
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    th.cuda.set_device(local_rank)
-    th.distributed.init_process_group(backend="nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    th.cuda.set_device(optim.local_device_index())
+    th.distributed.init_process_group(backend=optim.dist_backend())  # "nccl" = RCCL over xGMI
     if optim.native_comm_requested():  # SRLZ_COMM=rccl: the bucket travels through srlz_comm_allreduce_f32 (include/srlz.h)
         optim.init_native_comm()
     return th.distributed.get_rank(), world_size
@@ -188,4 +188,5 @@ if __name__ == '__main__':
         np.savez('{}/loss_history.npz'.format(args.log_folder), **loss_history)
         correlationCall(exp_config, plot=False)
     if world_size > 1:
+        optim.destroy_native_comm()  # (no-op unless SRLZ_COMM=rccl created the library's own communicator)
         th.distributed.destroy_process_group()

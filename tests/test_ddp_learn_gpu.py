@@ -1,0 +1,147 @@
+"""The multi-rank control flow of `train.py` / `SRL4robotics.learn()` EXECUTED with two ranks (reference
+models/learner.py:285-292,501-522 is the single-process loop these ranks replicate): one process per rank started the way
+torch.distributed.run starts them, the product's command line unmodified (tests/ddp_train_launcher.py only observes).
+
+With >= 2 GPUs the ranks use backend "nccl" (RCCL over xGMI), one GPU each — the product configuration.  On a 1-GPU box
+both ranks share GPU 0 and the process group is gloo (SRLZ_DIST_BACKEND=gloo: RCCL refuses two ranks on one device; the
+bucket bounces through host memory, every kernel still runs on the GPU), so the test runs wherever one MI355X is visible.
+
+Checked: ONE log folder (rank 0's timestamped choice, broadcast), identical loss_history / parameters on both ranks, lock-step
+validation, the checkpoint's BatchNorm running statistics = the ranks' average, learn() returns on every rank and rank 0 writes
+the reference's output files; a NaN injected on rank 1 makes BOTH ranks exit with pipeline.NAN_ERROR (11) together.
+"""
+import glob
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from dataset_util import make_dataset
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAUNCHER = os.path.join(REPO, "tests", "ddp_train_launcher.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(world, args, cwd, extra_env, timeout=600):
+    """Start `world` ranks of the launcher; returns [(returncode, combined output)] per rank."""
+    port = _free_port()
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   SRLZ_DIST_BACKEND=backend)
+        env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, LAUNCHER] + args, cwd=cwd, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    out = []
+    for p in procs:
+        try:
+            text, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            text, _ = p.communicate()
+            text += b"\n[test] TIMEOUT"
+        out.append((p.returncode, text.decode("utf-8", "replace")))
+    return out, backend
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    root = tmp_path_factory.mktemp("ddp_learn")
+    make_dataset(str(root), name="tiny_ddp", n_episodes=4, ep_len=26)
+    return root
+
+
+COMMON = ["--no-display-plots", "--data-folder", "tiny_ddp", "--epochs", "2", "--seed", "0", "--val-size", "0.2", "--state-dim", "10",
+          "--model-type", "custom_cnn", "-bs", "8", "-lr", "0.001", "--losses", "autoencoder", "inverse", "forward"]
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.timeout(900)
+def test_two_rank_train_cli(dataset):
+    digest = dataset / "digest"
+    digest.mkdir()
+    results, backend = _run_ranks(2, COMMON, str(dataset), {"SRLZ_TEST_DIGEST_DIR": str(digest)})
+    for rc, text in results:
+        assert rc == 0, text[-4000:]
+    ranks = [json.load(open(str(digest / ("rank%d.json" % r)))) for r in range(2)]
+    assert [d["world"] for d in ranks] == [2, 2] and ranks[0]["backend"] == backend
+    # ---- one log folder: rank 0's (timestamped) choice, used by both
+    folders = glob.glob(str(dataset / "logs" / "tiny_ddp" / "*"))
+    assert len(folders) == 1, folders
+    assert ranks[0]["log_folder"] == ranks[1]["log_folder"]
+    log = folders[0]
+    assert os.path.samefile(log, os.path.join(str(dataset), ranks[0]["log_folder"]))
+    # ---- identical histories and parameters (the scalar tail and the gradients travel in one bucket)
+    assert ranks[0]["loss_history"] == ranks[1]["loss_history"]
+    h = ranks[0]["loss_history"]
+    assert set(h) >= {"train_loss", "val_loss", "reconstruction_loss", "inverse_loss", "forward_loss"}
+    assert all(len(v) == 2 and np.isfinite(v).all() for v in h.values())
+    assert ranks[0]["param_sum"] == ranks[1]["param_sum"] and ranks[0]["param_abs_sum"] == ranks[1]["param_abs_sum"]
+    # 12 minibatches of 8, 2 for validation -> every rank: 5 optimisation steps and 1 validation step per epoch
+    assert ranks[0]["adam_steps"] == ranks[1]["adam_steps"] == 10
+    for d in ranks:
+        assert d["states_shape"] == [104, 10] and d["states_finite"]
+    # ---- checkpoints: every save averaged the ranks' LOCAL running statistics (they differ: different minibatches)
+    assert len(ranks[0]["saves"]) == len(ranks[1]["saves"]) >= 1
+    for s0, s1 in zip(ranks[0]["saves"], ranks[1]["saves"]):
+        assert s0["local_mean"] != s1["local_mean"]
+        mean = (np.array(s0["local_mean"]) + np.array(s1["local_mean"])) / 2
+        np.testing.assert_allclose(s0["avg_mean"], mean, rtol=1e-6, atol=1e-7)
+        assert s0["avg_mean"] == s1["avg_mean"] and s0["tracked"] == s1["tracked"]
+    sd = torch.load(os.path.join(log, "srl_model.pth"), map_location="cpu")
+    saved = sd["model.encoder_conv.1.running_mean"].double().numpy()
+    assert any(np.allclose(saved, s["avg_mean"], rtol=1e-6, atol=1e-7) for s in ranks[0]["saves"])
+    # ---- rank 0 wrote the reference's output files
+    for f in ("srl_model.pth", "exp_config.json", "states_rewards.npz", "image_to_state.json", "loss_history.npz"):
+        assert os.path.exists(os.path.join(log, f)), f
+    z = np.load(os.path.join(log, "loss_history.npz"))
+    np.testing.assert_allclose(z["train_loss"], h["train_loss"])
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.timeout(900)
+def test_nan_on_one_rank_exits_every_rank_with_11(dataset):
+    results, _ = _run_ranks(2, COMMON + ["--log-folder", str(dataset / "logs" / "nan_run")], str(dataset), {"SRLZ_TEST_NAN_RANK": "1"})
+    for rc, text in results:
+        assert rc == 11, (rc, text[-3000:])
+        assert "NaN Loss" in text
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.timeout(600)
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself and rank 0 prints ONE
+    JSON line with n_gpus = rccl_ranks = 2 (on a 1-GPU box: both ranks on GPU 0 over gloo)."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["SRLZ_DIST_BACKEND"] = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                           "--batch-size", "8", "--timer-steps", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=500)
+    assert proc.returncode == 0, proc.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [l for l in proc.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["global_batch"] == 16
+    assert out["value"] > 0 and out["scaling"] == "weak" and "cpu_baseline" not in out
+    assert np.isfinite(out["config"]["final_loss"])

@@ -83,6 +83,9 @@ CASES = [
     ("vae_c6", ["vae"], 3, 6, None),
     ("cnn", ["inverse", "forward"], 4, 3, None),
     ("split_ae", ["autoencoder", "inverse", "forward"], 2, 3, OrderedDict([("autoencoder", 20), ("inverse", 20), ("forward", -1)])),
+    # split + VAE: forwardVAE hands out the mu MASKED to the 'vae' split, getStates must still return the full mu (reference
+    # modules.py:133-134 -> models.py:131-139) or the inverse / forward heads train on zeros (round-2 advisor finding)
+    ("split_vae", ["vae", "inverse", "forward"], 2, 3, OrderedDict([("vae", 20), ("inverse", 20), ("forward", -1)])),
 ]
 
 
@@ -113,6 +116,39 @@ def test_forward_pair_equals_two_calls(name, losses, B, C, split):
             scale = max(float(two[2][wk].abs().max()), 1e-30)  # analytically zero: compare on the weight gradient's scale
         err = float((g1.double() - g2.double()).abs().max()) / scale
         assert err <= 1e-5, "grad %s: %.3e" % (k, err)
+
+
+def test_split_vae_pair_states_are_the_unmasked_mu():
+    """getStates after a batched split-VAE forward: the full mu (columns of the inverse / forward splits alive), so that
+    detachSplit(states, 'inverse') is not all zeros."""
+    split = OrderedDict([("vae", 20), ("inverse", 20), ("forward", -1)])
+    model = build(["vae", "inverse", "forward"], split=split)
+    o, n, _ = gu.golden_inputs(2, 3, 6, seed=77)
+    obs, nxt = torch.from_numpy(o).cuda(), torch.from_numpy(n).cuda()
+    model.train()
+    (dec, mu_s, _), (_, nmu_s, _) = model.forwardPair(obs, nxt)
+    states, next_states = model.getStates(obs), model.getStates(nxt)
+    assert float(mu_s[:, 20:].abs().max()) == 0.0 and float(states[:, 20:].abs().max()) > 0.0
+    assert torch.equal(states[:, :20], mu_s[:, :20]) and torch.equal(next_states[:, :20], nmu_s[:, :20])
+    assert float(model.detachSplit(states, "inverse").abs().max()) > 0.0
+
+
+def test_pair_draws_the_vae_noise_like_two_calls():
+    """Default noise source (torch's generator, reference models.py:161): the batched pair consumes it exactly like the two
+    model calls it stands for — same seed, same reconstructions."""
+    model = build(["vae"])
+    o, n, _ = gu.golden_inputs(2, 3, 6, seed=78)
+    obs, nxt = torch.from_numpy(o).cuda(), torch.from_numpy(n).cuda()
+    init = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+    model.train()
+    torch.manual_seed(123)
+    with torch.no_grad():
+        a, b = model(obs), model(nxt)
+    model.load_state_dict(init)
+    torch.manual_seed(123)
+    with torch.no_grad():
+        pa, pb = model.forwardPair(obs, nxt)
+    assert torch.equal(a[0], pa[0]) and torch.equal(b[0], pb[0])
 
 
 def test_pair_over_adjacent_halves_is_zero_copy():

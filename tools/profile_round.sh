@@ -28,6 +28,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --
 python - "$tag" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
+sys.path.insert(0, ".")
+import bench  # csrc_sha16(): the kernel-source fingerprint bench.py compares against (roofline.stale)
+SHA = bench.csrc_sha16()
 
 
 def short(name):
@@ -42,6 +45,7 @@ def load(root):
 
 
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 2",
+       "csrc_sha16": SHA,
        "unit_note": "counter unit KiB; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as is",
        "kernels": {}}
 per = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
@@ -73,6 +77,7 @@ for r in rows:
         a["ns"] += float(k["End_Timestamp"]) - float(k["Start_Timestamp"])
         a["launches"] += 1
 mf = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace -- python bench.py --steps 3 --warmup 2",
+      "csrc_sha16": SHA,
       "formulas": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); clock_ghz = GRBM_GUI_ACTIVE / 8 / duration",
       "kernels": {}}
 for name, a in acc.items():
