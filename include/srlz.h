@@ -184,9 +184,26 @@ int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* 
  * bn_bwd_partial has srlz_convT_out_bwd_fused_tiles(d) rows of 128 floats; ws >= srlz_convT_out_bwd_fused_workspace(d) bytes. */
 int srlz_convT_out_bwd_fused_tiles(const srlz_skinny_desc* d);
 size_t srlz_convT_out_bwd_fused_workspace(const srlz_skinny_desc* d);
+/* dy_gain_dev != NULL: `dy_nchw` holds the reconstruction ERROR dec - obs left behind by srlz_convT_out_fwd_loss, and the loss
+ * gradient d(loss)/d(dec) = ((dy_gain_dev[0] / dy_gain_div) * dy_gain_coef) * (dec - obs) is formed while it is staged
+ * (dy_gain_dev = the upstream gradient of the loss scalar on the device; div = numel per frame for the mean form, 1 for the sum
+ * form; coef = 2) — the rounding order autograd uses for sum((dec-obs)^2)/numel.  NULL: dy_nchw is the gradient itself. */
 int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw, const float* x_bnp,
                              float* bn_bwd_partial, float* dw_ref, float* dbias /* may be NULL */, void* ws, size_t ws_bytes,
+                             const float* dy_gain_dev, float dy_gain_div, float dy_gain_coef,
                              const srlz_skinny_desc* d, srlz_stream_t stream);
+
+/* The last ConvTranspose forward WITH the reconstruction / generation loss of the step taken in its epilogue (SURVEY.md 8a' K11 /
+ * K12; replaces reconstructionLoss / autoEncoderLoss, /root/reference/losses/losses.py:172-196, and generationLoss, :199-214,
+ * on the training path — there `obs` is read twice and `decoded` three times, here `decoded` never leaves the chip):
+ * the batch is the two frames of a step (images [0, n/2) = obs, [n/2, n) = next_obs; d->groups = BatchNorm groups as usual);
+ * err_nchw = dec - target (what the backward needs), dec_nchw = the reconstruction itself (optional, NULL on the training path),
+ * loss_partial[2][srlz_convT_out_fwd_loss_workgroups(d)] = per-frame, per-workgroup sums of squared errors (fp64), to be
+ * combined by srlz_pair_loss_finalize.  The gradient is err times a scalar: see srlz_convT_out_bwd_fused / srlz_scale_by_scalar. */
+int srlz_convT_out_fwd_loss_workgroups(const srlz_skinny_desc* d);
+int srlz_convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const float* target_nchw, float* err_nchw,
+                            float* dec_nchw, const float* x_bnp, double* loss_partial, const srlz_skinny_desc* d,
+                            srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BatchNorm2d(64) (+ ReLU (+ MaxPool 3x3 s2)) — nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d,
@@ -303,6 +320,15 @@ int srlz_sqdiff_grad_groups(const float* a, const float* b, const float* coef_de
 /* The loss of a batched pair a = [a0 ; a1], b = [b0 ; b1] in one go: sums[g] = sum((a_g - b_g)^2) and
  * comb[0] = sums[0]/n + sums[1]/n (mean != 0: autoEncoderLoss, losses.py:184-196) or sums[0] + sums[1] (generationLoss,
  * losses.py:199-214), rounded like the reference's separate fp32 operations. */
+/* Second stage of a pair loss whose fp64 partials [2][nb] another kernel wrote (srlz_convT_out_fwd_loss): sums[g] and
+ * comb = sums[0]/n + sums[1]/n (mean) or sums[0] + sums[1], rounded exactly like srlz_sqdiff_pair_loss.
+ * (/root/reference/losses/losses.py:181,196 / :210-214) */
+int srlz_pair_loss_finalize(const double* partial, int nb, long long n_per_group, int mean, float* sums, float* comb,
+                            srlz_stream_t stream);
+/* out = ((gain_dev[0] / div) * coef) * x (in place allowed): the gradient of a fused pair loss materialised from the stored
+ * error for consumers that cannot apply the factor themselves (autograd of F.mse_loss, /root/reference/losses/losses.py:210). */
+int srlz_scale_by_scalar(const float* x, const float* gain_dev, float div, float coef, float* out, long long n,
+                         srlz_stream_t stream);
 int srlz_sqdiff_pair_loss(const float* a, const float* b, long long n_per_group, int mean, float* sums, float* comb,
                           void* ws, size_t ws_bytes, srlz_stream_t stream);
 /* out = [a ; b] (n_each floats each) — joins the halves of a batched pair (th.cat of learner.py's obs / next_obs) */

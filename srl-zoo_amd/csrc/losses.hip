@@ -471,6 +471,47 @@ extern "C" int srlz_sqdiff_pair_loss(const float* a, const float* b, long long n
   return 0;
 }
 
+// Second stage of a pair loss whose per-workgroup fp64 partials were written by another kernel (convT_out_kernel<true>: the
+// reconstruction / generation loss taken in the last ConvTranspose's epilogue): partial[2][nb] -> sums[2], comb — the same
+// fixed-order final sum and the same fp32 roundings as srlz_sqdiff_pair_loss.
+extern "C" int srlz_pair_loss_finalize(const double* partial, int nb, long long n_per_group, int mean, float* sums, float* comb,
+                                       srlz_stream_t stream) {
+  SRLZ_REQUIRE(partial && sums && comb, SRLZ_ERR_NULL, "pair_loss_finalize: null pointer");
+  SRLZ_REQUIRE(nb > 0 && n_per_group > 0, SRLZ_ERR_BAD_DESC, "pair_loss_finalize: nb = %d, n = %lld", nb, n_per_group);
+  hipLaunchKernelGGL(pair_loss_final, dim3(1), dim3(128), 0, as_stream(stream), partial, nb, sums, comb, (float)n_per_group, mean);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+// out = ((gain_dev[0] / div) * coef) * x — the gradient of a fused pair loss materialised from the stored error (only where the
+// consumer cannot apply the factor itself: the un-fused ConvTranspose-5 backward of C = 6 / 9 images); in place when out == x.
+namespace {
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ gain_dev, float div,
+                                                             float coef, float* __restrict__ out, long long n) {
+  const float g = (gain_dev[0] / div) * coef;
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = *(const f32x4*)(x + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= g;
+    *(f32x4*)(out + i * 4) = v;
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = g * x[i];
+}
+}  // namespace
+
+extern "C" int srlz_scale_by_scalar(const float* x, const float* gain_dev, float div, float coef, float* out, long long n,
+                                    srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && gain_dev && out, SRLZ_ERR_NULL, "scale_by_scalar: null pointer");
+  SRLZ_REQUIRE(div != 0.f && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, SRLZ_ERR_BAD_DESC,
+               "scale_by_scalar: zero divisor or unaligned buffers");
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(blocks_for((n + 3) / 4, 8192)), dim3(256), 0, as_stream(stream), x, gain_dev, div,
+                     coef, out, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
 extern "C" int srlz_join2(const float* a, const float* b, float* out, long long n_each, srlz_stream_t stream) {
   SRLZ_REQUIRE(a && b && out, SRLZ_ERR_NULL, "join2: null pointer");
   SRLZ_REQUIRE(n_each > 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0 && (n_each & 3) == 0, SRLZ_ERR_BAD_DESC,

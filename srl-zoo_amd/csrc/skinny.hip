@@ -117,8 +117,10 @@ __device__ __forceinline__ void image_request(ImgRegs<K, TR>& r, const float* __
   }
 }
 
+// `gain`: factor applied to every element on its way into LDS (1 = none; the fused ConvTranspose-5 backward turns the stored
+// reconstruction error dec - obs into d(loss)/d(dec) = gain * (dec - obs) here, see convT_out_kernel<true>)
 template <int K, bool HOIST = false, int TR = 16>
-__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K, TR>& r) {
+__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K, TR>& r, const float gain = 1.f) {
 #pragma unroll
   for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) {
     int c, row, xl;
@@ -126,7 +128,7 @@ __device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<
     // (branch-free — elements past the end of the window go to a spare float of the first plane's padding: a wait inside a branch
     // leaves the compiler unsure, at the join, whether the load has landed, and it then waits for EVERYTHING at the next re-use
     // of the register, including the loads meant to stay in flight)
-    T[live ? (c * 2 + (xl & 1)) * Geo<K, TR>::PP + row * XP + (xl >> 1) : Geo<K, TR>::PP - 1] = ((r.inside >> j) & 1u) ? r.v[j] : 0.f;
+    T[live ? (c * 2 + (xl & 1)) * Geo<K, TR>::PP + row * XP + (xl >> 1) : Geo<K, TR>::PP - 1] = ((r.inside >> j) & 1u) ? r.v[j] * gain : 0.f;
   }
 }
 
@@ -717,7 +719,12 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
                                                               int WF, int tiles_y, int tiles_x,
                                                               const float* __restrict__ y_raw,
                                                               const float* __restrict__ y_bnp, int npg,
-                                                              double* __restrict__ bias_partial) {
+                                                              double* __restrict__ bias_partial,
+                                                              const float* __restrict__ gain_dev, float gain_div, float gain_coef) {
+  // gain_dev != NULL: `img` holds the reconstruction error dec - obs that convT_out_kernel<true> left behind, and
+  // d(loss)/d(dec) = ((upstream / div) * coef) * (dec - obs) — autograd's rounding order for sum(.)/numel — is formed while the
+  // window lands in LDS: the gradient tensor of the reconstruction / generation loss is never written.
+  const float gain = gain_dev ? (gain_dev[0] / gain_div) * gain_coef : 1.f;
   constexpr int K = 4, PAD = 0, C = 3, TR = FTR;
   using G = Geo<K, TR>;
   constexpr int KT = G::KT, KS = G::KS, NT = 2;
@@ -802,13 +809,13 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
     const unsigned own = nx.inside & (last_y ? ~0u : mrow) & (last_x ? ~0u : mcol);
 #pragma unroll
     for (int j = 0; j < PER; ++j)
-      bsum[j] += __builtin_bit_cast(float, __builtin_bit_cast(unsigned, nx.v[j]) & (unsigned)(-(int)((own >> j) & 1u)));
+      bsum[j] += __builtin_bit_cast(float, __builtin_bit_cast(unsigned, nx.v[j] * gain) & (unsigned)(-(int)((own >> j) & 1u)));
   };
   y_request(blockIdx.x);
   if ((int)blockIdx.x < ntiles) {
     const int n = blockIdx.x / tpi, trem = blockIdx.x - n * tpi;
     image_request<K, PAD, true, TR>(nx, img, n, C, 0, H, W, (trem / tiles_x) * TR, (trem % tiles_x) * 16, true);
-    image_land<K, true, TR>(T, nx);
+    image_land<K, true, TR>(T, nx, gain);
     bias_accumulate(trem);
   }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
         for (int j = 0; j < NT; ++j) accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j][i], accw[j], 0, 0, 0);
     }
     __syncthreads();  // every wave is done with T and F: the next window lands
-    image_land<K, true, TR>(T, nx);
+    image_land<K, true, TR>(T, nx, gain);
     bias_accumulate((tile + (int)gridDim.x) % tpi);  // (past the last tile nothing is inside: adds zeros)
   }
   if (bias_partial) {  // [3][gridDim.x] fp64, summed over workgroups in a fixed order by nchw_chan_sum_final
@@ -943,11 +950,21 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int TP = 49;  // LDS pitch (floats) of one feature pixel's 48 products
 
+// LOSS (reconstruction / generation loss fused into the epilogue, /root/reference/losses/losses.py:172-214 — K11 / K12 of SURVEY.md
+// 8a'): the gather phase holds every output pixel in a register on its way to the NCHW store; with `target` (the observation the
+// decoder reconstructs) it stores the ERROR dec - target instead (`img`; the reconstruction itself only when `dec_out` is
+// given) and accumulates its square: one fp32 partial per thread and tile, fp64 across tiles, per LOSS group (images
+// [g*lpg, (g+1)*lpg): the two frames of a step) -> loss_partial[g][workgroup], summed in a fixed order by srlz_pair_loss_finalize.
+// The passes of srlz_sqdiff_pair_loss (read dec and obs) and srlz_sqdiff_grad_groups (read both again, write the gradient)
+// disappear; the gradient is the stored error times a scalar, applied where the backward kernel stages it (convT_out_bwd_kernel).
+template <bool LOSS>
 __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ w_ref,
                                                           const float* __restrict__ bias, float* __restrict__ img,
                                                           int N, int C, int H, int W, int HF, int WF, int tiles_y,
-                                                          int tiles_x, const float* __restrict__ feat_bnp, int npg) {
+                                                          int tiles_x, const float* __restrict__ feat_bnp, int npg,
+                                                          const float* __restrict__ target, float* __restrict__ dec_out,
+                                                          double* __restrict__ loss_partial, int lpg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Tt = (float*)smem;  // [304][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1006,6 +1023,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
   };
   f32x4 q[DEPTH][4];
   bool qok[DEPTH];
+  double lacc0 = 0.0, lacc1 = 0.0;  // LOSS: this thread's sum of squared errors per loss group
   int nt = blockIdx.x, nm = wave;  // the next (tile, M-tile) to request
   auto advance = [&]() { nm += 4; if (nm >= 19) { nm = wave; nt += gridDim.x; } };
 #pragma unroll
@@ -1021,6 +1039,21 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
     }
     const int trem = tile - n * tpi;
     const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
+    // LOSS: this thread's 12 target pixels of the tile are requested here and travel under the MFMA phase (branch-free: a pixel
+    // outside the image reads a clamped address and is never used)
+    float tg[LOSS ? 12 : 1];
+    if (LOSS) {
+      const int oxl_ = tid & 31, rg_ = tid >> 5;
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int oy = 2 * a0 + rg_ + 8 * i, ox = 2 * b0 + oxl_;
+          const bool ok = oy < H && ox < W;
+          tg[LOSS ? co * 4 + i : 0] = target[ok ? ((size_t)(n * C + cg * 3 + co) * H + oy) * W + ox : (size_t)0];
+        }
+      __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the requests next to their use, behind the MFMA phase)
+    }
     __syncthreads();  // previous tile's gather is done with Tt
     for (int mtile = wave; mtile < 19; mtile += 4) {
       f32x4 a[4];
@@ -1056,6 +1089,11 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
     const int oxl = tid & 31, rg = tid >> 5;
     const int bl = oxl >> 1, px = oxl & 1;
     const int ox = 2 * b0 + oxl;
+    float lsum = 0.f;
+    if (LOSS) {  // every target load is waited for HERE, once, outside the branches that hold the stores
+#pragma unroll
+      for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(tg[LOSS ? j : 0]));
+    }
 #pragma unroll
     for (int co = 0; co < 3; ++co) {
 #pragma unroll
@@ -1069,8 +1107,31 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx)
             v += Tt[((al + 1 - dy) * 17 + (bl + 1 - dx)) * TP + co * 16 + (py + 2 * dy) * 4 + (px + 2 * dx)];
-        if (oy < H && ox < W) img[((size_t)(n * C + cg * 3 + co) * H + oy) * W + ox] = v;
+        if (oy < H && ox < W) {
+          const size_t o = ((size_t)(n * C + cg * 3 + co) * H + oy) * W + ox;
+          if (LOSS) {
+            const float d = v - tg[LOSS ? co * 4 + i : 0];
+            img[o] = d;
+            if (dec_out) dec_out[o] = v;
+            lsum += d * d;
+          } else {
+            img[o] = v;
+          }
+        }
       }
+    }
+    if (LOSS) { if (n / lpg == 0) lacc0 += (double)lsum; else lacc1 += (double)lsum; }
+  }
+  if (LOSS) {
+    // [2 loss groups][workgroups of the launch] — every workgroup writes both slots (zeros included), fixed-order final sum
+    __syncthreads();
+    double* lred = (double*)smem;  // [2][4 waves]
+    const double w0 = wave_sum_d(lacc0), w1 = wave_sum_d(lacc1);
+    if (lane == 0) { lred[wave] = w0; lred[4 + wave] = w1; }
+    __syncthreads();
+    if (tid < 2) {
+      const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+      loss_partial[(size_t)tid * nwg + wg] = (lred[tid * 4] + lred[tid * 4 + 1]) + (lred[tid * 4 + 2] + lred[tid * 4 + 3]);
     }
   }
 }
@@ -1265,8 +1326,33 @@ extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const
   const int ty = (d->himg / 2 + 15) / 16, tx = (d->wimg / 2 + 15) / 16;
   const int ntiles = d->n * ty * tx;
   const size_t lds = (size_t)304 * TP * 4;
-  hipLaunchKernelGGL(convT_out_kernel, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
-                     w_ref, bias, y_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp, images_per_group(d));
+  hipLaunchKernelGGL(convT_out_kernel<false>, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
+                     w_ref, bias, y_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp, images_per_group(d),
+                     (const float*)nullptr, (float*)nullptr, (double*)nullptr, d->n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_convT_out_fwd_loss_workgroups(const srlz_skinny_desc* d) {
+  if (check_skinny(d)) return -1;
+  const int ty = (d->himg / 2 + 15) / 16, tx = (d->wimg / 2 + 15) / 16;
+  return persistent_grid(d->n * ty * tx) * (d->c / 3);
+}
+
+extern "C" int srlz_convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const float* target_nchw,
+                                       float* err_nchw, float* dec_nchw, const float* x_bnp, double* loss_partial,
+                                       const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: descriptor kind must be 1");
+  SRLZ_REQUIRE(x_nhwc && w_ref && target_nchw && err_nchw && loss_partial, SRLZ_ERR_NULL, "convT_out_fwd_loss: null pointer");
+  SRLZ_REQUIRE(d->n % 2 == 0, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: the batch is the two frames of a step (n = %d is odd)", d->n);
+  SRLZ_REQUIRE((((uintptr_t)loss_partial) & 7) == 0, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: unaligned partial buffer");
+  const int ty = (d->himg / 2 + 15) / 16, tx = (d->wimg / 2 + 15) / 16;
+  const int ntiles = d->n * ty * tx;
+  const size_t lds = (size_t)304 * TP * 4;
+  hipLaunchKernelGGL(convT_out_kernel<true>, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
+                     w_ref, bias, err_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp, images_per_group(d),
+                     target_nchw, dec_nchw, loss_partial, d->n / 2);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -1298,13 +1384,15 @@ extern "C" size_t srlz_convT_out_bwd_fused_workspace(const srlz_skinny_desc* d) 
 
 extern "C" int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,
                                         const float* x_bnp, float* bn_bwd_partial, float* dw_ref, float* dbias, void* ws,
-                                        size_t ws_bytes, const srlz_skinny_desc* d, srlz_stream_t stream) {
+                                        size_t ws_bytes, const float* dy_gain_dev, float dy_gain_div, float dy_gain_coef,
+                                        const srlz_skinny_desc* d, srlz_stream_t stream) {
   if (int rc = check_skinny(d)) return rc;
   SRLZ_REQUIRE(d->kind == 1 && d->c == 3, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: kind 1, 3 image channels");
   SRLZ_REQUIRE(dy_nchw && w_ref && dx_nhwc && x_raw && x_bnp && bn_bwd_partial && dw_ref && ws, SRLZ_ERR_NULL,
                "convT_out_bwd_fused: null pointer");
   SRLZ_REQUIRE(ws_bytes >= srlz_convT_out_bwd_fused_workspace(d), SRLZ_ERR_WORKSPACE,
                "convT_out_bwd_fused: workspace too small (%zu)", ws_bytes);
+  SRLZ_REQUIRE(dy_gain_dev == nullptr || dy_gain_div != 0.f, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: dy_gain_div is zero");
   hipStream_t st = as_stream(stream);
   const int ty = (d->hf + FTR - 1) / FTR, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
@@ -1315,7 +1403,8 @@ extern "C" int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref
   SRLZ_REQUIRE((((uintptr_t)bias_part) & 7) == 0, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: unaligned workspace");
   SRLZ_MAX_LDS(convT_out_bwd_kernel, lds);
   hipLaunchKernelGGL(convT_out_bwd_kernel, dim3(g), dim3(256), lds, st, dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, partial, d->n,
-                     d->himg, d->wimg, d->hf, d->wf, ty, tx, x_raw, x_bnp, images_per_group(d), bias_part);
+                     d->himg, d->wimg, d->hf, d->wf, ty, tx, x_raw, x_bnp, images_per_group(d), bias_part, dy_gain_dev,
+                     dy_gain_div, dy_gain_coef);
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3(64 * 48 / WRED_OUTS), dim3(1024), 0, st, partial, 2 * g, d->c, 16, 48, 64, dw_ref);
   SRLZ_LAUNCHED();

@@ -311,14 +311,26 @@ class SRL4robotics(BaseLearner):
         if self.rank == 0:
             th.save(OrderedDict((k, v.cpu()) for k, v in sd.items()), path)
 
-    def _forwardPair(self, x, next_x):
-        """(self.model(x), self.model(next_x)) — in that program order for the BatchNorm running statistics, but
-        enqueued on two streams."""
-        # (one launch takes at most 65535 / 57 = 1149 images — the pooling kernels' grid.y, DESIGN.md §2 — so a batched pair
-        # needs 2 B <= 1149; larger minibatches fall back to the two calls)
+    def _forwardPair(self, x, next_x, recon=None):
+        """(self.model(x), self.model(next_x)) — in that program order for the BatchNorm running statistics — as ONE batched
+        model call with two BatchNorm groups when possible.
+
+        recon = (target, next_target, mean): the caller only needs the reconstruction / generation LOSS of the two decoded
+        frames against these targets, not the frames: the loss is then taken inside the last ConvTranspose (ops.DecOutLossFn)
+        and returned as third value (None when that was not possible: the caller computes the loss from the decoded frames).
+        Minibatches above 574 samples (one launch takes at most 65535 / 57 = 1149 images — the pooling kernels' grid.y, DESIGN.md
+        section 2) fall back to two separate model calls."""
+        from srlz import hotpath, ops
         if self._use_pair and self._frame_streams is None and x.shape == next_x.shape and 2 * x.shape[0] <= 1149 \
                 and not self.use_triplets:
-            return self.model.forwardPair(x, next_x)
+            target = ops.pair_of(recon[0], recon[1]) if recon is not None else None
+            if target is not None:
+                with hotpath.recon_loss_into(target, recon[2]) as req:
+                    out = self.model.forwardPair(x, next_x)
+                return out[0], out[1], req.loss
+            return self.model.forwardPair(x, next_x) + ((None,) if recon is not None else ())
+        if recon is not None:
+            return self._forwardPair(x, next_x) + (None,)
         if self._frame_streams is None:
             return self.model(x), self.model(next_x)
         main = th.cuda.current_stream(self.device)
@@ -419,6 +431,7 @@ class SRL4robotics(BaseLearner):
         loss_manager.resetLosses()
 
         decoded_obs = decoded_next_obs = None
+        recon_loss = None  # the reconstruction / generation loss when it was taken inside the last ConvTranspose
         if self.use_triplets:
             # anchor / positive / negative views stacked along channels (reference learner.py:383-391); the frozen trunk runs
             # once per view (six passes per step, each with its own BatchNorm batch statistics, as in the reference)
@@ -427,9 +440,14 @@ class SRL4robotics(BaseLearner):
             next_states, _next_positive, _next_negative = self.model.forwardTriplets(
                 next_obs[:, :3].contiguous(), next_obs[:, 3:6].contiguous(), next_obs[:, 6:].contiguous())
         elif self.use_autoencoder:
-            (states, decoded_obs), (next_states, decoded_next_obs) = self._forwardPair(obs, next_obs)
+            (states, decoded_obs), (next_states, decoded_next_obs), recon_loss = self._forwardPair(obs, next_obs, (obs, next_obs, True))
         elif self.use_dae:
-            (states, decoded_obs), (next_states, decoded_next_obs) = self._forwardPair(noisy_obs, next_noisy_obs)
+            (states, decoded_obs), (next_states, decoded_next_obs), recon_loss = self._forwardPair(noisy_obs, next_noisy_obs,
+                                                                                                  (obs, next_obs, True))
+        elif self.use_vae and not self.perceptual_similarity_loss:
+            (decoded_obs, mu, logvar), (decoded_next_obs, next_mu, next_logvar), recon_loss = self._forwardPair(
+                obs, next_obs, (obs, next_obs, False))
+            states, next_states = self.model.getStates(obs), self.model.getStates(next_obs)
         elif self.use_vae:
             (decoded_obs, mu, logvar), (decoded_next_obs, next_mu, next_logvar) = self._forwardPair(obs, next_obs)
             states, next_states = self.model.getStates(obs), self.model.getStates(next_obs)
@@ -458,7 +476,10 @@ class SRL4robotics(BaseLearner):
         if self.use_reward_loss:
             rewards_pred = self.model.rewardModel(states, next_states)
             rewardModelLoss(rewards_pred, rewards_st, weight=w['reward'], loss_manager=loss_manager)
-        if self.use_autoencoder or self.use_dae:
+        if (self.use_autoencoder or self.use_dae) and recon_loss is not None:
+            # (decoded_* hold the error dec - obs here, not the reconstruction: the loss came out of the decoder's last kernel)
+            loss_manager.addToLosses('reconstruction_loss', w["dae" if self.use_dae else "autoencoder"], recon_loss)
+        elif self.use_autoencoder or self.use_dae:
             autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs,
                             weight=w["dae" if self.use_dae else "autoencoder"], loss_manager=loss_manager)
         if self.use_vae:
@@ -467,6 +488,8 @@ class SRL4robotics(BaseLearner):
                 perceptualSimilarityLoss(states_denoiser, states_denoiser_predicted, next_states_denoiser,
                                          next_states_denoiser_predicted, weight=w['perceptual'],
                                          loss_manager=loss_manager)
+            elif recon_loss is not None:
+                loss_manager.addToLosses('generation_loss', w['vae'], recon_loss)
             else:
                 generationLoss(decoded_obs, decoded_next_obs, obs, next_obs, weight=w['vae'], loss_manager=loss_manager)
 

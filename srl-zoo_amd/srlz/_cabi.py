@@ -89,7 +89,11 @@ _PROTOS = {
     "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _SK, P]),
     "srlz_convT_out_bwd_fused_tiles": (c_int, [_SK]),
     "srlz_convT_out_bwd_fused_workspace": (c_size_t, [_SK]),
-    "srlz_convT_out_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, _SK, P]),
+    "srlz_convT_out_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, P, c_float, c_float, _SK, P]),
+    "srlz_convT_out_fwd_loss_workgroups": (c_int, [_SK]),
+    "srlz_convT_out_fwd_loss": (c_int, [P, P, P, P, P, P, P, P, _SK, P]),
+    "srlz_pair_loss_finalize": (c_int, [P, c_int, c_longlong, c_int, P, P, P]),
+    "srlz_scale_by_scalar": (c_int, [P, P, c_float, c_float, P, c_longlong, P]),
     "srlz_bn_finalize": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),
     "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),
@@ -138,7 +142,7 @@ _PROTOS = {
 
 # entry points whose int return value is data, not a status
 _NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
-               "srlz_convT_out_bwd_fused_tiles",
+               "srlz_convT_out_bwd_fused_tiles", "srlz_convT_out_fwd_loss_workgroups",
                "srlz_conv64_debug_program", "srlz_comm_world"}
 
 EXPORTED = sorted(_PROTOS.keys())

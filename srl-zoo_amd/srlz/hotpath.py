@@ -30,6 +30,29 @@ _FUSE_ENC_IN = os.environ.get("SRLZ_FUSE_ENC_IN", "1") != "0"
 _DEFER_BN_BWD = os.environ.get("SRLZ_DEFER_BN_BWD", "1") != "0"
 
 
+# ---- the step's reconstruction / generation loss taken inside the last ConvTranspose (ops.DecOutLossFn) -------------------------
+# SRL4robotics._eagerStep opens `with recon_loss_into(target, mean) as req:` around the batched model call; decoder_forward then
+# ends in ONE node that yields the loss scalar (req.loss) and, in place of the reconstruction, the error tensor dec - target
+# (flagged `_srlz_recon_error`; the reconstruction itself is not written).  A/B switch: SRLZ_FUSED_RECON=0.
+_FUSE_RECON = os.environ.get("SRLZ_FUSED_RECON", "1") != "0"
+_RECON = None
+
+
+class recon_loss_into(object):
+    def __init__(self, target, mean):
+        self.target, self.mean, self.loss = target, bool(mean), None
+
+    def __enter__(self):
+        global _RECON
+        self.prev, _RECON = _RECON, (self if _FUSE_RECON else None)
+        return self
+
+    def __exit__(self, *exc):
+        global _RECON
+        _RECON = self.prev
+        return False
+
+
 def _bn_args(bn):
     # nn.BatchNorm2d increments num_batches_tracked once per training-mode call: the counter travels with the running mean
     # (ops._bn_params hands it to srlz_bn_finalize, which advances it by the number of calls the launch stands for)
@@ -100,6 +123,12 @@ def decoder_forward(seq, z, training):
     _tick(bn, training)
     if TAPS is not None:
         _record_activation(11, y, st, bn, training)
+    req = _RECON
+    if req is not None and req.loss is None and TAPS is None and torch.is_grad_enabled() and y.shape[0] % 2 == 0 \
+            and req.target.shape[0] == y.shape[0] and req.target.shape[1] == last.weight.shape[1] and not req.target.requires_grad:
+        req.loss, err = ops.DecOutLossFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias, in_link, req.target, req.mean)
+        err._srlz_recon_error = True  # NOT the reconstruction: dec - target (the caller asked for the loss, not for the image)
+        return err
     return _tap("decoder_conv", 12, ops.DecOutFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias, in_link))
 
 

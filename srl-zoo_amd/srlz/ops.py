@@ -601,36 +601,87 @@ class DecOutFn(Function):
     @staticmethod
     def backward(ctx, dy):
         y_prev, bnp, w = ctx.saved_tensors
-        d = ctx.desc
         dy = _check(dy, "decoder output dy")
-        dw = _gbuf(w)
-        db = _gbuf(ctx.params[2], d.c, dy.device)
-        if ctx.in_link is not None and d.c == 3 and _FUSED_OUT_BWD:
-            # data gradient, its BatchNorm-backward partials and the weight / bias gradients in one pass over (dy, y_prev)
-            da = torch.empty_like(y_prev)
-            partial = torch.empty((C.convT_out_bwd_fused_tiles(d), 128), dtype=torch.float32, device=dy.device)
-            nbytes = C.convT_out_bwd_fused_workspace(d)
-            ws = _ws(nbytes, dy.device, slot=1)
-            C.convT_out_bwd_fused(ptr(dy), ptr(w), ptr(da), ptr(y_prev), ptr(bnp), ptr(partial), ptr(dw), ptr(db), ptr(ws), nbytes, d,
-                                  stream())
-            dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial, gb=ctx.params[:2])
-            gp, bp, cp = ctx.params
-            return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(w, dw), _give(cp, db), None
-        nbytes = C.skinny_bwd_weight_workspace(d)
-        ws = _ws(nbytes, dy.device, slot=1)
-        with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
-            C.convT_out_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream())
+        return _dec_out_backward(ctx, y_prev, bnp, w, dy, None) + (None,)
+
+
+def _dec_out_backward(ctx, y_prev, bnp, w, dy, gain):
+    """Backward of the last ConvTranspose (DecOutFn / DecOutLossFn): gradients for (y_prev, stats, gamma, beta, rm, rv, training,
+    w, bias).  gain = (upstream scalar tensor, div, coef): `dy` holds the reconstruction error and the loss gradient is
+    ((upstream / div) * coef) * dy — applied inside the fused kernel, or materialised in place for the two-launch path."""
+    d = ctx.desc
+    dw = _gbuf(w)
+    db = _gbuf(ctx.params[2], d.c, dy.device)
+    if ctx.in_link is not None and d.c == 3 and _FUSED_OUT_BWD:
+        # data gradient, its BatchNorm-backward partials and the weight / bias gradients in one pass over (dy, y_prev)
         da = torch.empty_like(y_prev)
-        # with the BatchNorm backward deferred (in_link), its two sums come out of this kernel's epilogue
-        partial = None
-        if ctx.in_link is not None:
-            partial = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=dy.device)
-        C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), ptr(y_prev) if partial is not None else None,
-                             ptr(bnp) if partial is not None else None, ptr(partial), d, stream())
+        partial = torch.empty((C.convT_out_bwd_fused_tiles(d), 128), dtype=torch.float32, device=dy.device)
+        nbytes = C.convT_out_bwd_fused_workspace(d)
+        ws = _ws(nbytes, dy.device, slot=1)
+        g_dev, g_div, g_coef = (ptr(gain[0]), gain[1], gain[2]) if gain is not None else (None, 1.0, 1.0)
+        C.convT_out_bwd_fused(ptr(dy), ptr(w), ptr(da), ptr(y_prev), ptr(bnp), ptr(partial), ptr(dw), ptr(db), ptr(ws), nbytes,
+                              g_dev, g_div, g_coef, d, stream())
         dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial, gb=ctx.params[:2])
-        side.join()
         gp, bp, cp = ctx.params
-        return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(w, dw), _give(cp, db), None
+        return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(w, dw), _give(cp, db)
+    if gain is not None:  # the two-launch kernels take the gradient itself: error -> gradient, in place (the error has no other use)
+        C.scale_by_scalar(ptr(dy), ptr(gain[0]), gain[1], gain[2], ptr(dy), dy.numel(), stream())
+    nbytes = C.skinny_bwd_weight_workspace(d)
+    ws = _ws(nbytes, dy.device, slot=1)
+    with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
+        C.convT_out_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream())
+    da = torch.empty_like(y_prev)
+    # with the BatchNorm backward deferred (in_link), its two sums come out of this kernel's epilogue
+    partial = None
+    if ctx.in_link is not None:
+        partial = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=dy.device)
+    C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), ptr(y_prev) if partial is not None else None,
+                         ptr(bnp) if partial is not None else None, ptr(partial), d, stream())
+    dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial, gb=ctx.params[:2])
+    side.join()
+    gp, bp, cp = ctx.params
+    return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(w, dw), _give(cp, db)
+
+
+class DecOutLossFn(Function):
+    """The last ConvTranspose AND the step's reconstruction / generation loss as one node (K11 / K12 of SURVEY.md 8a'; reference
+    models/models.py:79-82 followed by losses/losses.py:172-214): (y_prev raw, stats, BN params, weights, target [obs ; next_obs])
+    -> (loss scalar, err = dec - target [not differentiable; the backward's operand]).  mean: reconstructionLoss x 2
+    (sum / numel per frame, added), else F.mse_loss(reduction='sum') x 2.  The batch is the pair of frames of a step.
+    Backward: d(loss)/d(dec) = ((upstream / div) * 2) * err, formed inside the ConvTranspose's backward kernel."""
+
+    @staticmethod
+    def forward(ctx, y_prev, stats_prev, gamma, beta, running_mean, running_var, training, w, bias, in_link, target, mean):
+        y_prev, w = _check(y_prev, "decoder output input"), _check(w, "convT_out weight")
+        target = _check(target, "reconstruction target")
+        n, hf, wf, _ = y_prev.shape
+        bnp, _ = _bn_params(stats_prev, n * hf * wf, gamma, beta, running_mean, running_var, training, y_prev.device)
+        c = w.shape[1]
+        d = SkinnyDesc(n, c, (hf - 1) * 2 + 4, (wf - 1) * 2 + 4, hf, wf, 1, cur_groups(training))
+        if tuple(target.shape) != (n, c, d.himg, d.wimg) or n % 2:
+            raise C.SrlzError("fused reconstruction loss: target %s does not match the decoder output %s"
+                              % (tuple(target.shape), (n, c, d.himg, d.wimg)))
+        err = torch.empty((n, c, d.himg, d.wimg), dtype=torch.float32, device=y_prev.device)
+        nwg = C.convT_out_fwd_loss_workgroups(d)
+        part = _ws(2 * nwg * 8, y_prev.device, slot=2)
+        C.convT_out_fwd_loss(ptr(y_prev), ptr(w), ptr(bias), ptr(target), ptr(err), None, ptr(bnp), ptr(part), d, stream())
+        sums = torch.empty(2, dtype=torch.float32, device=y_prev.device)
+        comb = torch.empty((), dtype=torch.float32, device=y_prev.device)
+        per_frame = err.numel() // 2
+        C.pair_loss_finalize(ptr(part), nwg, per_frame, 1 if mean else 0, ptr(sums), ptr(comb), stream())
+        ctx.save_for_backward(y_prev, bnp, w, err)
+        ctx.desc, ctx.training, ctx.in_link = d, training, in_link
+        ctx.params = (gamma, beta, bias)
+        ctx.div = float(per_frame) if mean else 1.0
+        ctx.mark_non_differentiable(err)
+        ctx.set_materialize_grads(False)
+        return comb, err
+
+    @staticmethod
+    def backward(ctx, g, _derr):
+        y_prev, bnp, w, err = ctx.saved_tensors
+        g = _check(g, "loss grad")
+        return _dec_out_backward(ctx, y_prev, bnp, w, err, (g, ctx.div, 2.0)) + (None, None, None)
 
 
 def bn_relu_materialise(y, bnp_source):

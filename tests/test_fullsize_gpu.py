@@ -136,7 +136,10 @@ def test_full_size_loop_body(losses):
             taken["grad"] = srl.flat_params.grad.clone()
             return orig_step(grad_scale)
         srl.optimizer.step = step_spy
-        total = srl.trainStep(obs.cuda(), nxt.cuda(), act.view(-1, 1).cuda(), lm)
+        # as the learner's feed delivers them: the two frames are the halves of one device buffer -> the product's default route
+        # (batched pair; reconstruction / generation loss taken inside the last ConvTranspose)
+        o, no = srl._toDevicePair(obs, nxt)
+        total = srl.trainStep(o, no, act.view(-1, 1).cuda(), lm)
         vals = dict(zip(lm.names, lm.lossValues()))
         torch.cuda.synchronize()
         return srl, init, vals, float(total.detach()), taken["grad"]

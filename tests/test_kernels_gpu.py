@@ -670,7 +670,7 @@ def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
     ws1 = torch.empty(n1, dtype=torch.uint8, device=DEV)
     dw1, db1 = torch.full((64, 3, 4, 4), float("nan"), device=DEV), torch.full((3,), float("nan"), device=DEV)
     C.convT_out_bwd_fused(C.ptr(dimg), C.ptr(w), C.ptr(da1), C.ptr(x_raw), C.ptr(bnp), C.ptr(p1), C.ptr(dw1), C.ptr(db1), C.ptr(ws1),
-                          n1, d, st)
+                          n1, None, 1.0, 1.0, d, st)
     out = [[torch.empty(k, device=DEV) for k in (128 * groups, 64, 64)] for _ in range(2)]
     for p, o in ((p0, out[0]), (p1, out[1])):
         C.bn_bwd_finalize_partials(C.ptr(p), p.shape[0], groups, C.ptr(o[0]), C.ptr(o[1]), C.ptr(o[2]), C.ptr(wsb), nb, st)
@@ -683,6 +683,106 @@ def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
     tol = 3e-6 * (n * himg * himg) ** 0.5  # unit-variance data: a few fp32 ulps of the typical |sum|
     assert float((db0.double() - ref).abs().max()) <= tol
     assert float((db1.double() - ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("n,c,hf,mean,groups", [(2, 3, 111, 1, 2), (4, 3, 37, 0, 2), (2, 6, 21, 1, 1), (6, 3, 111, 1, 2)])
+def test_convT_out_forward_with_the_loss_in_its_epilogue(C, n, c, hf, mean, groups):
+    """srlz_convT_out_fwd_loss (K11 / K12: the reconstruction / generation loss of the step's two frames taken where the last
+    ConvTranspose holds its output) against the un-fused chain srlz_convT_out_fwd -> srlz_sqdiff_pair_loss ->
+    srlz_sqdiff_grad_groups, and the torch oracle: the stored error is dec - target bit for bit, the optional reconstruction is
+    srlz_convT_out_fwd's bit for bit, the loss agrees to fp32 rounding (fp64 partial sums in a different fixed order), and the
+    gradient formed from the error is the un-fused gradient bit for bit (srlz_scale_by_scalar; the fused backward kernel is
+    checked in test_convT_out_bwd_fused_with_the_loss_gain)."""
+    g = torch.Generator().manual_seed(5 * hf + c)
+    himg = (hf - 1) * 2 + 4
+    x = (torch.randn(n, hf, hf, 64, generator=g) * 1.1 + 0.1).to(DEV)
+    w = (torch.randn(64, c, 4, 4, generator=g) * 0.1).to(DEV)
+    b = torch.randn(c, generator=g).to(DEV)
+    tgt = (torch.randn(n, c, himg, himg, generator=g) * 1.3 + 0.2).to(DEV)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    recs = []
+    for gi in range(groups):
+        xg = x[gi * (n // groups):(gi + 1) * (n // groups)].double().cpu()
+        m, v = xg.mean((0, 1, 2)), xg.var((0, 1, 2), unbiased=False)
+        inv = 1.0 / torch.sqrt(v + 1e-5)
+        recs.append(torch.cat((m, inv, gamma.double() * inv, beta.double() - m * gamma.double() * inv)).float())
+    bnp = torch.cat(recs).to(DEV)
+    d = C.SkinnyDesc(n, c, himg, himg, hf, hf, 1, groups)
+    st = C.stream()
+    # ---- un-fused chain
+    dec0 = torch.empty(n, c, himg, himg, device=DEV)
+    C.convT_out_fwd(C.ptr(x), C.ptr(w), C.ptr(b), C.ptr(dec0), C.ptr(bnp), d, st)
+    nb = C.reduce_workspace(dec0.numel())
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    sums0, comb0 = torch.empty(2, device=DEV), torch.empty((), device=DEV)
+    per = dec0.numel() // 2
+    C.sqdiff_pair_loss(C.ptr(dec0), C.ptr(tgt), per, mean, C.ptr(sums0), C.ptr(comb0), C.ptr(ws), nb, st)
+    up = torch.tensor(0.37, device=DEV)
+    div = float(per) if mean else 1.0
+    grad0 = torch.empty_like(dec0)
+    C.sqdiff_grad_groups(C.ptr(dec0), C.ptr(tgt), C.ptr(up), 0, div, 2.0, C.ptr(grad0), per, 2, st)
+    # ---- fused
+    err = torch.full((n, c, himg, himg), float("nan"), device=DEV)
+    dec1 = torch.full((n, c, himg, himg), float("nan"), device=DEV)
+    nwg = C.convT_out_fwd_loss_workgroups(d)
+    assert nwg > 0
+    part = torch.full((2 * nwg,), float("nan"), dtype=torch.float64, device=DEV)
+    C.convT_out_fwd_loss(C.ptr(x), C.ptr(w), C.ptr(b), C.ptr(tgt), C.ptr(err), C.ptr(dec1), C.ptr(bnp), C.ptr(part), d, st)
+    sums1, comb1 = torch.empty(2, device=DEV), torch.empty((), device=DEV)
+    C.pair_loss_finalize(C.ptr(part), nwg, per, mean, C.ptr(sums1), C.ptr(comb1), st)
+    grad1 = torch.empty_like(err)
+    C.scale_by_scalar(C.ptr(err), C.ptr(up), div, 2.0, C.ptr(grad1), err.numel(), st)
+    # the reconstruction may be skipped (the training path): same error, same partials
+    err2 = torch.full_like(err, float("nan"))
+    part2 = torch.full_like(part, float("nan"))
+    C.convT_out_fwd_loss(C.ptr(x), C.ptr(w), C.ptr(b), C.ptr(tgt), C.ptr(err2), None, C.ptr(bnp), C.ptr(part2), d, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dec1, dec0)
+    assert torch.equal(err, dec0 - tgt) and torch.equal(err2, err) and torch.equal(part2, part)
+    assert torch.equal(grad1, grad0)
+    assert rel_err(sums1, sums0) < 2e-7 and abs(float(comb1) - float(comb0)) <= 2e-7 * abs(float(comb0))
+    # oracle: F.conv_transpose2d on relu(bn(x)) in fp64, per-frame sums of squares
+    xs = nchw(x).double().cpu()
+    half = n // groups
+    act = torch.cat([torch.relu(xs[gi * half:(gi + 1) * half] * recs[gi][128:192].double().view(1, 64, 1, 1) +
+                                recs[gi][192:].double().view(1, 64, 1, 1)) for gi in range(groups)])
+    ref = F.conv_transpose2d(act, w.double().cpu(), b.double().cpu(), stride=2)
+    sq = ((ref - tgt.double().cpu()) ** 2).reshape(2, -1).sum(1)
+    assert rel_err(sums1, sq) < 1e-5
+    expect = (sq[0] / per + sq[1] / per) if mean else (sq[0] + sq[1])
+    assert abs(float(comb1) - float(expect)) <= 1e-5 * abs(float(expect))
+
+
+def test_convT_out_bwd_fused_with_the_loss_gain(C):
+    """srlz_convT_out_bwd_fused fed with the stored error + (upstream, div, coef) == the same kernel fed with the materialised
+    gradient ((upstream / div) * coef) * error: every output bit for bit."""
+    n, hf = 4, 37
+    g = torch.Generator().manual_seed(99)
+    himg = (hf - 1) * 2 + 4
+    x_raw = (torch.randn(n, hf, hf, 64, generator=g) * 1.3 + 0.2).to(DEV)
+    w = (torch.randn(64, 3, 4, 4, generator=g) * 0.1).to(DEV)
+    err = torch.randn(n, 3, himg, himg, generator=g).to(DEV)
+    bnp = torch.cat([torch.cat((torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5,
+                                torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2)) for _ in range(2)]).to(DEV)
+    up = torch.tensor(1.7, device=DEV)
+    div, coef = float(err.numel() // 2), 2.0
+    d = C.SkinnyDesc(n, 3, himg, himg, hf, hf, 1, 2)
+    st = C.stream()
+    grad = torch.empty_like(err)
+    C.scale_by_scalar(C.ptr(err), C.ptr(up), div, coef, C.ptr(grad), err.numel(), st)
+    outs = []
+    for src, gain in ((grad, (None, 1.0, 1.0)), (err, (C.ptr(up), div, coef))):
+        da = torch.full((n, hf, hf, 64), float("nan"), device=DEV)
+        p = torch.full((C.convT_out_bwd_fused_tiles(d), 128), float("nan"), device=DEV)
+        nws = C.convT_out_bwd_fused_workspace(d)
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        dw, db = torch.full((64, 3, 4, 4), float("nan"), device=DEV), torch.full((3,), float("nan"), device=DEV)
+        C.convT_out_bwd_fused(C.ptr(src), C.ptr(w), C.ptr(da), C.ptr(x_raw), C.ptr(bnp), C.ptr(p), C.ptr(dw), C.ptr(db), C.ptr(ws),
+                              nws, gain[0], gain[1], gain[2], d, st)
+        outs.append((da, p, dw, db))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 @pytest.mark.parametrize("n,c,h", [(2, 3, 224), (1, 6, 64), (2, 3, 50)])

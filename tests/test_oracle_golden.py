@@ -51,8 +51,8 @@ CASES = [("step_ae_b2", ["autoencoder"], 2, 3, "linear"),
 
 
 def run_twin(losses, B, C, inverse, n_steps=1, lr=None, S=200, split=None, weights=None, l1_reg=0.0, l2_reg=0.0,
-             dae_seed=None, val_steps=()):
-    torch.set_num_threads(1)
+             dae_seed=None, val_steps=(), threads=1):
+    torch.set_num_threads(threads)
     model = build(losses, C=C, S=S, inverse=inverse, split=split)
     sd = T.clone_state(model.state_dict())
     dae_sd = None
@@ -173,7 +173,9 @@ TRACES = [("trace_ae_b2", ["autoencoder"], {}), ("trace_vae_b2", ["vae"], {}),
           ("trace10_ae_b2", ["autoencoder"], {}), ("trace10_vae_b2", ["vae"], {}),
           ("trace_val_aeif_b2", ["autoencoder", "inverse", "forward"], dict(val_steps=(1,))),
           ("trace_val_vae_b2", ["vae"], dict(val_steps=(2,))),
-          ("trace_ae_l1l2_b2", ["autoencoder"], dict(l1_reg=1e-5, l2_reg=1e-4))]
+          ("trace_ae_l1l2_b2", ["autoencoder"], dict(l1_reg=1e-5, l2_reg=1e-4)),
+          # the reference's default minibatch (bs = 32, BASELINE.json configs[0]); 8 threads: a step is 64 images on the CPU
+          ("trace10_ae_b32", ["autoencoder"], dict(B=32, threads=8))]
 
 
 @pytest.mark.parametrize("name,losses,extra", TRACES)
@@ -182,7 +184,8 @@ def test_twin_adam_trace_matches_reference(name, losses, extra):
     fixtures: per-step losses follow the reference."""
     g = gu.load(name)
     n_steps = int(g["trace/values"].shape[0])
-    sd, outs = run_twin(losses, 2, 3, "linear", n_steps=n_steps, lr=1e-4, **extra)
+    extra = dict(extra)
+    sd, outs = run_twin(losses, extra.pop("B", 2), 3, "linear", n_steps=n_steps, lr=1e-4, **extra)
     names = [str(n) for n in g["trace/names"]]
     for step, out in enumerate(outs):
         for j, nm in enumerate(names):

@@ -202,3 +202,88 @@ def test_train_step_pair_follows_two_call_path(losses):
             assert int(x) == int(y)
         else:
             assert float((x.double() - y.double()).abs().max()) <= 1e-3 * max(float(y.double().abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("losses,C,split", [(["autoencoder", "inverse", "forward"], 3, None), (["vae"], 3, None), (["vae"], 6, None),
+                                            (["dae"], 3, None),
+                                            (["autoencoder", "inverse"], 3, OrderedDict([("autoencoder", 16), ("inverse", 8)]))],
+                         ids=["aeif", "vae", "vae_c6", "dae", "split_ae"])
+def test_recon_loss_in_the_decoder_epilogue_follows_the_unfused_step(losses, C, split):
+    """SRL4robotics.trainStep with the reconstruction / generation loss taken inside the last ConvTranspose (default) against
+    SRLZ_FUSED_RECON=0 (decoded frames written, loss and its gradient as separate passes): the same loss values (fp64 partial
+    sums in another fixed order: equal to fp32 rounding), and — the gradient handed to the decoder being bit-identical — the
+    same parameters after a few steps including a validation one."""
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from losses.losses import LossManager
+    from srlz import hotpath
+    pre.N_CHANNELS = C
+    learner.BATCH_SIZE = 3
+
+    def trace(fused):
+        hotpath._FUSE_RECON = fused
+        try:
+            srl = learner.SRL4robotics(24, model_type="custom_cnn", seed=5, learning_rate=1e-4, cuda=True, losses=losses, n_actions=6,
+                                       log_folder="/tmp", multi_view=C > 3, split_dimensions=split if split is not None else -1,
+                                       losses_weights_dict=None if split is None else {k: 1.0 for k in split})
+            lm = LossManager(srl.model, None)
+            rows = []
+            for step in range(4):
+                o, n, a = gu.golden_inputs(3, C, 6, seed=900 + step)
+                both = torch.from_numpy(np.concatenate((o, n), 0)).cuda()  # the learner's feed: two halves of one buffer
+                obs, nxt = both[:3], both[3:]
+                noisy = None
+                if "dae" in losses:
+                    nb = torch.from_numpy(np.concatenate((gu.golden_noisy(o, 1 + step), gu.golden_noisy(n, 2 + step)), 0)).cuda()
+                    noisy = (nb[:3], nb[3:])
+                if "vae" in losses:
+                    torch.manual_seed(40 + step)
+                    it = iter([torch.randn(3, 24), torch.randn(3, 24)])
+                    srl.model.model.eps_fn = lambda mu: next(it).to(mu.device)
+                loss = srl.trainStep(obs, nxt, torch.from_numpy(a).view(-1, 1).cuda(), lm, validation_mode=(step == 2),
+                                     noisy_obs=None if noisy is None else noisy[0], next_noisy_obs=None if noisy is None else noisy[1])
+                rows.append(lm.lossValues() + [float(loss.detach())])
+                names = list(lm.names)
+            torch.cuda.synchronize()
+            return np.array(rows), names, srl.flat_params.flat.detach().clone(), [b.detach().clone() for b in srl.model.buffers()]
+        finally:
+            hotpath._FUSE_RECON = True
+
+    plain, names0, p0, b0 = trace(False)
+    fused, names1, p1, b1 = trace(True)
+    assert names0 == names1
+    np.testing.assert_allclose(fused[0], plain[0], rtol=3e-7)  # identical parameters: only the order of the fp64 partial sums differs
+    np.testing.assert_allclose(fused, plain, rtol=2e-5)
+    assert float((p1 - p0).abs().max()) <= 2e-5 * float(p0.abs().max())
+    for x, y in zip(b1, b0):
+        if x.dtype == torch.long:
+            assert int(x) == int(y)
+        else:
+            assert float((x.double() - y.double()).abs().max()) <= 1e-4 * max(float(y.double().abs().max()), 1e-30)
+
+
+def test_recon_loss_fusion_is_what_the_default_step_runs():
+    """The product path takes the fused node (the decoded frames of the step are the error tensor, flagged as such)."""
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from losses.losses import LossManager
+    from srlz import ops
+    pre.N_CHANNELS = 3
+    learner.BATCH_SIZE = 2
+    srl = learner.SRL4robotics(16, model_type="custom_cnn", seed=5, learning_rate=1e-4, cuda=True, losses=["autoencoder"], n_actions=6,
+                               log_folder="/tmp")
+    o, n, a = gu.golden_inputs(2, 3, 6, seed=5)
+    both = torch.from_numpy(np.concatenate((o, n), 0)).cuda()
+    seen = []
+    real = ops.DecOutLossFn.apply
+
+    def spy(*args):
+        seen.append(1)
+        return real(*args)
+    ops.DecOutLossFn.apply = spy
+    try:
+        lm = LossManager(srl.model, None)
+        srl.trainStep(both[:2], both[2:], torch.from_numpy(a).view(-1, 1).cuda(), lm)
+    finally:
+        ops.DecOutLossFn.apply = real
+    assert seen == [1] and lm.names == ["reconstruction_loss"]

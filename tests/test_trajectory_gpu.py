@@ -61,6 +61,9 @@ CASES = {
     "trace_val_aeif_b2": dict(losses=["autoencoder", "inverse", "forward"], n_steps=4, val_steps=(1,)),
     "trace_val_vae_b2": dict(losses=["vae"], n_steps=4, val_steps=(2,)),
     "trace_ae_l1l2_b2": dict(losses=["autoencoder"], n_steps=3, l1_reg=1e-5, l2_reg=1e-4),
+    # the reference's DEFAULT minibatch (bs = 32, BASELINE.json configs[0]): 16x the samples per gradient -> far fewer
+    # rounding-noise gradient elements -> its end point is held to ITS OWN (much smaller) measured spread
+    "trace10_ae_b32": dict(losses=["autoencoder"], n_steps=10, B=32),
 }
 
 
@@ -96,8 +99,12 @@ def product_step(srl, lm, losses, inp, validation):
         it = iter(inp["eps"])
         srl.model.model.eps_fn = lambda mu: next(it).to(mu.device)
     to = lambda t: None if t is None else t.to(dev)
-    loss = srl.trainStep(to(inp["obs"]), to(inp["next_obs"]), inp["actions"].view(-1, 1).to(dev), lm,
-                         validation_mode=validation, noisy_obs=to(inp["noisy"][0]), next_noisy_obs=to(inp["noisy"][1]),
+    # as the learner's feed delivers them (SRL4robotics._toDevicePair): the two frames are the halves of ONE device buffer, which
+    # is what lets the product take its default route (batched pair, reconstruction loss inside the last ConvTranspose)
+    obs, next_obs = srl._toDevicePair(inp["obs"], inp["next_obs"])
+    noisy = (None, None) if inp["noisy"][0] is None else srl._toDevicePair(inp["noisy"][0], inp["noisy"][1])
+    loss = srl.trainStep(obs, next_obs, inp["actions"].view(-1, 1).to(dev), lm,
+                         validation_mode=validation, noisy_obs=noisy[0], next_noisy_obs=noisy[1],
                          rewards_st=to(inp["rewards"]))
     rec = dict(zip(lm.names, lm.lossValues()))
     rec["total"] = float(loss.detach())
@@ -154,7 +161,8 @@ def test_train_step_trajectory_follows_reference(name):
     worst, table = gu.endpoint_errors(sd, g, LR, n_steps, st)
     with open(os.path.join(gu.GOLDEN_DIR, "trajectory_spread.json")) as f:
         spreads = json.load(f)["cases"]
-    peers = [c for c in spreads if (CASES[c]["n_steps"] > 4) == (n_steps > 4)]
+    big = lambda c: CASES[c].get("B", 2) >= 32  # a default-size minibatch is held to its own class's spread, not to B = 2's
+    peers = [c for c in spreads if (CASES[c]["n_steps"] > 4) == (n_steps > 4) and big(c) == big(name)]
     spread = {kind: max(spreads[c][kind] for c in peers) for kind in worst}
     for kind, err in worst.items():
         tol = max(ENDPOINT_FLOOR[kind], SPREAD_FACTOR * spread[kind])

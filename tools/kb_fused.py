@@ -14,4 +14,4 @@ nb = C.convT_out_bwd_fused_workspace(d); ws = torch.empty(nb, dtype=torch.uint8,
 dw, db = torch.empty(64, 3, 4, 4, device="cuda"), torch.empty(3, device="cuda")
 st = C.stream()
 flop = 2 * 2.0 * 48 * 64 * N * 111 * 111
-report("convT5 bwd fused ABLATE=%s" % os.environ.get("SRLZ_ABLATE", "0"), *timeit(lambda: C.convT_out_bwd_fused(C.ptr(dimg), C.ptr(w), C.ptr(da), C.ptr(x), C.ptr(bnp), C.ptr(p), C.ptr(dw), C.ptr(db), C.ptr(ws), nb, d, st)), flop=flop, bytes_=4.0 * N * (2 * 111 * 111 * 64 + 3 * 224 * 224))
+report("convT5 bwd fused ABLATE=%s" % os.environ.get("SRLZ_ABLATE", "0"), *timeit(lambda: C.convT_out_bwd_fused(C.ptr(dimg), C.ptr(w), C.ptr(da), C.ptr(x), C.ptr(bnp), C.ptr(p), C.ptr(dw), C.ptr(db), C.ptr(ws), nb, None, 1.0, 1.0, d, st)), flop=flop, bytes_=4.0 * N * (2 * 111 * 111 * 64 + 3 * 224 * 224))

@@ -466,6 +466,10 @@ def main():
                                                val_steps=(2,)))
     save("trace_ae_l1l2_b2", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=2, n_steps=3, lr=1e-4,
                                                l1_reg=1e-5, l2_reg=1e-4))
+    # (6) round 3: a trajectory at the reference's DEFAULT minibatch (bs = 32, BASELINE.json configs[0]): with 16x the samples per
+    # gradient, near-zero gradient elements (the ones Adam turns into +-lr steps of arbitrary sign) are far rarer than at B = 2,
+    # so a free-running end point can be held much tighter (tests/test_trajectory_gpu.py, tools/measure_spread.py)
+    save("trace10_ae_b32", lambda: step_case(th, ref_pre, SRLModules, RL, ["autoencoder"], B=32, n_steps=10, lr=1e-4))
     for lname in LOOP_CASES:
         save(lname, lambda: run_loop_child(lname))
 

@@ -65,8 +65,11 @@ def run(case, threads, noise_seed=None):
 
 
 def main():
-    out = {}
-    for case in sorted(traj.CASES):
+    """python tools/measure_spread.py [case ...]: (re)measure the named cases (default: all) and merge them into the JSON."""
+    path = os.path.join(REPO, "tests", "golden", "trajectory_spread.json")
+    only = sys.argv[1:]
+    out = json.load(open(path))["cases"] if only and os.path.exists(path) else {}
+    for case in (only or sorted(traj.CASES)):
         g = gu.load(case)
         n_steps = traj.CASES[case]["n_steps"]
         res = []
@@ -76,7 +79,7 @@ def main():
         # the runs' distances to the reference fixture; the largest one is the "self spread" of the algorithm
         out[case] = {k: max(r[k] for r in res) for k in res[0]}
         print(case, json.dumps(out[case]))
-    with open(os.path.join(REPO, "tests", "golden", "trajectory_spread.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump({"metric": "tests/golden_util.py::endpoint_errors of the CPU twin (1 thread, 8 threads, 3 x gradient rounding noise 1e-6) vs the reference fixture, max",
                    "cases": out}, f, indent=1, sort_keys=True)
 
