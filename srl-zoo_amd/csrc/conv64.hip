@@ -51,7 +51,20 @@ struct ConvProg {
   int min_off, span;
   int s2;          // 1 if taps are grouped {4,2,2,1} by class, 0 if a single group of 9
   int dbg;         // ablation switches for tools/kbench.py (env SRLZ_ABLATE): 1 skip A staging, 2 skip epilogue
+  unsigned mPHW, mPW;  // q / PHW and r / PW for 0 <= q, r < 2^31 as (__umulhi(q, m) >> sh): a run-time integer division is ~20
+  int sPHW, sPW;       // VALU instructions and a reciprocal the compiler keeps in a register for the whole kernel (fastdiv)
 };
+
+// Granlund-Montgomery division by an invariant for 31-bit dividends: l = ceil(log2 d), m = floor(2^(31+l) / d) + 1 (< 2^32),
+// q / d == umulhi(q, m) >> (l - 1) for every 0 <= q < 2^31 (d >= 2).
+static void fastdiv_init(unsigned d, unsigned* m, int* sh) {
+  int l = 0;
+  while ((1u << l) < d) ++l;
+  if (l == 0) l = 1;  // d == 1: m = 2^32 does not fit; callers have d >= 2 (checked in build_program)
+  *m = (unsigned)((((unsigned long long)1 << (31 + l)) / d) + 1);
+  *sh = l - 1;
+}
+__device__ __forceinline__ int fastdiv(int q, unsigned m, int sh) { return (int)(__umulhi((unsigned)q, m) >> sh); }
 
 struct Axis {
   int cls[3], d[3];  // per kernel index ky: class (parity) and grid offset
@@ -106,6 +119,9 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
   P->PW = extent(Ws, Wd);
   if (P->PH <= 0 || P->PW <= 0) return -1;
   P->PHW = P->PH * P->PW;
+  if (P->PW < 2) return -1;
+  fastdiv_init((unsigned)P->PHW, &P->mPHW, &P->sPHW);
+  fastdiv_init((unsigned)P->PW, &P->mPW, &P->sPW);
   long long tq = (long long)N * P->PHW;
   if (tq > 0x7fffff00LL) return -1;
   P->total_q = (int)tq;
@@ -257,10 +273,10 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
         else if (bnp) {
           if (BWD) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float z = yv[j][e] * sc4[e] + sh4[e];
+            for (int e = 0; e < 4; ++e) {  // (explicit fused multiply-adds: the same roundings in every kernel that rebuilds dy)
+              const float z = __builtin_fmaf(yv[j][e], sc4[e], sh4[e]);
               const float dz = z > 0.f ? v[j][e] : 0.f;
-              v[j][e] = sc4[e] * dz - (c0[e] + c1[e] * yv[j][e]);
+              v[j][e] = __builtin_fmaf(sc4[e], dz, -__builtin_fmaf(c1[e], yv[j][e], c0[e]));
             }
             if (f.dy_out && (unsigned)(R - core_lo) < (unsigned)core_n) *(f32x4*)(f.dy_out + (size_t)offs[j]) = v[j];
           } else {
@@ -536,6 +552,279 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
     if (tid < 128) {
       const float v = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
       stats_partial[(size_t)tile * 128 + tid] = v;  // [0,64): sum, [64,128): sum of squares
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fused data gradient of the ConvTranspose blocks (what conv64_fwd_kernel<4, true> computes), software-pipelined.
+// A stride-2 gather tile stages its source FOUR times (one class of 128 + span rows of (dA, y) per tap group 4 / 2 / 2 / 1), and
+// in conv64_fwd_kernel every one of those stagings is a synchronous HBM round trip between two barriers: at the 111x111 layer
+// the kernel moves 5.5 GB in 1.5 ms — neither the matrix pipe (52 % busy) nor HBM (3.7 TB/s) is busy, they take turns.  Here
+//  * the rows of class c+1 are REQUESTED into registers right after the barrier that opens the first tap of class c and LAND
+//    in LDS (BatchNorm+ReLU backward rebuilt, dy_out stored) after the barrier that closes its last tap: they travel under
+//    4 / 2 / 2 taps of MFMAs; the requests are branch-free (clamped addresses, masks applied at the landing), so hipcc's wait
+//    insertion keeps them in flight (DESIGN.md 5.2 — the round-2 attempt at this, tools/experiments/gather_pipe_kernel.patch, had
+//    its requests inside branches);
+//  * workgroups are persistent (2 per CU) and walk a contiguous run of their XCD's tiles, so class 0 of the NEXT tile travels
+//    under the single tap of class 3 and the epilogue, and the weight slab of tap 0 under tap 8;
+//  * the tap structure is compile-time (groups {0..3}, {4, 5}, {6, 7}, {8}): no run-time class switch inside the pipeline.
+// Same arithmetic, same accumulation order and same tiles as conv64_fwd_kernel<4, true>: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GP_THREADS = 512;                 // 8 waves: wave = 32 rows x 32 columns, one accumulator (the rows of a class in
+constexpr int GP_RP = GP_THREADS / 16;          // flight cost 376 bytes per thread at 256 threads — with the 4-wave kernel's 64
+constexpr int GP_BATCH = 6;                     // accumulator registers on top, that spills; at 512 threads it is 48 + 16)
+constexpr int GP_CORE = TM / GP_RP;             // a tile's own rows are its first TM (these programs have min_off == 0)
+                                                // rows per pass / rows (of 16 lanes) per thread and class: 128 + span <= 192
+
+struct GatherRows {
+  f32x4 v[GP_BATCH], yv[GP_BATCH];
+  unsigned offs[GP_CORE];   // float offset of the rows that can lie in the tile's own range (dy_out is indexed like y)
+  unsigned ok;              // bit j: row j lies inside the tensor
+};
+
+__device__ __forceinline__ void gather_request(GatherRows& r, const float* __restrict__ src, const float* __restrict__ y, int H,
+                                               int W, int cls, const ConvProg& P, int qstart, int nrows) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));  // opaque: nothing derived from the thread index here is worth a register across the tile loop
+  const int slot = t & 15;
+  const int cy = cls >> 1, cx = cls & 1;
+  const int PW = P.PW, PH = P.PH, PHW = P.PHW;
+  const int sa = fastdiv(GP_RP, P.mPW, P.sPW), sb = GP_RP - sa * PW;
+  const int qq = qstart + (t >> 4) + PHW;  // shifted by one image: the first rows of the first tile (negative q) stay non-negative
+  int n1 = fastdiv(qq, P.mPHW, P.sPHW);
+  const int rem = qq - n1 * PHW;
+  int a = fastdiv(rem, P.mPW, P.sPW);
+  int b = rem - a * PW;
+  const int N1max = P.N;
+  unsigned okmask = 0;
+#pragma unroll
+  for (int j = 0; j < GP_BATCH; ++j) {
+    const int yy = a * 2 + cy, xx = b * 2 + cx;
+    const bool ok = (t >> 4) + GP_RP * j < nrows && n1 >= 1 && n1 <= N1max && yy < H && xx < W;
+    okmask |= (ok ? 1u : 0u) << j;
+    // branch-free: a padding row reads pixel 0 (always valid) and is zeroed when it lands
+    const unsigned off = (ok ? (unsigned)(((n1 - 1) * H + yy) * W + xx) * 64u : 0u) + slot * 4;
+    r.v[j] = *(const f32x4*)(src + off);
+    r.yv[j] = *(const f32x4*)(y + off);
+    if (j < GP_CORE) r.offs[j] = off;
+    b += sb; a += sa;
+    if (b >= PW) { b -= PW; ++a; }
+    if (a >= PH) { a -= PH; ++n1; }
+  }
+  r.ok = okmask;
+}
+
+// A buffer resource over `bytes` bytes at `p` (raw, unstrided): buffer stores whose offset lies outside are DROPPED by the hardware,
+// which makes a conditional store branch-free (offset = GP_DROP for a lane that must not write).  That matters beyond the branch
+// itself: vmcnt counts stores too and is in-order, and behind a store inside a branch hipcc can only wait for everything, so
+// every later "wait for the weight slab" would also wait for these stores' HBM round trip.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gp_buffer(float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000);
+}
+constexpr unsigned GP_DROP = 0xFFFFFF00u;
+
+// lrec: [4][64] in LDS — scale, shift, c0, c1 of the rows' BatchNorm group (see stage_rows); dy_rsrc: the group's dy_out tensor
+// (zero-sized when the rebuilt gradient is not to be stored)
+__device__ __forceinline__ void gather_land(float* __restrict__ lds, GatherRows& r, int nrows, const float* __restrict__ lrec,
+                                            __amdgpu_buffer_rsrc_t dy_rsrc, int core_lo, int core_n) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int slot = t & 15;
+  const f32x4 sc4 = *(const f32x4*)(lrec + slot * 4), sh4 = *(const f32x4*)(lrec + 64 + slot * 4);
+  const f32x4 c0 = *(const f32x4*)(lrec + 128 + slot * 4), c1 = *(const f32x4*)(lrec + 192 + slot * 4);
+#pragma unroll
+  for (int j = 0; j < GP_BATCH; ++j) {
+    const int R = (t >> 4) + GP_RP * j;
+    const bool ok = (r.ok >> j) & 1u;
+    f32x4 v = r.v[j];
+    const f32x4 yy = r.yv[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // (explicit fused multiply-adds: exactly stage_rows' roundings)
+      const float z = __builtin_fmaf(yy[e], sc4[e], sh4[e]);
+      const float dz = z > 0.f ? v[e] : 0.f;
+      v[e] = ok ? __builtin_fmaf(sc4[e], dz, -__builtin_fmaf(c1[e], yy[e], c0[e])) : 0.f;
+    }
+    if (j < GP_CORE) {
+      const bool core = ok && R < nrows && (unsigned)(R - core_lo) < (unsigned)core_n;
+      __builtin_amdgcn_raw_buffer_store_b128(v, dy_rsrc, core ? r.offs[j < GP_CORE ? j : 0] * 4u : GP_DROP, 0, 0);
+    }
+    if (R < nrows) *(f32x4*)(lds + R * 64 + ((slot ^ (R & 15)) << 2)) = v;  // (an LDS write only: no vector-memory op in a branch)
+  }
+}
+
+__global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const float* __restrict__ src_all,
+                                                                         const float* __restrict__ wpack,
+                                                                         float* __restrict__ dst_all, const ConvProg P, int ntiles,
+                                                                         const OpFuse fuse_all) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* As = (float*)smem;                 // (TM + span) x 64, swizzled: the rows of the current class
+  float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap
+  int* rowinfo = (int*)(Bs + 4096);         // [2 (tile parity)][3][TM]: image index (or -1), a*ds, b*ds
+  float* frec = (float*)(rowinfo + 6 * TM); // [G <= 2][4][64]: scale, shift, c0, c1 per BatchNorm group
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave & 3, wcol = wave >> 2;  // 32-row group, 32-column half
+  const int nrows = TM + P.span;
+  const int cls0 = P.tsrc[0], cls1 = P.tsrc[4], cls2 = P.tsrc[6], cls3 = P.tsrc[8];
+
+  // this workgroup's tiles: a strided walk over the contiguous run of tiles that belongs to its XCD (block b runs on XCD b % 8;
+  // concurrently running workgroups of an XCD therefore work on neighbouring tiles, which share halo rows in that XCD's L2)
+  const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tbase = (xcd < tr) ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tcnt = tq + (xcd < tr ? 1 : 0);
+
+  // BatchNorm-backward coefficients of every group, once per workgroup
+  if (tid < 64 * P.G) {
+    const int g = tid >> 6, c = tid & 63;
+    const float* bnp = fuse_all.bnp + g * 256;
+    const float* sums = fuse_all.sums + g * 128;
+    const float sc = bnp[128 + c], sh = bnp[192 + c];
+    float c0 = 0.f, c1 = 0.f;
+    if (fuse_all.training) {
+      c1 = sc * bnp[64 + c] * sums[64 + c] * fuse_all.inv_count;
+      c0 = sc * sums[c] * fuse_all.inv_count - c1 * bnp[c];
+    }
+    float* fr = frec + g * 256;
+    fr[c] = sc; fr[64 + c] = sh; fr[128 + c] = c0; fr[192 + c] = c1;
+  }
+
+  constexpr int BV = 1024 / GP_THREADS;  // 16-byte vectors of the 16 KB slab per thread; wave w moves (and may scribble on) its own 2 KB
+  const int bslot = wave * (BV * 64) + lane;
+  f32x4 breg[BV];
+  {
+    const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[0] * 4096);
+#pragma unroll
+    for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
+  }
+
+  // bytes of one group's dy_out / dst tensor (< 2^32: checked by the host); a zero-sized dy_out drops every store
+  const unsigned dy_bytes = fuse_all.dy_out ? (unsigned)P.src_gstride * 4u : 0u;
+  const unsigned dst_bytes = (unsigned)P.dst_gstride * 4u;
+
+  GatherRows rr;
+  int k = wi;
+  int parity = 0;
+  if (k < tcnt) {  // the first tile's class 0 is staged the plain way
+    const int tile = tbase + k;
+    const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;  // (G <= 2, checked by the host)
+    const int q0 = (tile - grp * P.tpg) * TM;
+    gather_request(rr, src_all + grp * P.src_gstride, fuse_all.y + grp * P.src_gstride, P.Hs, P.Ws, cls0, P, q0 + P.min_off, nrows);
+    __syncthreads();  // frec is complete
+    gather_land(As, rr, nrows, frec + grp * 256, gp_buffer(fuse_all.dy_out + grp * P.src_gstride, dy_bytes), -P.min_off, TM);
+  }
+  for (; k < tcnt; k += wpx, parity ^= 1) {
+    const int tile = tbase + k;
+    const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;
+    const int q0 = (tile - grp * P.tpg) * TM;
+    const float* __restrict__ src = src_all + grp * P.src_gstride;
+    const float* __restrict__ ysrc = fuse_all.y + grp * P.src_gstride;
+    const __amdgpu_buffer_rsrc_t dyo = gp_buffer(fuse_all.dy_out + grp * P.src_gstride, dy_bytes);
+    const __amdgpu_buffer_rsrc_t dst = gp_buffer(dst_all + grp * P.dst_gstride, dst_bytes);
+    const float* lrec = frec + grp * 256;
+    int* ri = rowinfo + parity * (3 * TM);
+    if (tid < TM) {  // (the other parity's copy may still be read by a wave that is flushing the previous tile)
+      const int q = q0 + tid;
+      int n = -1, ya = 0, xb = 0;
+      if (q < P.total_q) {
+        n = fastdiv(q, P.mPHW, P.sPHW);
+        const int rem = q - n * P.PHW;
+        const int a = fastdiv(rem, P.mPW, P.sPW);
+        ya = a * P.ds;
+        xb = (rem - a * P.PW) * P.ds;
+      }
+      ri[tid] = n; ri[TM + tid] = ya; ri[2 * TM + tid] = xb;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // Everything the nine taps derive from the lane index is tile-independent, and left to itself the compiler keeps all of it
+    // (nine operand addresses, the slab offsets ...) in registers across the tile loop — which pushes the rows in flight into
+    // scratch, and every scratch reload is a "s_waitcnt vmcnt(0)" in front of a tap's MFMAs, i.e. the end of the pipeline.  One
+    // opaque copy of the lane index per tile keeps those few VALU instructions inside the loop instead.
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
+    const int h_t = lane_t >> 5, l31_t = lane_t & 31;
+    const int arow0 = wrow * 32 + l31_t - P.min_off;
+    const float* brow = Bs + (wcol * 32 + l31_t) * 64;
+    const int bkey = lane_t & 15;
+    const int bslot_t = wave * (BV * 64) + lane_t;  // (likewise: nine 64-bit slab addresses would be hoisted otherwise)
+
+#pragma unroll
+    for (int ti = 0; ti < NTAPS; ++ti) {
+      __syncthreads();  // all waves are done with the previous tap's Bs — and with As when this tap opens a new class
+      {  // the slab first: its loads are older than the rows in flight and are waited for with those still pending
+        f32x4* wdst = (f32x4*)Bs;
+#pragma unroll
+        for (int i = 0; i < BV; ++i) wdst[bslot_t + i * 64] = breg[i];
+      }
+      {  // the next tap's slab (tap 0 of the next tile behind tap 8: same weights) — requested BEFORE the landing's dy_out stores:
+         // vmcnt is in-order and counts stores, so the next tap's slab wait lets everything issued after these loads (the stores,
+         // the next class's rows) stay in flight, and a store's HBM round trip travels under two taps like the rows do
+        const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[(ti + 1) % NTAPS] * 4096);
+#pragma unroll
+        for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot_t + i * 64];
+      }
+      if (ti == 4 || ti == 6 || ti == 8) gather_land(As, rr, nrows, lrec, dyo, -P.min_off, TM);
+      __syncthreads();
+      // the next class's rows
+      if (ti == 0) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls1, P, q0 + P.min_off, nrows);
+      if (ti == 4) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls2, P, q0 + P.min_off, nrows);
+      if (ti == 6) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls3, P, q0 + P.min_off, nrows);
+      if (ti == 8) {  // class 0 of this workgroup's NEXT tile (past the end: nrows = 0 -> every row reads pixel 0 and is dropped)
+        const int k2 = k + wpx;
+        const int tile2 = tbase + (k2 < tcnt ? k2 : k);
+        const int grp2 = (P.G > 1 && tile2 >= P.tpg) ? 1 : 0;
+        const int q02 = (tile2 - grp2 * P.tpg) * TM;
+        gather_request(rr, src_all + grp2 * P.src_gstride, fuse_all.y + grp2 * P.src_gstride, P.Hs, P.Ws, cls0, P, q02 + P.min_off,
+                       k2 < tcnt ? nrows : 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // every request goes out HERE, ahead of the tap's MFMAs (the scheduler sinks them otherwise)
+      const int R = arow0 + P.toff[ti];
+      int abase = (R * 64 + ((h_t ^ (R & 15)) << 2)) * 4;  // bytes; slot (2kc + h) ^ (R & 15) is this XOR (kc << 5)
+      asm volatile("" : "+v"(abase));
+      // (no register double-buffering of the fragments here: four waves per SIMD hide the LDS latency, and the 8 registers are
+      // needed for the rows in flight)
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const f32x4 a = *(const f32x4*)((const char*)As + (abase ^ (kc << 5)));
+        const f32x4 b = *(const f32x4*)(brow + (((kc * 2 + h_t) ^ bkey) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave is done with the last tap's slab and with As: Bs becomes scratch, As takes the next tile
+    // (the landing first: it waits for its rows only; behind the flush's stores — in branches — it would wait for those too)
+    if (k + wpx < tcnt) {
+      const int tile2 = tbase + k + wpx;
+      const int grp2 = (P.G > 1 && tile2 >= P.tpg) ? 1 : 0;
+      gather_land(As, rr, nrows, frec + grp2 * 256, gp_buffer(fuse_all.dy_out + grp2 * P.src_gstride, dy_bytes), -P.min_off, TM);
+    }
+    {  // flush through this wave's own 2 KB of the idle slab, 16 tile rows x 32 columns at a time: every global store is 16 bytes per
+       // lane (lane = (row eg = lane >> 3, 4 channels at eslot = lane & 7); see conv64_fwd_kernel::flush16)
+      float* S = Bs + wave * 512;
+      const int eg = lane_t >> 3, eslot = lane_t & 7;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int rq = 0; rq < 8; ++rq) {
+          const int rowl = (rq & 3) + 8 * (rq >> 2) + 4 * h_t;
+          S[rowl * 32 + l31_t] = acc[8 * half + rq];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int rowl = eg + 8 * kk;
+          const int row = wrow * 32 + 16 * half + rowl;
+          const f32x4 v = *(const f32x4*)(S + rowl * 32 + eslot * 4);
+          const int n = ri[row];
+          const int y = ri[TM + row], x = ri[2 * TM + row];
+          const bool inside = n >= 0 && y < P.Hd && x < P.Wd;  // (branch-free store: see gp_buffer)
+          __builtin_amdgcn_raw_buffer_store_b128(v, dst, inside ? (unsigned)((n * P.Hd + y) * P.Wd + x) * 256u + wcol * 128 + eslot * 16 : GP_DROP,
+                                                 0, 0);
+        }
+      }
     }
   }
 }
@@ -1106,6 +1395,21 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
   if (src_fuse.y) {
     SRLZ_REQUIRE((long long)P.N * P.Hs * P.Ws * 64 < (1LL << 32), SRLZ_ERR_BAD_DESC,
                  "conv64: a group's operand has %lld floats (the fused staging keeps 32-bit row offsets)", (long long)P.N * P.Hs * P.Ws * 64);
+    // the software-pipelined persistent kernel (SRLZ_DGRAD_PIPE=0: the synchronous conv64_fwd_kernel<4, true>)
+    static const int use_pipe = [] { const char* e = getenv("SRLZ_DGRAD_PIPE"); return e ? atoi(e) : 1; }();
+    bool grouped = P.s2 && P.ss == 2 && P.G <= 2;
+    for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
+    int pgrid = 2 * srlz_device_cus();
+    if (pgrid > ntiles) pgrid = ntiles;
+    pgrid &= ~7;
+    const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;  // buffer resources: 32-bit byte counts
+    if (use_pipe && grouped && fits32 && !P.dbg && P.min_off == 0 && TM + P.span <= GP_RP * GP_BATCH && pgrid >= 8 && GP_RP <= P.PHW) {
+      const size_t plds = (size_t)(TM + P.span) * 256 + 16384 + 6 * TM * 4 + 2 * 256 * 4;
+      SRLZ_MAX_LDS(conv64_dgrad_pipe_kernel, plds);
+      hipLaunchKernelGGL(conv64_dgrad_pipe_kernel, dim3(pgrid), dim3(GP_THREADS), plds, st, src, wpack, dst, P, ntiles, src_fuse);
+      SRLZ_LAUNCHED();
+      return 0;
+    }
     if (nw_bwd == 8) SRLZ_FWD_LAUNCH(8, true);
     else SRLZ_FWD_LAUNCH(4, true);
   } else {

@@ -848,3 +848,55 @@ def test_total_loss_is_pythons_left_to_right_fp32_sum(C):
     for a, b in zip(vals, ref_terms):
         assert torch.equal(a.grad, b.grad)
 
+
+
+_DGRAD_SCRIPT = r'''
+import sys, torch
+sys.path[:0] = [sys.argv[1]]
+from srlz import _cabi as C
+n, hi, groups, store = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+ho = (hi - 1) * 2 + 3
+g = torch.Generator().manual_seed(4321 + hi)
+da = torch.randn(n, ho, ho, 64, generator=g).cuda()
+y = (torch.randn(n, ho, ho, 64, generator=g) * 1.2 + 0.1).cuda()
+w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda()
+bnp = torch.cat([torch.cat((torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5, torch.rand(64, generator=g) + 0.5,
+                            torch.randn(64, generator=g) * 0.2)) for _ in range(groups)]).cuda()
+sums = (torch.randn(128 * groups, generator=g) * 50).cuda()
+d = C.Conv64Desc(n, hi, hi, ho, ho, 3, 2, 0, 1, groups)
+st = C.stream()
+packs = torch.empty(2, C.conv64_packed_floats(), device="cuda")
+C.conv64_pack_weights(C.ptr(w), C.ptr(packs[0]), C.ptr(packs[1]), d, st)
+dx = torch.full((n, hi, hi, 64), float("nan"), device="cuda")
+dy_out = torch.full((n, ho, ho, 64), float("nan"), device="cuda")
+op = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), n // groups * ho * ho, 1, dy_out.data_ptr() if store else None)
+C.conv64_bwd_data(C.ptr(da), C.ptr(packs[1]), C.ptr(dx), op, d, st)
+torch.cuda.synchronize()
+torch.save({"dx": dx.cpu(), "dy_out": dy_out.cpu()}, sys.argv[2])
+'''
+
+
+@pytest.mark.parametrize("n,hi,groups,store", [(8, 27, 2, 1), (6, 55, 2, 1), (5, 27, 1, 0), (32, 13, 2, 1)])
+def test_pipelined_fused_dgrad_is_the_synchronous_kernel_bit_for_bit(C, tmp_path, n, hi, groups, store):
+    """conv64_dgrad_pipe_kernel (the software-pipelined, persistent fused ConvTranspose data gradient: default) against
+    conv64_fwd_kernel<4, true> (SRLZ_DGRAD_PIPE=0): same tiles, same arithmetic, same accumulation order -> identical dx and
+    identical dy_out (every element written exactly once), with two BatchNorm groups, several tiles per workgroup, tiles of
+    both groups in one workgroup's walk, and without the dy_out store.  (Parity with torch: test_fused_bn_backward_operand.)"""
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "srl-zoo_amd")
+    outs = []
+    for pipe in ("0", "1"):
+        path = str(tmp_path / ("out%s.pt" % pipe))
+        env = dict(os.environ, SRLZ_DGRAD_PIPE=pipe)
+        proc = subprocess.run([sys.executable, "-c", _DGRAD_SCRIPT, pkg, path, str(n), str(hi), str(groups), str(store)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert proc.returncode == 0, proc.stdout.decode("utf-8", "replace")[-2000:]
+        outs.append(torch.load(path))
+    assert torch.isfinite(outs[0]["dx"]).all()
+    assert torch.equal(outs[0]["dx"], outs[1]["dx"])
+    if store:
+        assert torch.isfinite(outs[0]["dy_out"]).all() and torch.equal(outs[0]["dy_out"], outs[1]["dy_out"])
+    else:
+        assert torch.isnan(outs[1]["dy_out"]).all()

@@ -164,8 +164,11 @@ def test_train_step_trajectory_follows_reference(name):
     big = lambda c: CASES[c].get("B", 2) >= 32  # a default-size minibatch is held to its own class's spread, not to B = 2's
     peers = [c for c in spreads if (CASES[c]["n_steps"] > 4) == (n_steps > 4) and big(c) == big(name)]
     spread = {kind: max(spreads[c][kind] for c in peers) for kind in worst}
+    # (at the reference's default minibatch the product has been measured INSIDE the reference's own spread — eval-mode states 1.1 %
+    # against 1.4 % — so that class is held to twice its spread instead of five times)
+    factor = 2.0 if big(name) else SPREAD_FACTOR
     for kind, err in worst.items():
-        tol = max(ENDPOINT_FLOOR[kind], SPREAD_FACTOR * spread[kind])
+        tol = max(ENDPOINT_FLOOR[kind], factor * spread[kind])
         if not err <= tol:
             fails.append("end point %s: %.3e > %.3e (reference self-spread %.3e)" % (kind, err, tol, spread[kind]))
     worst["loss"] = worst_loss
