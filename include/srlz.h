@@ -98,6 +98,18 @@ typedef struct {
 /* dx = d(loss)/d(x) from dy (dy_bn may be NULL: dy is then the plain gradient). */
 int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx, const srlz_bn_bwd_operand* dy_bn,
                          const srlz_conv64_desc* d, srlz_stream_t stream);
+/* The WHOLE backward of a decoder block's ConvTranspose2d(64, 64, 3, stride 2) + BatchNorm2d + ReLU (models/models.py:70-80, as
+ * autograd runs it for loss.backward(), models/learner.py:489) in ONE launch: srlz_conv64_bwd_data(dy, dy_bn) and
+ * srlz_conv64_bwd_weight(x, dy_out, x_bnp) on a single staging of the rebuilt d(loss)/dy, which therefore never touches memory
+ * (dy_bn->dy_out must be NULL).  x = the RAW input tensor of the layer, x_bnp its BatchNorm record(s) (the layer's input is
+ * relu(batchnorm(x)); required), dy / dy_bn as in srlz_conv64_bwd_data (dy_bn required).  dx is bit-identical to
+ * srlz_conv64_bwd_data's; dw_ref / dbias are deterministic (per-workgroup partials in `ws`, fixed-order fp64 second stage).
+ * Only where srlz_conv64_bwd_fused_supported(d) != 0 (stride-2 transposed layers with at least 8 tiles; groups <= 2). */
+int srlz_conv64_bwd_fused_supported(const srlz_conv64_desc* d);
+size_t srlz_conv64_bwd_fused_workspace(const srlz_conv64_desc* d);
+int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const float* dy, const srlz_bn_bwd_operand* dy_bn,
+                          const float* wpack_bwd, float* dx, float* dw_ref, float* dbias /* may be NULL */, void* ws, size_t ws_bytes,
+                          const srlz_conv64_desc* d, srlz_stream_t stream);
 /* workspace (bytes) for bwd_weight */
 size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d);
 /* dw_ref (reference layout) = d(loss)/d(w); dbias[64] = sum of dy over n,h,w (may be NULL).

@@ -830,6 +830,370 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The WHOLE backward of a decoder block's ConvTranspose2d(64, 64, 3, stride 2) in one launch: data gradient, weight gradient and
+// bias gradient from ONE staging of the rebuilt d(loss)/dy.
+// conv64_dgrad_pipe_kernel reads (dA, y) = 3.2 GB at the 111x111 layer, rebuilds dy and — only so that the weight-gradient
+// kernel can read it back — stores it (1.6 GB written, 1.6 GB read again).  Both contractions consume the same operand:
+//     da(p)  = sum_t dy_{c_t}(p + off_t) . Wb[t]          (M = positions, N = ci, K = co)
+//     dW[t]  = sum_p a(p)^T . dy_{c_t}(p + off_t)         (M = ci, N = co, K = positions),    a = relu(bn(y_prev)),
+// so here a tile (128 positions p of the low-resolution grid) stages each class of dy rows once in LDS, runs the data-gradient
+// taps on it as the pipelined kernel does, and ALSO multiplies it with the tile's 128 rows of a.  dy never leaves the chip:
+// 3.2 GB of the pair's 7.2 GB disappear, and the MFMA work per staged byte doubles.
+//  * 512 threads, ONE workgroup per CU (256 registers per lane, 150 KB of LDS): the class rows are double-buffered in LDS, so a
+//    class lands two taps after it was requested — where the in-order vmcnt completes its loads anyway — while the previous
+//    class is still being read; the a-tile of the next tile lands at the tile boundary.
+//  * data gradient: wave = 32 positions x 32 channels (as conv64_dgrad_pipe_kernel).  Weight gradient: the 36 blocks
+//    (9 taps x 2x2 quadrants of 32x32) are spread over the 8 waves per CLASS so that every wave has 32 weight-gradient MFMAs
+//    in every tap period: class of 4 taps — wave w owns tap (w >> 1), quadrants (w & 1, {0, 1}), a quarter of the positions per
+//    period; classes of 2 taps — tap (w >> 2), quadrant (w & 1, (w >> 1) & 1), half of the positions per period; the 1-tap
+//    class — quadrant as before, position half (w >> 2), the two halves added through LDS at the end.  80 accumulator
+//    registers per lane instead of 144.
+//  * positions are visited as p = 16 i + jj + 8 h (h = the MFMA's two k-lanes): for fixed (jj, h) the rows 16 i apart share the
+//    XOR key of the swizzled dy rows, so a lane reaches its eight k-steps from ONE address with immediate offsets
+//    (ds_read2st64_b32), for the dy operand as for the (unswizzled) a-tile.
+// Results: dx bit-identical to conv64_dgrad_pipe_kernel; dW / db differ from the two-kernel path by summation order only
+// (per-workgroup partials, fixed-order fp64 second stage: deterministic).
+// ---------------------------------------------------------------------------------------------------------------
+struct FusedBwd {
+  const float* x;        // raw y_prev [N, Hd, Wd, 64] (the ConvTranspose's input before BatchNorm + ReLU)
+  const float* x_bnp;    // its BatchNorm record(s): a = relu(bn(x))
+  float* wpartial;       // [workgroups][9 * 4096 + 64]
+};
+
+struct YRows { f32x4 v[4]; unsigned ok; };  // the tile's 128 rows of y_prev: rows (t >> 4) + 32 j
+
+__device__ __forceinline__ void ytile_request(YRows& r, const float* __restrict__ x, const ConvProg& P, int q0, bool live) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int slot = t & 15;
+  const int PW = P.PW, PH = P.PH, PHW = P.PHW;
+  const int sa = fastdiv(GP_RP, P.mPW, P.sPW), sb = GP_RP - sa * PW;
+  const int qq = q0 + (t >> 4);
+  int n = fastdiv(qq, P.mPHW, P.sPHW);
+  const int rem = qq - n * PHW;
+  int a = fastdiv(rem, P.mPW, P.sPW);
+  int b = rem - a * PW;
+  unsigned okmask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = live && n < P.N && a < P.Hd && b < P.Wd;
+    okmask |= (ok ? 1u : 0u) << j;
+    const unsigned off = (ok ? (unsigned)((n * P.Hd + a) * P.Wd + b) * 64u : 0u) + slot * 4;
+    r.v[j] = *(const f32x4*)(x + off);
+    b += sb; a += sa;
+    if (b >= PW) { b -= PW; ++a; }
+    if (a >= PH) { a -= PH; ++n; }
+  }
+  r.ok = okmask;
+}
+
+// xrec: [2][64] in LDS — scale, shift of the previous layer's BatchNorm for the tile's group
+__device__ __forceinline__ void ytile_land(float* __restrict__ Ys, YRows& r, const float* __restrict__ xrec) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int slot = t & 15;
+  const f32x4 sc4 = *(const f32x4*)(xrec + slot * 4), sh4 = *(const f32x4*)(xrec + 64 + slot * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = (r.ok >> j) & 1u;
+    f32x4 v = r.v[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = __builtin_fmaf(v[e], sc4[e], sh4[e]);
+      v[e] = (ok && z > 0.f) ? z : 0.f;
+    }
+    *(f32x4*)(Ys + ((t >> 4) + GP_RP * j) * 64 + slot * 4) = v;
+  }
+}
+
+// as gather_land, without the dy_out store; bs4 += the tile's own rows (every dy element belongs to exactly one tile's range)
+__device__ __forceinline__ void gather_land_sum(float* __restrict__ lds, GatherRows& r, int nrows, const float* __restrict__ lrec,
+                                                f32x4& bs4) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int slot = t & 15;
+  const f32x4 sc4 = *(const f32x4*)(lrec + slot * 4), sh4 = *(const f32x4*)(lrec + 64 + slot * 4);
+  const f32x4 c0 = *(const f32x4*)(lrec + 128 + slot * 4), c1 = *(const f32x4*)(lrec + 192 + slot * 4);
+#pragma unroll
+  for (int j = 0; j < GP_BATCH; ++j) {
+    const int R = (t >> 4) + GP_RP * j;
+    const bool ok = (r.ok >> j) & 1u;
+    f32x4 v = r.v[j];
+    const f32x4 yy = r.yv[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = __builtin_fmaf(yy[e], sc4[e], sh4[e]);
+      const float dz = z > 0.f ? v[e] : 0.f;
+      v[e] = ok ? __builtin_fmaf(sc4[e], dz, -__builtin_fmaf(c1[e], yy[e], c0[e])) : 0.f;
+    }
+    if (j < GP_CORE) bs4 += v;  // (min_off == 0: rows [0, TM) are the tile's own; rows outside the tensor are zero)
+    if (R < nrows) *(f32x4*)(lds + R * 64 + ((slot ^ (R & 15)) << 2)) = v;
+  }
+}
+
+// NJJ k-groups (jj0 .. jj0 + NJJ - 1) of one tap's weight gradient for NB (1 or 2) column quadrants sharing the row quadrant mi:
+// acc[b] += a-tile[p][32 mi ..]^T . dy[p + off][32 (nj0 + b) ..]  over p = 16 i + jj + 8 h.
+template <int NB, int NJJ>
+__device__ __forceinline__ void wgrad_steps(f32x16 (&acc)[NB], const float* __restrict__ Ys, const float* __restrict__ Ac, int off,
+                                            int mi, int nj0, int jj0, int h, int l31) {
+#pragma unroll
+  for (int q = 0; q < NJJ; ++q) {
+    const int jj = jj0 + q;
+    const float* ap = Ys + (jj + 8 * h) * 64 + mi * 32 + l31;
+    const int Rj = jj + 8 * h + off, key = Rj & 15;
+    const float* bp[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int co = (nj0 + b) * 32 + l31;
+      bp[b] = Ac + Rj * 64 + ((((co >> 2) ^ key) << 2) | (co & 3));
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < 8; i0 += 4) {  // (four k-steps at a time: the fragments of eight would cost 12 more registers)
+      float av[4], bv[NB][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[i] = ap[(i0 + i) * 1024];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bv[b][i] = bp[b][(i0 + i) * 1024];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[b][i], acc[b], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const float* __restrict__ src_all,
+                                                                        const float* __restrict__ wpack,
+                                                                        float* __restrict__ dst_all, const ConvProg P, int ntiles,
+                                                                        const OpFuse fuse_all, const FusedBwd fb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nrows = TM + P.span;
+  float* As0 = (float*)smem;                // class rows, double-buffered: classes 0 / 2 here,
+  float* As1 = As0 + nrows * 64;            // classes 1 / 3 here
+  float* Ys = As1 + nrows * 64;             // [TM][64]: relu(bn(y_prev)) of the tile's positions
+  float* Bs = Ys + TM * 64;                 // 64 x 64 weight slab of the current tap
+  int* rowinfo = (int*)(Bs + 4096);         // [2 (tile parity)][3][TM]
+  float* frec = (float*)(rowinfo + 6 * TM); // [G <= 2][4][64]: scale, shift, c0, c1 of this layer's BatchNorm backward
+  float* xrec = frec + 512;                 // [G <= 2][2][64]: scale, shift of the previous layer's BatchNorm
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave & 3, wcol = wave >> 2;
+  const int cls0 = P.tsrc[0], cls1 = P.tsrc[4], cls2 = P.tsrc[6], cls3 = P.tsrc[8];
+  // weight-gradient assignment of this wave (wave-uniform)
+  const int wmi = wave & 1, wnj = (wave >> 1) & 1, wk = wave >> 2;
+  const int tap_c0 = wave >> 1, tap_c1 = 4 + wk, tap_c2 = 6 + wk;
+  const int off_c0 = P.toff[tap_c0], off_c1 = P.toff[tap_c1], off_c2 = P.toff[tap_c2], off_c3 = P.toff[8];
+
+  const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tbase = (xcd < tr) ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tcnt = tq + (xcd < tr ? 1 : 0);
+
+  if (tid < 64 * P.G) {
+    const int g = tid >> 6, c = tid & 63;
+    const float* bnp = fuse_all.bnp + g * 256;
+    const float* sums = fuse_all.sums + g * 128;
+    const float sc = bnp[128 + c], sh = bnp[192 + c];
+    float c0 = 0.f, c1 = 0.f;
+    if (fuse_all.training) {
+      c1 = sc * bnp[64 + c] * sums[64 + c] * fuse_all.inv_count;
+      c0 = sc * sums[c] * fuse_all.inv_count - c1 * bnp[c];
+    }
+    float* fr = frec + g * 256;
+    fr[c] = sc; fr[64 + c] = sh; fr[128 + c] = c0; fr[192 + c] = c1;
+    xrec[g * 128 + c] = fb.x_bnp[g * 256 + 128 + c];
+    xrec[g * 128 + 64 + c] = fb.x_bnp[g * 256 + 192 + c];
+  }
+
+  constexpr int BV = 1024 / GP_THREADS;
+  f32x4 breg[BV];
+  {
+    const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[0] * 4096);
+#pragma unroll
+    for (int i = 0; i < BV; ++i) breg[i] = wsrc[wave * (BV * 64) + lane + i * 64];
+  }
+  const unsigned dst_bytes = (unsigned)P.dst_gstride * 4u;
+
+  f32x16 aw0[2], aw1[1], aw2[1], aw3[1];  // weight-gradient accumulators of the four classes
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aw0[0][r] = 0.f; aw0[1][r] = 0.f; aw1[0][r] = 0.f; aw2[0][r] = 0.f; aw3[0][r] = 0.f; }
+  f32x4 bs4 = {0.f, 0.f, 0.f, 0.f};  // bias gradient: column sums of the tile's own dy rows (channels 4 slot .. of this thread's rows)
+
+  GatherRows rr;
+  YRows yr;
+  int k = wi;
+  int parity = 0;
+  if (k < tcnt) {  // the first tile's class 0 and a-tile are staged the plain way
+    const int tile = tbase + k;
+    const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;
+    const int q0 = (tile - grp * P.tpg) * TM;
+    gather_request(rr, src_all + grp * P.src_gstride, fuse_all.y + grp * P.src_gstride, P.Hs, P.Ws, cls0, P, q0, nrows);
+    ytile_request(yr, fb.x + grp * P.dst_gstride, P, q0, true);
+    __syncthreads();  // frec / xrec are complete
+    gather_land_sum(As0, rr, nrows, frec + grp * 256, bs4);
+    ytile_land(Ys, yr, xrec + grp * 128);
+  }
+  for (; k < tcnt; k += wpx, parity ^= 1) {
+    const int tile = tbase + k;
+    const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;
+    const int q0 = (tile - grp * P.tpg) * TM;
+    const float* __restrict__ src = src_all + grp * P.src_gstride;
+    const float* __restrict__ ysrc = fuse_all.y + grp * P.src_gstride;
+    const __amdgpu_buffer_rsrc_t dst = gp_buffer(dst_all + grp * P.dst_gstride, dst_bytes);
+    const float* lrec = frec + grp * 256;
+    const int k2 = k + wpx;
+    const bool more = k2 < tcnt;
+    const int tile2 = tbase + (more ? k2 : k);
+    const int grp2 = (P.G > 1 && tile2 >= P.tpg) ? 1 : 0;
+    const int q02 = (tile2 - grp2 * P.tpg) * TM;
+    int* ri = rowinfo + parity * (3 * TM);
+    if (tid < TM) {
+      const int q = q0 + tid;
+      int n = -1, ya = 0, xb = 0;
+      if (q < P.total_q) {
+        n = fastdiv(q, P.mPHW, P.sPHW);
+        const int rem = q - n * P.PHW;
+        const int a = fastdiv(rem, P.mPW, P.sPW);
+        ya = a * P.ds;
+        xb = (rem - a * P.PW) * P.ds;
+      }
+      ri[tid] = n; ri[TM + tid] = ya; ri[2 * TM + tid] = xb;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // (one opaque copy of the lane index per tile: see conv64_dgrad_pipe_kernel)
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
+    const int h_t = lane_t >> 5, l31_t = lane_t & 31;
+    const int arow0 = wrow * 32 + l31_t;
+    const float* brow = Bs + (wcol * 32 + l31_t) * 64;
+    const int bkey = lane_t & 15;
+    const int bslot_t = wave * (BV * 64) + lane_t;
+
+#pragma unroll
+    for (int ti = 0; ti < NTAPS; ++ti) {
+      // class of this tap and the LDS buffer that holds it (compile-time after unrolling)
+      const float* Ac = (ti < 4 || ti == 6 || ti == 7) ? As0 : As1;
+      __syncthreads();  // all waves are done with the previous tap's Bs — and with the class buffer that is about to be refilled
+      {
+        f32x4* wdst = (f32x4*)Bs;
+#pragma unroll
+        for (int i = 0; i < BV; ++i) wdst[bslot_t + i * 64] = breg[i];
+      }
+      {
+        const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[(ti + 1) % NTAPS] * 4096);
+#pragma unroll
+        for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot_t + i * 64];
+      }
+      // rows requested two taps ago land now (the in-order vmcnt has completed them with the slab just written): class 1 -> As1
+      // while taps 2, 3 still read class 0 in As0; class 2 -> As0 once class 0 is done; class 3 -> As1; the next tile's class 0 -> As0
+      if (ti == 2) gather_land_sum(As1, rr, nrows, lrec, bs4);
+      if (ti == 4) gather_land_sum(As0, rr, nrows, lrec, bs4);
+      if (ti == 6) gather_land_sum(As1, rr, nrows, lrec, bs4);
+      if (ti == 8) gather_land_sum(As0, rr, nrows, frec + grp2 * 256, bs4);  // (past the last tile: every row masked off -> zeros; no
+                                                                             // run-time branch around a landing, or its join costs a full vmcnt(0))
+      __syncthreads();
+      if (ti == 0) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls1, P, q0, nrows);
+      if (ti == 2) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls2, P, q0, nrows);
+      if (ti == 4) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls3, P, q0, nrows);
+      if (ti == 6) gather_request(rr, src_all + grp2 * P.src_gstride, fuse_all.y + grp2 * P.src_gstride, P.Hs, P.Ws, cls0, P, q02,
+                                  more ? nrows : 0);
+      if (ti == 8) ytile_request(yr, fb.x + grp2 * P.dst_gstride, P, q02, more);
+      __builtin_amdgcn_sched_barrier(0);
+      {  // ---- data gradient: 32 positions x 32 channels of this wave
+        const int R = arow0 + P.toff[ti];
+        int abase = (R * 64 + ((h_t ^ (R & 15)) << 2)) * 4;
+        asm volatile("" : "+v"(abase));
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          const f32x4 a = *(const f32x4*)((const char*)Ac + (abase ^ (kc << 5)));
+          const f32x4 b = *(const f32x4*)(brow + (((kc * 2 + h_t) ^ bkey) << 2));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+        }
+      }
+      // ---- weight gradient: this wave's share of the class that is resident during this tap period
+      // (the lane index opaque once more, per tap: the operand addresses of all nine taps are tile-invariant functions of it, and
+      // computed early and kept they cost more registers than there are)
+      int lane_p = lane_t;
+      asm volatile("" : "+v"(lane_p));
+      const int h_p = lane_p >> 5, l31_p = lane_p & 31;
+      if (ti < 4) wgrad_steps<2, 2>(aw0, Ys, As0, off_c0, wmi, 0, 2 * ti, h_p, l31_p);
+      else if (ti < 6) wgrad_steps<1, 4>(aw1, Ys, As1, off_c1, wmi, wnj, 4 * (ti - 4), h_p, l31_p);
+      else if (ti < 8) wgrad_steps<1, 4>(aw2, Ys, As0, off_c2, wmi, wnj, 4 * (ti - 6), h_p, l31_p);
+      else wgrad_steps<1, 4>(aw3, Ys, As1, off_c3, wmi, wnj, 4 * wk, h_p, l31_p);
+    }
+    __syncthreads();  // every wave is done with the last tap's slab, with class 3 and with the a-tile
+    ytile_land(Ys, yr, xrec + grp2 * 128);  // (past the last tile: zeros)
+    {  // flush of the data gradient (see conv64_dgrad_pipe_kernel)
+      float* S = Bs + wave * 512;
+      const int eg = lane_t >> 3, eslot = lane_t & 7;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int rq = 0; rq < 8; ++rq) {
+          const int rowl = (rq & 3) + 8 * (rq >> 2) + 4 * h_t;
+          S[rowl * 32 + l31_t] = acc[8 * half + rq];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int rowl = eg + 8 * kk;
+          const int row = wrow * 32 + 16 * half + rowl;
+          const f32x4 v = *(const f32x4*)(S + rowl * 32 + eslot * 4);
+          const int n = ri[row];
+          const int y = ri[TM + row], x = ri[2 * TM + row];
+          const bool inside = n >= 0 && y < P.Hd && x < P.Wd;
+          __builtin_amdgcn_raw_buffer_store_b128(v, dst, inside ? (unsigned)((n * P.Hd + y) * P.Wd + x) * 256u + wcol * 128 + eslot * 16 : GP_DROP,
+                                                 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- the workgroup's weight-gradient partial [9 (reference tap index)][64 ci][64 co] and bias partial [64]
+  __syncthreads();  // (everything in LDS is dead from here on)
+  {
+    const int h = lane >> 5, l31 = lane & 31;
+    float* out = fb.wpartial + (size_t)blockIdx.x * (NTAPS * 4096 + 64);
+    auto put = [&](const f32x16& a, int tap, int mi, int nj) {
+      float* o = out + (size_t)P.tw[tap] * 4096;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + nj * 32 + l31] = a[r];
+    };
+    put(aw0[0], tap_c0, wmi, 0);
+    put(aw0[1], tap_c0, wmi, 1);
+    put(aw1[0], tap_c1, wmi, wnj);
+    put(aw2[0], tap_c2, wmi, wnj);
+    // tap 8: the two position halves (waves w and w + 4) are added through LDS
+    float* X = As0;  // [4 quadrants][16 regs][64 lanes]
+    if (wk == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[((wave & 3) * 16 + r) * 64 + lane] = aw3[0][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) aw3[0][r] += X[((wave & 3) * 16 + r) * 64 + lane];
+      put(aw3[0], 8, wmi, wnj);
+    }
+    __syncthreads();
+    float* red = As0;  // [32 row groups][64 channels]
+    *(f32x4*)(red + (tid >> 4) * 64 + (tid & 15) * 4) = bs4;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < GP_RP; ++r) t += red[r * 64 + tid];
+      out[NTAPS * 4096 + tid] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Weight-gradient kernel: dW[w][ci][co] = sum_q S_c(q+off)[ci] * G_d(q)[co]   (G = dy at dest class d).
 // GEMM view: M = ci (64), N = co (64), K = grid positions.  4 waves = 4 quadrants of 32x32, each holding all 9 taps
 // (144 accumulator registers); persistent over K-chunks of 64 positions; per-workgroup partials are reduced by
@@ -1295,7 +1659,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const floa
 // 1024 threads per block: 256 outputs x 4 slices of the workgroup range, 4 loads in flight per thread, fp64 combine.
 __global__ __launch_bounds__(1024) void conv64_wgrad_reduce(const float* __restrict__ partial, int nwg,
                                                            float* __restrict__ dw_ref, float* __restrict__ dbias,
-                                                           int transposed) {
+                                                           int transposed, int interleaved) {
   const int o = threadIdx.x & 255, part = threadIdx.x >> 8;
   const int id = blockIdx.x * 256 + o;
   constexpr int TOT = NTAPS * 4096;
@@ -1303,9 +1667,9 @@ __global__ __launch_bounds__(1024) void conv64_wgrad_reduce(const float* __restr
   const int w0 = part * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (id < TOT + 64) {
-    // bias partials live after all workgroups' tap blocks: [nwg][64]
-    const float* base = (id < TOT) ? partial + id : partial + (size_t)nwg * TOT + (id - TOT);
-    const size_t stride = (id < TOT) ? (size_t)TOT : 64;
+    // bias partials live after all workgroups' tap blocks: [nwg][64] — or, interleaved (= the record size), behind each workgroup's own
+    const float* base = interleaved ? partial + id : (id < TOT) ? partial + id : partial + (size_t)nwg * TOT + (id - TOT);
+    const size_t stride = interleaved ? (size_t)interleaved : (id < TOT) ? (size_t)TOT : 64;
     int w = w0;
     for (; w + 3 < w1; w += 4) {
       s0 += (double)base[(size_t)w * stride];
@@ -1760,7 +2124,66 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   }
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(1024), 0, st, partial, launched_grid,
-                     dw_ref, dbias, d->transposed);
+                     dw_ref, dbias, d->transposed, 0);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+// ---- the fused backward of a decoder block's ConvTranspose (conv64_bwd_fused_kernel) ----
+static int fused_bwd_grid(const ConvProg& P) {
+  int g = srlz_device_cus();  // ONE workgroup per CU (150 KB of LDS, 256 registers per lane)
+  const int ntiles = P.G * P.tpg;
+  if (g > ntiles) g = ntiles;
+  return g & ~7;
+}
+
+static bool fused_bwd_ok(const ConvProg& P) {
+  bool grouped = P.s2 && P.ss == 2 && P.G <= 2 && P.min_off == 0 && !P.dbg;
+  for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
+  const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;
+  return grouped && fits32 && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && fused_bwd_grid(P) >= 8;
+}
+
+extern "C" int srlz_conv64_bwd_fused_supported(const srlz_conv64_desc* d) {
+  if (check_desc(d) || !d->transposed || d->stride != 2) return 0;
+  ConvProg P;
+  if (program_for(&P, d, 1)) return 0;
+  return fused_bwd_ok(P) ? 1 : 0;
+}
+
+extern "C" size_t srlz_conv64_bwd_fused_workspace(const srlz_conv64_desc* d) {
+  if (check_desc(d)) return 0;
+  ConvProg P;
+  if (program_for(&P, d, 1)) return 0;
+  return (size_t)fused_bwd_grid(P) * (NTAPS * 4096 + 64) * sizeof(float);
+}
+
+extern "C" int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const float* dy, const srlz_bn_bwd_operand* dy_bn,
+                                     const float* wpack_bwd, float* dx, float* dw_ref, float* dbias, void* ws, size_t ws_bytes,
+                                     const srlz_conv64_desc* d, srlz_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRLZ_REQUIRE(d->transposed && d->stride == 2, SRLZ_ERR_BAD_DESC, "conv64_bwd_fused: ConvTranspose2d(64, 64, 3, stride 2) only");
+  SRLZ_REQUIRE(x && x_bnp && dy && dy_bn && wpack_bwd && dx && dw_ref && ws, SRLZ_ERR_NULL, "conv64_bwd_fused: null pointer");
+  OpFuse gf;
+  if (int rc = make_bwd_fuse(&gf, dy_bn, "conv64_bwd_fused")) return rc;
+  SRLZ_REQUIRE(gf.dy_out == nullptr, SRLZ_ERR_BAD_DESC, "conv64_bwd_fused: d(loss)/dy is not materialised by this entry point");
+  ConvProg P;
+  if (int rc = program_for(&P, d, 1)) return rc;
+  SRLZ_REQUIRE(fused_bwd_ok(P), SRLZ_ERR_BAD_DESC, "conv64_bwd_fused: shape not supported (ask srlz_conv64_bwd_fused_supported)");
+  const int grid = fused_bwd_grid(P);
+  SRLZ_REQUIRE(ws_bytes >= (size_t)grid * (NTAPS * 4096 + 64) * sizeof(float), SRLZ_ERR_WORKSPACE,
+               "conv64_bwd_fused: workspace too small (%zu bytes)", ws_bytes);
+  hipStream_t st = as_stream(stream);
+  const size_t lds = (size_t)(TM + P.span) * 256 * 2 + (size_t)TM * 256 + 16384 + 6 * TM * 4 + 512 * 4 + 256 * 4;
+  SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64_bwd_fused: tile needs %zu bytes of LDS", lds);
+  FusedBwd fb;
+  fb.x = x; fb.x_bnp = x_bnp; fb.wpartial = (float*)ws;
+  SRLZ_MAX_LDS(conv64_bwd_fused_kernel, lds);
+  hipLaunchKernelGGL(conv64_bwd_fused_kernel, dim3(grid), dim3(GP_THREADS), lds, st, dy, wpack_bwd, dx, P, P.G * P.tpg, gf, fb);
+  SRLZ_LAUNCHED();
+  // second stage: fixed-order fp64 sum over the workgroups (the partial's bias block sits behind EACH workgroup's taps here)
+  hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(1024), 0, st, (const float*)ws, grid, dw_ref, dbias,
+                     1, NTAPS * 4096 + 64);
   SRLZ_LAUNCHED();
   return 0;
 }

@@ -509,17 +509,23 @@ def _bn_backward_sums_from_partials(partial, gb=(None, None), groups=1):
     return sums, dgamma, dbeta
 
 
-def _operand_from(link):
+def _operand_from(link, materialise=True):
     """(ctypes record or None, dy_out or None, keep-alive tuple) for the gradient arriving at a producer block.
-    The record asks the data-gradient kernel to also store the rebuilt d(loss)/dy (dy_out) for the weight gradient."""
+    materialise: the record asks the data-gradient kernel to also store the rebuilt d(loss)/dy (dy_out) for a separate
+    weight-gradient launch; False when one kernel consumes the operand for both gradients (srlz_conv64_bwd_fused)."""
     rec = link.take() if link is not None else None
     if rec is None:
         return None, None, None
     y, bnp, sums, training = rec
-    dy_out = torch.empty_like(y)
+    dy_out = torch.empty_like(y) if materialise else None
     op = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), y.numel() // 64 // _groups_of(bnp), 1 if training else 0,
-                        dy_out.data_ptr())
+                        dy_out.data_ptr() if materialise else None)
     return op, dy_out, rec
+
+
+# A/B switch: data + weight + bias gradient of a decoder block's ConvTranspose as ONE launch (0: data-gradient launch that stores the
+# rebuilt d(loss)/dy + weight-gradient launch that reads it back)
+_FUSED_CONVT_BWD = _os.environ.get("SRLZ_FUSED_CONVT_BWD", "1") != "0"
 
 
 class DecBlockFn(Function):
@@ -554,6 +560,21 @@ class DecBlockFn(Function):
         y_prev, bnp, packs = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "decoder block dy")
+        if ctx.out_link is not None and ctx.out_link.record is not None and _FUSED_CONVT_BWD and C.conv64_bwd_fused_supported(d):
+            # `dy` is dA of the following BatchNorm+ReLU: ONE kernel rebuilds the true dy while staging it and contracts it both ways
+            # (data gradient and weight / bias gradient) — it is never written to memory
+            dy_bn, _, keep = _operand_from(ctx.out_link, materialise=False)
+            da = torch.empty_like(y_prev)
+            dw = _gbuf(ctx.params[2])
+            db = _gbuf(ctx.params[3], 64, dy.device)
+            nbytes = C.conv64_bwd_fused_workspace(d)
+            ws = _ws(nbytes, dy.device, slot=1)
+            _launch("conv64_bwd_fused_kernel", _conv64_key(d, "dgrad+wgrad"), 2.0 * _conv64_flop(d),
+                    lambda: C.conv64_bwd_fused(ptr(y_prev), ptr(bnp), ptr(dy), dy_bn, ptr(packs[1]), ptr(da), ptr(dw), ptr(db), ptr(ws),
+                                               nbytes, d, stream()))
+            dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, gb=ctx.params[:2])
+            gp, bp, wp, cp = ctx.params
+            return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(wp, dw), _give(cp, db), None, None, None
         # dy_bn not None: `dy` is dA of the following BatchNorm+ReLU; the data-gradient kernel rebuilds the true dy in its
         # operand load and stores it (dy_true) for the weight-gradient kernel, which therefore runs second
         dy_bn, dy_true, keep = _operand_from(ctx.out_link)

@@ -900,3 +900,97 @@ def test_pipelined_fused_dgrad_is_the_synchronous_kernel_bit_for_bit(C, tmp_path
         assert torch.isfinite(outs[0]["dy_out"]).all() and torch.equal(outs[0]["dy_out"], outs[1]["dy_out"])
     else:
         assert torch.isnan(outs[1]["dy_out"]).all()
+
+
+@pytest.mark.parametrize("n,hi,groups,training", [(2, 27, 1, 1), (8, 27, 2, 1), (6, 55, 2, 1), (32, 13, 2, 1), (4, 27, 2, 0)])
+def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
+    """srlz_conv64_bwd_fused — data, weight and bias gradient of ConvTranspose2d(64,64,3,2) whose output went through
+    BatchNorm2d + ReLU and whose input was relu(batchnorm(x)), from ONE staging of the rebuilt d(loss)/dy — against
+    (i) fp64 autograd through relu(bn(x)) -> conv_transpose2d -> batch_norm -> relu per BatchNorm group, and
+    (ii) the two-launch path srlz_conv64_bwd_data(dy_out) + srlz_conv64_bwd_weight: dx bit for bit, dw / db to rounding."""
+    assert n % groups == 0
+    g = torch.Generator().manual_seed(77 * hi + n)
+    ho = (hi - 1) * 2 + 3
+    x = torch.randn(n, 64, hi, hi, generator=g) * 1.2 + 0.1            # raw output of the previous layer
+    w, b = torch.randn(64, 64, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g) * 0.1
+    gx, bx = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    rm, rv = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
+    da = torch.randn(n, 64, ho, ho, generator=g)
+    per = n // groups
+    # ---- fp64 reference, group by group (per-call BatchNorm statistics)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    dx_ref, xrecs, yrecs, sums_l = [], [], [], []
+    for gi in range(groups):
+        xs = x[gi * per:(gi + 1) * per].double()
+        m, v = xs.mean((0, 2, 3)), xs.var((0, 2, 3), unbiased=False)
+        inv = 1.0 / torch.sqrt(v + 1e-5)
+        sc, sh = gx.double() * inv, bx.double() - m * gx.double() * inv
+        xrecs.append(torch.cat((m, inv, sc, sh)).float())
+        a = torch.relu(xs * sc.view(1, 64, 1, 1) + sh.view(1, 64, 1, 1)).requires_grad_(True)
+        y = F.conv_transpose2d(a, wr, br, stride=2)
+        out = F.relu(F.batch_norm(y, rm.double().clone(), rv.double().clone(), gamma.double(), beta.double(), bool(training), 0.1, 1e-5))
+        out.backward(da[gi * per:(gi + 1) * per].double())
+        dx_ref.append(a.grad)
+    dx_ref = torch.cat(dx_ref)
+    # ---- device: forward through the C ABI to get y, its statistics and the backward sums
+    st = C.stream()
+    d = C.Conv64Desc(n, hi, hi, ho, ho, 3, 2, 0, 1, groups)
+    assert C.conv64_bwd_fused_supported(d) == 1
+    xd, wd, bd, dad = nhwc(x).to(DEV), w.to(DEV), b.to(DEV), nhwc(da).to(DEV)
+    xbnp = torch.cat(xrecs).to(DEV)
+    packs = torch.empty(2, C.conv64_packed_floats(), device=DEV)
+    C.conv64_pack_weights(C.ptr(wd), C.ptr(packs[0]), C.ptr(packs[1]), d, st)
+    y = torch.empty(n, ho, ho, 64, device=DEV)
+    stats = torch.empty(C.conv64_fwd_tiles(d), 128, device=DEV)
+    C.conv64_fwd(C.ptr(xd), C.ptr(packs[0]), C.ptr(bd), C.ptr(y), C.ptr(stats), C.ptr(xbnp), d, st)
+    gd, bed, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    bnp = torch.empty(256 * groups, device=DEV)
+    nbn = C.bn_bwd_workspace(0)
+    bws = torch.empty(nbn, dtype=torch.uint8, device=DEV)
+    if training:
+        bstat = torch.empty(128 * groups, device=DEV)
+        C.bn_finalize(C.ptr(stats), stats.shape[0], groups, per * ho * ho, C.ptr(gd), C.ptr(bed), 1e-5, 0.1, 1, C.ptr(rmd), C.ptr(rvd),
+                      None, C.ptr(bnp), C.ptr(bstat), C.ptr(bws), nbn, st)
+    else:
+        one = torch.empty(256, device=DEV)
+        C.bn_eval_params(C.ptr(gd), C.ptr(bed), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(one), st)
+        bnp = one.repeat(groups)
+    sums, dgm, dbt = torch.empty(128 * groups, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    C.bn_relu_bwd_sums(C.ptr(y), C.ptr(bnp), C.ptr(dad), C.ptr(sums), C.ptr(dgm), C.ptr(dbt), C.ptr(bws), nbn, n * ho * ho, groups, st)
+    # ---- two launches
+    dy_out = torch.full((n, ho, ho, 64), float("nan"), device=DEV)
+    op = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), per * ho * ho, training, dy_out.data_ptr())
+    dx0 = torch.full((n, hi, hi, 64), float("nan"), device=DEV)
+    C.conv64_bwd_data(C.ptr(dad), C.ptr(packs[1]), C.ptr(dx0), op, d, st)
+    nbytes = C.conv64_bwd_weight_workspace(d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw0, db0 = torch.full((64, 64, 3, 3), float("nan"), device=DEV), torch.full((64,), float("nan"), device=DEV)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dy_out), C.ptr(dw0), C.ptr(db0), C.ptr(xbnp), None, C.ptr(ws), nbytes, d, st)
+    # ---- one launch
+    op1 = C.BnBwdOperand(y.data_ptr(), bnp.data_ptr(), sums.data_ptr(), per * ho * ho, training, None)
+    dx1 = torch.full((n, hi, hi, 64), float("nan"), device=DEV)
+    dw1, db1 = torch.full((64, 64, 3, 3), float("nan"), device=DEV), torch.full((64,), float("nan"), device=DEV)
+    nb1 = C.conv64_bwd_fused_workspace(d)
+    ws1 = torch.full((nb1 // 4,), float("nan"), device=DEV)
+    C.conv64_bwd_fused(C.ptr(xd), C.ptr(xbnp), C.ptr(dad), op1, C.ptr(packs[1]), C.ptr(dx1), C.ptr(dw1), C.ptr(db1), C.ptr(ws1), nb1, d, st)
+    # determinism: a second launch, bit for bit
+    dx2, dw2, db2 = torch.empty_like(dx1), torch.empty_like(dw1), torch.empty_like(db1)
+    C.conv64_bwd_fused(C.ptr(xd), C.ptr(xbnp), C.ptr(dad), op1, C.ptr(packs[1]), C.ptr(dx2), C.ptr(dw2), C.ptr(db2), C.ptr(ws1), nb1, d, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx1).all() and torch.equal(dx1, dx0)
+    assert torch.equal(dx2, dx1) and torch.equal(dw2, dw1) and torch.equal(db2, db1)
+    # fp64 oracle: two correct evaluations decide a ReLU at |bn(y)| ~ 1e-7 differently a handful of times per few million
+    # elements, and one flipped decision moves the ~256 dx values it reaches by ~1e-2 of the tensor's maximum: all but a
+    # vanishing fraction of dx must agree to 5e-5 (small cases: every element)
+    dev_dx = (nchw(dx1).double().cpu() - dx_ref).abs() / float(dx_ref.abs().max())
+    assert float((dev_dx > 5e-5).double().mean()) <= (0.0 if n * ho * ho < 20000 else 3e-3), float(dev_dx.max())
+    assert rel_err(dw1, dw0) < 2e-5
+    if n * ho * ho < 20000:  # (one flipped ReLU decision moves a weight gradient by ~1e-2 of its maximum at these batch sizes)
+        assert rel_err(dw1, wr.grad) < 5e-5
+    scale = float(da.abs().sum()) / 64
+    assert float((db1 - db0).abs().max()) < 1e-5 * scale
+    if training:  # the bias gradient of a convolution followed by train-mode BatchNorm is identically zero
+        assert float(db1.abs().max()) < 1e-3 * scale
+    else:
+        assert rel_err(db1, br.grad) < 5e-5
