@@ -500,7 +500,11 @@ class SRL4robotics(BaseLearner):
         # of the gradient bucket: with several GPUs every rank reads the SAME (mean) losses back, so the NaN exit and the
         # best-model decision are taken by all ranks together
         from srlz import ops
-        if _FUSED_TOTAL and 1 <= len(loss_manager.losses) < self.flat_params.TAIL:
+        if len(loss_manager.losses) >= self.flat_params.TAIL:
+            # (the step's scalars — total first — ride in the TAIL slots behind the gradients, whichever branch runs below)
+            raise ValueError("a training step carries at most {} loss terms (got {}: {})".format(
+                self.flat_params.TAIL - 1, len(loss_manager.losses), loss_manager.names))
+        if _FUSED_TOTAL and len(loss_manager.losses) >= 1:
             loss = ops.TotalLossFn.apply(tuple(loss_manager.weights), self.flat_params.tail, *loss_manager.losses)
             loss.backward()  # the reference backpropagates on validation minibatches too (learner.py:487-489)
         else:

@@ -60,15 +60,9 @@ def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var
 
 
-def _tick(bn, training):
-    """(kept as a no-op marker of where the reference's layer call sits; the count happens inside srlz_bn_finalize)"""
-    return None
-
-
 def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
     """models/models.py:47-63.  x: [N,C,H,W] (reference layout) -> [N,64,6,6] (NCHW, ready for .view(N,-1))."""
     conv1, bn1, conv2, bn2, conv3, bn3 = seq[0], seq[1], seq[4], seq[5], seq[8], seq[9]
-    _tick(bn1, training)
     if _FUSE_ENC_IN and not x.requires_grad:  # (an image that carries a gradient needs conv1's data gradient: plain chain)
         p, y = ops.EncInFn.apply(x, conv1.weight, *_bn_args(bn1), training, 1, stat_sink)
         _tap(name, 0, y)
@@ -79,11 +73,9 @@ def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
         p = _tap(name, 3, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink))
     y, st = ops.Conv64Fn.apply(p, conv2.weight, None, 1, 1, False, training)
     _tap(name, 4, y)
-    _tick(bn2, training)
     p = _tap(name, 7, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn2), training, 0, False, stat_sink))
     y, st = ops.Conv64Fn.apply(p, conv3.weight, None, 2, 1, False, training)
     _tap(name, 8, y)
-    _tick(bn3, training)
     return _tap(name, 11, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn3), training, 0, True, stat_sink))
 
 
@@ -112,7 +104,6 @@ def decoder_forward(seq, z, training):
     in_link = None  # the first transposed convolution is a plain Conv64Fn: its BatchNorm backward is materialised
     for bi, ci in ((1, 3), (4, 6), (7, 9)):
         bn, conv = seq[bi], seq[ci]
-        _tick(bn, training)
         if TAPS is not None:
             _record_activation(bi + 1, y, st, bn, training)
         out_link = ops.BwdLink() if defer else None
@@ -120,7 +111,6 @@ def decoder_forward(seq, z, training):
         in_link = out_link
         _tap("decoder_conv", ci, y)
     bn, last = seq[10], seq[12]
-    _tick(bn, training)
     if TAPS is not None:
         _record_activation(11, y, st, bn, training)
     req = _RECON

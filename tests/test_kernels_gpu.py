@@ -683,6 +683,18 @@ def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
     tol = 3e-6 * (n * himg * himg) ** 0.5  # unit-variance data: a few fp32 ulps of the typical |sum|
     assert float((db0.double() - ref).abs().max()) <= tol
     assert float((db1.double() - ref).abs().max()) <= tol
+    # ---- and against the torch oracle (fp64 autograd of ConvTranspose2d(64, 3, 4, 2) on relu(bn(x_raw)), per BatchNorm group): the
+    # data gradient w.r.t. the activated input and the weight gradient — not only against the product's own two-launch path
+    wr = w.double().cpu().requires_grad_(True)
+    per = n // groups
+    da_ref = []
+    for gi in range(groups):
+        sc, sh = recs[gi][128:192].double().view(1, 64, 1, 1), recs[gi][192:].double().view(1, 64, 1, 1)
+        a = torch.relu(nchw(x_raw[gi * per:(gi + 1) * per]).double().cpu() * sc + sh).requires_grad_(True)
+        F.conv_transpose2d(a, wr, None, stride=2).backward(dimg[gi * per:(gi + 1) * per].double().cpu())
+        da_ref.append(a.grad)
+    assert rel_err(nchw(da1), torch.cat(da_ref)) < 2e-5
+    assert rel_err(dw1, wr.grad) < 2e-5
 
 
 @pytest.mark.parametrize("n,c,hf,mean,groups", [(2, 3, 111, 1, 2), (4, 3, 37, 0, 2), (2, 6, 21, 1, 1), (6, 3, 111, 1, 2)])
