@@ -42,6 +42,13 @@ struct PoolFuse {
   float inv_count;
 };
 
+// A persistent workgroup walks the virtual sequence v = blockIdx.x, blockIdx.x + gridDim.x, ...; the tile it works on is
+// xcd_remap(v): block b runs on XCD b % 8, so every XCD gets ONE contiguous run of tiles and its workgroups process neighbouring
+// tiles at the same time — the image windows of neighbouring tiles overlap (37 rows / columns for 32 at conv1) and share cache
+// lines, and walked in plain order (tile = v) neighbours sit on different XCDs, each fetching those lines into its own L2
+// (rocprofv3: conv1 forward read 884 MB for a 308 MB input).  v >= ntiles -> ntiles ("no tile").
+__device__ __forceinline__ int vtile(int v, int ntiles) { return v < ntiles ? xcd_remap(v, ntiles) : ntiles; }
+
 template <int K, int TR = 16>
 __host__ __device__ constexpr int koff(int k) {
   // LDS offset of tap k = (c,ky,kx) relative to the pixel base (2*ty*XP + tx)
@@ -190,13 +197,15 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
   ImgRegs<K> nx;
   image_index<K>(nx);
   if (PIPE && (int)blockIdx.x < ntiles) {  // the first window is staged the plain way
-    const int n = blockIdx.x / (tiles_y * tiles_x);
-    const int trem = blockIdx.x - n * (tiles_y * tiles_x);
+    const int t0 = vtile(blockIdx.x, ntiles);
+    const int n = t0 / (tiles_y * tiles_x);
+    const int trem = t0 - n * (tiles_y * tiles_x);
     image_request<K, PAD, false>(nx, img, n, C, 0, H, W, (trem / tiles_x) * 16, (trem % tiles_x) * 16, true);
     image_land<K, HOIST>(T, nx);
     if (MULTI) stage_weights(0);
   }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_remap(v, ntiles);
     const int n = tile / (tiles_y * tiles_x);
     const int trem = tile - n * (tiles_y * tiles_x);
     const int oy0 = (trem / tiles_x) * 16, ox0 = (trem % tiles_x) * 16;
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
       int cg2 = cg + 1;
       if (PIPE) {
         int tile2 = tile;
-        if (cg2 == ncg) { cg2 = 0; tile2 += gridDim.x; }
+        if (cg2 == ncg) { cg2 = 0; tile2 = vtile(v + gridDim.x, ntiles); }
         const int n2 = tile2 / (tiles_y * tiles_x);
         const int trem2 = tile2 - n2 * (tiles_y * tiles_x);
         image_request<K, PAD, false>(nx, img, n2, C, cg2, H, W, (trem2 / tiles_x) * 16, (trem2 % tiles_x) * 16, tile2 < ntiles);
@@ -593,8 +602,9 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
     const int trem_ = tile_ - n_ * tpi;
     image_request<K, PAD, K == 4>(ir, img, n_, C, cg, H, W, (trem_ / tiles_x) * 16, (trem_ % tiles_x) * 16, tile_ < ntiles);
   };
-  if ((int)blockIdx.x < ntiles) { f_request(blockIdx.x, 0); i_request(blockIdx.x); }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  if ((int)blockIdx.x < ntiles) { f_request(vtile(blockIdx.x, ntiles), 0); i_request(vtile(blockIdx.x, ntiles)); }
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_remap(v, ntiles);
     const int n = tile / tpi;
     const int grp = n / npg;
     if (grp != cur_grp) {
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
       f_resolve();
       __syncthreads();
       if (half + 1 < NSTAGE) f_request(tile, half + 1);
-      else { f_request(tile + gridDim.x, 0); i_request(tile + gridDim.x); }
+      else { f_request(vtile(v + gridDim.x, ntiles), 0); i_request(vtile(v + gridDim.x, ntiles)); }
       // RPS*4 k-steps per wave, in blocks of 4: step i of block blk covers pixel (row (RPS/2)*sub + (blk>>1) of the stage, column
       // 8*(blk&1) + 2i + h).  Everything that varies inside a block is an immediate offset of a ds_read2 (columns 0,2 / 4,6) and
       // everything that varies between blocks is wave-uniform, so a block costs one address per operand column (1 + NT VALU adds)
@@ -811,14 +821,16 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
     for (int j = 0; j < PER; ++j)
       bsum[j] += __builtin_bit_cast(float, __builtin_bit_cast(unsigned, nx.v[j] * gain) & (unsigned)(-(int)((own >> j) & 1u)));
   };
-  y_request(blockIdx.x);
+  y_request(vtile(blockIdx.x, ntiles));
   if ((int)blockIdx.x < ntiles) {
-    const int n = blockIdx.x / tpi, trem = blockIdx.x - n * tpi;
+    const int t0 = vtile(blockIdx.x, ntiles);
+    const int n = t0 / tpi, trem = t0 - n * tpi;
     image_request<K, PAD, true, TR>(nx, img, n, C, 0, H, W, (trem / tiles_x) * TR, (trem % tiles_x) * 16, true);
     image_land<K, true, TR>(T, nx, gain);
     bias_accumulate(trem);
   }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_remap(v, ntiles);
     const int n = tile / tpi, trem = tile - n * tpi;
     const int oy0 = (trem / tiles_x) * TR, ox0 = (trem % tiles_x) * 16;
     if (n / npg != cur_grp) {
@@ -831,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
     yin = yin_next;
     __syncthreads();  // T of this tile has landed; the previous tile's weight-gradient pass is done with T and F
     {
-      const int tile2 = tile + gridDim.x;
+      const int tile2 = vtile(v + gridDim.x, ntiles);
       const int n2 = tile2 / tpi, trem2 = tile2 - n2 * tpi;
       image_request<K, PAD, true, TR>(nx, img, n2, C, 0, H, W, (trem2 / tiles_x) * TR, (trem2 % tiles_x) * 16, tile2 < ntiles);
     }
@@ -878,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
       }
       *(f32x4*)cell = act;
     }
-    y_request(tile + gridDim.x);
+    y_request(vtile(v + gridDim.x, ntiles));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       s1[e] += __shfl_xor(s1[e], 16, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
@@ -910,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __re
     }
     __syncthreads();  // every wave is done with T and F: the next window lands
     image_land<K, true, TR>(T, nx, gain);
-    bias_accumulate((tile + (int)gridDim.x) % tpi);  // (past the last tile nothing is inside: adds zeros)
+    bias_accumulate(vtile(v + gridDim.x, ntiles) % tpi);  // (past the last tile nothing is inside: adds zeros)
   }
   if (bias_partial) {  // [3][gridDim.x] fp64, summed over workgroups in a fixed order by nchw_chan_sum_final
     float cs[3] = {0.f, 0.f, 0.f};
@@ -997,7 +1009,8 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
   // would wait for the load right at the request and nothing would stay in flight behind the MFMAs.
   constexpr int DEPTH = 4;
   const int tpi = tiles_y * tiles_x;
-  auto load_a = [&](int t, int mtile, f32x4 (&a)[4]) -> bool {
+  auto load_a = [&](int vt, int mtile, f32x4 (&a)[4]) -> bool {
+    const int t = vtile(vt, ntiles);
     const int n = t / tpi;
     const int trem = t - n * tpi;
     const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
@@ -1029,7 +1042,8 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) { qok[d] = load_a(nt, nm, q[d]); advance(); }
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_remap(v, ntiles);
     const int n = tile / tpi;
     if (feat_bnp && n / npg != cur_grp) {
       cur_grp = n / npg;
