@@ -228,8 +228,14 @@ def main():
                     help="instrumented steps (HIP events around every MFMA launch) run AFTER the timed region for the roofline object")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--host-input", action="store_true",
-                    help="NOT the contract's metric: every step starts from uint8 frames in pinned HOST memory (H2D copy + "
-                         "srlz_normalize_u8 inside the timed region) — the PCIe-inclusive rate quoted in DESIGN.md")
+                    help="NOT the contract's metric: every step starts from uint8 frames [B,C,W,H] in pinned HOST memory (the H2D "
+                         "copy inside the timed region; conv1 and the fused loss read the bytes) — the PCIe-inclusive rate "
+                         "quoted in DESIGN.md")
+    ap.add_argument("--u8-resident", action="store_true",
+                    help="the resident synthetic batch is the loader's uint8 frames [B,C,W,H] instead of the normalised float tensor "
+                         "(what learn() feeds the step; conv1 and the fused loss read the bytes)")
+    ap.add_argument("--host-input-nhwc", action="store_true",
+                    help="with --host-input: frames as decoded ([B,H,W,C]) + the separate srlz_normalize_u8 pass (A/B)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -279,20 +285,29 @@ def main():
     if "reward" in args.losses:
         rewards = torch.from_numpy(np.random.RandomState(99 + rank).randint(0, 2, (B,)).astype(np.int64)).to(device)
 
-    host_frames = None
-    if args.host_input:
-        # what the loader hands over every step (DataLoader(raw_uint8=True)): uint8 frames in pinned host memory.  As in
-        # SRL4robotics.learn() (_DeviceFeed), the NEXT step's frames cross PCIe on a copy stream while this step computes;
-        # normalisation + layout change happen on the GPU (srlz_normalize_u8).
+    if args.u8_resident:
         rs = np.random.RandomState(4321 + rank)
-        host_frames = [[torch.from_numpy(rs.randint(0, 256, (B, 224, 224, channels)).astype(np.uint8)).pin_memory()
+        both = torch.from_numpy(rs.randint(0, 256, (2 * B, channels, 224, 224)).astype(np.uint8)).to(device)
+        obs, next_obs = srl._toDevicePair(both[:B], both[B:])
+    host_frames = None
+    if args.host_input or args.host_input_nhwc:
+        # what the loader hands over every step (SRL4robotics.learn(): DataLoader(raw_uint8="planar")): uint8 frames [B,C,W,H] in
+        # pinned host memory.  As in learn() (_DeviceFeed), the NEXT step's frames cross PCIe on a copy stream while this step
+        # computes and land as the halves of one device buffer; conv1 and the fused reconstruction loss read the bytes
+        # (srlz_conv1_fwd_u8 ...).  --host-input-nhwc: the frames as decoded ([B,H,W,C]) + srlz_normalize_u8 (the round-2 route).
+        rs = np.random.RandomState(4321 + rank)
+        fshape = (B, 224, 224, channels) if args.host_input_nhwc else (B, channels, 224, 224)
+        host_frames = [[torch.from_numpy(rs.randint(0, 256, fshape).astype(np.uint8)).pin_memory()
                         for _ in range(2)] for _ in range(2)]  # two alternating minibatches
         copy_stream = torch.cuda.Stream(device=device)
         ahead = {}
 
         def upload(i):
             with torch.cuda.stream(copy_stream):
-                dev = [t.to(device, non_blocking=True) for t in host_frames[i % 2]]
+                both = torch.empty((2 * B,) + fshape[1:], dtype=torch.uint8, device=device)
+                both[:B].copy_(host_frames[i % 2][0], non_blocking=True)
+                both[B:].copy_(host_frames[i % 2][1], non_blocking=True)
+                dev = [both[:B], both[B:]]
             ev = torch.cuda.Event()
             ev.record(copy_stream)
             ahead[i] = (dev, ev)
@@ -310,7 +325,7 @@ def main():
         for t in dev:
             t.record_stream(cur)
         upload(i + 1)  # next minibatch travels while this step runs
-        o, no = srl._toDevicePair(dev[0], dev[1])  # uint8 -> normalised fp32 halves of one buffer, on the GPU
+        o, no = srl._toDevicePair(dev[0], dev[1])  # the bytes themselves when the step reads bytes, else normalised fp32
         return srl.trainStep(o, no, actions, loss_manager, rewards_st=rewards)
 
     def sync():
@@ -349,7 +364,7 @@ def main():
             "metric": "images/sec (224x224x3) AE+VAE train step", "value": round(images / dt, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" if host_frames is None else "synthetic, uint8 frames in pinned host memory every step (PCIe-inclusive)",
+            "data": ("synthetic, uint8 frames resident in HBM" if args.u8_resident else "synthetic") if host_frames is None else "synthetic, uint8 frames in pinned host memory every step (PCIe-inclusive)",
             "samples_per_s": round(B * world * args.steps / dt, 1),
             "config": {"workload": "synthetic 224x224x%d obs, --losses %s, custom_cnn, state-dim %d, bs=%d per GPU "
                                    "(%d frames fwd+bwd per step per GPU), Adam lr 0.005, data resident in HBM"

@@ -156,6 +156,13 @@ int srlz_skinny_tiles(const srlz_skinny_desc* d); /* BN partial records written 
 /* kind 0 forward: x_nchw [N,C,H,W] -> y_nhwc [N,hf,wf,64]; w_ref [64,C,7,7]. stats_partial as in srlz_conv64_fwd. */
 int srlz_conv1_fwd(const float* x_nchw, const float* w_ref, float* y_nhwc, float* stats_partial,
                    const srlz_skinny_desc* d, srlz_stream_t stream);
+/* The same layer on frames that are still the loader's BYTES: x_u8 [N,C,himg,wimg] uint8, planar — the reference's tensor layout
+ * (preprocessing/data_loader.py:255: transpose(0,3,2,1) of the [B,H,W,C] image batch) taken BEFORE preprocessInput — and
+ * norm_lut = the 3 x 256 table of srlz_normalize_lut.  ((v/255) - mean[c]) / std[c] (preprocessing/utils.py:20-32) is applied
+ * while the window lands in LDS: identical bits to srlz_conv1_fwd on the normalised float tensor, a quarter of the input bytes,
+ * and no normalisation pass in the step.  Same for the fused weight gradient and the fused reconstruction loss below. */
+int srlz_conv1_fwd_u8(const uint8_t* x_u8, const float* norm_lut, const float* w_ref, float* y_nhwc, float* stats_partial,
+                      const srlz_skinny_desc* d, srlz_stream_t stream);
 size_t srlz_skinny_bwd_weight_workspace(const srlz_skinny_desc* d);
 /* kind 0 data gradient: dx_nchw [N,C,himg,wimg] = d(loss)/d(image) from dy_nhwc [N,hf,wf,64].  The training path never
  * needs it (conv1 is the first layer); it exists for the perceptual loss (losses/losses.py:217-236), whose frozen
@@ -173,6 +180,10 @@ int srlz_conv1_bwd_weight_fused(const float* x_nchw, const float* y_nhwc, const 
                                 const float* dpooled, const float* sums, int training, float* dw_ref, void* ws,
                                 size_t ws_bytes, const srlz_skinny_desc* d, const struct srlz_pool_desc_s* pd,
                                 srlz_stream_t stream);
+int srlz_conv1_bwd_weight_fused_u8(const uint8_t* x_u8, const float* norm_lut, const float* y_nhwc, const float* bnp,
+                                   const uint8_t* argmax, const float* dpooled, const float* sums, int training, float* dw_ref,
+                                   void* ws, size_t ws_bytes, const srlz_skinny_desc* d, const struct srlz_pool_desc_s* pd,
+                                   srlz_stream_t stream);
 /* kind 1 forward: x_nhwc [N,hf,wf,64] -> y_nchw [N,C,H,W] = convT(x) + bias; w_ref [64,C,4,4]. */
 int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
                        const float* x_bnp /* may be NULL, see srlz_conv64_fwd */, const srlz_skinny_desc* d,
@@ -216,6 +227,10 @@ int srlz_convT_out_fwd_loss_workgroups(const srlz_skinny_desc* d);
 int srlz_convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const float* target_nchw, float* err_nchw,
                             float* dec_nchw, const float* x_bnp, double* loss_partial, const srlz_skinny_desc* d,
                             srlz_stream_t stream);
+/* target_u8: the observations as uint8 [N,C,himg,wimg] + the normalisation table (see srlz_conv1_fwd_u8) */
+int srlz_convT_out_fwd_loss_u8(const float* x_nhwc, const float* w_ref, const float* bias, const uint8_t* target_u8,
+                               const float* norm_lut, float* err_nchw, float* dec_nchw, const float* x_bnp, double* loss_partial,
+                               const srlz_skinny_desc* d, srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BatchNorm2d(64) (+ ReLU (+ MaxPool 3x3 s2)) — nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d,
@@ -388,6 +403,13 @@ int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, int B, int 
  * (preprocessing/data_loader.py:255), bit-identical to the host arithmetic.  Lets the loader ship uint8 over PCIe.
  * ------------------------------------------------------------------------------------------------------------ */
 int srlz_normalize_u8(const uint8_t* img_nhwc, float* out_ncwh, int n, int h, int w, int c, srlz_stream_t stream);
+/* norm_lut[c][v] (3 x 256 floats) = ((v / 255) - mean[c]) / std[c] for v = 0..255 and the image_net mean / std of channel c —
+ * preprocessInput (preprocessing/utils.py:20-32) tabulated with its three fp32 roundings; the operand of the *_u8 entry points. */
+int srlz_normalize_lut(float* norm_lut, srlz_stream_t stream);
+/* Frames already in the reference's tensor layout but still uint8 ([N,C,*] planar, `plane` bytes per channel plane) -> the float
+ * tensor, through the table (for consumers that have no *_u8 form; bit-identical to srlz_normalize_u8 of the NHWC frames). */
+int srlz_normalize_u8_planar(const uint8_t* x_u8, const float* norm_lut, float* out, int n, int c, long long plane,
+                             srlz_stream_t stream);
 
 /* SRLModulesSplit.detachSplit (models/modules.py:191-236): the state rebuilt from zero blocks and ONE kept slice is a
  * column mask: y[r][c] = x[r][c] for lo <= c < hi, else 0.  Its backward is the same call on the gradient. */

@@ -42,6 +42,26 @@ __global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __rest
   }
 }
 
+// lut[c][v] = ((v / 255) - mean[c]) / std[c], v = 0..255, c = R, G, B: the same three roundings as normalize_u8_kernel
+__global__ void normalize_lut_kernel(float* __restrict__ lut) {
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+  const int v = threadIdx.x, c = blockIdx.x;
+  lut[c * 256 + v] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v, 255.0f), mean[c]), stdv[c]);
+}
+
+// planar frames [N*C planes][plane] uint8 -> float through the table (16 bytes in, 4 x 16 bytes out per thread and step)
+__global__ __launch_bounds__(256) void normalize_u8_planar_kernel(const uint8_t* __restrict__ x, const float* __restrict__ lut,
+                                                                 float* __restrict__ out, int C, long long plane) {
+  __shared__ float tab[256];
+  const int c = (blockIdx.y % C) % 3;
+  tab[threadIdx.x] = lut[c * 256 + threadIdx.x];
+  __syncthreads();
+  const uint8_t* src = x + (size_t)blockIdx.y * plane;
+  float* dst = out + (size_t)blockIdx.y * plane;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < plane; i += (long long)gridDim.x * 256) dst[i] = tab[src[i]];
+}
+
 }  // namespace
 
 extern "C" int srlz_normalize_u8(const uint8_t* img_nhwc, float* out_ncwh, int n, int h, int w, int c,
@@ -51,6 +71,25 @@ extern "C" int srlz_normalize_u8(const uint8_t* img_nhwc, float* out_ncwh, int n
                "normalize_u8: channels must be 3, 6 or 9 (got %d)", c);
   const int tiles = n * ((h + 31) / 32) * ((w + 31) / 32);
   hipLaunchKernelGGL(normalize_u8_kernel, dim3(tiles), dim3(256), 0, as_stream(stream), img_nhwc, out_ncwh, n, h, w, c);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_normalize_lut(float* lut, srlz_stream_t stream) {
+  SRLZ_REQUIRE(lut, SRLZ_ERR_NULL, "normalize_lut: null pointer");
+  hipLaunchKernelGGL(normalize_lut_kernel, dim3(3), dim3(256), 0, as_stream(stream), lut);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_normalize_u8_planar(const uint8_t* x_u8, const float* norm_lut, float* out, int n, int c, long long plane,
+                                        srlz_stream_t stream) {
+  SRLZ_REQUIRE(x_u8 && norm_lut && out, SRLZ_ERR_NULL, "normalize_u8_planar: null pointer");
+  SRLZ_REQUIRE(n > 0 && plane > 0 && c > 0 && c <= 9 && c % 3 == 0 && (long long)n * c <= 65535, SRLZ_ERR_BAD_DESC,
+               "normalize_u8_planar: channels must be 3, 6 or 9 (got %d) and n * c <= 65535", c);
+  int gx = (int)((plane + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(normalize_u8_planar_kernel, dim3(gx, n * c), dim3(256), 0, as_stream(stream), x_u8, norm_lut, out, c, plane);
   SRLZ_LAUNCHED();
   return 0;
 }

@@ -108,8 +108,10 @@ __device__ __forceinline__ bool image_decode(const ImgRegs<K, TR>& r, int j, int
 
 // HOIST = true: the unpacked decomposition may live in registers for the whole kernel (no opaque copy): ~35 more registers, ~270
 // fewer VALU instructions per tile — worth it where the registers exist (conv1 forward: 1.10 vs 1.16 ms).
-template <int K, int PAD, bool HOIST = false, int TR = 16>
-__device__ __forceinline__ void image_request(ImgRegs<K, TR>& r, const float* __restrict__ img, int n, int C, int cg, int H,
+// PT = uint8_t: the frames are still the loader's bytes ([N,C,W,H] planar, /root/reference/preprocessing/data_loader.py:255 applied
+// to the uint8 image); the raw byte travels in the register and is normalised when it lands (image_land<U8>).
+template <int K, int PAD, bool HOIST = false, int TR = 16, typename PT = float>
+__device__ __forceinline__ void image_request(ImgRegs<K, TR>& r, const PT* __restrict__ img, int n, int C, int cg, int H,
                                               int W, int oy0, int ox0, bool valid) {
   const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
   r.inside = 0;
@@ -119,15 +121,34 @@ __device__ __forceinline__ void image_request(ImgRegs<K, TR>& r, const float* __
     const bool live = image_decode<K, HOIST, TR>(r, j, c, row, xl);
     const int iy = iy0 + row, ix = ix0 + xl;
     const bool ok = valid && live && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    r.v[j] = img[ok ? ((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix : (size_t)0];
+    const PT raw = img[ok ? ((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix : (size_t)0];
+    if constexpr (sizeof(PT) == 1) r.v[j] = __uint_as_float((unsigned)raw);  // (the byte load zero-extends: no instruction, no wait)
+    else r.v[j] = raw;
     r.inside |= (ok ? 1u : 0u) << j;
   }
 }
 
 // `gain`: factor applied to every element on its way into LDS (1 = none; the fused ConvTranspose-5 backward turns the stored
 // reconstruction error dec - obs into d(loss)/d(dec) = gain * (dec - obs) here, see convT_out_kernel<true>)
-template <int K, bool HOIST = false, int TR = 16>
-__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K, TR>& r, const float gain = 1.f) {
+// U8: the registers hold raw bytes; the value that lands is lut[c][byte] = ((byte / 255) - mean[c]) / std[c], the three fp32
+// roundings of /root/reference/preprocessing/utils.py:20-32 tabulated once by srlz_normalize_lut (768 floats, L1-resident) — a
+// table because two IEEE divisions per element cost more VALU time than the rest of the landing, and because it makes the
+// bit-for-bit equality with the separate normalisation kernel a matter of construction.
+template <int K, bool HOIST = false, int TR = 16, bool U8 = false>
+__device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K, TR>& r, const float gain = 1.f,
+                                           const float* __restrict__ lut = nullptr) {
+  float val[ImgRegs<K, TR>::PER];
+  if constexpr (U8) {
+#pragma unroll
+    for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) {  // all look-ups requested before the first one is used
+      int c, row, xl;
+      const bool live = image_decode<K, HOIST, TR>(r, j, c, row, xl);
+      val[j] = lut[(live ? c : 0) * 256 + (int)__float_as_uint(r.v[j])];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) val[j] = r.v[j] * gain;
+  }
 #pragma unroll
   for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) {
     int c, row, xl;
@@ -135,7 +156,7 @@ __device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<
     // (branch-free — elements past the end of the window go to a spare float of the first plane's padding: a wait inside a branch
     // leaves the compiler unsure, at the join, whether the load has landed, and it then waits for EVERYTHING at the next re-use
     // of the register, including the loads meant to stay in flight)
-    T[live ? (c * 2 + (xl & 1)) * Geo<K, TR>::PP + row * XP + (xl >> 1) : Geo<K, TR>::PP - 1] = ((r.inside >> j) & 1u) ? r.v[j] * gain : 0.f;
+    T[live ? (c * 2 + (xl & 1)) * Geo<K, TR>::PP + row * XP + (xl >> 1) : Geo<K, TR>::PP - 1] = ((r.inside >> j) & 1u) ? val[j] : 0.f;
   }
 }
 
@@ -144,14 +165,16 @@ __device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<
 // 256 threads, tile = 16x16 output pixels; wave w owns tile rows 4w..4w+3 (two 32-pixel M-tiles) x 64 channels.
 // Persistent over tiles; for C == 3 the 64 x KT weight matrix is staged in LDS once per workgroup.
 // ------------------------------------------------------------------------------------------------------------------
-template <int K, int PAD, bool BNBWD = false, bool MULTI = false>
-__global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __restrict__ img,
+template <int K, int PAD, bool BNBWD = false, bool MULTI = false, typename PT = float>
+__global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const PT* __restrict__ img,
                                                             const float* __restrict__ w_ref,
                                                             float* __restrict__ feat,
                                                             float* __restrict__ stats_partial, int N, int C, int H,
                                                             int W, int HF, int WF, int tiles_y, int tiles_x,
                                                             const float* __restrict__ y_raw,
-                                                            const float* __restrict__ y_bnp, int npg) {
+                                                            const float* __restrict__ y_bnp, int npg,
+                                                            const float* __restrict__ lut = nullptr) {
+  constexpr bool U8 = sizeof(PT) == 1;  // uint8 frames + the normalisation table (image_land)
   // npg = images per BatchNorm group (N when there is one group): image n uses the record y_bnp[(n / npg) * 256 ..]
   // BNBWD (data-gradient use, kind 1; y_raw != NULL): `feat` is dA = d(loss)/d(relu(bn(y_raw))) and the per-tile partials become
   // the two BatchNorm-backward sums  sum dz  and  sum dz*xhat  (dz = dA*[bn(y)>0]) instead of  sum v  and  sum v^2 —
@@ -169,6 +192,12 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
   constexpr bool HOIST = (K == 7) && !BNBWD;  // the LDS offsets of the landing are kept in registers (see image_decode); the request
                                               // side (3 values per element) unpacks from pk — hoisting both spills
   float* E = PIPE ? red + 512 : T;              // [4 waves][16 pixels][64 channels]
+  if constexpr (U8) {  // the normalisation table moves into LDS (PIPE kernels only: E is their own 16 KB)
+    float* L = E + 4096;
+    for (int i = threadIdx.x; i < 768; i += 256) L[i] = lut[i];
+    lut = L;
+    __syncthreads();  // (the first window lands before the tile loop's first barrier)
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -201,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
     const int n = t0 / (tiles_y * tiles_x);
     const int trem = t0 - n * (tiles_y * tiles_x);
     image_request<K, PAD, false>(nx, img, n, C, 0, H, W, (trem / tiles_x) * 16, (trem % tiles_x) * 16, true);
-    image_land<K, HOIST>(T, nx);
+    image_land<K, HOIST, 16, U8>(T, nx, 1.f, lut);
     if (MULTI) stage_weights(0);
   }
   for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
@@ -234,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
         image_request<K, PAD, false>(nx, img, n2, C, cg2, H, W, (trem2 / tiles_x) * 16, (trem2 % tiles_x) * 16, tile2 < ntiles);
       } else {
         image_request<K, PAD, false>(nx, img, n, C, cg, H, W, oy0, ox0, true);
-        image_land<K, HOIST>(T, nx);
+        image_land<K, HOIST, 16, U8>(T, nx, 1.f, lut);
         if (MULTI) stage_weights(cg);
       }
       if (BNBWD && (!MULTI || cg == 0)) {  // (after the image loads: they are waited for first, these stay in flight behind the MFMAs)
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void skinny_conv_kernel(const float* __rest
       }
       if (PIPE) {
         __syncthreads();  // every wave is done reading T (and Wl): the next window lands
-        image_land<K, HOIST>(T, nx);
+        image_land<K, HOIST, 16, U8>(T, nx, 1.f, lut);
         if (MULTI) stage_weights(cg2);
       }
     }
@@ -437,13 +466,14 @@ __global__ __launch_bounds__(256, 2) void conv1_dgrad_kernel(const float* __rest
 // address-path bound (measured 2 TB/s).  Wave w owns M-tile (w&1), ALL N-tiles and 64 of a half's 128 pixels.
 // Persistent over tiles; each (workgroup, w>>1) writes its own partial [64][NT*32] -> skinny_wgrad_reduce.
 // ------------------------------------------------------------------------------------------------------------------
-template <int K, int PAD, bool FUSED = false>
-__global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __restrict__ img,
+template <int K, int PAD, bool FUSED = false, typename PT = float>
+__global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restrict__ img,
                                                              const float* __restrict__ feat,
                                                              float* __restrict__ partial, int N, int C, int H, int W,
                                                              int HF, int WF, int tiles_y, int tiles_x,
                                                              const float* __restrict__ feat_bnp, const PoolFuse pf, int npg,
-                                                             int dephase) {
+                                                             int dephase, const float* __restrict__ lut = nullptr) {
+  constexpr bool U8 = sizeof(PT) == 1;  // uint8 frames + the normalisation table (image_land)
   // FUSED (K = 7): the feature operand is rebuilt from (y, argmax, dpooled) by the BatchNorm + ReLU + MaxPool backward (PoolFuse)
   // dephase: the second resident workgroup of every CU (blocks >= gridDim.x / 2 of the persistent grid) starts `dephase`
   // x ~8k cycles late, so that its operand-staging phases fall into the other workgroup's MFMA phases instead of both
@@ -456,6 +486,11 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* T = (float*)smem;                  // image window
   float* F = T + Geo<K>::TILE_FLOATS;       // [RPS*16 pixels][64 channels] feature rows of the current stage
+  if constexpr (U8) {  // the normalisation table moves into LDS (published by the first stage's barrier)
+    float* L = F + 128 * 64;
+    for (int i = threadIdx.x; i < 768; i += 256) L[i] = lut[i];
+    lut = L;
+  }
   // A tile is consumed in NSTAGE stages of RPS tile rows (8 = half a tile; 4 for FUSED, whose in-flight state per row is larger)
   constexpr int RPS = FUSED ? 4 : 8, NSTAGE = 16 / RPS;
 
@@ -629,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const float* __res
 #pragma unroll 1
     for (int half = 0; half < NSTAGE; ++half) {
       __syncthreads();
-      if (half == 0) image_land<K, K == 4>(T, ir);
+      if (half == 0) image_land<K, K == 4, 16, U8>(T, ir, 1.f, lut);
       f_resolve();
       __syncthreads();
       if (half + 1 < NSTAGE) f_request(tile, half + 1);
@@ -969,20 +1004,28 @@ constexpr int TP = 49;  // LDS pitch (floats) of one feature pixel's 48 products
 // [g*lpg, (g+1)*lpg): the two frames of a step) -> loss_partial[g][workgroup], summed in a fixed order by srlz_pair_loss_finalize.
 // The passes of srlz_sqdiff_pair_loss (read dec and obs) and srlz_sqdiff_grad_groups (read both again, write the gradient)
 // disappear; the gradient is the stored error times a scalar, applied where the backward kernel stages it (convT_out_bwd_kernel).
-template <bool LOSS>
+// TT = uint8_t: `target` is the observation as the loader's bytes ([N,C,W,H]) and `lut` the normalisation table (image_land<U8>).
+template <bool LOSS, typename TT = float>
 __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ w_ref,
                                                           const float* __restrict__ bias, float* __restrict__ img,
                                                           int N, int C, int H, int W, int HF, int WF, int tiles_y,
                                                           int tiles_x, const float* __restrict__ feat_bnp, int npg,
-                                                          const float* __restrict__ target, float* __restrict__ dec_out,
-                                                          double* __restrict__ loss_partial, int lpg) {
+                                                          const TT* __restrict__ target, float* __restrict__ dec_out,
+                                                          double* __restrict__ loss_partial, int lpg,
+                                                          const float* __restrict__ lut = nullptr) {
+  constexpr bool U8 = sizeof(TT) == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Tt = (float*)smem;  // [304][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int cg = blockIdx.y;
   const int ntiles = N * tiles_y * tiles_x;
+  if constexpr (U8) {  // the normalisation table moves into LDS (published by the tile loop's first barrier)
+    float* L = Tt + 304 * TP;
+    for (int i = threadIdx.x; i < 768; i += 256) L[i] = lut[i];
+    lut = L;
+  }
 
   // B fragments: breg[co][c][r] = w_ref[ci = 16c + 4kq + r][cg*3 + co][tap = li]
   f32x4 breg[3][4];
@@ -1064,7 +1107,8 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
         for (int i = 0; i < 4; ++i) {
           const int oy = 2 * a0 + rg_ + 8 * i, ox = 2 * b0 + oxl_;
           const bool ok = oy < H && ox < W;
-          tg[LOSS ? co * 4 + i : 0] = target[ok ? ((size_t)(n * C + cg * 3 + co) * H + oy) * W + ox : (size_t)0];
+          const TT raw = target[ok ? ((size_t)(n * C + cg * 3 + co) * H + oy) * W + ox : (size_t)0];
+          if constexpr (U8) tg[LOSS ? co * 4 + i : 0] = __uint_as_float((unsigned)raw); else tg[LOSS ? co * 4 + i : 0] = raw;
         }
       __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the requests next to their use, behind the MFMA phase)
     }
@@ -1107,6 +1151,12 @@ __global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restri
     if (LOSS) {  // every target load is waited for HERE, once, outside the branches that hold the stores
 #pragma unroll
       for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(tg[LOSS ? j : 0]));
+      if constexpr (U8) {  // bytes -> normalised observation (all 12 look-ups requested together)
+#pragma unroll
+        for (int j = 0; j < 12; ++j) tg[LOSS ? j : 0] = lut[(j >> 2) * 256 + (int)__float_as_uint(tg[LOSS ? j : 0])];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(tg[LOSS ? j : 0]));  // (and waited for, once, like the bytes above)
+      }
     }
 #pragma unroll
     for (int co = 0; co < 3; ++co) {
@@ -1205,22 +1255,22 @@ static int persistent_grid(int ntiles, bool wgrad = false) {
   return g > ntiles ? ntiles : g;
 }
 
-template <int K, int PAD>
-static int launch_conv(const float* img, const float* w, float* feat, float* stats, const srlz_skinny_desc* d, hipStream_t st,
-                       const float* y_raw = nullptr, const float* y_bnp = nullptr) {
+template <int K, int PAD, typename PT = float>
+static int launch_conv(const PT* img, const float* w, float* feat, float* stats, const srlz_skinny_desc* d, hipStream_t st,
+                       const float* y_raw = nullptr, const float* y_bnp = nullptr, const float* lut = nullptr) {
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
   const bool multi = d->c > 3;
   const dim3 grid(persistent_grid(ntiles)), block(256);
 #define SRLZ_CONV_LAUNCH(BN, MU, PIPED)                                                                                   \
   do {                                                                                                                    \
-    const size_t lds = conv_lds<K>(PIPED);                                                                                \
-    SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, BN, MU>), lds);                                                              \
-    hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, BN, MU>), grid, block, lds, st, img, w, feat, stats, d->n, d->c,       \
-                       d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp, images_per_group(d));                        \
+    const size_t lds = conv_lds<K>(PIPED) + (sizeof(PT) == 1 ? 768 * 4 : 0);                                              \
+    SRLZ_MAX_LDS((skinny_conv_kernel<K, PAD, BN, MU, PT>), lds);                                                          \
+    hipLaunchKernelGGL((skinny_conv_kernel<K, PAD, BN, MU, PT>), grid, block, lds, st, img, w, feat, stats, d->n, d->c,   \
+                       d->himg, d->wimg, d->hf, d->wf, ty, tx, y_raw, y_bnp, images_per_group(d), lut);                   \
   } while (0)
   bool launched = false;
-  if constexpr (K == 4) if (y_raw) {
+  if constexpr (K == 4 && sizeof(PT) == 4) if (y_raw) {
     if (multi) SRLZ_CONV_LAUNCH(true, true, false); else SRLZ_CONV_LAUNCH(true, false, false);
     launched = true;
   }
@@ -1240,29 +1290,29 @@ static size_t wgrad_ws(const srlz_skinny_desc* d) {
   return (size_t)(d->c / 3) * g * 2 * 64 * NT * 32 * sizeof(float) + (size_t)d->n * d->c * sizeof(double);
 }
 
-template <int K, int PAD>
-static int launch_wgrad(const float* img, const float* feat, float* dw, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
-                        hipStream_t st, const float* feat_bnp = nullptr, const PoolFuse* pfuse = nullptr) {
+template <int K, int PAD, typename PT = float>
+static int launch_wgrad(const PT* img, const float* feat, float* dw, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
+                        hipStream_t st, const float* feat_bnp = nullptr, const PoolFuse* pfuse = nullptr, const float* lut = nullptr) {
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
   const int g = persistent_grid(ntiles, true);
   SRLZ_REQUIRE(ws_bytes >= wgrad_ws<K>(d), SRLZ_ERR_WORKSPACE, "skinny wgrad: workspace too small (%zu)", ws_bytes);
   SRLZ_REQUIRE(K == 4 || feat_bnp == nullptr, SRLZ_ERR_BAD_DESC, "skinny wgrad: a fused forward operand exists for the 4x4 layer only");
-  const size_t lds = (size_t)(Geo<K>::TILE_FLOATS + 128 * 64) * 4;
+  const size_t lds = (size_t)(Geo<K>::TILE_FLOATS + 128 * 64) * 4 + (sizeof(PT) == 1 ? 768 * 4 : 0);
   float* partial = (float*)ws;
   PoolFuse pf = {};
   if (pfuse) pf = *pfuse;
   static const int dephase = [] { const char* e = getenv("SRLZ_DEPHASE"); return e ? atoi(e) : 0; }();
   bool launched = false;
   if constexpr (K == 7) if (pf.y) {
-    hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD, true>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase);
+    hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD, true, PT>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
+                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase, lut);
     launched = true;
   }
   if (!launched)
-    hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD, false>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase);
+    hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD, false, PT>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
+                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase, lut);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + WRED_OUTS - 1) / WRED_OUTS), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
@@ -1284,6 +1334,14 @@ extern "C" int srlz_conv1_fwd(const float* x_nchw, const float* w_ref, float* y_
   SRLZ_REQUIRE(d->kind == 0, SRLZ_ERR_BAD_DESC, "conv1_fwd: descriptor kind must be 0");
   SRLZ_REQUIRE(x_nchw && w_ref && y_nhwc, SRLZ_ERR_NULL, "conv1_fwd: null pointer");
   return launch_conv<7, 3>(x_nchw, w_ref, y_nhwc, stats_partial, d, as_stream(stream));
+}
+
+extern "C" int srlz_conv1_fwd_u8(const uint8_t* x_u8, const float* norm_lut, const float* w_ref, float* y_nhwc,
+                                 float* stats_partial, const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = check_skinny(d)) return rc;
+  SRLZ_REQUIRE(d->kind == 0, SRLZ_ERR_BAD_DESC, "conv1_fwd_u8: descriptor kind must be 0");
+  SRLZ_REQUIRE(x_u8 && norm_lut && w_ref && y_nhwc, SRLZ_ERR_NULL, "conv1_fwd_u8: null pointer");
+  return launch_conv<7, 3, uint8_t>(x_u8, w_ref, y_nhwc, stats_partial, d, as_stream(stream), nullptr, nullptr, norm_lut);
 }
 
 extern "C" size_t srlz_skinny_bwd_weight_workspace(const srlz_skinny_desc* d) {
@@ -1314,10 +1372,11 @@ extern "C" int srlz_conv1_bwd_weight(const float* x_nchw, const float* dy_nhwc, 
   return launch_wgrad<7, 3>(x_nchw, dy_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream));
 }
 
-extern "C" int srlz_conv1_bwd_weight_fused(const float* x_nchw, const float* y_nhwc, const float* bnp, const uint8_t* argmax,
-                                           const float* dpooled, const float* sums, int training, float* dw_ref, void* ws,
-                                           size_t ws_bytes, const srlz_skinny_desc* d, const srlz_pool_desc* pd,
-                                           srlz_stream_t stream) {
+template <typename PT>
+static int conv1_bwd_weight_fused(const PT* x_nchw, const float* lut, const float* y_nhwc, const float* bnp, const uint8_t* argmax,
+                                  const float* dpooled, const float* sums, int training, float* dw_ref, void* ws,
+                                  size_t ws_bytes, const srlz_skinny_desc* d, const srlz_pool_desc* pd,
+                                  srlz_stream_t stream) {
   if (int rc = check_skinny(d)) return rc;
   SRLZ_REQUIRE(d->kind == 0 && pd, SRLZ_ERR_BAD_DESC, "conv1_bwd_weight_fused: descriptor kind must be 0");
   SRLZ_REQUIRE(x_nchw && y_nhwc && bnp && argmax && dpooled && sums && dw_ref && ws, SRLZ_ERR_NULL,
@@ -1329,7 +1388,24 @@ extern "C" int srlz_conv1_bwd_weight_fused(const float* x_nchw, const float* y_n
   pf.y = y_nhwc; pf.argmax = argmax; pf.dpooled = dpooled; pf.bnp = bnp; pf.sums = sums;
   pf.HP = pd->hp; pf.WP = pd->wp; pf.pad = pd->pool_pad; pf.training = training;
   pf.inv_count = 1.0f / (float)((double)images_per_group(d) * d->hf * d->wf);  // BatchNorm count of ONE group
-  return launch_wgrad<7, 3>(x_nchw, y_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream), nullptr, &pf);
+  return launch_wgrad<7, 3, PT>(x_nchw, y_nhwc, dw_ref, ws, ws_bytes, d, as_stream(stream), nullptr, &pf, lut);
+}
+
+extern "C" int srlz_conv1_bwd_weight_fused(const float* x_nchw, const float* y_nhwc, const float* bnp, const uint8_t* argmax,
+                                           const float* dpooled, const float* sums, int training, float* dw_ref, void* ws,
+                                           size_t ws_bytes, const srlz_skinny_desc* d, const srlz_pool_desc* pd,
+                                           srlz_stream_t stream) {
+  return conv1_bwd_weight_fused<float>(x_nchw, nullptr, y_nhwc, bnp, argmax, dpooled, sums, training, dw_ref, ws, ws_bytes, d, pd,
+                                       stream);
+}
+
+extern "C" int srlz_conv1_bwd_weight_fused_u8(const uint8_t* x_u8, const float* norm_lut, const float* y_nhwc, const float* bnp,
+                                              const uint8_t* argmax, const float* dpooled, const float* sums, int training,
+                                              float* dw_ref, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
+                                              const srlz_pool_desc* pd, srlz_stream_t stream) {
+  SRLZ_REQUIRE(norm_lut, SRLZ_ERR_NULL, "conv1_bwd_weight_fused_u8: null normalisation table");
+  return conv1_bwd_weight_fused<uint8_t>(x_u8, norm_lut, y_nhwc, bnp, argmax, dpooled, sums, training, dw_ref, ws, ws_bytes, d, pd,
+                                         stream);
 }
 
 extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
@@ -1353,9 +1429,10 @@ extern "C" int srlz_convT_out_fwd_loss_workgroups(const srlz_skinny_desc* d) {
   return persistent_grid(d->n * ty * tx) * (d->c / 3);
 }
 
-extern "C" int srlz_convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const float* target_nchw,
-                                       float* err_nchw, float* dec_nchw, const float* x_bnp, double* loss_partial,
-                                       const srlz_skinny_desc* d, srlz_stream_t stream) {
+template <typename TT>
+static int convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const TT* target_nchw, const float* lut,
+                              float* err_nchw, float* dec_nchw, const float* x_bnp, double* loss_partial,
+                              const srlz_skinny_desc* d, srlz_stream_t stream) {
   if (int rc = check_skinny(d)) return rc;
   SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: descriptor kind must be 1");
   SRLZ_REQUIRE(x_nhwc && w_ref && target_nchw && err_nchw && loss_partial, SRLZ_ERR_NULL, "convT_out_fwd_loss: null pointer");
@@ -1363,12 +1440,26 @@ extern "C" int srlz_convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, 
   SRLZ_REQUIRE((((uintptr_t)loss_partial) & 7) == 0, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: unaligned partial buffer");
   const int ty = (d->himg / 2 + 15) / 16, tx = (d->wimg / 2 + 15) / 16;
   const int ntiles = d->n * ty * tx;
-  const size_t lds = (size_t)304 * TP * 4;
-  hipLaunchKernelGGL(convT_out_kernel<true>, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
+  const size_t lds = (size_t)304 * TP * 4 + (sizeof(TT) == 1 ? 768 * 4 : 0);
+  SRLZ_MAX_LDS((convT_out_kernel<true, TT>), lds);
+  hipLaunchKernelGGL((convT_out_kernel<true, TT>), dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
                      w_ref, bias, err_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp, images_per_group(d),
-                     target_nchw, dec_nchw, loss_partial, d->n / 2);
+                     target_nchw, dec_nchw, loss_partial, d->n / 2, lut);
   SRLZ_LAUNCHED();
   return 0;
+}
+
+extern "C" int srlz_convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const float* target_nchw,
+                                       float* err_nchw, float* dec_nchw, const float* x_bnp, double* loss_partial,
+                                       const srlz_skinny_desc* d, srlz_stream_t stream) {
+  return convT_out_fwd_loss<float>(x_nhwc, w_ref, bias, target_nchw, nullptr, err_nchw, dec_nchw, x_bnp, loss_partial, d, stream);
+}
+
+extern "C" int srlz_convT_out_fwd_loss_u8(const float* x_nhwc, const float* w_ref, const float* bias, const uint8_t* target_u8,
+                                          const float* norm_lut, float* err_nchw, float* dec_nchw, const float* x_bnp,
+                                          double* loss_partial, const srlz_skinny_desc* d, srlz_stream_t stream) {
+  SRLZ_REQUIRE(norm_lut, SRLZ_ERR_NULL, "convT_out_fwd_loss_u8: null normalisation table");
+  return convT_out_fwd_loss<uint8_t>(x_nhwc, w_ref, bias, target_u8, norm_lut, err_nchw, dec_nchw, x_bnp, loss_partial, d, stream);
 }
 
 extern "C" int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,

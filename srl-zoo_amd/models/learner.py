@@ -74,7 +74,19 @@ class _DeviceFeed(object):
             self.exhausted = True
             return None
         with th.cuda.stream(self.copy):
-            moved = tuple(t.to(self.device, non_blocking=True) if th.is_tensor(t) else t for t in item)
+            # (idx, obs, next_obs, ...): the two frames land as the halves of ONE device buffer, which is how the batched
+            # model call and the pair-aware losses want them (BaseLearner._toDevicePair then has nothing to copy)
+            pair = len(item) >= 3 and th.is_tensor(item[1]) and th.is_tensor(item[2]) and item[1].shape == item[2].shape \
+                and item[1].dtype == item[2].dtype and item[1].dim() == 4
+            moved = [t.to(self.device, non_blocking=True) if th.is_tensor(t) and not (pair and i in (1, 2)) else t
+                     for i, t in enumerate(item)]
+            if pair:
+                n = item[1].shape[0]
+                both = th.empty((2 * n,) + tuple(item[1].shape[1:]), dtype=item[1].dtype, device=self.device)
+                both[:n].copy_(item[1], non_blocking=True)
+                both[n:].copy_(item[2], non_blocking=True)
+                moved[1], moved[2] = both[:n], both[n:]
+            moved = tuple(moved)
         done = th.cuda.Event()
         done.record(self.copy)
         return moved, done
@@ -122,13 +134,22 @@ class BaseLearner(object):
             th.cuda.manual_seed(seed)
         self.device = th.device("cuda" if th.cuda.is_available() and cuda else "cpu")
 
+    @staticmethod
+    def _isPlanar(frames):
+        """uint8 frames [B, C, W, H] (DataLoader(raw_uint8="planar")) as opposed to [B, H, W, C] (raw_uint8=True)."""
+        return frames.dtype == th.uint8 and frames.dim() == 4 and frames.shape[1] in (3, 6, 9) and frames.shape[3] not in (3, 6, 9)
+
+    def _readsBytes(self):
+        """Whether the training step can take the loader's bytes as they are (subclasses that own such a step say so)."""
+        return False
+
     def _toDevice(self, frames):
-        """Loader minibatch -> observation tensor on the device.  uint8 frames (DataLoader(raw_uint8=True)) are
-        normalised and laid out by the GPU; float tensors are the reference's ready-made observations."""
+        """Loader minibatch -> observation tensor on the device.  uint8 frames (DataLoader(raw_uint8=...)) are
+        normalised (and, for [B, H, W, C] frames, laid out) by the GPU; float tensors are the reference's ready-made observations."""
         frames = frames.to(self.device, non_blocking=True)
         if frames.dtype == th.uint8:
             from srlz import ops
-            frames = ops.normalize_u8(frames)
+            frames = ops.frames_as_float(frames) if self._isPlanar(frames) else ops.normalize_u8(frames)
         return frames
 
     def _toDevicePair(self, frames, next_frames):
@@ -140,7 +161,22 @@ class BaseLearner(object):
         if frames.shape != next_frames.shape:
             return self._toDevice(frames), self._toDevice(next_frames)
         n = frames.shape[0]
-        if frames.dtype == th.uint8:
+        if self._isPlanar(frames):
+            # the reference's layout already, still bytes: a step whose only readers of the observations are conv1 and the fused
+            # reconstruction loss takes them as they are (srlz_conv1_fwd_u8 ...); anything else gets the float tensor
+            keep = self._readsBytes()
+            if keep and frames.is_contiguous() and next_frames.is_contiguous() \
+                    and frames.untyped_storage().data_ptr() == next_frames.untyped_storage().data_ptr() \
+                    and next_frames.storage_offset() == frames.storage_offset() + frames.numel():
+                return frames, next_frames  # (the feed delivered them as one buffer already)
+            both = th.empty((2 * n,) + tuple(frames.shape[1:]), dtype=th.uint8 if keep else th.float32, device=self.device)
+            if keep:
+                both[:n].copy_(frames, non_blocking=True)
+                both[n:].copy_(next_frames, non_blocking=True)
+            else:
+                ops.frames_as_float(frames, out=both[:n])
+                ops.frames_as_float(next_frames, out=both[n:])
+        elif frames.dtype == th.uint8:
             _, h, w, c = frames.shape
             both = th.empty((2 * n, c, w, h), dtype=th.float32, device=self.device)
             ops.normalize_u8(frames, out=both[:n])
@@ -311,6 +347,18 @@ class SRL4robotics(BaseLearner):
         if self.rank == 0:
             th.save(OrderedDict((k, v.cpu()) for k, v in sd.items()), path)
 
+    def _readsBytes(self):
+        """True when the ONLY readers of the step's observations are the first convolution (forward and weight gradient) and the
+        reconstruction / generation loss inside the last ConvTranspose — the kernels that take the loader's uint8 frames as they
+        are (ops.EncInFn / ops.DecOutLossFn): the default AE / VAE / priors steps of the custom_cnn models.  Everything else
+        (DAE noise, perceptual loss, triplets, the ResNet trunks, graph replay, the A/B switches that undo those fusions) gets the
+        normalised float tensor (ops.frames_as_float)."""
+        from srlz import hotpath
+        return (RAW_UINT8_INPUT and self.model_type == "custom_cnn" and self._use_pair and self._frame_streams is None
+                and not self._use_graph and not self.use_triplets and not self.use_dae
+                and not (self.use_vae and self.perceptual_similarity_loss)
+                and hotpath._FUSE_RECON and hotpath._FUSE_ENC_IN and hotpath.TAPS is None)
+
     def _forwardPair(self, x, next_x, recon=None):
         """(self.model(x), self.model(next_x)) — in that program order for the BatchNorm running statistics — as ONE batched
         model call with two BatchNorm groups when possible.
@@ -430,6 +478,9 @@ class SRL4robotics(BaseLearner):
         self.optimizer.zero_grad()
         loss_manager.resetLosses()
 
+        from srlz import ops
+        if ops.is_u8_frames(obs) and not self._readsBytes():
+            obs, next_obs = ops.frames_as_float(obs), ops.frames_as_float(next_obs)
         decoded_obs = decoded_next_obs = None
         recon_loss = None  # the reconstruction / generation loss when it was taken inside the last ConvTranspose
         if self.use_triplets:
@@ -480,7 +531,7 @@ class SRL4robotics(BaseLearner):
             # (decoded_* hold the error dec - obs here, not the reconstruction: the loss came out of the decoder's last kernel)
             loss_manager.addToLosses('reconstruction_loss', w["dae" if self.use_dae else "autoencoder"], recon_loss)
         elif self.use_autoencoder or self.use_dae:
-            autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs,
+            autoEncoderLoss(ops.frames_as_float(obs), decoded_obs, ops.frames_as_float(next_obs), decoded_next_obs,
                             weight=w["dae" if self.use_dae else "autoencoder"], loss_manager=loss_manager)
         if self.use_vae:
             kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager=loss_manager, beta=self.beta)
@@ -491,7 +542,8 @@ class SRL4robotics(BaseLearner):
             elif recon_loss is not None:
                 loss_manager.addToLosses('generation_loss', w['vae'], recon_loss)
             else:
-                generationLoss(decoded_obs, decoded_next_obs, obs, next_obs, weight=w['vae'], loss_manager=loss_manager)
+                generationLoss(decoded_obs, decoded_next_obs, ops.frames_as_float(obs), ops.frames_as_float(next_obs),
+                               weight=w['vae'], loss_manager=loss_manager)
 
         if self.use_triplets:
             tripletLoss(states, positive_states, negative_states, weight=w['triplet'], loss_manager=loss_manager, alpha=0.2)
@@ -499,7 +551,6 @@ class SRL4robotics(BaseLearner):
         # LossManager.computeTotalLoss() as one launch, which also drops the step's scalars [total, l_0, l_1, ...] into the tail
         # of the gradient bucket: with several GPUs every rank reads the SAME (mean) losses back, so the NaN exit and the
         # best-model decision are taken by all ranks together
-        from srlz import ops
         if len(loss_manager.losses) >= self.flat_params.TAIL:
             # (the step's scalars — total first — ride in the TAIL slots behind the gradients, whichever branch runs below)
             raise ValueError("a training step carries at most {} loss terms (got {}: {})".format(
@@ -579,12 +630,13 @@ class SRL4robotics(BaseLearner):
         data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
                                  use_triplets=self.use_triplets, is_training=True, apply_occlusion=self.use_dae,
                                  occlusion_percentage=self.occlusion_percentage, rank=self.rank,
-                                 world_size=self.world_size, val_indices=val_indices, raw_uint8=RAW_UINT8_INPUT and not self.use_dae)
+                                 world_size=self.world_size, val_indices=val_indices,
+                                 raw_uint8="planar" if RAW_UINT8_INPUT and not self.use_dae else False)
         test_data_loader = DataLoader(test_minibatchlist, images_path, n_workers=N_WORKERS,
                                       multi_view=self.multi_view, use_triplets=self.use_triplets, max_queue_len=1,
                                       is_training=False, apply_occlusion=self.use_dae,
                                       occlusion_percentage=self.occlusion_percentage,
-                                      raw_uint8=RAW_UINT8_INPUT and not self.use_dae)
+                                      raw_uint8="planar" if RAW_UINT8_INPUT and not self.use_dae else False)
 
         loss_history = defaultdict(list)
         loss_manager = LossManager(self.model, loss_history)

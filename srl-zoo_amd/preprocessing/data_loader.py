@@ -135,9 +135,12 @@ class DataLoader(object):
         :param apply_occlusion: (bool) also produce occluded copies (DAE)
         :param occlusion_percentage: (float)
         :param rank, world_size: data-parallel shard of the per-epoch permutation
-        :param raw_uint8: yield the decoded frames as uint8 [B, H, W, C] instead of normalised float32 [B, C, W, H]:
-                          the learner then normalises / transposes on the GPU (srlz_normalize_u8, bit-identical) and
-                          only a quarter of the bytes cross PCIe.  Not available with occlusion (DAE).
+        :param raw_uint8: yield the decoded frames as uint8 instead of normalised float32 [B, C, W, H], so that only a
+                          quarter of the bytes cross PCIe.  True: [B, H, W, C] as decoded — the learner normalises and
+                          transposes on the GPU (srlz_normalize_u8, bit-identical).  "planar": [B, C, W, H], i.e. the
+                          reference's transpose(0, 3, 2, 1) (data_loader.py:255) applied by the worker to the uint8 frame —
+                          the first convolution and the reconstruction loss then read the bytes themselves (srlz_conv1_fwd_u8
+                          ...), no normalisation pass.  Not available with occlusion (DAE).
         :param val_indices: minibatch ids used for validation; with world_size > 1 training and validation
                             minibatches are sharded separately (train first) so all ranks stay in lock-step
         """
@@ -225,7 +228,7 @@ class DataLoader(object):
     def _makeBatchElement(cls, image_path, multi_view=False, use_triplets=False, apply_occlusion=False,
                           occlusion_percentage=None, raw_uint8=False):
         """One image path (without 'data/' prefix, '.jpg' optional) -> float32 tensor [1, C, W, H]
-        (raw_uint8: the decoded RGB frame(s) as uint8 [1, H, W, C])."""
+        (raw_uint8: the decoded RGB frame(s) as uint8 [1, H, W, C]; "planar": [1, C, W, H])."""
         stem = 'data/' + image_path.split('.jpg')[0]
         names = ["{}_{}.jpg".format(stem, i + 1) for i in range(2)] if multi_view else ["{}.jpg".format(stem)]
         occlude = [apply_occlusion] * len(names)
@@ -247,6 +250,8 @@ class DataLoader(object):
                 raise ValueError("tried to load {}, but it was not found".format(name))
             views.append(np.ascontiguousarray(rgb) if raw_uint8 else _normalised(rgb, occ, occlusion_percentage))
         im = np.dstack(views) if multi_view else views[0]
+        if raw_uint8 == "planar":
+            return th.from_numpy(np.ascontiguousarray(im.transpose(2, 1, 0)).reshape((1, im.shape[2], im.shape[1], im.shape[0])))
         if raw_uint8:
             return th.from_numpy(np.ascontiguousarray(im).reshape((1,) + im.shape))
         # channel first + batch dim; note the (W, H) order of the last two axes

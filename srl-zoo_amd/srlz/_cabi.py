@@ -81,6 +81,11 @@ _PROTOS = {
     "srlz_triplet_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "srlz_skinny_tiles": (c_int, [_SK]),
     "srlz_conv1_fwd": (c_int, [P, P, P, P, _SK, P]),
+    "srlz_conv1_fwd_u8": (c_int, [P, P, P, P, P, _SK, P]),
+    "srlz_conv1_bwd_weight_fused_u8": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_size_t, _SK, _PD, P]),
+    "srlz_convT_out_fwd_loss_u8": (c_int, [P, P, P, P, P, P, P, P, P, _SK, P]),
+    "srlz_normalize_lut": (c_int, [P, P]),
+    "srlz_normalize_u8_planar": (c_int, [P, P, P, c_int, c_int, c_longlong, P]),
     "srlz_skinny_bwd_weight_workspace": (c_size_t, [_SK]),
     "srlz_conv1_bwd_weight": (c_int, [P, P, P, P, c_size_t, _SK, P]),
     "srlz_conv1_bwd_data": (c_int, [P, P, P, _SK, P]),

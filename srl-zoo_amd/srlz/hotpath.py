@@ -63,6 +63,8 @@ def _bn_args(bn):
 def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
     """models/models.py:47-63.  x: [N,C,H,W] (reference layout) -> [N,64,6,6] (NCHW, ready for .view(N,-1))."""
     conv1, bn1, conv2, bn2, conv3, bn3 = seq[0], seq[1], seq[4], seq[5], seq[8], seq[9]
+    if not _FUSE_ENC_IN:
+        x = ops.frames_as_float(x)  # (only the fused first block reads the loader's bytes)
     if _FUSE_ENC_IN and not x.requires_grad:  # (an image that carries a gradient needs conv1's data gradient: plain chain)
         p, y = ops.EncInFn.apply(x, conv1.weight, *_bn_args(bn1), training, 1, stat_sink)
         _tap(name, 0, y)
@@ -181,6 +183,7 @@ def resnet18_forward(trunk, x, training):
     """torchvision resnet18 up to (and including) avgpool: x [B,3,224,224] (reference layout) -> [B,512] features.
     Forward only (the trunk is frozen, reference models/triplet.py:17-19): runs under no_grad, the result carries no
     gradient.  `training` selects BatchNorm's mode exactly as nn.Module.train()/eval() would."""
+    x = ops.frames_as_float(x)
     require_gpu(x, "resnet18 trunk")
     with torch.no_grad():
         x = ops._check(x, "resnet18 input")

@@ -192,6 +192,51 @@ def _check(t, name):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# uint8 frames: observations that are still the loader's bytes, [N,C,W,H] planar (the reference's tensor layout,
+# preprocessing/data_loader.py:255, before preprocessInput).  conv1 (forward, fused weight gradient) and the fused reconstruction
+# loss normalise them through a 3 x 256 table while they stage their windows; everything else asks for the float tensor.
+# ----------------------------------------------------------------------------------------------------------------
+_NORM_LUT = {}
+
+
+def norm_lut(device):
+    """((v / 255) - mean[c]) / std[c] for v = 0..255, c = R, G, B (preprocessing/utils.py:20-32), one table per device."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    lut = _NORM_LUT.get(key)
+    if lut is None:
+        lut = torch.empty((3, 256), dtype=torch.float32, device=device)
+        C.normalize_lut(ptr(lut), stream())
+        _NORM_LUT[key] = lut
+    return lut
+
+
+def is_u8_frames(t):
+    return isinstance(t, torch.Tensor) and t.dtype == torch.uint8
+
+
+def _check_u8(t, name):
+    if t.device.type != "cuda":
+        raise C.SrlzError("%s must live on the GPU: the srl-zoo_amd hot path has no CPU fallback" % name)
+    if t.dim() != 4 or t.shape[1] not in (3, 6, 9):
+        raise C.SrlzError("%s: uint8 frames must be [N,C,W,H] planar with C in (3, 6, 9), got %s" % (name, tuple(t.shape)))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def frames_as_float(frames, out=None):
+    """uint8 [N,C,W,H] planar frames -> the normalised fp32 observation tensor (float tensors pass through)."""
+    if not is_u8_frames(frames):
+        return frames
+    frames = _check_u8(frames, "frames")
+    n, c = frames.shape[:2]
+    if out is None:
+        out = torch.empty(frames.shape, dtype=torch.float32, device=frames.device)
+    elif tuple(out.shape) != tuple(frames.shape) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise C.SrlzError("frames_as_float: `out` must be a contiguous float32 tensor of the frames' shape")
+    C.normalize_u8_planar(ptr(frames), ptr(norm_lut(frames.device)), ptr(out), n, c, frames[0, 0].numel(), stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # conv1: nn.Conv2d(C, 64, 7, stride 2, pad 3, bias=False) — models/models.py:49
 # ----------------------------------------------------------------------------------------------------------------
 def _skinny_desc(n, c, himg, wimg, kind, groups=1):
@@ -386,12 +431,16 @@ class EncInFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, running_mean, running_var, training, pool_pad, stat_sink):
-        x, w = _check(x, "conv1 input"), _check(w, "conv1 weight")
+        u8 = is_u8_frames(x)  # the loader's bytes: normalised inside the kernels' window staging
+        x, w = (_check_u8(x, "conv1 input") if u8 else _check(x, "conv1 input")), _check(w, "conv1 weight")
         n, c, h, wd = x.shape
         d = _skinny_desc(n, c, h, wd, 0, cur_groups(training))
         y = torch.empty((n, d.hf, d.wf, 64), dtype=torch.float32, device=x.device)
         stats = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=x.device) if training else None
-        C.conv1_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), d, stream())
+        if u8:
+            C.conv1_fwd_u8(ptr(x), ptr(norm_lut(x.device)), ptr(w), ptr(y), ptr(stats), d, stream())
+        else:
+            C.conv1_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), d, stream())
         hp, wp = (d.hf + 2 * pool_pad - 3) // 2 + 1, (d.wf + 2 * pool_pad - 3) // 2 + 1
         pd = PoolDesc(n, d.hf, d.wf, hp, wp, pool_pad, 0, cur_groups(training))
         bnp, batch_stat = _bn_params(stats, n * d.hf * d.wf, gamma, beta, running_mean, running_var, training, x.device)
@@ -424,8 +473,12 @@ class EncInFn(Function):
         dw = _gbuf(w)
         nbytes = C.skinny_bwd_weight_workspace(ctx.desc)
         ws = _ws(nbytes, dev)
-        C.conv1_bwd_weight_fused(ptr(x), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums), 1 if ctx.training else 0,
-                                 ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc, stream())
+        if is_u8_frames(x):
+            C.conv1_bwd_weight_fused_u8(ptr(x), ptr(norm_lut(dev)), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums),
+                                        1 if ctx.training else 0, ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc, stream())
+        else:
+            C.conv1_bwd_weight_fused(ptr(x), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums), 1 if ctx.training else 0,
+                                     ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc, stream())
         return None, _give(w, dw), _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None
 
 
@@ -674,7 +727,8 @@ class DecOutLossFn(Function):
     @staticmethod
     def forward(ctx, y_prev, stats_prev, gamma, beta, running_mean, running_var, training, w, bias, in_link, target, mean):
         y_prev, w = _check(y_prev, "decoder output input"), _check(w, "convT_out weight")
-        target = _check(target, "reconstruction target")
+        u8 = is_u8_frames(target)
+        target = _check_u8(target, "reconstruction target") if u8 else _check(target, "reconstruction target")
         n, hf, wf, _ = y_prev.shape
         bnp, _ = _bn_params(stats_prev, n * hf * wf, gamma, beta, running_mean, running_var, training, y_prev.device)
         c = w.shape[1]
@@ -685,7 +739,11 @@ class DecOutLossFn(Function):
         err = torch.empty((n, c, d.himg, d.wimg), dtype=torch.float32, device=y_prev.device)
         nwg = C.convT_out_fwd_loss_workgroups(d)
         part = _ws(2 * nwg * 8, y_prev.device, slot=2)
-        C.convT_out_fwd_loss(ptr(y_prev), ptr(w), ptr(bias), ptr(target), ptr(err), None, ptr(bnp), ptr(part), d, stream())
+        if u8:
+            C.convT_out_fwd_loss_u8(ptr(y_prev), ptr(w), ptr(bias), ptr(target), ptr(norm_lut(y_prev.device)), ptr(err), None,
+                                    ptr(bnp), ptr(part), d, stream())
+        else:
+            C.convT_out_fwd_loss(ptr(y_prev), ptr(w), ptr(bias), ptr(target), ptr(err), None, ptr(bnp), ptr(part), d, stream())
         sums = torch.empty(2, dtype=torch.float32, device=y_prev.device)
         comb = torch.empty((), dtype=torch.float32, device=y_prev.device)
         per_frame = err.numel() // 2
@@ -913,6 +971,14 @@ class SqDiffSumFn(Function):
 # ----------------------------------------------------------------------------------------------------------------
 def pair_cat(a, b):
     """[a ; b] along dim 0.  No copy when b starts where a ends in the same storage."""
+    if is_u8_frames(a) and is_u8_frames(b):  # the loader's bytes: no gradient, any route
+        a, b = _check_u8(a, "pair half"), _check_u8(b, "pair half")
+        if a.shape == b.shape and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() \
+                and b.storage_offset() == a.storage_offset() + a.numel():
+            return torch.empty(0, dtype=a.dtype, device=a.device).set_(a.untyped_storage(), a.storage_offset(),
+                                                                       (2 * a.shape[0],) + tuple(a.shape[1:]))
+        return torch.cat([a, b], 0)
+    a, b = frames_as_float(a), frames_as_float(b)
     a, b = _check(a, "pair half"), _check(b, "pair half")
     if a.shape != b.shape:
         raise C.SrlzError("pair_cat: the two halves differ in shape (%s vs %s)" % (tuple(a.shape), tuple(b.shape)))
@@ -982,7 +1048,8 @@ def pair_of(a, b):
     if ra is not None and ra[1] == 0 and ra[2]() is b:
         return ra[0]
     if torch.is_tensor(a) and torch.is_tensor(b) and not (a.requires_grad or b.requires_grad) and a.is_cuda and b.is_cuda \
-            and a.dtype == torch.float32 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous() \
+            and a.dtype in (torch.float32, torch.uint8) and a.dtype == b.dtype and a.shape == b.shape \
+            and a.is_contiguous() and b.is_contiguous() \
             and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() \
             and b.storage_offset() == a.storage_offset() + a.numel():
         return pair_cat(a, b)  # two adjacent constant tensors (obs, next_obs): a view over both

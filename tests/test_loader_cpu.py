@@ -111,6 +111,19 @@ def test_raw_uint8_stream(dataset):
     with pytest.raises(ValueError):
         DataLoader(ml, paths, is_training=True, raw_uint8=True, apply_occlusion=True)
     del raw
+    # raw_uint8="planar": the same bytes in the reference's tensor layout (transpose(0, 3, 2, 1), data_loader.py:255) — what
+    # learn() ships to the kernels that normalise while staging (srlz_conv1_fwd_u8 ...)
+    for i in (0, 5):
+        a = DataLoader._makeBatchElement(paths[i], raw_uint8=True)
+        b = DataLoader._makeBatchElement(paths[i], raw_uint8="planar")
+        assert b.dtype == torch.uint8 and tuple(b.shape) == (1, 3, 224, 224) and b.is_contiguous()
+        assert torch.equal(b, a.permute(0, 3, 2, 1))
+    planar = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8="planar")
+    idx, obs, next_obs, noisy, next_noisy = next(iter(planar))
+    assert obs.dtype == torch.uint8 and tuple(obs.shape) == (3, 3, 224, 224) and tuple(next_obs.shape) == (3, 3, 224, 224)
+    ref = preprocessInput(obs[1].numpy().transpose(2, 1, 0).astype(np.float32), mode="image_net").transpose(2, 1, 0)
+    np.testing.assert_array_equal(ref, expected_tensor(paths[ml[int(idx)][1]]))
+    del planar
 
 
 def test_triplet_stream(tmp_path):
