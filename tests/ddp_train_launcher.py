@@ -70,7 +70,8 @@ if nan_rank is not None and int(nan_rank) == RANK:
     def poisoned(self, obs, next_obs, *a, **k):
         calls[0] += 1
         if calls[0] == 2:
-            obs = obs.clone()
+            from srlz import ops
+            obs, next_obs = ops.frames_as_float(obs).clone(), ops.frames_as_float(next_obs)  # (learn() feeds the loader's bytes)
             obs[0, 0, 0, 0] = float("nan")
         return real_step(self, obs, next_obs, *a, **k)
     learner.SRL4robotics.trainStep = poisoned
