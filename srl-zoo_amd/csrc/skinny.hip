@@ -134,7 +134,8 @@ __device__ __forceinline__ void image_request(ImgRegs<K, TR>& r, const PT* __res
 // roundings of /root/reference/preprocessing/utils.py:20-32 tabulated once by srlz_normalize_lut (768 floats, L1-resident) — a
 // table because two IEEE divisions per element cost more VALU time than the rest of the landing, and because it makes the
 // bit-for-bit equality with the separate normalisation kernel a matter of construction.
-template <int K, bool HOIST = false, int TR = 16, bool U8 = false>
+// XPV / PPV: row pitch and (channel, column-parity) plane pitch of T (the conv1 weight gradient has its own, see TAP7).
+template <int K, bool HOIST = false, int TR = 16, bool U8 = false, int XPV = XP, int PPV = Geo<K, TR>::PP>
 __device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<K, TR>& r, const float gain = 1.f,
                                            const float* __restrict__ lut = nullptr) {
   float val[ImgRegs<K, TR>::PER];
@@ -156,7 +157,7 @@ __device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<
     // (branch-free — elements past the end of the window go to a spare float of the first plane's padding: a wait inside a branch
     // leaves the compiler unsure, at the join, whether the load has landed, and it then waits for EVERYTHING at the next re-use
     // of the register, including the loads meant to stay in flight)
-    T[live ? (c * 2 + (xl & 1)) * Geo<K, TR>::PP + row * XP + (xl >> 1) : Geo<K, TR>::PP - 1] = ((r.inside >> j) & 1u) ? val[j] : 0.f;
+    T[live ? (c * 2 + (xl & 1)) * PPV + row * XPV + (xl >> 1) : PPV - 1] = ((r.inside >> j) & 1u) ? val[j] : 0.f;
   }
 }
 
@@ -458,6 +459,26 @@ __global__ __launch_bounds__(256, 2) void conv1_dgrad_kernel(const float* __rest
   }
 }
 
+// Column order of conv1's weight-gradient GEMM (K = 7: 147 taps in 5 N-tiles of 32 lanes).  The 32 lanes of a tile read 32
+// DIFFERENT taps of the image window with one ds_read_b32, and with the taps in natural order some two of them always share one of
+// the 32 banks whatever the pitches (a tile spans 4.6 window rows of 7 taps): every operand read took two LDS cycles per lane group
+// — 67 M conflict cycles per launch, 8 % of the kernel's time (profiles/r03d_pmc_mfma.json).  dW's columns can be computed in any order,
+// so the taps are DEALT to the tiles by bank instead: with row pitch 23 and plane pitch 861 no bank holds more than five taps, and
+// tile j takes the j-th tap of every bank (generated by tools/tap_banks.py, which also checks it).  255 = unused lane (it reads its
+// tile's first tap — a broadcast — and its column is not stored).
+constexpr int WG7_XP = 23, WG7_PP = 861;
+__constant__ unsigned char TAP7[160] = {
+      0,   1,   2,   4,   5,   7,   8,  11,  12,  13,  14,  15,  18,  19,  20,  21,
+     25,  27,  28,  32,  33,  35,  42,  58,  59,  89,  96, 108, 124, 138, 255, 255,
+     10,  22,  26,  29,  30,  31,  34,  36,  37,  38,  41,  43,  44,  45,  48,  50,
+     51,  53,  57,  60,  64,  67,  72,  74,  75,  88, 101, 107, 114, 137, 255, 255,
+      9,  23,  39,  49,  54,  55,  56,  61,  62,  63,  68,  69,  70,  71,  76,  77,
+     78,  79,  84,  85,  86,  91,  92,  93, 115, 123, 130, 131, 140, 255, 255, 255,
+      6,  17,  47,  52,  66,  73,  80,  82,  83,  87,  90,  94,  97,  99, 102, 103,
+    104, 106, 109, 110, 111, 113, 116, 117, 118, 121, 125, 141, 144, 255, 255, 255,
+      3,  16,  24,  40,  46,  65,  81,  95,  98, 100, 105, 112, 119, 120, 122, 126,
+    127, 128, 129, 132, 133, 134, 135, 136, 139, 142, 143, 145, 146, 255, 255, 255};
+
 // ------------------------------------------------------------------------------------------------------------------
 // dW[ch][k] = sum_{n,pix} feat[n,pix,ch] * im2col(img)[n,pix,k]     ch in [0,64), k = (c,ky,kx) of channel group cg.
 // GEMM view: M = 64 feature channels (2 M-tiles), N = KT taps (NT tiles of 32), K = pixels.
@@ -501,13 +522,17 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
   const int ntiles = N * tiles_y * tiles_x;
   const int tpi = tiles_y * tiles_x;
 
+  constexpr bool DEALT = (K == 7);  // columns dealt to the N-tiles by LDS bank (TAP7), window pitches of their own
+  constexpr int WXP = DEALT ? WG7_XP : XP, WPP = DEALT ? WG7_PP : Geo<K>::PP;
+  static_assert(6 * WPP <= Geo<K>::TILE_FLOATS && Geo<K>::ROWS * WXP <= WPP - 1, "window does not fit its planes");
   int kb[NT];  // per-lane LDS offset of this lane's tap in N-tile j (+h: the odd pixel of a k-step is one column on)
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int k = j * 32 + l31;
-    const int kk = (k < KT) ? k : 0;
+    int kk = (k < KT) ? k : 0;
+    if constexpr (DEALT) { kk = TAP7[k]; if (kk == 255) kk = TAP7[j * 32]; }
     const int c = kk / (K * K), ky = (kk / K) % K, kx = kk % K;
-    kb[j] = (c * 2 + (kx & 1)) * Geo<K>::PP + ky * XP + (kx >> 1) + h;
+    kb[j] = (c * 2 + (kx & 1)) * WPP + ky * WXP + (kx >> 1) + h;
   }
   f32x16 acc[NT];
 #pragma unroll
@@ -664,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
 #pragma unroll 1
     for (int half = 0; half < NSTAGE; ++half) {
       __syncthreads();
-      if (half == 0) image_land<K, K == 4, 16, U8>(T, ir, 1.f, lut);
+      if (half == 0) image_land<K, K == 4, 16, U8, WXP, WPP>(T, ir, 1.f, lut);
       f_resolve();
       __syncthreads();
       if (half + 1 < NSTAGE) f_request(tile, half + 1);
@@ -678,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
       for (int blk = 0; blk < RPS; ++blk) {
         const int lrow = (RPS / 2) * subu + (blk >> 1), tx0 = 8 * (blk & 1);
         const float* fa = fcol + (lrow * 16 + tx0) * 64;
-        const int boff = 2 * (RPS * half + lrow) * XP + tx0;
+        const int boff = 2 * (RPS * half + lrow) * WXP + tx0;
         float a[4], b[NT][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = fa[2 * i * 64];
@@ -696,10 +721,13 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
   float* out = partial + (((size_t)cg * gridDim.x + blockIdx.x) * 2 + sub) * (64 * NT * 32);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
+    int col = j * 32 + l31;  // the column of dW this lane accumulated (natural tap index; skinny_wgrad_reduce reads columns < KT)
+    if constexpr (DEALT) col = TAP7[col];
+    if (col == 255) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      out[row * (NT * 32) + j * 32 + l31] = acc[j][r];
+      out[row * (NT * 32) + col] = acc[j][r];
     }
   }
 }
