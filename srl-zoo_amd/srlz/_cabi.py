@@ -67,6 +67,7 @@ _PROTOS = {
     "srlz_conv64_debug_program": (c_int, [_C64, c_int, POINTER(c_int), c_int]),
     "srlz_debug_placement": (c_int, [P, c_int, c_int, c_int, P]),
     "srlz_debug_mfma_peak": (c_int, [P, c_int, c_int, P]),
+    "srlz_debug_mfma_valu": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P]),
     "srlz_convn_packed_floats": (c_size_t, [_CN]),
     "srlz_convn_pack_weights": (c_int, [P, P, _CN, P]),
     "srlz_convn_fwd_tiles": (c_int, [_CN]),

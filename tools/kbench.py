@@ -155,6 +155,25 @@ def bench_peak(sel):
         report("fp32 MFMA 32x32x2 peak, %d WG/CU" % per_cu, sec, best, flop=flop)
 
 
+def bench_mfma_valu(sel):
+    """What does an instruction next to fp32 MFMAs cost?  us per launch of 256 x per_cu workgroups, 4 x 4000 MFMAs per wave."""
+    if not sel("valu"):
+        return
+    cus = C.device_cus()
+    names = ["v_fma_f32", "v_add_u32", "v_pk_fma_f32", "v_mov_b32"]
+    iters = 4000
+    out = torch.empty(cus * 2 * 512, device=DEV)
+    for split in (0, 1):
+        for per_cu in ((1, 2) if not split else (1,)):
+            for kind in range(4):
+                row = []
+                for kv in (0, 1, 2, 4, 8, 16):
+                    sec, best = timeit(lambda: C.debug_mfma_valu(C.ptr(out), cus * per_cu, iters, kv, kind, split, C.stream()), reps=3, warm=1)
+                    row.append("%d: %.0f" % (kv, best * 1e6))
+                print("mfma+valu %-12s %s %d WG/CU   us by instructions per MFMA  %s" % (
+                    names[kind], "other wave of the SIMD" if split else "same wave", per_cu, "  ".join(row)))
+
+
 def main():
     keys = [k.lower() for k in sys.argv[1:]]
 
@@ -165,6 +184,7 @@ def main():
         return sel
     print("N = %d images per call, device %s" % (N, torch.cuda.get_device_name(0)))
     bench_peak(group("peak"))
+    bench_mfma_valu(group("mfma"))
     bench_conv64(group("conv64"))
     bench_skinny(group("skinny"))
     bench_bn(group("bn"))
