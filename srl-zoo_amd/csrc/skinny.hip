@@ -114,14 +114,18 @@ template <int K, int PAD, bool HOIST = false, int TR = 16, typename PT = float>
 __device__ __forceinline__ void image_request(ImgRegs<K, TR>& r, const PT* __restrict__ img, int n, int C, int cg, int H,
                                               int W, int oy0, int ox0, bool valid) {
   const int iy0 = 2 * oy0 - PAD, ix0 = 2 * ox0 - PAD;
+  const int plane0 = n * C + cg * 3;  // (uniform)
   r.inside = 0;
 #pragma unroll
   for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) {
     int c, row, xl;
     const bool live = image_decode<K, HOIST, TR>(r, j, c, row, xl);
     const int iy = iy0 + row, ix = ix0 + xl;
-    const bool ok = valid && live && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    const PT raw = img[ok ? ((size_t)(n * C + cg * 3 + c) * H + iy) * W + ix : (size_t)0];
+    // every instruction here is paid for in MFMA time: 32-bit element offsets from the uniform base (the host checks
+    // that the tensor has fewer than 2^31 elements), one unsigned compare per axis, a select instead of a masked 64-bit address chain
+    const bool ok = valid && live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const unsigned off = ((unsigned)(plane0 + c) * (unsigned)H + (unsigned)iy) * (unsigned)W + (unsigned)ix;
+    const PT raw = img[ok ? off : 0u];
     if constexpr (sizeof(PT) == 1) r.v[j] = __uint_as_float((unsigned)raw);  // (the byte load zero-extends: no instruction, no wait)
     else r.v[j] = raw;
     r.inside |= (ok ? 1u : 0u) << j;
@@ -1257,6 +1261,9 @@ __global__ void nchw_chan_sum_final(const double* __restrict__ partial, int N, f
 
 static int check_skinny(const srlz_skinny_desc* d) {
   SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "skinny: null descriptor");
+  SRLZ_REQUIRE((long long)d->n * d->c * d->himg * d->wimg < (1LL << 31), SRLZ_ERR_BAD_DESC,
+               "skinny: image tensor of %lld elements (the window staging keeps 32-bit element offsets)",
+               (long long)d->n * d->c * d->himg * d->wimg);
   SRLZ_REQUIRE(d->n > 0 && d->c > 0 && d->c % 3 == 0 && d->c <= 9, SRLZ_ERR_BAD_DESC, "skinny: C must be 3, 6 or 9 (got %d)", d->c);
   SRLZ_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->n % d->groups == 0), SRLZ_ERR_BAD_DESC,
                "skinny: n = %d is not a multiple of groups = %d", d->n, d->groups);
