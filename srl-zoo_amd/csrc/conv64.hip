@@ -195,6 +195,10 @@ __device__ __forceinline__ OpFuse fuse_for_group(OpFuse f, int grp, long long go
   return f;
 }
 
+// Reciprocals of the virtual grid's PH * PW and PW (fastdiv) for rows64_load.
+struct GridDiv { unsigned mPHW, mPW; int sPHW, sPW; };
+__device__ __forceinline__ GridDiv grid_div(const ConvProg& P) { return GridDiv{P.mPHW, P.mPW, P.sPHW, P.sPW}; }
+
 template <bool SWZ, int BATCH = 8, int NTHREADS = 256, bool BWD = false>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ src, int H, int W,
                                            int stride, int cls, int PW, int PH, int total_q, int qstart,
@@ -213,6 +217,8 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
   const int cy = cls >> 1, cx = cls & 1;
   const int PHW = PH * PW;
   constexpr int RP = NTHREADS / 16;  // rows per pass
+  // (true divisions: with the uniform divisors hipcc keeps one reciprocal per kernel, and fastdiv here measured 0.5 % SLOWER in
+  // conv64_fwd_kernel — unlike in rows64_load, where it is worth 1.5 % of the weight-gradient ring)
   const int sa = RP / PW, sb = RP - sa * PW;
   // shift by one image so the first rows of the first tile (negative q) stay non-negative: n1 = n + 1
   const int qq = qstart + (t >> 4) + PHW;
@@ -1322,17 +1328,18 @@ __device__ __forceinline__ int ring_slot(int q) { return (q + 4 * ROWS) % ROWS; 
 // <J0, NJ>: only this thread's rows J0 .. J0+NJ-1 (v[j - J0]); the other bits of okmask are left alone.
 template <int J0 = 0, int NJ = 4>
 __device__ __forceinline__ void rows64_load(f32x4 (&v)[NJ], unsigned& okmask, const float* __restrict__ src, int H, int W,
-                                            int stride, int cls, int PW, int PH, int total_q, int qstart) {
+                                            int stride, int cls, int PW, int PH, int total_q, int qstart, const GridDiv gd) {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));  // opaque: nothing derived from the thread index here is worth a register across the caller's loops
   const int slot = t & 15;
   const int cy = cls >> 1, cx = cls & 1;
   const int PHW = PH * PW;
-  const int sa = 16 / PW, sb = 16 - sa * PW;
+  // (fastdiv: three true divisions here were ~120 VALU instructions per call — per 64-position chunk and thread)
+  const int sa = fastdiv(16, gd.mPW, gd.sPW), sb = 16 - sa * PW;
   const int qq = qstart + (t >> 4) + PHW;  // shifted by one image: non-negative for the first rows of the first chunk
-  int n1 = qq / PHW;
+  int n1 = fastdiv(qq, gd.mPHW, gd.sPHW);
   int rem = qq - n1 * PHW;
-  int a = rem / PW;
+  int a = fastdiv(rem, gd.mPW, gd.sPW);
   int b = rem - a * PW;
   const int N1max = total_q / PHW;
   if (J0 == 0) okmask = 0;
@@ -1341,9 +1348,9 @@ __device__ __forceinline__ void rows64_load(f32x4 (&v)[NJ], unsigned& okmask, co
     if (j >= J0) {
       v[j - J0] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int y = a * stride + cy, x = b * stride + cx;
-      const bool ok = n1 >= 1 && n1 <= N1max && y < H && x < W;
+      const bool ok = (unsigned)(n1 - 1) < (unsigned)N1max && y < H && x < W;
       okmask |= (ok ? 1u : 0u) << j;
-      if (ok) v[j - J0] = *(const f32x4*)(src + ((size_t)((n1 - 1) * H + y) * W + x) * 64 + slot * 4);
+      if (ok) v[j - J0] = *(const f32x4*)(src + ((((unsigned)(n1 - 1) * (unsigned)H + (unsigned)y) * (unsigned)W + (unsigned)x) * 64u + (unsigned)(slot * 4)));
     }
     b += sb; a += sa;
     if (b >= PW) { b -= PW; ++a; }
@@ -1427,10 +1434,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
     f32x4 v[4];
     unsigned ok;
     for (int r0 = 0; r0 < TK + P.span; r0 += 64) {
-      rows64_load(v, ok, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0);
+      rows64_load(v, ok, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0, grid_div(P));
       rows64_store<true>(Ss, q0 + P.min_off + r0, v, ok, xq);
     }
-    rows64_load(v, ok, g, P.Hd, P.Wd, P.ds, P.tdst[0], P.PW, P.PH, P.total_q, q0);
+    rows64_load(v, ok, g, P.Hd, P.Wd, P.ds, P.tdst[0], P.PW, P.PH, P.total_q, q0, grid_div(P));
     rows64_store<false>(Gs, 0, v, ok, noq);
     bs4 += (v[0] + v[1]) + (v[2] + v[3]);  // (rows outside the tensor are zero)
   }
@@ -1458,9 +1465,9 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
         const int nq0 = last_group ? q0 + TK : q0;
         constexpr int ntap = last_group ? 0 : GSTART[gi + 1];  // first tap of the next class
         const int ncls = P.tdst[ntap];
-        rows64_load(pg, okg, g, P.Hd, P.Wd, P.ds, ncls, P.PW, P.PH, P.total_q, nq0);
+        rows64_load(pg, okg, g, P.Hd, P.Wd, P.ds, ncls, P.PW, P.PH, P.total_q, nq0, grid_div(P));
       }
-      if (want_s) rows64_load<SJ0, SNJ>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span);
+      if (want_s) rows64_load<SJ0, SNJ>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span, grid_div(P));
       // ---- this group's work
       // 8 blocks of 4 k-steps; k-step i of block b multiplies grid rows q0 + 8b + 2i + h.  Per tap the ring slot of row
       // q0 + toff + 8b is wave-uniform (u[t], wrapped with scalar instructions); the 4 rows of a lane are u + h + {0,2,4,6}
@@ -1572,7 +1579,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const floa
   auto g_request = [&](int q0_) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      rows64_load<0, 2>(pg[c], okg[c], g, P.Hd, P.Wd, P.ds, P.tdst[GFIRST[c]], P.PW, P.PH, P.total_q, q0_);
+      rows64_load<0, 2>(pg[c], okg[c], g, P.Hd, P.Wd, P.ds, P.tdst[GFIRST[c]], P.PW, P.PH, P.total_q, q0_, grid_div(P));
   };
   auto g_land = [&]() {
 #pragma unroll
@@ -1584,7 +1591,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const floa
   if (c_begin < c_end) {
     const int q0 = c_begin * TK;
     for (int r0 = 0; r0 < TK + P.span; r0 += 32) {
-      rows64_load<0, 2>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0);
+      rows64_load<0, 2>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + r0, grid_div(P));
       rows64_store<true, 0, 2, RING_ROWS_S2>(Ss, q0 + P.min_off + r0, ps, oks, xq);
     }
     g_request(q0);
@@ -1599,7 +1606,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_s2_kernel(const floa
     const bool more = chunk + 1 < c_end;
     if (more) {
       g_request(q0 + TK);
-      rows64_load<0, 2>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span);
+      rows64_load<0, 2>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span, grid_div(P));
     }
     int u[NTAPS];
 #pragma unroll
@@ -1839,9 +1846,9 @@ __global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restri
     const int q = q0 + tid;
     int n = -1, ya = 0, xb = 0;
     if (q < P.total_q) {
-      n = q / P.PHW;
+      n = fastdiv(q, P.mPHW, P.sPHW);
       const int rem = q - n * P.PHW;
-      const int a = rem / P.PW;
+      const int a = fastdiv(rem, P.mPW, P.sPW);
       ya = a * P.ds;
       xb = (rem - a * P.PW) * P.ds;
     }
