@@ -146,8 +146,13 @@ def test_triplet_stream(tmp_path):
         others = [p for p in paths[:6] if p != paths[2]]  # the other frames of record 0
         assert any(np.allclose(el[0, 6:].numpy(), view(p, 1), atol=1e-6) for p in others)
         assert not np.allclose(el[0, 6:].numpy(), view(paths[2], 1), atol=1e-6)
+        import random
+        random.seed(5)
         raw = DataLoader._makeBatchElement(paths[8], multi_view=True, use_triplets=True, raw_uint8=True)
         assert raw.dtype == torch.uint8 and tuple(raw.shape) == (1, 224, 224, 9)
+        random.seed(5)  # (the negative view is drawn with Python's `random`: same draw -> same frame)
+        planar = DataLoader._makeBatchElement(paths[8], multi_view=True, use_triplets=True, raw_uint8="planar")
+        assert planar.dtype == torch.uint8 and tuple(planar.shape) == (1, 9, 224, 224) and torch.equal(planar, raw.permute(0, 3, 2, 1))
         loader = DataLoader([np.array([0, 1]), np.array([6, 7])], paths, n_workers=2, multi_view=True, use_triplets=True,
                             is_training=True, infinite_loop=False)
         items = list(loader)
