@@ -9,6 +9,11 @@ generation loss, and the whole training step (loss terms, gradient bucket, param
 """
 from collections import OrderedDict
 
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -193,3 +198,36 @@ def test_device_feed_delivers_the_pair_as_one_buffer():
         feed.advance()
     assert [s[0] for s in seen] == [0, 1]
     assert torch.equal(seen[0][1], frames[:4]) and torch.equal(seen[0][2], frames[4:]) and torch.equal(seen[1][1], frames[4:])
+
+
+@pytest.mark.timeout(600)
+def test_full_size_step_on_bytes_bit_for_bit():
+    """BASELINE.json configs[1] at its full size (bs = 256: 512 frames of 224x224x3 per step) fed with bytes vs floats."""
+    B = 256
+    frames = _frames(2 * B, 3, 224, 224, 2024)
+    a = _one_step(["autoencoder"], B, frames, True)
+    b = _one_step(["autoencoder"], B, frames, False)
+    assert a[4] == torch.uint8 and a[0] == b[0] and a[1] == b[1]
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert all(torch.equal(a[5][k], b[5][k]) for k in a[5])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("flag", ["--u8-resident", "--host-input", "--host-input-nhwc"])
+def test_bench_input_modes(flag):
+    """bench.py's input modes (frames as bytes resident in HBM / arriving over PCIe every step / the round-2 NHWC route) run the same
+    step: one JSON line, the contract's fields, a finite loss."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "3", "--warmup", "1", "--batch-size", "8",
+                           "--no-cpu-baseline", "--no-kernel-timers", flag], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=500)
+    assert proc.returncode == 0, proc.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [l for l in proc.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["unit"] == "images/s" and out["dtype"] == "f32"
+    assert np.isfinite(out["config"]["final_loss"])
+    assert ("uint8" in out["data"]) and out["data"].startswith("synthetic")
