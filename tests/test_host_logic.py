@@ -272,3 +272,83 @@ def test_device_feed_protocol(monkeypatch):
         assert seen == [(1, 1.0), (2, 2.0), (3, 3.0)]
         assert feed.exhausted
     assert loader.pulls == 2 * 4  # three minibatches + one end marker per epoch, nothing beyond
+
+
+def _fake_cuda(monkeypatch, learner):
+    class FakeStream(object):
+        def __init__(self, device=None):
+            pass
+
+        def wait_event(self, ev):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    class FakeEvent(object):
+        def record(self, stream):
+            pass
+
+    monkeypatch.setattr(learner.th.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(learner.th.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(learner.th.cuda, "stream", lambda s: s)
+    monkeypatch.setattr(learner.th.cuda, "current_stream", lambda device=None: FakeStream())
+    monkeypatch.setattr(torch.Tensor, "record_stream", lambda self, s: None, raising=False)
+
+
+def test_device_feed_hands_the_two_frames_over_as_one_buffer(monkeypatch):
+    """(idx, obs, next_obs, ...) items: the two frames land as the halves of ONE buffer (what the batched model call and the
+    pair-aware losses want), whatever their dtype; everything else in the item is moved as it is."""
+    import models.learner as learner
+    _fake_cuda(monkeypatch, learner)
+    for dtype in (torch.uint8, torch.float32):
+        obs = (torch.arange(2 * 3 * 4 * 5) % 251).reshape(2, 3, 4, 5).to(dtype)
+        nxt = obs.flip(0).contiguous()
+        items = [(7, obs, nxt, None, None), (8, obs, nxt[:1], None, None)]
+        feed = learner._DeviceFeed(items, "cpu")
+        out = []
+        for item in feed:
+            out.append(item)
+            feed.advance()
+        (i0, a, b, n0, n1), (i1, c, d, _, _) = out
+        assert (i0, i1) == (7, 8) and n0 is None and n1 is None
+        assert torch.equal(a, obs) and torch.equal(b, nxt) and a.dtype == dtype
+        assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and b.storage_offset() == a.numel()
+        assert torch.equal(c, obs) and torch.equal(d, nxt[:1])  # different shapes: moved separately
+        assert c.untyped_storage().data_ptr() != d.untyped_storage().data_ptr()
+
+
+def test_which_steps_read_the_loaders_bytes(monkeypatch):
+    """SRL4robotics._readsBytes: only steps whose sole readers of the observations are conv1 and the fused reconstruction loss keep
+    the uint8 frames; every configuration with another reader gets the float tensor."""
+    import models.learner as learner
+    from srlz import hotpath
+
+    class Stub(object):
+        model_type, _use_pair, _frame_streams, _use_graph = "custom_cnn", True, None, False
+        use_triplets = use_dae = use_vae = perceptual_similarity_loss = False
+
+    reads = learner.SRL4robotics._readsBytes
+    assert reads(Stub()) is True
+    for attr, value in (("model_type", "resnet"), ("_use_pair", False), ("_frame_streams", (1, 2)), ("_use_graph", True),
+                        ("use_triplets", True), ("use_dae", True)):
+        s = Stub()
+        setattr(s, attr, value)
+        assert not reads(s), attr
+    s = Stub()
+    s.use_vae = True
+    assert reads(s)
+    s.perceptual_similarity_loss = True
+    assert not reads(s)
+    monkeypatch.setattr(hotpath, "_FUSE_RECON", False)
+    assert not reads(Stub())
+    monkeypatch.setattr(hotpath, "_FUSE_RECON", True)
+    monkeypatch.setattr(learner, "RAW_UINT8_INPUT", False)
+    assert not reads(Stub())
+    # planar frames are recognised by their layout
+    is_planar = learner.BaseLearner._isPlanar
+    assert is_planar(torch.zeros(2, 3, 224, 224, dtype=torch.uint8)) and is_planar(torch.zeros(2, 9, 224, 224, dtype=torch.uint8))
+    assert not is_planar(torch.zeros(2, 224, 224, 3, dtype=torch.uint8)) and not is_planar(torch.zeros(2, 3, 224, 224))
