@@ -117,14 +117,19 @@ __global__ void bn_replay_kernel(const float* batch_stat, float momentum, float*
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                               float* __restrict__ pooled, uint8_t* __restrict__ argmax,
                                                               int N, int H, int W, int HP, int WP, int pad, int out_nchw,
-                                                              int npg) {
-  // grid: x covers (px, c4) of one pooled row, y = n*HP + py  -> no per-thread integer division
+                                                              int npg, int gx) {
+  // 1-D grid of gx * N * HP blocks: gx blocks cover (px, c4) of one pooled row -> no per-thread integer division.
+  // Block b runs on XCD b % 8; xcd_remap hands every XCD one contiguous run of (row, x-block) pairs.  Pooled rows py and py + 1 both
+  // read y row 2*py + 1 (3x3 windows, stride 2): in plain order they sit on different XCDs and that row crosses HBM twice, once
+  // into each L2 — rocprofv3 counted 1.5x the algorithmic reads for this (HBM-bound) kernel.
   // npg = images per BatchNorm group: image n uses record bnp[(n / npg) * 256 ..]
   {
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int prow = t / gx, xb = t - prow * gx;  // (uniform)
     const int c4 = threadIdx.x & 15;
-    const int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int px = (xb * blockDim.x + threadIdx.x) >> 4;
     if (px >= WP) return;
-    const int n = blockIdx.y / HP, py = blockIdx.y - n * HP;
+    const int n = prow / HP, py = prow - n * HP;
     bnp += (n / npg) * 256;
     const long long pix = ((long long)n * HP + py) * WP + px;
     const f32x4 sc = *(const f32x4*)(bnp + 128 + c4 * 4);
@@ -638,8 +643,9 @@ extern "C" int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* po
   if (int rc = check_pool(d)) return rc;
   SRLZ_REQUIRE(y && bnp && pooled, SRLZ_ERR_NULL, "bn_relu_pool_fwd: null pointer");
   SRLZ_REQUIRE((long long)d->n * d->hp <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*hp too large for one launch");
-  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((d->wp * 16 + 255) / 256, d->n * d->hp), dim3(256), 0, as_stream(stream), y, bnp, pooled,
-                     argmax, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, d->n / norm_groups(d->groups));
+  const int gx = (d->wp * 16 + 255) / 256;
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(gx * d->n * d->hp), dim3(256), 0, as_stream(stream), y, bnp, pooled,
+                     argmax, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, d->n / norm_groups(d->groups), gx);
   SRLZ_LAUNCHED();
   return 0;
 }
