@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="every leg of BASELINE.md section 3's CPU protocol (minutes) instead of the bounded default")
-    ap.add_argument("--timer-steps", type=int, default=5,
+    ap.add_argument("--timer-steps", type=int, default=10,
                     help="instrumented steps (HIP events around every MFMA launch) run AFTER the timed region for the roofline object")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--host-input", action="store_true",
@@ -350,12 +350,15 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     # the roofline's per-launch HIP-event times: the SAME steps, instrumented, after the clock has stopped
-    timer_steps = 0 if args.no_kernel_timers or rank != 0 else max(0, args.timer_steps)
-    if timer_steps:
-        ops.timers_enable(True)
-    for _ in range(args.timer_steps if not args.no_kernel_timers else 0):  # (every rank runs them: the steps hold collectives)
-        step()
-    sync()
+    # (two instrumented steps are discarded first: the first ~200 event pairs are created cold and their launches measured
+    # 3-4 % long — 448 vs 432 us for the dominant kernel against rocprofv3's 434)
+    timer_steps = 0 if args.no_kernel_timers else max(0, args.timer_steps)
+    for phase, count in (("settle", 2 if timer_steps else 0), ("measure", timer_steps)):
+        if count and rank == 0:
+            ops.timers_enable(True)  # (clears what the settling steps recorded)
+        for _ in range(count):  # (every rank runs them: the steps hold collectives)
+            step()
+        sync()
     ops.timers_enable(False)
 
     if rank == 0:
@@ -411,7 +414,7 @@ def main():
                                "stale": bool(traffic_stale or busy_stale), "csrc_sha16": csrc_sha16(),
                                "stale_note": "traffic / mfma_busy_frac / clock_ghz come from committed rocprofv3 PMC passes; stale = "
                                              "those passes were recorded at other kernel sources than this build's",
-                               "timing": "%d instrumented steps after the timed region (HIP events on the launch stream)" % timer_steps,
+                               "timing": "%d instrumented steps (after 2 discarded ones) behind the timed region (HIP events on the launch stream)" % timer_steps,
                                "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),
                                "layers": layers, "fused_dgrad_layers": fused}
