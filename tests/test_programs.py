@@ -195,3 +195,31 @@ def test_programs_for_random_shapes(cabi):
     assert checked >= 20, (checked, declined)
     assert all(not (s == 1 and p == 1 and not t) and not (s == 2 and p == 0 and t) and not (s == 2 and p == 1 and not t)
                for (_, s, p, t) in declined), "a geometry of the network's own layers was declined: %r" % declined
+
+
+def test_conv1_weight_gradient_tap_table_is_a_conflict_free_deal():
+    """TAP7 in csrc/skinny.hip (the column order of conv1's weight-gradient GEMM): every one of the 147 taps exactly once, and no two
+    taps of an N-tile on the same LDS bank for the window pitches the kernel uses — the property the table exists for, checked on
+    the table that is compiled (tools/tap_banks.py generated it)."""
+    import os
+    import re
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "tools"))
+    import tap_banks
+    src = open(os.path.join(os.path.dirname(here), "srl-zoo_amd", "csrc", "skinny.hip")).read()
+    xp, pp = (int(v) for v in re.search(r"constexpr int WG7_XP = (\d+), WG7_PP = (\d+);", src).groups())
+    body = re.search(r"__constant__ unsigned char TAP7\[160\] = \{(.*?)\};", src, re.S).group(1)
+    table = [int(v) for v in re.findall(r"\d+", body)]
+    assert len(table) == 160
+    assert sorted(t for t in table if t != 255) == list(range(147))
+    for j in range(5):
+        group = [t for t in table[32 * j:32 * j + 32] if t != 255]
+        banks = [tap_banks.off(t, xp, pp) % 32 for t in group]
+        assert len(set(banks)) == len(banks), (j, sorted(banks))
+        assert table[32 * j] != 255  # unused lanes re-read the tile's first tap (a broadcast)
+    assert table == tap_banks.deal(xp, pp)
+    # the window fits its planes: 37 rows of the row pitch per (channel, column-parity) plane, one spare cell for dead elements
+    assert 37 * xp <= pp - 1 and 6 * pp <= 5400
+    # and the natural order does conflict, which is why the table exists
+    assert max(tap_banks.natural_conflicts(24, 900)) >= 1
