@@ -98,6 +98,18 @@ typedef struct {
 /* dx = d(loss)/d(x) from dy (dy_bn may be NULL: dy is then the plain gradient). */
 int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, float* dx, const srlz_bn_bwd_operand* dy_bn,
                          const srlz_conv64_desc* d, srlz_stream_t stream);
+/* The same data gradient for a layer whose INPUT was a pooled map — conv3x3 after BatchNorm2d + ReLU + MaxPool2d(3, 2)
+ * (models/models.py:50-54, 55-59) — with the BatchNorm-backward sums of that pooled block taken in the epilogue: dx is d(loss)/d(pooled),
+ * and the tile that writes it also reads `pooled` (same shape) and leaves, per tile,  bn_bwd_partial[tile][0..64) = sum dz,
+ * [64..128) = sum dz * xhat  with dz = dx where pooled > 0 (the gradient of max-pool + ReLU lives at the argmax, where the pooled value
+ * is relu(bn(y)): xhat follows from it; pool_y / pool_argmax are read only for channels whose BatchNorm scale is exactly 0).
+ * srlz_bn_bwd_finalize_partials turns the srlz_conv64_bwd_data_tiles(d) records into sums / dgamma / dbeta: the separate pass of
+ * srlz_bn_relu_pool_bwd_sums over (d pooled, pooled, argmax) disappears.  pd describes the pooling that produced `pooled`. */
+struct srlz_pool_desc_s;
+int srlz_conv64_bwd_data_tiles(const srlz_conv64_desc* d);
+int srlz_conv64_bwd_data_pool_sums(const float* dy, const float* wpack_bwd, float* dx, const float* pooled, const float* pool_bnp,
+                                   const float* pool_y, const uint8_t* pool_argmax, const struct srlz_pool_desc_s* pd,
+                                   float* bn_bwd_partial, const srlz_conv64_desc* d, srlz_stream_t stream);
 /* The WHOLE backward of a decoder block's ConvTranspose2d(64, 64, 3, stride 2) + BatchNorm2d + ReLU (models/models.py:70-80, as
  * autograd runs it for loss.backward(), models/learner.py:489) in ONE launch: srlz_conv64_bwd_data(dy, dy_bn) and
  * srlz_conv64_bwd_weight(x, dy_out, x_bnp) on a single staging of the rebuilt d(loss)/dy, which therefore never touches memory
@@ -293,6 +305,10 @@ int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uint8_t* argma
                           const float* pooled /* forward output, may be NULL (slower) */, float* dy, float* dgamma,
                           float* dbeta, int training, void* ws, size_t ws_bytes, const srlz_pool_desc* d,
                           srlz_stream_t stream);
+/* Stage 2 alone: dy from sums that are already known (srlz_bn_relu_pool_bwd_sums, or srlz_bn_bwd_finalize_partials over the records of
+ * srlz_conv64_bwd_data_pool_sums). */
+int srlz_bn_relu_pool_bwd_apply(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled, const float* sums,
+                                float* dy, int training, const srlz_pool_desc* d, srlz_stream_t stream);
 /* a = relu(y*scale+shift) over `pixels` x 64 */
 int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long long pixels, srlz_stream_t stream);
 /* Second stage for the per-tile partials of a data-gradient epilogue (srlz_convT_out_bwd_data, srlz_conv64_bwd_data):

@@ -703,6 +703,21 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   return 0;
 }
 
+extern "C" int srlz_bn_relu_pool_bwd_apply(const float* y, const float* bnp, const uint8_t* argmax, const float* dpooled,
+                                           const float* sums, float* dy, int training, const srlz_pool_desc* d,
+                                           srlz_stream_t stream) {
+  if (int rc = check_pool(d)) return rc;
+  SRLZ_REQUIRE(y && bnp && argmax && dpooled && sums && dy, SRLZ_ERR_NULL, "bn_relu_pool_bwd_apply: null pointer");
+  const int HB = (d->h + d->pool_pad + 1) / 2, WB = (d->w + d->pool_pad + 1) / 2;
+  SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
+  const int npg = d->n / norm_groups(d->groups);
+  const float inv_count = 1.0f / (float)((double)npg * d->h * d->w);
+  hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3((WB * 16 + 255) / 256, d->n * HB), dim3(256), 0, as_stream(stream), y, bnp, argmax,
+                     dpooled, sums, dy, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count, npg);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
 extern "C" int srlz_bn_relu_fwd(const float* y, const float* bnp, float* a, long long pixels, srlz_stream_t stream) {
   SRLZ_REQUIRE(y && bnp && a, SRLZ_ERR_NULL, "bn_relu_fwd: null pointer");
   hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(grid_for(pixels * 16, 256)), dim3(256), 0, as_stream(stream), y, bnp, a, pixels);

@@ -185,6 +185,22 @@ struct OpFuse {
 };
 #define SRLZ_NO_FUSE OpFuse{nullptr, nullptr, nullptr, 0.f, 0, nullptr}
 
+// Epilogue option of the data-gradient launches whose output is the gradient of a POOLED map (conv2 -> d pooled1, conv3 -> d pooled2;
+// conv64_dgrad_poolsum_kernel<1 / 2>): instead of BatchNorm-forward statistics the tile's partial record receives the two
+// BatchNorm-BACKWARD sums of the block that produced the pooled map,  sum dz  and  sum dz*xhat  with dz = d pooled where pooled > 0
+// (the gradient lives at the window's argmax, and the pooled value IS relu(bn(y)) there: xhat follows from it) — what
+// bn_relu_pool_bwd_reduce computes in a pass of its own over (d pooled, pooled, argmax).  y / argmax are only touched for channels
+// whose BatchNorm scale is exactly 0 (xhat cannot be recovered from the pooled value there).
+struct PoolSum {
+  const float* pooled;    // [N,Hd,Wd,64] like the launch's dst; NULL = off
+  const float* bnp;       // records of the pooled block's BatchNorm (256 floats per group)
+  const float* y;         // raw convolution output under the pooling [N,H,W,64]
+  const uint8_t* argmax;  // [N,Hd,Wd,64]
+  long long y_gstride;    // floats between two groups' images in y
+  int H, W, pad;
+};
+#define SRLZ_NO_POOLSUM PoolSum{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0}
+
 // The records of BatchNorm group `grp` (bnp: 256 floats per group, sums: 128) and the group's slice of the tensors that are
 // indexed like the staged source (y, dy_out): `goff` floats further.
 __device__ __forceinline__ OpFuse fuse_for_group(OpFuse f, int grp, long long goff) {
@@ -304,13 +320,17 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
 // BWD = true is the data-gradient launch whose operand is rebuilt from (dA, y) by the fused BatchNorm+ReLU backward (and
 // optionally stored): a separate instantiation, so the plain kernel keeps its register budget and shows up under its own
 // name in rocprof.
-template <int NW, bool BWD = false>
-__global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float* __restrict__ src,
-                                                                    const float* __restrict__ wpack,
-                                                                    const float* __restrict__ bias,
-                                                                    float* __restrict__ dst,
-                                                                    float* __restrict__ stats_partial,
-                                                                    const ConvProg P, int ntiles, const OpFuse src_fuse_all) {
+// PSUM: 0 = statistics of a forward launch; 1 / 2 = the pooled-block epilogue (PoolSum) of a data gradient with ONE destination class
+// (its pooled values are requested before the first tap and travel under the whole tile) / with several (requested inside every
+// flush: the small stride-2 layer).
+// (The body is shared by two kernel symbols: conv64_fwd_kernel<NW, BWD> — PSUM = 0, what rocprof has listed since round 1 — and
+// conv64_dgrad_poolsum_kernel<PSUM>.)
+template <int NW, bool BWD, int PSUM>
+__device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, const float* __restrict__ wpack,
+                                                const float* __restrict__ bias, float* __restrict__ dst,
+                                                float* __restrict__ stats_partial, const ConvProg& P, int ntiles,
+                                                const OpFuse& src_fuse_all, const PoolSum& ps) {
+  static_assert(PSUM == 0 || (NW == 4 && !BWD), "the pooled-block epilogue exists for the plain 4-wave kernel");
   constexpr int NT = NW * 64;      // threads
   constexpr int NACC = 8 / NW;     // 32-column tiles per wave
   // rows (of 16 lanes) a thread requests per HBM round trip of the source staging: a stride-1 tile (244 rows = 15.25 passes) or a
@@ -372,6 +392,26 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
 
   int cur_src = -1, cur_dst = -1;
 
+  // PSUM: v = (z - shift) / scale and xhat = (v - mean) * invstd as two fused multiply-adds per element, for this lane's four channels
+  // of the flush layout (4 * (lane & 15) ..); channels with scale == 0 take the gather path (pz_zero)
+  f32x4 pisc = {0.f, 0.f, 0.f, 0.f}, pc1 = pisc, pinv = pisc, pc2 = pisc, psc = pisc, psh = pisc;
+  unsigned pz_zero = 0;
+  const float* __restrict__ ppool = nullptr;
+  if constexpr (PSUM) {
+    const float* __restrict__ rec = ps.bnp + grp * 256 + (lane & 15) * 4;
+    const f32x4 mean = *(const f32x4*)rec;
+    pinv = *(const f32x4*)(rec + 64); psc = *(const f32x4*)(rec + 128); psh = *(const f32x4*)(rec + 192);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool zero = psc[e] == 0.f;
+      pz_zero |= (zero ? 1u : 0u) << e;
+      pisc[e] = zero ? 0.f : 1.f / psc[e];
+      pc1[e] = -psh[e] * pisc[e];
+      pc2[e] = -mean[e] * pinv[e];
+    }
+    ppool = ps.pooled + grp * P.dst_gstride;
+  }
+
   // NW == 4: the accumulators leave through a 4 KB wave-private transposition buffer (this wave's part of the idle weight slab),
   // 16 tile rows at a time, so that every global store is a 16-byte one — lane (g = lane >> 4, slot = lane & 15) stores channels
   // [4*slot, 4*slot+4) of rows g, g+4, g+8, g+12 — instead of 32 dword-per-lane stores per flush (the dword path sustains ~5 B per
@@ -379,6 +419,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
   // in the same layout (s4 / q4).  Rows 4..7 and 12..15 of the buffer hold their two 32-channel halves swapped, so that the lanes
   // h = 0 / 1 of one ds_write_b32 (rows 4 apart, same column) hit different banks.
   f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pz[PSUM ? 8 : 1];  // PSUM: the pooled values of this lane's eight rows of a flush (rows 16*(hk >> 2) + (lane >> 4) + 4*(hk & 3))
+  auto pz_request = [&](int d) {  // branch-free, clamped: a row outside the tensor reads pixel 0 and is never used
+    const int dy = d >> 1, dx = d & 1;
+#pragma unroll
+    for (int hk = 0; hk < 8; ++hk) {
+      const int row = wrow * 32 + 16 * (hk >> 2) + (lane >> 4) + 4 * (hk & 3);
+      const int n = rowinfo[row];
+      const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
+      const bool ok = n >= 0 && y < P.Hd && x < P.Wd;
+      pz[PSUM ? hk : 0] = *(const f32x4*)(ppool + (ok ? ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 : (size_t)0) + (lane & 15) * 4);
+    }
+  };
   auto flush16 = [&](int d) {
     if (P.dbg & 2) {
       if (acc[0][0] + acc[NACC - 1][5] == 123.456f) dst[tid] = acc[0][1];
@@ -387,6 +439,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
     const int dy = d >> 1, dx = d & 1;
     float* S = Bs + wave * 1024;
     const int eg = lane >> 4, eslot = lane & 15;
+    // PSUM == 2: the pooled values are requested here, up front; PSUM == 1: they were requested before the tile's first tap.
+    // Either way they are waited for once, in straight-line code, before the first conditional store
+    if constexpr (PSUM == 2) pz_request(d);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -404,10 +459,43 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
         const f32x4 v = *(const f32x4*)(S + rowl * 64 + ((eslot ^ ((rowl & 4) << 1)) << 2));
         const int n = rowinfo[row];
         const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
+        if constexpr (PSUM) {
+          if (half == 0 && k == 0) {
+#pragma unroll
+            for (int hk = 0; hk < 8; ++hk) asm volatile("" : "+v"(pz[hk]));
+          }
+        }
         if (n >= 0 && y < P.Hd && x < P.Wd) {
           *(f32x4*)(dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 + eslot * 4) = v;
+          if constexpr (PSUM) {
+            const f32x4 z = pz[half * 4 + k];
+            f32x4 xh;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }
+            for (int e = 0; e < 4; ++e) xh[e] = __builtin_fmaf(__builtin_fmaf(z[e], pisc[e], pc1[e]), pinv[e], pc2[e]);
+            bool pos[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pos[e] = z[e] > 0.f;
+            if (pz_zero) {  // scale == 0: relu(bn(.)) is the constant shift; xhat needs the convolution output under the argmax
+              const uint32_t packed = *(const uint32_t*)(ps.argmax + ((size_t)(grp * P.N + n) * P.Hd + y) * P.Wd * 64 + (size_t)x * 64 + eslot * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if ((pz_zero >> e) & 1u) {
+                  const int a = (packed >> (8 * e)) & 0xff;
+                  const int iy = y * 2 - ps.pad + a / 3, ix = x * 2 - ps.pad + a % 3;
+                  const float vy = ps.y[grp * ps.y_gstride + ((size_t)(n * ps.H + iy) * ps.W + ix) * 64 + eslot * 4 + e];
+                  xh[e] = __builtin_fmaf(vy, pinv[e], pc2[e]);
+                  pos[e] = psh[e] > 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float dz = pos[e] ? v[e] : 0.f;
+              s4[e] += dz; q4[e] += dz * xh[e];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }
+          }
         }
       }
     }
@@ -452,6 +540,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
   // right after this tap's second barrier): fetched at their point of use, each costs a scalar-memory round trip in front of the
   // slab requests / the first LDS reads of every tap.
   int w0 = P.tp[0], w1 = P.tp[1];
+  if constexpr (PSUM == 1) {  // the tile's one flush is known now: its pooled values travel under the whole tile
+    __syncthreads();          // (rowinfo)
+    pz_request(P.tdst[0]);
+  }
 #pragma unroll
   for (int ti = 0; ti < NTAPS; ++ti) {
     const int w2 = P.tp[ti + 2];
@@ -560,6 +652,27 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float
       stats_partial[(size_t)tile * 128 + tid] = v;  // [0,64): sum, [64,128): sum of squares
     }
   }
+}
+
+template <int NW, bool BWD = false>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv64_fwd_kernel(const float* __restrict__ src,
+                                                                    const float* __restrict__ wpack,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ dst,
+                                                                    float* __restrict__ stats_partial,
+                                                                    const ConvProg P, int ntiles, const OpFuse src_fuse_all) {
+  conv64_fwd_body<NW, BWD, 0>(src, wpack, bias, dst, stats_partial, P, ntiles, src_fuse_all, SRLZ_NO_POOLSUM);
+}
+
+// The data gradient of a convolution whose input was a pooled map, with the pooled block's BatchNorm-backward sums in its epilogue
+// (PoolSum; PSUM = 1: one destination class, 2: several).
+template <int PSUM>
+__global__ __launch_bounds__(256, 2) void conv64_dgrad_poolsum_kernel(const float* __restrict__ src,
+                                                                     const float* __restrict__ wpack,
+                                                                     float* __restrict__ dst,
+                                                                     float* __restrict__ bn_bwd_partial, const ConvProg P,
+                                                                     int ntiles, const PoolSum ps) {
+  conv64_fwd_body<4, false, PSUM>(src, wpack, nullptr, dst, bn_bwd_partial, P, ntiles, SRLZ_NO_FUSE, ps);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1749,10 +1862,24 @@ static size_t wgrad_lds_bytes(const ConvProg& P, int tk) { return (size_t)(tk + 
 static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried: the extra staging registers spill
 
 static int launch_fwd(const float* src, const float* wpack, const float* bias, float* dst, float* stats,
-                      const ConvProg& P, hipStream_t st, const OpFuse src_fuse = SRLZ_NO_FUSE) {
+                      const ConvProg& P, hipStream_t st, const OpFuse src_fuse = SRLZ_NO_FUSE, const PoolSum* psum = nullptr) {
   const int ntiles = P.G * P.tpg;
   const size_t lds = fwd_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64: tile needs %zu bytes of LDS", lds);
+  if (psum) {  // data gradient whose epilogue takes the pooled block's BatchNorm-backward sums (its own instantiation)
+    SRLZ_REQUIRE(!src_fuse.y && !src_fuse.bnp && stats && !bias, SRLZ_ERR_BAD_DESC, "conv64: the pooled-block epilogue takes a plain operand");
+    bool one_class = true;
+    for (int t = 1; t < NTAPS; ++t) one_class = one_class && P.tdst[t] == P.tdst[0];
+    if (one_class) {
+      SRLZ_MAX_LDS(conv64_dgrad_poolsum_kernel<1>, lds);
+      hipLaunchKernelGGL(conv64_dgrad_poolsum_kernel<1>, dim3(ntiles), dim3(256), lds, st, src, wpack, dst, stats, P, ntiles, *psum);
+    } else {
+      SRLZ_MAX_LDS(conv64_dgrad_poolsum_kernel<2>, lds);
+      hipLaunchKernelGGL(conv64_dgrad_poolsum_kernel<2>, dim3(ntiles), dim3(256), lds, st, src, wpack, dst, stats, P, ntiles, *psum);
+    }
+    SRLZ_LAUNCHED();
+    return 0;
+  }
   // 4 waves (32x64 per wave) is the default; SRLZ_NW=8 selects 8 waves of 32x32 (measured within +-3 %: the kernel is
   // bound by the power-limited matrix rate, not by latency hiding)
   static const int nw = [] { const char* e = getenv("SRLZ_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
@@ -2061,6 +2188,32 @@ extern "C" int srlz_conv64_bwd_data(const float* dy, const float* wpack_bwd, flo
   OpFuse gf;
   if (int rc = make_bwd_fuse(&gf, dy_bn, "conv64_bwd_data")) return rc;
   return launch_fwd(dy, wpack_bwd, nullptr, dx, nullptr, P, as_stream(stream), gf);
+}
+
+extern "C" int srlz_conv64_bwd_data_tiles(const srlz_conv64_desc* d) {
+  if (check_desc(d)) return -1;
+  ConvProg P;
+  if (program_for(&P, d, 1)) return -1;
+  return P.G * P.tpg;
+}
+
+extern "C" int srlz_conv64_bwd_data_pool_sums(const float* dy, const float* wpack_bwd, float* dx, const float* pooled,
+                                              const float* pool_bnp, const float* pool_y, const uint8_t* pool_argmax,
+                                              const srlz_pool_desc* pd, float* bn_bwd_partial, const srlz_conv64_desc* d,
+                                              srlz_stream_t stream) {
+  if (int rc = check_desc(d)) return rc;
+  SRLZ_REQUIRE(dy && wpack_bwd && dx && pooled && pool_bnp && pool_y && pool_argmax && pd && bn_bwd_partial, SRLZ_ERR_NULL,
+               "conv64_bwd_data_pool_sums: null pointer");
+  // dx (this layer's input gradient) is the gradient of the pooled map pd describes: same images, same spatial size, NHWC
+  SRLZ_REQUIRE(pd->n == d->n && pd->hp == d->hi && pd->wp == d->wi && !pd->out_nchw &&
+               (pd->groups > 1 ? pd->groups : 1) == (d->groups > 1 ? d->groups : 1), SRLZ_ERR_BAD_DESC,
+               "conv64_bwd_data_pool_sums: the pooled map [%d,%d,%d] is not this layer's input [%d,%d,%d]", pd->n, pd->hp, pd->wp, d->n,
+               d->hi, d->wi);
+  ConvProg P;
+  if (int rc = program_for(&P, d, 1)) return rc;
+  const int G = d->groups > 1 ? d->groups : 1;
+  PoolSum ps = {pooled, pool_bnp, pool_y, pool_argmax, (long long)(pd->n / G) * pd->h * pd->w * 64, pd->h, pd->w, pd->pool_pad};
+  return launch_fwd(dy, wpack_bwd, nullptr, dx, bn_bwd_partial, P, as_stream(stream), SRLZ_NO_FUSE, &ps);
 }
 
 extern "C" size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d) {

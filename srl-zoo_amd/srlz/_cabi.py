@@ -81,6 +81,8 @@ _PROTOS = {
     "srlz_triplet_fwd": (c_int, [P, P, P, c_int, c_int, c_float, P, P, P]),
     "srlz_triplet_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "srlz_skinny_tiles": (c_int, [_SK]),
+    "srlz_conv64_bwd_data_tiles": (c_int, [_C64]),
+    "srlz_conv64_bwd_data_pool_sums": (c_int, [P, P, P, P, P, P, P, _PD, P, _C64, P]),
     "srlz_conv1_fwd": (c_int, [P, P, P, P, _SK, P]),
     "srlz_conv1_fwd_u8": (c_int, [P, P, P, P, P, _SK, P]),
     "srlz_conv1_bwd_weight_fused_u8": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_size_t, _SK, _PD, P]),
@@ -109,6 +111,7 @@ _PROTOS = {
     "srlz_bn_relu_pool_fwd": (c_int, [P, P, P, P, _PD, P]),
     "srlz_bn_bwd_workspace": (c_size_t, [c_longlong]),
     "srlz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, c_size_t, _PD, P]),
+    "srlz_bn_relu_pool_bwd_apply": (c_int, [P, P, P, P, P, P, c_int, _PD, P]),
     "srlz_bn_relu_fwd": (c_int, [P, P, P, c_longlong, P]),
     "srlz_bn_relu_bwd_sums": (c_int, [P, P, P, P, P, P, P, c_size_t, c_longlong, c_int, P]),
     "srlz_bn_relu_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_size_t, c_longlong, c_int, P]),
@@ -152,6 +155,7 @@ _PROTOS = {
 # entry points whose int return value is data, not a status
 _NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
                "srlz_convT_out_bwd_fused_tiles", "srlz_convT_out_fwd_loss_workgroups", "srlz_conv64_bwd_fused_supported",
+               "srlz_conv64_bwd_data_tiles",
                "srlz_conv64_debug_program", "srlz_comm_world"}
 
 EXPORTED = sorted(_PROTOS.keys())

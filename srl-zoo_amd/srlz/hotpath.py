@@ -65,18 +65,22 @@ def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
     conv1, bn1, conv2, bn2, conv3, bn3 = seq[0], seq[1], seq[4], seq[5], seq[8], seq[9]
     if not _FUSE_ENC_IN:
         x = ops.frames_as_float(x)  # (only the fused first block reads the loader's bytes)
+    # ops.PoolLink: the BatchNorm-backward sums of a pooled block come out of the epilogue of the NEXT convolution's data gradient
+    # (which writes d(pooled) anyway); with TAPS on every gradient is looked at from outside: plain chain
+    link1 = ops.PoolLink() if TAPS is None else None
+    link2 = ops.PoolLink() if TAPS is None else None
     if _FUSE_ENC_IN and not x.requires_grad:  # (an image that carries a gradient needs conv1's data gradient: plain chain)
-        p, y = ops.EncInFn.apply(x, conv1.weight, *_bn_args(bn1), training, 1, stat_sink)
+        p, y = ops.EncInFn.apply(x, conv1.weight, *_bn_args(bn1), training, 1, stat_sink, link1)
         _tap(name, 0, y)
         _tap(name, 3, p)
     else:
         y, st = ops.Conv1Fn.apply(x, conv1.weight, training)
         _tap(name, 0, y)
-        p = _tap(name, 3, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink))
-    y, st = ops.Conv64Fn.apply(p, conv2.weight, None, 1, 1, False, training)
+        p = _tap(name, 3, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink, link1))
+    y, st = ops.Conv64Fn.apply(p, conv2.weight, None, 1, 1, False, training, link1)
     _tap(name, 4, y)
-    p = _tap(name, 7, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn2), training, 0, False, stat_sink))
-    y, st = ops.Conv64Fn.apply(p, conv3.weight, None, 2, 1, False, training)
+    p = _tap(name, 7, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn2), training, 0, False, stat_sink, link2))
+    y, st = ops.Conv64Fn.apply(p, conv3.weight, None, 2, 1, False, training, link2)
     _tap(name, 8, y)
     return _tap(name, 11, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn3), training, 0, True, stat_sink))
 

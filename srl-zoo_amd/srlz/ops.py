@@ -293,9 +293,28 @@ def conv64_desc(n, hi, wi, stride, pad, transposed, groups=1):
     return Conv64Desc(n, hi, wi, ho, wo, 3, stride, pad, 1 if transposed else 0, groups)
 
 
+class PoolLink:
+    """Hand-over between an encoder block (conv -> BatchNorm -> ReLU -> MaxPool, producer of a pooled map) and the convolution that
+    consumes the pooled map: the consumer's data-gradient launch computes d(pooled) tile by tile and can take the two
+    BatchNorm-backward sums of the producing block in its epilogue (srlz_conv64_bwd_data_pool_sums) instead of the producer running a
+    pass of its own over (d pooled, pooled, argmax).  The producer's forward leaves (pooled, bnp, y, argmax, pool descriptor) here; the
+    consumer's backward leaves the per-tile records; the producer's backward finalises them.  One producer, one consumer, one pass."""
+
+    def __init__(self):
+        self.record = None    # (pooled, bnp, y, argmax, pool desc), set by the producer's forward
+        self.partials = None  # [tiles, 128] per-tile sums, set by the consumer's backward
+
+    def take_partials(self):
+        p, self.partials, self.record = self.partials, None, None
+        return p
+
+
+_POOL_LINK = _os.environ.get("SRLZ_POOL_BWD_IN_DGRAD", "1") != "0"
+
+
 class Conv64Fn(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, transposed, want_stats):
+    def forward(ctx, x, w, bias, stride, pad, transposed, want_stats, in_link=None):
         x, w = _check(x, "conv64 input"), _check(w, "conv64 weight")
         n, hi, wi, ch = x.shape
         assert ch == 64 and tuple(w.shape) == (64, 64, 3, 3)
@@ -312,6 +331,7 @@ class Conv64Fn(Function):
         ctx.has_bias = bias is not None
         ctx.needs_dx = ctx.needs_input_grad[0]
         ctx.params = (w, bias)
+        ctx.in_link = in_link  # (x is the pooled map of the block that filled this link)
         if stats is None:
             stats = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(stats)
@@ -337,10 +357,21 @@ class Conv64Fn(Function):
         dx = None
         if ctx.needs_dx:
             dx = torch.empty_like(x)
-            _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
-                    lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), None, d, stream()))
+            link = ctx.in_link
+            rec = link.record if (link is not None and _POOL_LINK) else None
+            if rec is not None and rec[0].data_ptr() == x.data_ptr():
+                # dx = d(pooled): the pooled block's BatchNorm-backward sums come out of this launch's epilogue
+                pooled, pbnp, py, pargmax, pd = rec
+                part = torch.empty((C.conv64_bwd_data_tiles(d), 128), dtype=torch.float32, device=x.device)
+                _launch("conv64_dgrad_poolsum_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                        lambda: C.conv64_bwd_data_pool_sums(ptr(dy), ptr(packs[1]), ptr(dx), ptr(pooled), ptr(pbnp), ptr(py),
+                                                            ptr(pargmax), pd, ptr(part), d, stream()))
+                link.partials = part
+            else:
+                _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                        lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), None, d, stream()))
         side.join()
-        return dx, _give(ctx.params[0], dw), _give(ctx.params[1], db), None, None, None, None
+        return dx, _give(ctx.params[0], dw), _give(ctx.params[1], db), None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -390,7 +421,7 @@ class BNReLUPoolFn(Function):
     """y (raw conv output, NHWC) -> maxpool(relu(bn(y))).  `stats` are the conv's per-tile partial sums."""
 
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, training, pool_pad, out_nchw, stat_sink):
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, training, pool_pad, out_nchw, stat_sink, out_link=None):
         y = _check(y, "bn input")
         n, h, w, _ = y.shape
         hp, wp = (h + 2 * pool_pad - 3) // 2 + 1, (w + 2 * pool_pad - 3) // 2 + 1
@@ -405,7 +436,9 @@ class BNReLUPoolFn(Function):
         C.bn_relu_pool_fwd(ptr(y), ptr(bnp), ptr(pooled), ptr(argmax), d, stream())
         if need_bwd:
             ctx.save_for_backward(y, bnp, argmax, pooled)
-        ctx.desc, ctx.training = d, training
+            if out_link is not None and not out_nchw:
+                out_link.record = (pooled, bnp, y, argmax, d)
+        ctx.desc, ctx.training, ctx.out_link = d, training, out_link
         ctx.params = (gamma, beta)
         return pooled
 
@@ -416,11 +449,19 @@ class BNReLUPoolFn(Function):
         dy = torch.empty_like(y)
         dgamma = _gbuf(ctx.params[0])
         dbeta = _gbuf(ctx.params[1])
+        part = ctx.out_link.take_partials() if ctx.out_link is not None else None
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, y.device)
-        C.bn_relu_pool_bwd(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(dy), ptr(dgamma), ptr(dbeta),
-                           1 if ctx.training else 0, ptr(ws), nbytes, ctx.desc, stream())
-        return dy, None, _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None, None
+        if part is not None:  # the consumer's data gradient took the two sums in its epilogue (PoolLink)
+            sums = torch.empty(128 * max(ctx.desc.groups, 1), dtype=torch.float32, device=y.device)
+            C.bn_bwd_finalize_partials(ptr(part), part.shape[0], max(ctx.desc.groups, 1), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                       nbytes, stream())
+            C.bn_relu_pool_bwd_apply(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums), ptr(dy), 1 if ctx.training else 0,
+                                     ctx.desc, stream())
+        else:
+            C.bn_relu_pool_bwd(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(dy), ptr(dgamma), ptr(dbeta),
+                               1 if ctx.training else 0, ptr(ws), nbytes, ctx.desc, stream())
+        return dy, None, _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None, None, None
 
 
 class EncInFn(Function):
@@ -430,7 +471,7 @@ class EncInFn(Function):
     (srlz_conv1_bwd_weight_fused).  Saved tensors start with (y, bnp, argmax) like BNReLUPoolFn's."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, running_mean, running_var, training, pool_pad, stat_sink):
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, training, pool_pad, stat_sink, out_link=None):
         u8 = is_u8_frames(x)  # the loader's bytes: normalised inside the kernels' window staging
         x, w = (_check_u8(x, "conv1 input") if u8 else _check(x, "conv1 input")), _check(w, "conv1 weight")
         n, c, h, wd = x.shape
@@ -452,6 +493,9 @@ class EncInFn(Function):
         C.bn_relu_pool_fwd(ptr(y), ptr(bnp), ptr(pooled), ptr(argmax), pd, stream())
         if need_bwd:
             ctx.save_for_backward(y, bnp, argmax, pooled, x, w)
+            if out_link is not None:
+                out_link.record = (pooled, bnp, y, argmax, pd)
+        ctx.out_link = out_link
         ctx.desc, ctx.pdesc, ctx.training = d, pd, training
         ctx.params = (gamma, beta)
         ctx.mark_non_differentiable(y)
@@ -468,8 +512,13 @@ class EncInFn(Function):
         sums = torch.empty(128 * max(ctx.pdesc.groups, 1), dtype=torch.float32, device=dev)
         nbytes = C.bn_bwd_workspace(0)
         ws = _ws(nbytes, dev)
-        C.bn_relu_pool_bwd_sums(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(sums), ptr(dgamma), ptr(dbeta),
-                                ptr(ws), nbytes, ctx.pdesc, stream())
+        part = ctx.out_link.take_partials() if ctx.out_link is not None else None
+        if part is not None:  # conv2's data gradient took the two sums in its epilogue (PoolLink)
+            C.bn_bwd_finalize_partials(ptr(part), part.shape[0], max(ctx.pdesc.groups, 1), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                       nbytes, stream())
+        else:
+            C.bn_relu_pool_bwd_sums(ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(pooled), ptr(sums), ptr(dgamma), ptr(dbeta),
+                                    ptr(ws), nbytes, ctx.pdesc, stream())
         dw = _gbuf(w)
         nbytes = C.skinny_bwd_weight_workspace(ctx.desc)
         ws = _ws(nbytes, dev)
@@ -479,7 +528,7 @@ class EncInFn(Function):
         else:
             C.conv1_bwd_weight_fused(ptr(x), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums), 1 if ctx.training else 0,
                                      ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc, stream())
-        return None, _give(w, dw), _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None
+        return None, _give(w, dw), _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -1006,3 +1006,70 @@ def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
         assert float(db1.abs().max()) < 1e-3 * scale
     else:
         assert rel_err(db1, br.grad) < 5e-5
+
+
+@pytest.mark.parametrize("n,h,pool_pad,stride,groups,training,zero_gamma", [
+    (4, 112, 1, 1, 2, True, False),   # block 1 -> conv2 (3x3 s1 p1 on the 56x56 pooled map), the pair's two BatchNorm groups
+    (2, 56, 0, 2, 1, True, False),    # block 2 -> conv3 (3x3 s2 p1 on the 27x27 pooled map): a four-class scatter data gradient
+    (6, 56, 0, 2, 2, True, True),     # a channel whose BatchNorm scale is exactly 0 (xhat from the convolution output under the argmax)
+    (2, 40, 1, 1, 1, False, False),   # eval mode (validation minibatches backpropagate too)
+])
+def test_pool_block_bn_backward_sums_from_the_next_convs_data_gradient(C, n, h, pool_pad, stride, groups, training, zero_gamma):
+    """ops.PoolLink: BatchNorm -> ReLU -> MaxPool(3, 2) followed by conv3x3 — the block's two BatchNorm-backward sums taken in the
+    epilogue of the convolution's data-gradient launch (srlz_conv64_bwd_data_pool_sums + srlz_bn_bwd_finalize_partials) against
+    (i) the separate pass (srlz_bn_relu_pool_bwd: same product path with the link off): dy of the pooled block, dgamma, dbeta,
+    and bit-identical d(pooled); (ii) fp64 autograd of the same chain."""
+    from srlz import ops
+    g = torch.Generator().manual_seed(31 * h + n)
+    y0 = torch.randn(n, 64, h, h, generator=g) * 1.3 + 0.2
+    gamma0, beta0 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    if zero_gamma:
+        gamma0[5] = 0.0
+        beta0[5] = 0.25   # relu(bn(.)) = 0.25 everywhere in that channel: every window's first position is the argmax
+        gamma0[40] = 0.0
+        beta0[40] = -0.1  # ... and here nothing passes the ReLU
+    w0 = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    hp = (h + 2 * pool_pad - 3) // 2 + 1
+    ho = (hp + 2 - 3) // stride + 1
+    dz0 = torch.randn(n, 64, ho, ho, generator=g)
+
+    # fp64 reference, one BatchNorm call per group
+    yr, gr, br, wr = (t.double().requires_grad_(True) for t in (y0, gamma0, beta0, w0))
+    outs = []
+    per = n // groups
+    for gi in range(groups):
+        ys = yr[gi * per:(gi + 1) * per]
+        z = F.batch_norm(ys, torch.zeros(64, dtype=torch.float64), torch.ones(64, dtype=torch.float64), gr, br, training, 0.1, 1e-5)
+        outs.append(F.conv2d(F.max_pool2d(F.relu(z), 3, 2, pool_pad), wr, None, stride=stride, padding=1))
+    (torch.cat(outs) * dz0.double()).sum().backward()
+
+    def run(link_on):
+        yd = nhwc(y0).to(DEV).requires_grad_(True)
+        gd, bd, wd = (t.clone().to(DEV).requires_grad_(True) for t in (gamma0, beta0, w0))
+        rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        # per-tile statistics of y as the producing convolution would have left them (training mode)
+        with ops.batch_groups(groups):
+            st = None
+            if training:
+                d1 = ops.conv64_desc(n, h, h, 1, 1, False, groups)
+                ntiles = C.conv64_fwd_tiles(d1)
+                st = torch.zeros((ntiles, 128), dtype=torch.float32, device=DEV)
+                tpg = ntiles // groups
+                for gi in range(groups):
+                    ysl = yd.detach()[gi * per:(gi + 1) * per].reshape(-1, 64).double()
+                    st[gi * tpg, :64] = ysl.sum(0).float()
+                    st[gi * tpg, 64:] = (ysl * ysl).sum(0).float()
+            link = ops.PoolLink() if link_on else None
+            p = ops.BNReLUPoolFn.apply(yd, st, gd, bd, rm, rv, training, pool_pad, False, None, link)
+            out, _ = ops.Conv64Fn.apply(p, wd, None, stride, 1, False, training, link)  # (want_stats = training, as in hotpath)
+            p.retain_grad()
+            (out * nhwc(dz0).to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        assert (link is None) or (link.record is None and link.partials is None)  # consumed
+        return yd.grad, gd.grad, bd.grad, wd.grad, p.grad
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[4], b[4]) and torch.equal(a[3], b[3])       # d(pooled), dW: the same launches' arithmetic
+    for i, tol in ((0, 2e-5), (1, 2e-5), (2, 2e-5)):                  # dy of the block, dgamma, dbeta: summation order only
+        assert rel_err(a[i], b[i]) < tol, (i, rel_err(a[i], b[i]))
+    assert rel_err(nchw(a[0]), yr.grad) < 1e-4 and rel_err(a[1], gr.grad) < 1e-4 and rel_err(a[2], br.grad) < 1e-4
