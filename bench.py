@@ -384,28 +384,46 @@ def main():
             out["step_roofline"] = {"algorithmic_tflop_per_step": round(per_image * 2 * B / 1e12, 4),
                                     "achieved_tflops": round(step_tf, 2), "frac_of_fp32_mfma_peak": round(step_tf / PEAK_FP32_MFMA_TFLOPS, 4)}
         rep = ops.timers_report()
-        k = rep.get("conv64_fwd_kernel")
+        # every instrumented kernel symbol (the MFMA launches of the step): launches, average, achieved rate, share of their time
+        SYMBOL = {"conv64_fwd_kernel": "conv64_fwd_kernel<4, false>", "conv64_bwd_fused_kernel": "conv64_bwd_fused_kernel",
+                  "conv64_dgrad_poolsum_kernel": "conv64_dgrad_poolsum_kernel<1>",
+                  "conv64_fwd_kernel<bn-bwd operand>": "conv64_dgrad_pipe_kernel"}
+        NOTE = {"conv64_fwd_kernel": "3x3 64->64 conv / convT forward and ConvT1 data gradient, 7 launches per step",
+                "conv64_bwd_fused_kernel": "data + weight + bias gradient of a ConvTranspose block in one launch (ConvT2-4); flop = 2 x the "
+                                           "layer's forward flop",
+                "conv64_dgrad_poolsum_kernel": "conv2 / conv3 data gradient with the pooled block's BatchNorm-backward sums in its epilogue"}
+        symbols = {name: v for name, v in rep.items() if "/" not in name and v["ms"] > 0}
+        total_ms = sum(v["ms"] for v in symbols.values())
+        by_symbol = {}
+        for name, v in sorted(symbols.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = v["flop"] / (v["ms"] * 1e-3) / 1e12 if v["flop"] else None
+            by_symbol[name] = {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                               "share_of_instrumented_time": round(v["ms"] / total_ms, 4),
+                               "tflops": None if tf is None else round(tf, 2),
+                               "frac": None if tf is None else round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+        with_flop = [n for n in by_symbol if by_symbol[n]["tflops"] is not None]
+        dom = with_flop[0] if with_flop else None  # (sorted by time: the dominant MFMA kernel symbol of the step)
+        k = rep.get(dom) if dom else None
         if k and k["ms"] > 0:
             tf = k["flop"] / (k["ms"] * 1e-3) / 1e12
             layers = {}
             for name, v in sorted(rep.items()):
-                if name.startswith("conv64_fwd_kernel/") and v["ms"] > 0:
+                if name.startswith(dom + "/") and v["ms"] > 0:
                     layers[name.split("/", 1)[1]] = {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                                                      "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
-            fused = {}
-            for name, v in sorted(rep.items()):
-                if name.startswith("conv64_fwd_kernel<bn-bwd operand>/") and v["ms"] > 0:
-                    fused[name.split("/", 1)[1]] = {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
-                                                    "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
             alg_bytes = 0.0
             for key, v in layers.items():
-                alg_bytes += v["launches"] * conv64_algorithmic_bytes(key)
+                # forward / data gradient: input + output + weights; the fused block backward reads dA and y (output-sized), y_prev
+                # (input-sized) and writes dA_prev (input-sized)
+                b = conv64_algorithmic_bytes(key)
+                if dom == "conv64_bwd_fused_kernel":
+                    b = 2.0 * b - 4.0 * 9 * 64 * 64
+                alg_bytes += v["launches"] * b
             alg_bytes /= max(1, k["launches"])
-            traffic, traffic_src, traffic_stale = committed_pmc_traffic("conv64_fwd_kernel<4, false>")
-            busy, clock, busy_src, busy_stale = committed_pmc_mfma("conv64_fwd_kernel<4, false>")
-            out["roofline"] = {"kernel": "conv64_fwd_kernel<4,false> (3x3 64->64 conv / convT forward and data-gradient, all "
-                                         "layers; the <4,true> instantiation = data-gradient with the BatchNorm backward "
-                                         "fused into its operand load is listed under fused_dgrad_layers)",
+            sym = SYMBOL.get(dom, dom)
+            traffic, traffic_src, traffic_stale = committed_pmc_traffic(sym)
+            busy, clock, busy_src, busy_stale = committed_pmc_mfma(sym)
+            out["roofline"] = {"kernel": "%s (%s)" % (sym, NOTE.get(dom, "")),
                                "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
@@ -417,7 +435,7 @@ def main():
                                "timing": "%d instrumented steps (after 2 discarded ones) behind the timed region (HIP events on the launch stream)" % timer_steps,
                                "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),
-                               "layers": layers, "fused_dgrad_layers": fused}
+                               "layers": layers, "by_symbol": by_symbol}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(list(args.losses), full=args.cpu_baseline_full)
         print(json.dumps(out))
