@@ -350,7 +350,8 @@ class SRL4robotics(BaseLearner):
     def _readsBytes(self):
         """True when the ONLY readers of the step's observations are the first convolution (forward and weight gradient) and the
         reconstruction / generation loss inside the last ConvTranspose — the kernels that take the loader's uint8 frames as they
-        are (ops.EncInFn / ops.DecOutLossFn): the default AE / VAE / priors steps of the custom_cnn models.  Everything else
+        are (ops.EncInFn / ops.DecOutLossFn): the default AE / VAE steps and the heads-only steps (inverse / forward / reward on the
+        CustomCNN encoder) of the custom_cnn models.  Everything else
         (DAE noise, perceptual loss, triplets, the ResNet trunks, graph replay, the A/B switches that undo those fusions) gets the
         normalised float tensor (ops.frames_as_float)."""
         from srlz import hotpath
