@@ -292,15 +292,18 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply(const float* __res
                                                              const uint8_t* __restrict__ argmax,
                                                              const float* __restrict__ dpooled, const float* __restrict__ sums,
                                                              float* __restrict__ dy, int N, int H, int W, int HP, int WP,
-                                                             int pad, int dp_nchw, int training, float inv_count, int npg) {
+                                                             int pad, int dp_nchw, int training, float inv_count, int npg, int gx) {
   // block grid over (by, bx): iy = 2*by - pad .. +1, ix = 2*bx - pad .. +1 ; by in [0, HB), bx in [0, WB)
   const int HB = (H + pad + 1) / 2, WB = (W + pad + 1) / 2;
-  // grid: x covers (bx, c4) of one block-row, y = n*HB + by
+  // 1-D grid of gx * N * HB blocks in XCD-contiguous order (see bn_relu_pool_fwd_kernel): gx blocks cover (bx, c4) of one block-row;
+  // vertically adjacent block-rows share a pooled row (argmax, d pooled)
   {
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int brow = t / gx, xb = t - brow * gx;  // (uniform)
     const int c4 = threadIdx.x & 15;
-    const int bx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int bx = (xb * blockDim.x + threadIdx.x) >> 4;
     if (bx >= WB) return;
-    const int n = blockIdx.y / HB, by = blockIdx.y - n * HB;
+    const int n = brow / HB, by = brow - n * HB;
     bnp += (n / npg) * 256;   // this image's BatchNorm group (npg images per group)
     sums += (n / npg) * 128;
     const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
@@ -697,8 +700,9 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
   const int npg = d->n / norm_groups(d->groups);
   const float inv_count = 1.0f / (float)((double)npg * d->h * d->w);
-  hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3((WB * 16 + 255) / 256, d->n * HB), dim3(256), 0, st, y, bnp, argmax, dpooled, sums, dy,
-                     d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count, npg);
+  const int gx = (WB * 16 + 255) / 256;
+  hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3(gx * d->n * HB), dim3(256), 0, st, y, bnp, argmax, dpooled, sums, dy,
+                     d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count, npg, gx);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -712,8 +716,9 @@ extern "C" int srlz_bn_relu_pool_bwd_apply(const float* y, const float* bnp, con
   SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
   const int npg = d->n / norm_groups(d->groups);
   const float inv_count = 1.0f / (float)((double)npg * d->h * d->w);
-  hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3((WB * 16 + 255) / 256, d->n * HB), dim3(256), 0, as_stream(stream), y, bnp, argmax,
-                     dpooled, sums, dy, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count, npg);
+  const int gx = (WB * 16 + 255) / 256;
+  hipLaunchKernelGGL(bn_relu_pool_bwd_apply, dim3(gx * d->n * HB), dim3(256), 0, as_stream(stream), y, bnp, argmax,
+                     dpooled, sums, dy, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, training, inv_count, npg, gx);
   SRLZ_LAUNCHED();
   return 0;
 }

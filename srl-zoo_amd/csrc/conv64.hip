@@ -392,21 +392,24 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
 
   int cur_src = -1, cur_dst = -1;
 
-  // PSUM: v = (z - shift) / scale and xhat = (v - mean) * invstd as two fused multiply-adds per element, for this lane's four channels
-  // of the flush layout (4 * (lane & 15) ..); channels with scale == 0 take the gather path (pz_zero)
-  f32x4 pisc = {0.f, 0.f, 0.f, 0.f}, pc1 = pisc, pinv = pisc, pc2 = pisc, psc = pisc, psh = pisc;
+  // PSUM: the pooled value z = relu(gamma * xhat + beta), so where it is positive xhat = (z - beta) / gamma = z * pA + pB with
+  // pA = invstd / scale, pB = -(shift / scale + mean) * invstd — one fused multiply-add per element, for this lane's four channels of
+  // the flush layout (4 * (lane & 15) ..); channels with scale == 0 take the gather path (pz_zero: xhat = y * pinv + pc2 there)
+  f32x4 pA = {0.f, 0.f, 0.f, 0.f}, pB = pA, pinv = pA, pc2 = pA, psh = pA;
   unsigned pz_zero = 0;
   const float* __restrict__ ppool = nullptr;
   if constexpr (PSUM) {
     const float* __restrict__ rec = ps.bnp + grp * 256 + (lane & 15) * 4;
     const f32x4 mean = *(const f32x4*)rec;
-    pinv = *(const f32x4*)(rec + 64); psc = *(const f32x4*)(rec + 128); psh = *(const f32x4*)(rec + 192);
+    pinv = *(const f32x4*)(rec + 64); psh = *(const f32x4*)(rec + 192);
+    const f32x4 psc = *(const f32x4*)(rec + 128);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool zero = psc[e] == 0.f;
       pz_zero |= (zero ? 1u : 0u) << e;
-      pisc[e] = zero ? 0.f : 1.f / psc[e];
-      pc1[e] = -psh[e] * pisc[e];
+      const float isc = zero ? 0.f : 1.f / psc[e];
+      pA[e] = pinv[e] * isc;
+      pB[e] = -(psh[e] * isc + mean[e]) * pinv[e];
       pc2[e] = -mean[e] * pinv[e];
     }
     ppool = ps.pooled + grp * P.dst_gstride;
@@ -420,15 +423,21 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
   // h = 0 / 1 of one ds_write_b32 (rows 4 apart, same column) hit different banks.
   f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 pz[PSUM ? 8 : 1];  // PSUM: the pooled values of this lane's eight rows of a flush (rows 16*(hk >> 2) + (lane >> 4) + 4*(hk & 3))
+  unsigned ppix[PSUM ? 8 : 1];  // ... their pixel index (n * Hd + y) * Wd + x in the group's tensor, kept for the flush's stores
+  unsigned pok = 0;             // ... and whether they are inside it
   auto pz_request = [&](int d) {  // branch-free, clamped: a row outside the tensor reads pixel 0 and is never used
     const int dy = d >> 1, dx = d & 1;
+    pok = 0;
 #pragma unroll
     for (int hk = 0; hk < 8; ++hk) {
       const int row = wrow * 32 + 16 * (hk >> 2) + (lane >> 4) + 4 * (hk & 3);
       const int n = rowinfo[row];
       const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
       const bool ok = n >= 0 && y < P.Hd && x < P.Wd;
-      pz[PSUM ? hk : 0] = *(const f32x4*)(ppool + (ok ? ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 : (size_t)0) + (lane & 15) * 4);
+      const unsigned pix = ok ? (unsigned)((n * P.Hd + y) * P.Wd + x) : 0u;
+      ppix[PSUM ? hk : 0] = pix;
+      pok |= (ok ? 1u : 0u) << hk;
+      pz[PSUM ? hk : 0] = *(const f32x4*)(ppool + (size_t)pix * 64 + (lane & 15) * 4);
     }
   };
   auto flush16 = [&](int d) {
@@ -457,25 +466,35 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
         const int rowl = eg + 4 * k;
         const int row = wrow * 32 + 16 * half + rowl;
         const f32x4 v = *(const f32x4*)(S + rowl * 64 + ((eslot ^ ((rowl & 4) << 1)) << 2));
-        const int n = rowinfo[row];
-        const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
-        if constexpr (PSUM) {
+        int n = 0, y = 0, x = 0;
+        bool inside;
+        size_t pixel;
+        if constexpr (PSUM) {  // (position and validity of the row were worked out when its pooled value was requested)
           if (half == 0 && k == 0) {
 #pragma unroll
             for (int hk = 0; hk < 8; ++hk) asm volatile("" : "+v"(pz[hk]));
           }
+          inside = (pok >> (half * 4 + k)) & 1u;
+          pixel = ppix[half * 4 + k];
+        } else {
+          n = rowinfo[row];
+          y = rowinfo[TM + row] + dy; x = rowinfo[2 * TM + row] + dx;
+          inside = n >= 0 && y < P.Hd && x < P.Wd;
+          pixel = (size_t)(n * P.Hd + y) * P.Wd + x;
         }
-        if (n >= 0 && y < P.Hd && x < P.Wd) {
-          *(f32x4*)(dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 + eslot * 4) = v;
+        if (inside) {
+          *(f32x4*)(dst + pixel * 64 + eslot * 4) = v;
           if constexpr (PSUM) {
             const f32x4 z = pz[half * 4 + k];
             f32x4 xh;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xh[e] = __builtin_fmaf(__builtin_fmaf(z[e], pisc[e], pc1[e]), pinv[e], pc2[e]);
+            for (int e = 0; e < 4; ++e) xh[e] = __builtin_fmaf(z[e], pA[e], pB[e]);
             bool pos[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) pos[e] = z[e] > 0.f;
             if (pz_zero) {  // scale == 0: relu(bn(.)) is the constant shift; xhat needs the convolution output under the argmax
+              n = rowinfo[row];
+              y = rowinfo[TM + row] + dy; x = rowinfo[2 * TM + row] + dx;
               const uint32_t packed = *(const uint32_t*)(ps.argmax + ((size_t)(grp * P.N + n) * P.Hd + y) * P.Wd * 64 + (size_t)x * 64 + eslot * 4);
 #pragma unroll
               for (int e = 0; e < 4; ++e)
