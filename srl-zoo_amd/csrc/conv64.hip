@@ -394,23 +394,23 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
 
   // PSUM: the pooled value z = relu(gamma * xhat + beta), so where it is positive xhat = (z - beta) / gamma = z * pA + pB with
   // pA = invstd / scale, pB = -(shift / scale + mean) * invstd — one fused multiply-add per element, for this lane's four channels of
-  // the flush layout (4 * (lane & 15) ..); channels with scale == 0 take the gather path (pz_zero: xhat = y * pinv + pc2 there)
-  f32x4 pA = {0.f, 0.f, 0.f, 0.f}, pB = pA, pinv = pA, pc2 = pA, psh = pA;
+  // the flush layout (4 * (lane & 15) ..); channels with scale == 0 (pz_zero, pthr = +inf) are summed by the cold loop of the flush
+  f32x4 pA = {0.f, 0.f, 0.f, 0.f}, pB = pA, pthr = pA;
   unsigned pz_zero = 0;
   const float* __restrict__ ppool = nullptr;
   if constexpr (PSUM) {
     const float* __restrict__ rec = ps.bnp + grp * 256 + (lane & 15) * 4;
     const f32x4 mean = *(const f32x4*)rec;
-    pinv = *(const f32x4*)(rec + 64); psh = *(const f32x4*)(rec + 192);
+    const f32x4 pinv = *(const f32x4*)(rec + 64), psh = *(const f32x4*)(rec + 192);
     const f32x4 psc = *(const f32x4*)(rec + 128);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool zero = psc[e] == 0.f;
       pz_zero |= (zero ? 1u : 0u) << e;
+      pthr[e] = zero ? __builtin_inff() : 0.f;
       const float isc = zero ? 0.f : 1.f / psc[e];
       pA[e] = pinv[e] * isc;
       pB[e] = -(psh[e] * isc + mean[e]) * pinv[e];
-      pc2[e] = -mean[e] * pinv[e];
     }
     ppool = ps.pooled + grp * P.dst_gstride;
   }
@@ -441,9 +441,11 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
     }
   };
   auto flush16 = [&](int d) {
-    if (P.dbg & 2) {
-      if (acc[0][0] + acc[NACC - 1][5] == 123.456f) dst[tid] = acc[0][1];
-      return;
+    if constexpr (PSUM == 0) {  // (the ablation switches belong to the plain kernel)
+      if (P.dbg & 2) {
+        if (acc[0][0] + acc[NACC - 1][5] == 123.456f) dst[tid] = acc[0][1];
+        return;
+      }
     }
     const int dy = d >> 1, dx = d & 1;
     float* S = Bs + wave * 1024;
@@ -489,32 +491,45 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
             f32x4 xh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) xh[e] = __builtin_fmaf(z[e], pA[e], pB[e]);
-            bool pos[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pos[e] = z[e] > 0.f;
-            if (pz_zero) {  // scale == 0: relu(bn(.)) is the constant shift; xhat needs the convolution output under the argmax
-              n = rowinfo[row];
-              y = rowinfo[TM + row] + dy; x = rowinfo[2 * TM + row] + dx;
-              const uint32_t packed = *(const uint32_t*)(ps.argmax + ((size_t)(grp * P.N + n) * P.Hd + y) * P.Wd * 64 + (size_t)x * 64 + eslot * 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if ((pz_zero >> e) & 1u) {
-                  const int a = (packed >> (8 * e)) & 0xff;
-                  const int iy = y * 2 - ps.pad + a / 3, ix = x * 2 - ps.pad + a % 3;
-                  const float vy = ps.y[grp * ps.y_gstride + ((size_t)(n * ps.H + iy) * ps.W + ix) * 64 + eslot * 4 + e];
-                  xh[e] = __builtin_fmaf(vy, pinv[e], pc2[e]);
-                  pos[e] = psh[e] > 0.f;
-                }
-            }
+            // (pthr = 0, or +inf for a channel whose scale is 0: those are summed by the cold loop behind the stores — a load inside THIS
+            // loop's branches would put a full vmcnt wait behind every store)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float dz = pos[e] ? v[e] : 0.f;
+              const float dz = z[e] > pthr[e] ? v[e] : 0.f;
               s4[e] += dz; q4[e] += dz * xh[e];
             }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }
           }
+        }
+      }
+    }
+    if constexpr (PSUM != 0) {
+      if (pz_zero) {
+        // BatchNorm scale exactly 0 in one of this lane's channels: relu(bn(.)) is the constant max(shift, 0) there, every window's
+        // first position is the argmax, and xhat needs the convolution output under it.  Rare and slow on purpose: d(pooled) is read
+        // back from where this lane has just stored it.
+        const float* __restrict__ rec = ps.bnp + grp * 256 + eslot * 4;  // (the cold loop re-reads what it needs of the record)
+        const f32x4 mean = *(const f32x4*)rec, pinv = *(const f32x4*)(rec + 64), psh = *(const f32x4*)(rec + 192);
+#pragma unroll 1
+        for (int hk = 0; hk < 8; ++hk) {
+          if (!((pok >> hk) & 1u)) continue;
+          const int row = wrow * 32 + 16 * (hk >> 2) + eg + 4 * (hk & 3);
+          const int n = rowinfo[row];
+          const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
+          const size_t pixel = ppix[hk];
+          const uint32_t packed = *(const uint32_t*)(ps.argmax + (size_t)grp * P.dst_gstride + pixel * 64 + eslot * 4);
+          const f32x4 v = *(const f32x4*)(dst + pixel * 64 + eslot * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((pz_zero >> e) & 1u) {
+              const int a = (packed >> (8 * e)) & 0xff;
+              const int iy = y * 2 - ps.pad + a / 3, ix = x * 2 - ps.pad + a % 3;
+              const float vy = ps.y[grp * ps.y_gstride + ((size_t)(n * ps.H + iy) * ps.W + ix) * 64 + eslot * 4 + e];
+              const float dz = psh[e] > 0.f ? v[e] : 0.f;
+              s4[e] += dz; q4[e] += dz * ((vy - mean[e]) * pinv[e]);
+            }
         }
       }
     }
