@@ -297,6 +297,7 @@ def main():
         # (srlz_conv1_fwd_u8 ...).  --host-input-nhwc: the frames as decoded ([B,H,W,C]) + srlz_normalize_u8 (the round-2 route).
         rs = np.random.RandomState(4321 + rank)
         fshape = (B, 224, 224, channels) if args.host_input_nhwc else (B, channels, 224, 224)
+        srl.frame_layout = "nhwc" if args.host_input_nhwc else "planar"  # (stated, not guessed: BaseLearner.frame_layout)
         host_frames = [[torch.from_numpy(rs.randint(0, 256, fshape).astype(np.uint8)).pin_memory()
                         for _ in range(2)] for _ in range(2)]  # two alternating minibatches
         copy_stream = torch.cuda.Stream(device=device)
@@ -436,6 +437,33 @@ def main():
                                "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),
                                "layers": layers, "by_symbol": by_symbol}
+        # BASELINE.json north_star: ">= 70 % of the CDNA4 fp32 MFMA roofline on the 3x3 conv encoder" = conv2 (3x3 s1, 56x56) and
+        # conv3 (3x3 s2, 27x27 -> 14x14), reference models/models.py:54-62 — forward, data gradient and weight gradient of each,
+        # from the same instrumented pass as `roofline` (whatever kernel symbol a launch ran under), and their FLOP-weighted aggregate
+        ns, tot = {}, {"all": [0.0, 0.0], "conv2": [0.0, 0.0], "conv3": [0.0, 0.0]}  # [flop, ms]
+        for name, v in sorted(rep.items()):
+            if "/" not in name or v["ms"] <= 0 or not v["flop"]:
+                continue
+            symbol, key = name.split("/", 1)
+            layer = "conv2" if key.startswith("conv s1 ") else "conv3" if key.startswith("conv s2 ") else None
+            what = key.rsplit(" ", 1)[1]
+            if layer is None or what not in ("fwd", "dgrad", "wgrad"):
+                continue
+            tf = v["flop"] / (v["ms"] * 1e-3) / 1e12
+            ns["%s_%s" % (layer, what)] = {"kernel": symbol, "launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                                           "gflop_per_launch": round(v["flop"] / v["launches"] / 1e9, 3),
+                                           "tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+            for t in (tot["all"], tot[layer]):
+                t[0] += v["flop"]
+                t[1] += v["ms"]
+        if ns and channels == 3 and "triplet" not in args.losses:
+            frac = {k: round(f / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) for k, (f, ms) in tot.items() if ms > 0}
+            out["north_star"] = {"what": "the 3x3 conv encoder (conv2 3x3 s1 64->64 @56x56, conv3 3x3 s2 64->64 27x27->14x14): forward, data "
+                                         "gradient, weight gradient; FLOP-weighted aggregate vs the fp32 MFMA peak (target >= 0.70)",
+                                 "peak_tflops": PEAK_FP32_MFMA_TFLOPS, "launch": ns, "frac_conv2": frac.get("conv2"),
+                                 "frac_conv3": frac.get("conv3"), "aggregate_frac": frac.get("all"),
+                                 "aggregate_tflops": round(frac.get("all", 0.0) * PEAK_FP32_MFMA_TFLOPS, 2), "images_per_launch": 2 * B,
+                                 "timing": "same instrumented pass as roofline (HIP events on the launch stream)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(list(args.losses), full=args.cpu_baseline_full)
         print(json.dumps(out))

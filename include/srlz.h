@@ -39,6 +39,13 @@ enum srlz_status {
   SRLZ_ERR_NULL = -4        /* required pointer is NULL */
 };
 
+/* ABI version: bumped whenever an existing entry point changes its signature or the meaning / size of a buffer it fills, so that a
+ * binding built against an older header fails at load time instead of passing a pointer where a float is expected (a binding
+ * compares srlz_version() with the SRLZ_ABI_VERSION it was written for; srl-zoo_amd/srlz/_cabi.py does).
+ * 101 (round 4): srlz_convT_out_bwd_fused carries three gain arguments (added in round 3 without a bump); its partial records and
+ *                workspace follow the strip geometry of csrc/convt_out.hip; srlz_convT_out_fwd_loss_workgroups counts those strips'
+ *                workgroups. */
+#define SRLZ_ABI_VERSION 101
 int srlz_version(void);
 const char* srlz_last_error(void);
 /* Number of CUs of the current device (used by callers to size persistent grids / workspaces). */
@@ -212,11 +219,14 @@ int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* 
                               const float* x_bnp, void* ws, size_t ws_bytes, const srlz_skinny_desc* d,
                               srlz_stream_t stream);
 
-/* kind 1 data gradient + BatchNorm-backward partials + weight gradient + bias gradient in ONE pass over dy and x_raw (C == 3, the
- * layer input was relu(batchnorm(x_raw)): the autograd backward of nn.ConvTranspose2d(64, 3, 4, stride=2), models/models.py:82,
+/* kind 1 data gradient + BatchNorm-backward partials + weight gradient + bias gradient in ONE pass over dy and x_raw (C == 3 or 6,
+ * the layer input was relu(batchnorm(x_raw)): the autograd backward of nn.ConvTranspose2d(64, C, 4, stride=2), models/models.py:82,
  * as srlz_convT_out_bwd_data(x_raw, x_bnp, bn_bwd_partial) followed by srlz_convT_out_bwd_weight(x_bnp) would compute it, with
- * x_raw (1.6 GB at 512 images) and dy crossing HBM once instead of twice.  Tiles are 8 x 16 feature positions:
- * bn_bwd_partial has srlz_convT_out_bwd_fused_tiles(d) rows of 128 floats; ws >= srlz_convT_out_bwd_fused_workspace(d) bytes. */
+ * x_raw (1.6 GB at 512 images) and dy crossing HBM once instead of twice.  Round 4: output-stationary, one wave per strip of 16
+ * feature columns x R rows (csrc/convt_out.hip); bn_bwd_partial has srlz_convT_out_bwd_fused_tiles(d) rows of 128 floats (one per
+ * strip, image-major: the records of BatchNorm group g are rows [g, g+1) * tiles / groups); ws >=
+ * srlz_convT_out_bwd_fused_workspace(d) bytes.  srlz_convT_out_bwd_fused_supported: 1 for C in {3, 6}, else 0 (use the two calls). */
+int srlz_convT_out_bwd_fused_supported(const srlz_skinny_desc* d);
 int srlz_convT_out_bwd_fused_tiles(const srlz_skinny_desc* d);
 size_t srlz_convT_out_bwd_fused_workspace(const srlz_skinny_desc* d);
 /* dy_gain_dev != NULL: `dy_nchw` holds the reconstruction ERROR dec - obs left behind by srlz_convT_out_fwd_loss, and the loss

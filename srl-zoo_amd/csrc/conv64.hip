@@ -1914,10 +1914,8 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
     SRLZ_LAUNCHED();
     return 0;
   }
-  // 4 waves (32x64 per wave) is the default; SRLZ_NW=8 selects 8 waves of 32x32 (measured within +-3 %: the kernel is
-  // bound by the power-limited matrix rate, not by latency hiding)
-  static const int nw = [] { const char* e = getenv("SRLZ_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
-  static const int nw_bwd = [] { const char* e = getenv("SRLZ_NW_BWD"); return e ? ((atoi(e) == 8) ? 8 : 4) : nw; }();
+  // 4 waves (32x64 per wave); 8 waves of 32x32 were measured within +-3 % (the kernel is bound by the power-limited matrix
+  // rate, not by latency hiding) and are not instantiated any more
 #define SRLZ_FWD_LAUNCH(NWV, BWDV)                                                                                          \
   do {                                                                                                                     \
     SRLZ_MAX_LDS((conv64_fwd_kernel<NWV, BWDV>), lds);                                                                      \
@@ -1942,11 +1940,9 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
       SRLZ_LAUNCHED();
       return 0;
     }
-    if (nw_bwd == 8) SRLZ_FWD_LAUNCH(8, true);
-    else SRLZ_FWD_LAUNCH(4, true);
+    SRLZ_FWD_LAUNCH(4, true);
   } else {
-    if (nw == 8) SRLZ_FWD_LAUNCH(8, false);
-    else SRLZ_FWD_LAUNCH(4, false);
+    SRLZ_FWD_LAUNCH(4, false);
   }
 #undef SRLZ_FWD_LAUNCH
   SRLZ_LAUNCHED();
@@ -1968,8 +1964,7 @@ static int make_bwd_fuse(OpFuse* f, const srlz_bn_bwd_operand* o, const char* wh
 static int wgrad_grid(const ConvProg& P) {
   const int tk = wgrad_tk(P);
   const int nchunks = (P.total_q + tk - 1) / tk;  // per group
-  static const int per_cu = [] { const char* e = getenv("SRLZ_WGRAD_PER_CU"); return (e && atoi(e) == 1) ? 1 : 2; }();
-  int g = per_cu * srlz_device_cus() / P.G;      // per group
+  int g = 2 * srlz_device_cus() / P.G;           // two persistent workgroups per CU; per group
   if (g > nchunks) g = nchunks;
   if (g < 1) g = 1;
   return g * P.G;

@@ -1,0 +1,703 @@
+// convt_out.hip — the decoder's last layer, nn.ConvTranspose2d(64, C, 4, stride=2) (/root/reference/models/models.py:82): forward
+// (+ the step's reconstruction / generation loss, /root/reference/losses/losses.py:172-214) and its whole backward, both
+// OUTPUT-STATIONARY and WAVE-PRIVATE (round 4; the round-1..3 kernels — a pixel-GEMM into 48 products per pixel followed by a col2im
+// gather through LDS, and 8x16-position tiles for the backward — spent 5-7 VALU instructions per MFMA on gathers, transposes and
+// window bookkeeping and were the only kernels of the step with LDS bank conflicts).
+//
+// Geometry.  out[co, 2a+py, 2b+px] = bias[co] + sum_{dy,dx in {0,1}} sum_ci  in[a-dy, b-dx, ci] * W[ci, co, py+2dy, px+2dx]
+// for block positions (a, b) in [0, HF] x [0, WF]: every one of the 16 taps is used exactly once per 2x2 output block, nothing is
+// scattered and nothing gathered — the accumulators ARE output pixels.
+//
+// Work unit = one WAVE walking down a column strip: 16 block positions wide (one MFMA N-tile), `R` rows high.  A wave keeps what
+// it needs of the rows above in its own LDS (forward: the previous input row; backward: an 8-row ring of the error image) and
+// never synchronises with another wave: no __syncthreads in the main loops, the compiler's lgkmcnt waits order a wave's own LDS
+// traffic.  Per row the loads of the NEXT row are issued before the MFMAs of this one.
+//
+// MFMA: v_mfma_f32_16x16x4_f32 (16 x 16 outputs, 4 k per instruction; lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15], and receives D[i = 4 (l >> 4) + r][j = l & 15] in register r).
+//   forward   D[comp][pos]     = sum_k W[comp][k] * in[k][pos]      comp = co*4 + py*2 + px (12 of 16 rows used), k = (dy,dx,ci): 256
+//   data grad D[ci][pos]       = sum_k W[ci][k] * err[k][pos]       k = (co,ky,kx): 48 per channel group, exact
+//   wgt grad  D[ci][(ky,kx)]   = sum_pos act[ci][pos] * err[pos][co,ky,kx]   per co, exact
+// so a lane's four accumulator registers are: forward — the 2x2 output block of ONE channel co = lane >> 4 at position lane & 15
+// (two 8-byte NCHW stores, the loss taken in registers); data gradient — four consecutive channels of one position (16-byte NHWC
+// stores, the same layout the BatchNorm-backward sums read y in).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __forceinline__ int xcd_wg(int b, int nb) { return xcd_remap(b, nb); }
+
+constexpr int OSP = 68;            // LDS pitch (floats) of one staged 64-channel pixel: 8 consecutive pixels -> 8 distinct bank quads
+constexpr int OSROW = 18 * OSP;    // forward: 16 positions + the left halo pixel + one dummy pixel (branch-free tail of the landing)
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward.  NCG = C / 3 channel groups share one staging of the input row: NCG == 1 keeps the 64 A fragments (weights) of a lane in
+// registers, NCG > 1 reads them per group from LDS (16 x ds_read_b128 per group and row).
+// LOSS: target != NULL; img receives dec - target, dec_out (optional) the reconstruction; loss_partial[2][workgroups] (fp64).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCG, bool LOSS, typename TT>
+__global__ __launch_bounds__(256, 3) void convT_out_os_kernel(const float* __restrict__ feat, const float* __restrict__ w_ref,
+                                                             const float* __restrict__ bias, float* __restrict__ img, int N, int H,
+                                                             int W, int HF, int WF, const float* __restrict__ feat_bnp, int npg,
+                                                             const TT* __restrict__ target, float* __restrict__ dec_out,
+                                                             double* __restrict__ loss_partial, int lpg,
+                                                             const float* __restrict__ lut, int R, int nseg, int nchunk) {
+  constexpr bool U8 = sizeof(TT) == 1;
+  constexpr int C = 3 * NCG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* S = (float*)smem + wave * (2 * OSROW);         // this wave's two row slots
+  float* Wl = (float*)smem + 4 * 2 * OSROW;             // NCG > 1: A fragments [cg][t][jj][lane][4]
+  float* L = Wl + (NCG > 1 ? NCG * 4 * 4 * 64 * 4 : 0);  // U8: the normalisation table
+  const int p = lane & 15, kq = lane >> 4;              // compute roles: position / k-quarter (forward epilogue: kq = co)
+  const int c4 = lane & 15, pq = lane >> 4;             // staging roles: channels 4 c4 .. 4 c4 + 3 of pixel pq + 4 i
+
+  // ---- A fragments: lane (m = comp, kq) holds W[ci = 16 kq + j][co][py + 2 dy][px + 2 dx] for t = (dy, dx), j = 0..15
+  const int co_m = p >> 2, py_m = (p >> 1) & 1, px_m = p & 1;
+  float wr[NCG == 1 ? 4 : 1][16];
+  if constexpr (NCG == 1) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        wr[t][j] = w_ref[((size_t)(16 * kq + j) * C + (p < 12 ? co_m : 0)) * 16 + (py_m + 2 * (t >> 1)) * 4 + (px_m + 2 * (t & 1))];
+    if (p >= 12) {  // rows 12..15 of the 16 x 16 output tile do not exist
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wr[t][j] = 0.f;
+    }
+  } else {
+    for (int idx = tid; idx < NCG * 4 * 4 * 64 * 4; idx += 256) {
+      const int e = idx & 3, ln = (idx >> 2) & 63, jj = (idx >> 8) & 3, t = (idx >> 10) & 3, cg = idx >> 12;
+      const int m = ln & 15, q = ln >> 4;
+      Wl[idx] = m < 12 ? w_ref[((size_t)(16 * q + 4 * jj + e) * C + cg * 3 + (m >> 2)) * 16 + (((m >> 1) & 1) + 2 * (t >> 1)) * 4 +
+                               ((m & 1) + 2 * (t & 1))]
+                       : 0.f;
+    }
+  }
+  if constexpr (U8) {
+    for (int i = tid; i < 768; i += 256) L[i] = lut[i];  // (per channel of a group of 3, as image_land<U8>)
+  }
+  if constexpr (NCG > 1 || U8) __syncthreads();
+  float bs[NCG];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) bs[cg] = (bias && kq < 3) ? bias[cg * 3 + kq] : 0.f;
+
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};  // (no record: z = 1 * y + 0 = y exactly)
+  const float act_lo = feat_bnp ? 0.f : -__builtin_inff();
+  int cur_grp = -1;
+  double lacc0 = 0.0, lacc1 = 0.0;
+  const int njobs = N * nchunk * nseg;
+  const int wg = xcd_wg(blockIdx.x, gridDim.x);
+
+  for (int job = wg * 4 + wave; job < njobs; job += gridDim.x * 4) {
+    const int seg = job % nseg, jt = job / nseg;
+    const int chunk = jt % nchunk, n = jt / nchunk;
+    const int a0 = chunk * R, a1 = min(a0 + R, HF + 1), b0 = seg * 16;
+    if (feat_bnp && n / npg != cur_grp) {
+      cur_grp = n / npg;
+      const float* __restrict__ rec = feat_bnp + cur_grp * 256;
+      sc = *(const f32x4*)(rec + 128 + 4 * c4);
+      sh = *(const f32x4*)(rec + 192 + 4 * c4);
+    }
+    const float* __restrict__ fimg = feat + (size_t)n * HF * WF * 64 + 4 * c4;
+    f32x4 ld[5];
+    unsigned ldok = 0;
+    // row r of the input strip (pixels b0-1 .. b0+15) -> registers; a pixel outside the map reads a clamped address and lands as 0
+    auto request = [&](int r) {
+      const bool rowok = (unsigned)r < (unsigned)HF;
+      ldok = 0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int fx = b0 - 1 + pq + 4 * i;
+        const bool ok = rowok && (i < 4 || pq == 0) && (unsigned)fx < (unsigned)WF;
+        const unsigned off = ok ? (unsigned)((r * WF + fx) * 64) : 0u;
+        ld[i] = *(const f32x4*)(fimg + off);
+        ldok |= (ok ? 1u : 0u) << i;
+      }
+    };
+    // landing: relu(bn(.)) and the zero of a pixel outside the map are ONE v_med3 per element — med3(z, lo, hi) with (lo, hi) =
+    // (0, +inf) for a live pixel of a BatchNorm+ReLU operand, (-inf, +inf) when there is no BatchNorm record, (0, 0) outside
+    auto land = [&](int r) {
+      float* dst = S + (r & 1) * OSROW + 4 * c4;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const bool ok = (ldok >> i) & 1u;
+        const float lo = ok ? act_lo : 0.f, hi = ok ? __builtin_inff() : 0.f;
+        f32x4 v = ld[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * sc[e] + sh[e], lo, hi);
+        const int pl = (i < 4 || pq == 0) ? pq + 4 * i : 17;  // (pixel 17: the dummy the idle lanes of the fifth load write)
+        *(f32x4*)(dst + pl * OSP) = v;
+      }
+    };
+    request(a0 - 1);
+    land(a0 - 1);
+    request(a0);
+    for (int a = a0; a < a1; ++a) {
+      land(a);
+      // ---- targets of this row's 2x2 blocks (LOSS): requested BEFORE the next row — the memory counter is in-order, so waiting for
+      // them in the epilogue must not also wait for the row that is meant to stay in flight until the next iteration
+      const bool live = kq < 3 && b0 + p <= WF;
+      [[maybe_unused]] float tg[NCG][4];
+      if constexpr (LOSS) {
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            const size_t o = live ? ((size_t)(n * C + cg * 3 + kq) * H + 2 * a + py) * W + 2 * (b0 + p) : (size_t)0;
+            if constexpr (U8) {
+              const unsigned short raw = *(const unsigned short*)((const uint8_t*)target + o);
+              tg[cg][2 * py] = __uint_as_float((unsigned)(raw & 0xff));
+              tg[cg][2 * py + 1] = __uint_as_float((unsigned)(raw >> 8));
+            } else {
+              const float2 raw = *(const float2*)((const float*)target + o);
+              tg[cg][2 * py] = raw.x;
+              tg[cg][2 * py + 1] = raw.y;
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      request(a + 1);  // (past the strip's last row: clamped addresses, never landed)
+      __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the requests below the MFMAs, next to their first use)
+      float lsum = 0.f;
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // B fragments: the 4 x 16 bytes of shift t + 1 are read while the 16 MFMAs of shift t run
+        f32x4 bb[2][4];
+        auto read_b = [&](int t, f32x4 (&b)[4]) {
+          const float* bp = S + ((a - (t >> 1)) & 1) * OSROW + (p + 1 - (t & 1)) * OSP + 16 * kq;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) b[jj] = *(const f32x4*)(bp + 4 * jj);
+        };
+        read_b(0, bb[0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t < 3) read_b(t + 1, bb[(t + 1) & 1]);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 b = bb[t & 1][jj];
+            f32x4 wv;
+            if constexpr (NCG == 1) wv = f32x4{wr[t][4 * jj], wr[t][4 * jj + 1], wr[t][4 * jj + 2], wr[t][4 * jj + 3]};
+            else wv = *(const f32x4*)(Wl + (((cg * 4 + t) * 4 + jj) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (t < 2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], b[e], acc0, 0, 0, 0);
+              else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], b[e], acc1, 0, 0, 0);
+            }
+          }
+        }
+        // (pin the order the source states: hipcc's scheduler otherwise pairs every two reads with the eight MFMAs that use them)
+        if constexpr (NCG == 1) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            if (t < 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        // ---- epilogue: this lane holds out[co = kq][2a + py][2(b0 + p) + px] in register py*2 + px
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + bs[cg];
+        if constexpr (LOSS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(tg[cg][r]));  // waited for once, outside the branch below
+          if constexpr (U8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tg[cg][r] = L[(kq < 3 ? kq : 0) * 256 + (int)__float_as_uint(tg[cg][r])];
+          }
+        }
+        if (live) {
+          const size_t o = ((size_t)(n * C + cg * 3 + kq) * H + 2 * a) * W + 2 * (b0 + p);
+          if constexpr (LOSS) {
+            float d[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { d[r] = v[r] - tg[cg][r]; lsum += d[r] * d[r]; }
+            *(float2*)(img + o) = float2{d[0], d[1]};
+            *(float2*)(img + o + W) = float2{d[2], d[3]};
+            if (dec_out) {
+              *(float2*)(dec_out + o) = float2{v[0], v[1]};
+              *(float2*)(dec_out + o + W) = float2{v[2], v[3]};
+            }
+          } else {
+            *(float2*)(img + o) = float2{v[0], v[1]};
+            *(float2*)(img + o + W) = float2{v[2], v[3]};
+          }
+        }
+      }
+      if constexpr (LOSS) { if (n / lpg == 0) lacc0 += (double)lsum; else lacc1 += (double)lsum; }
+    }
+  }
+  if constexpr (LOSS) {
+    // [2 loss groups][workgroups of the launch] — every workgroup writes both slots (zeros included), fixed-order final sum
+    __syncthreads();
+    double* lred = (double*)smem;  // [2][4 waves]
+    const double w0 = wave_sum_d(lacc0), w1 = wave_sum_d(lacc1);
+    if (lane == 0) { lred[wave] = w0; lred[4 + wave] = w1; }
+    __syncthreads();
+    if (tid < 2) loss_partial[(size_t)tid * gridDim.x + blockIdx.x] = (lred[tid * 4] + lred[tid * 4 + 1]) + (lred[tid * 4 + 2] + lred[tid * 4 + 3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward: data gradient dA = d(loss)/d(relu(bn(y))), the two BatchNorm-backward sums of every strip (one record per job),
+// weight gradient and bias gradient from ONE read of err (= dy, or the stored reconstruction error times `gain`) and ONE read of y.
+//   err ring: [3 NCG channels][8 rows][RP] per wave — rows 2a .. 2a+3 serve position row a; two new rows per step.
+//   F:        relu(bn(y)) of the strip's current row, [16 positions][OSP] — the weight gradient's A operand.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int RP = 40;  // ring row pitch (34 columns used)
+
+template <int NCG>
+__global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* __restrict__ err, const float* __restrict__ w_ref,
+                                                                 float* __restrict__ dA, float* __restrict__ stats_partial,
+                                                                 float* __restrict__ wpartial, int N, int H, int W, int HF, int WF,
+                                                                 const float* __restrict__ y_raw, const float* __restrict__ y_bnp,
+                                                                 int npg, double* __restrict__ bias_partial,
+                                                                 const float* __restrict__ gain_dev, float gain_div, float gain_coef,
+                                                                 int R, int nseg, int nchunk) {
+  constexpr int C = 3 * NCG, RING = C * 8 * RP, FSZ = 16 * OSP, PERW = RING + FSZ + 192;
+  constexpr int NE = C * 34;                  // float2 elements of a 2-row err request: (channel, row of the pair, column pair)
+  constexpr int NSLOT = (NE + 63) / 64;
+  const float gain = gain_dev ? (gain_dev[0] / gain_div) * gain_coef : 1.f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* ring = (float*)smem + wave * PERW;
+  float* F = ring + RING;
+  float* Bn = F + FSZ;                        // the BatchNorm record of the strip's group: mean[64], scale[64], shift[64]
+  float* Wl = (float*)smem + 4 * PERW;        // NCG > 1: data-gradient A fragments [cg][mt][s][lane]
+  const int p = lane & 15, kq = lane >> 4;
+  const int ky_n = p >> 2, kx_n = p & 3;      // weight gradient: this lane's output column n = (ky, kx)
+
+  // ---- data-gradient A fragments: lane (m, kq = kx) holds W[ci = 16 mt + m][co][ky][kx] for step s = co*4 + ky
+  float wA[NCG == 1 ? 4 : 1][12];
+  if constexpr (NCG == 1) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int s = 0; s < 12; ++s) wA[mt][s] = w_ref[((size_t)(16 * mt + p) * C + (s >> 2)) * 16 + (s & 3) * 4 + kq];
+  } else {
+    for (int idx = tid; idx < NCG * 4 * 12 * 64; idx += 256) {
+      const int ln = idx & 63, s = (idx >> 6) % 12, mt = ((idx >> 6) / 12) & 3, cg = (idx >> 6) / 48;
+      Wl[idx] = w_ref[((size_t)(16 * mt + (ln & 15)) * C + cg * 3 + (s >> 2)) * 16 + (s & 3) * 4 + (ln >> 4)];
+    }
+    __syncthreads();
+  }
+  f32x4 accw[NCG][4][3];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int co = 0; co < 3; ++co) accw[cg][mt][co] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- err request slots: element e = lane + 64 k = (channel ch, row rs of the pair, column pair cp), packed in one register
+  int e_pk[NSLOT];  // (ch << 8) | (rs << 5) | cp, or -1 past the end of the request
+  float bsum[NSLOT];
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int e = lane + 64 * k;
+    e_pk[k] = e < NE ? ((e / 34) << 8) | (((e % 34) / 17) << 5) | (e % 17) : -1;
+    bsum[k] = 0.f;
+  }
+  int cur_grp = -1;
+  const int njobs = N * nchunk * nseg;
+  const int wg = xcd_wg(blockIdx.x, gridDim.x);
+
+  for (int job = wg * 4 + wave; job < njobs; job += gridDim.x * 4) {
+    const int seg = job % nseg, jt = job / nseg;
+    const int chunk = jt % nchunk, n = jt / nchunk;
+    const int a0 = chunk * R, a1 = min(a0 + R, HF), b0 = seg * 16;
+    if (n / npg != cur_grp) {
+      cur_grp = n / npg;
+      const float* __restrict__ rec = y_bnp + cur_grp * 256;
+      Bn[lane] = rec[lane];
+      Bn[64 + lane] = rec[128 + lane];
+      Bn[128 + lane] = rec[192 + lane];
+    }
+    const bool last_seg = seg == nseg - 1, last_chunk = a1 == HF;
+    const float* __restrict__ eimg = err + (size_t)n * C * H * W;
+    const float* __restrict__ yimg = y_raw + (size_t)n * HF * WF * 64 + 4 * kq;
+    float* __restrict__ dimg = dA + (size_t)n * HF * WF * 64 + 4 * kq;
+    // ---- per strip: where each request slot reads (element offset of row 0) and lands, which slots exist, which are owned
+    // (H and W are even and requests start at even rows / columns, so "row inside the image" and "row owned" are wave-uniform)
+    unsigned e_off[NSLOT];
+    int r_off[NSLOT];
+    unsigned livemask = 0, ownmask = 0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int ch = e_pk[k] >> 8, rs = (e_pk[k] >> 5) & 1, cp = e_pk[k] & 31;
+      const int xx = 2 * b0 + 2 * cp;
+      const bool lv = e_pk[k] >= 0 && xx < W;
+      e_off[k] = lv ? (unsigned)((ch * H + rs) * W + xx) : 0u;
+      // (elements past the end of the request land in the spare columns 36, 37 of channel 0)
+      r_off[k] = e_pk[k] >= 0 ? (ch * 8 + rs) * RP + 2 * cp : rs * RP + 36;
+      livemask |= (lv ? 1u : 0u) << k;
+      // bias gradient: a strip OWNS rows [2 a0, 2 a1) (the last chunk also the two tail rows) and column pairs 0..15 (the last
+      // segment also pair 16) of what it stages, so every pixel of the error image is counted exactly once
+      ownmask |= ((lv && (cp < 16 || last_seg)) ? 1u : 0u) << k;
+    }
+    float2 ev[NSLOT];
+    unsigned evin = 0, evown = 0;
+    // err rows y0, y0 + 1 (y0 even; columns 2 b0 .. 2 b0 + 33) -> registers
+    auto req_err = [&](int y0, bool any) {
+      const bool rows = any && y0 < H;
+      evin = rows ? livemask : 0u;
+      evown = (rows && (y0 < 2 * a1 || last_chunk)) ? ownmask : 0u;
+      const unsigned rowoff = (unsigned)(y0 * W);
+#pragma unroll
+      for (int k = 0; k < NSLOT; ++k) ev[k] = *(const float2*)(eimg + (((evin >> k) & 1u) ? e_off[k] + rowoff : 0u));
+    };
+    auto land_err = [&](int y0) {
+      float* dst = ring + (y0 & 7) * RP;
+#pragma unroll
+      for (int k = 0; k < NSLOT; ++k) {
+        const bool in = (evin >> k) & 1u;
+        const float2 g = float2{in ? ev[k].x * gain : 0.f, in ? ev[k].y * gain : 0.f};
+        bsum[k] += ((evown >> k) & 1u) ? g.x + g.y : 0.f;
+        *(float2*)(dst + r_off[k]) = g;
+      }
+    };
+    const bool pvalid = b0 + p < WF;
+    const unsigned ypos = (unsigned)((b0 + p) * 64);
+    f32x4 yv[4];
+    auto req_y = [&](int a, bool any) {
+      const unsigned off = (any && pvalid) ? (unsigned)(a * WF * 64) + ypos : 0u;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) yv[mt] = *(const f32x4*)(yimg + off + 16 * mt);
+    };
+    req_err(2 * a0, true);
+    land_err(2 * a0);
+    req_err(2 * a0 + 2, true);
+    req_y(a0, true);
+    f32x4 s1[4], s2[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) s1[mt] = s2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int a = a0; a < a1; ++a) {
+      land_err(2 * a + 2);
+      // ---- data gradient: D[ci][pos], K = (cg, co, ky, kx)
+      f32x4 acc[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+          const int co = s >> 2, ky = s & 3;
+          const float b = ring[((cg * 3 + co) * 8 + ((2 * a + ky) & 7)) * RP + 2 * p + kq];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            float w;
+            if constexpr (NCG == 1) w = wA[mt][s]; else w = Wl[((cg * 4 + mt) * 12 + s) * 64 + lane];
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, acc[mt], 0, 0, 0);
+          }
+        }
+      // ---- epilogue: this lane holds dA[pos p][ci = 16 mt + 4 kq + e]; y of the same (pos, channels) is in yv
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(yv[mt]));
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 bmean = *(const f32x4*)(Bn + 16 * mt + 4 * kq), bsc = *(const f32x4*)(Bn + 64 + 16 * mt + 4 * kq),
+                    bsh = *(const f32x4*)(Bn + 128 + 16 * mt + 4 * kq);
+        f32x4 act;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = yv[mt][e] * bsc[e] + bsh[e];
+          const bool on = z > 0.f && pvalid;
+          act[e] = on ? z : 0.f;
+          const float v = on ? acc[mt][e] : 0.f;
+          s1[mt][e] += v;
+          s2[mt][e] += v * (yv[mt][e] - bmean[e]);
+        }
+        *(f32x4*)(F + p * OSP + 16 * mt + 4 * kq) = act;
+      }
+      if (pvalid) {
+        const unsigned off = (unsigned)(a * WF * 64) + ypos;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *(f32x4*)(dimg + off + 16 * mt) = acc[mt];
+      }
+      // ---- the next row's operands travel under the weight-gradient MFMAs
+      req_err(2 * a + 4, a + 1 < a1);
+      req_y(a + 1, a + 1 < a1);
+      // (hipcc sinks a load whose only use is in the next iteration down to that use — behind the MFMAs it was meant to travel
+      // under; a memory clobber is a point no load may be moved across)
+      asm volatile("" ::: "memory");
+      // ---- weight gradient: D[ci][(ky,kx)] per co, K = the 16 positions of the row (k-step s, quarter kq -> position 4 s + kq)
+      const int rrow = ((2 * a + ky_n) & 7) * RP + 2 * kq + kx_n;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float af[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = F[(4 * s + kq) * OSP + 16 * mt + p];
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+          for (int co = 0; co < 3; ++co) {
+            const float b = ring[(cg * 3 + co) * 8 * RP + rrow + 8 * s];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) accw[cg][mt][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], b, accw[cg][mt][co], 0, 0, 0);
+          }
+      }
+    }
+    // ---- the strip's BatchNorm-backward record: [sum dz (64)] [sum dz * xhat (64)], summed over the 16 positions (lanes p)
+    {
+      const float* __restrict__ rec = y_bnp + cur_grp * 256;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 inv = *(const f32x4*)(rec + 64 + 16 * mt + 4 * kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = s1[mt][e], v = s2[mt][e];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
+          s1[mt][e] = u;
+          s2[mt][e] = v * inv[e];
+        }
+      }
+      if (p == 0) {
+        float* out = stats_partial + (size_t)job * 128 + 4 * kq;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          *(f32x4*)(out + 16 * mt) = s1[mt];
+          *(f32x4*)(out + 64 + 16 * mt) = s2[mt];
+        }
+      }
+    }
+  }
+
+  // ---- weight-gradient partial of the workgroup: the four waves' accumulators summed through LDS -> wpartial[cg][wg][ci][48]
+  __syncthreads();
+  float* red = (float*)smem;  // [4 waves][64 ci][48]
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 64 + 16 * mt + 4 * kq + r) * 48 + co * 16 + p] = accw[cg][mt][co][r];
+    __syncthreads();
+    float* out = wpartial + ((size_t)cg * gridDim.x + blockIdx.x) * (64 * 48);
+    for (int i = tid; i < 64 * 48; i += 256) out[i] = (red[i] + red[64 * 48 + i]) + (red[2 * 64 * 48 + i] + red[3 * 64 * 48 + i]);
+    __syncthreads();
+  }
+  if (bias_partial) {  // [C][gridDim.x] fp64, summed over workgroups in a fixed order by chan_sum_final
+    double* bred = (double*)smem;  // [C][4 waves]
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+      float cs = 0.f;
+#pragma unroll
+      for (int k = 0; k < NSLOT; ++k) cs += (e_pk[k] >= 0 && (e_pk[k] >> 8) == cc) ? bsum[k] : 0.f;
+      const double dsum = wave_sum_d((double)cs);
+      if (lane == 0) bred[cc * 4 + wave] = dsum;
+    }
+    __syncthreads();
+    if (tid < C) bias_partial[(size_t)tid * gridDim.x + blockIdx.x] = (bred[tid * 4] + bred[tid * 4 + 1]) + (bred[tid * 4 + 2] + bred[tid * 4 + 3]);
+  }
+}
+
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+int os_rows(const char* name, int dflt) {
+  const char* e = getenv(name);
+  const int r = e ? atoi(e) : 0;
+  return r > 0 ? r : dflt;
+}
+// rows per strip (development knobs; the defaults are the measured-best values)
+int fwd_rows() { static const int r = os_rows("SRLZ_OS_FWD_ROWS", 16); return r; }
+int bwd_rows() { static const int r = os_rows("SRLZ_OS_BWD_ROWS", 16); return r; }
+
+int os_check(const srlz_skinny_desc* d, const char* who) {
+  SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "%s: null descriptor", who);
+  SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "%s: descriptor kind must be 1", who);
+  SRLZ_REQUIRE(d->n > 0 && d->c > 0 && d->c % 3 == 0 && d->c <= 9, SRLZ_ERR_BAD_DESC, "%s: C must be 3, 6 or 9 (got %d)", who, d->c);
+  SRLZ_REQUIRE(d->himg == (d->hf - 1) * 2 + 4 && d->wimg == (d->wf - 1) * 2 + 4, SRLZ_ERR_BAD_DESC,
+               "%s: image %dx%d inconsistent with feature map %dx%d", who, d->himg, d->wimg, d->hf, d->wf);
+  SRLZ_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->n % d->groups == 0), SRLZ_ERR_BAD_DESC,
+               "%s: n = %d is not a multiple of groups = %d", who, d->n, d->groups);
+  // per-image element offsets are 32-bit in the kernels
+  SRLZ_REQUIRE((long long)d->hf * d->wf * 64 < (1LL << 31) && (long long)d->c * d->himg * d->wimg < (1LL << 31), SRLZ_ERR_BAD_DESC,
+               "%s: one image of %dx%d exceeds the 32-bit per-image offsets", who, d->himg, d->wimg);
+  return 0;
+}
+
+struct OsGeo { int nseg, nchunk, njobs, grid, rows; };
+OsGeo fwd_geo(const srlz_skinny_desc* d) {
+  OsGeo g;
+  g.rows = fwd_rows();
+  g.nseg = (d->wf + 1 + 15) / 16;
+  g.nchunk = (d->hf + 1 + g.rows - 1) / g.rows;
+  g.njobs = d->n * g.nchunk * g.nseg;
+  const int want = (g.njobs + 3) / 4, cap = 2 * srlz_device_cus();
+  g.grid = want < cap ? want : cap;
+  return g;
+}
+OsGeo bwd_geo(const srlz_skinny_desc* d) {
+  OsGeo g;
+  g.rows = bwd_rows();
+  g.nseg = (d->wf + 15) / 16;
+  g.nchunk = (d->hf + g.rows - 1) / g.rows;
+  g.njobs = d->n * g.nchunk * g.nseg;
+  const int want = (g.njobs + 3) / 4, cap = 2 * srlz_device_cus();
+  g.grid = want < cap ? want : cap;
+  return g;
+}
+int os_npg(const srlz_skinny_desc* d) { return d->n / (d->groups > 1 ? d->groups : 1); }
+
+template <int NCG, bool LOSS, typename TT>
+int os_fwd_launch(const float* x, const float* w, const float* bias, float* out, const float* bnp, const TT* target, float* dec,
+                  double* loss_partial, const float* lut, const srlz_skinny_desc* d, hipStream_t st) {
+  const OsGeo g = fwd_geo(d);
+  const size_t lds = (size_t)(4 * 2 * OSROW + (NCG > 1 ? NCG * 4096 : 0) + (sizeof(TT) == 1 ? 768 : 0)) * 4;
+  SRLZ_MAX_LDS((convT_out_os_kernel<NCG, LOSS, TT>), lds);
+  hipLaunchKernelGGL((convT_out_os_kernel<NCG, LOSS, TT>), dim3(g.grid), dim3(256), lds, st, x, w, bias, out, d->n, d->himg, d->wimg,
+                     d->hf, d->wf, bnp, os_npg(d), target, dec, loss_partial, d->n / 2 > 0 ? d->n / 2 : 1, lut, g.rows, g.nseg, g.nchunk);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+template <bool LOSS, typename TT>
+int os_fwd(const float* x, const float* w, const float* bias, float* out, const float* bnp, const TT* target, float* dec,
+           double* loss_partial, const float* lut, const srlz_skinny_desc* d, hipStream_t st) {
+  switch (d->c) {
+    case 3: return os_fwd_launch<1, LOSS, TT>(x, w, bias, out, bnp, target, dec, loss_partial, lut, d, st);
+    case 6: return os_fwd_launch<2, LOSS, TT>(x, w, bias, out, bnp, target, dec, loss_partial, lut, d, st);
+    default: return os_fwd_launch<3, LOSS, TT>(x, w, bias, out, bnp, target, dec, loss_partial, lut, d, st);
+  }
+}
+
+__global__ void os_chan_sum_final(const double* __restrict__ partial, int n, float* __restrict__ out) {
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[(size_t)c * n + i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+// dw_ref[ci][cg*3+co][ky][kx] = sum over workgroups of partial[cg][wg][ci][co*16 + ky*4 + kx]; fp64, fixed order
+__global__ __launch_bounds__(1024) void os_wgrad_reduce(const float* __restrict__ partial, int nwg, int C, float* __restrict__ dw_ref) {
+  constexpr int OUTS = 64, PARTS = 16;
+  const int o = threadIdx.x & (OUTS - 1), part = threadIdx.x / OUTS;
+  const int id = blockIdx.x * OUTS + o;  // (cg, ci, k) with k fastest; the grid covers NCG * 64 * 48 exactly
+  const int cg = id / (64 * 48), rem = id - cg * (64 * 48);
+  const float* base = partial + (size_t)cg * nwg * (64 * 48) + rem;
+  const int per = (nwg + PARTS - 1) / PARTS;
+  const int w0 = part * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int w = w0;
+  for (; w + 3 < w1; w += 4) {
+    s0 += (double)base[(size_t)w * (64 * 48)];
+    s1 += (double)base[(size_t)(w + 1) * (64 * 48)];
+    s2 += (double)base[(size_t)(w + 2) * (64 * 48)];
+    s3 += (double)base[(size_t)(w + 3) * (64 * 48)];
+  }
+  for (; w < w1; ++w) s0 += (double)base[(size_t)w * (64 * 48)];
+  __shared__ double sm[PARTS][OUTS];
+  sm[part][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (part == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) t += sm[q][o];
+    const int ci = rem / 48, k = rem - ci * 48;
+    dw_ref[((size_t)ci * C + cg * 3) * 16 + k] = (float)t;
+  }
+}
+
+}  // namespace
+
+// ---- C ABI (declared in include/srlz.h) ---------------------------------------------------------------------------------
+extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw, const float* x_bnp,
+                                  const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = os_check(d, "convT_out_fwd")) return rc;
+  SRLZ_REQUIRE(x_nhwc && w_ref && y_nchw, SRLZ_ERR_NULL, "convT_out_fwd: null pointer");
+  return os_fwd<false, float>(x_nhwc, w_ref, bias, y_nchw, x_bnp, nullptr, nullptr, nullptr, nullptr, d, as_stream(stream));
+}
+
+extern "C" int srlz_convT_out_fwd_loss_workgroups(const srlz_skinny_desc* d) {
+  if (os_check(d, "convT_out_fwd_loss_workgroups")) return -1;
+  return fwd_geo(d).grid;
+}
+
+template <typename TT>
+static int os_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const TT* target, const float* lut, float* err_nchw,
+                       float* dec_nchw, const float* x_bnp, double* loss_partial, const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = os_check(d, "convT_out_fwd_loss")) return rc;
+  SRLZ_REQUIRE(x_nhwc && w_ref && target && err_nchw && loss_partial, SRLZ_ERR_NULL, "convT_out_fwd_loss: null pointer");
+  SRLZ_REQUIRE(d->n % 2 == 0, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: the batch is the two frames of a step (n = %d is odd)", d->n);
+  SRLZ_REQUIRE((((uintptr_t)loss_partial) & 7) == 0, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: unaligned partial buffer");
+  return os_fwd<true, TT>(x_nhwc, w_ref, bias, err_nchw, x_bnp, target, dec_nchw, loss_partial, lut, d, as_stream(stream));
+}
+
+extern "C" int srlz_convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const float* target_nchw,
+                                       float* err_nchw, float* dec_nchw, const float* x_bnp, double* loss_partial,
+                                       const srlz_skinny_desc* d, srlz_stream_t stream) {
+  return os_fwd_loss<float>(x_nhwc, w_ref, bias, target_nchw, nullptr, err_nchw, dec_nchw, x_bnp, loss_partial, d, stream);
+}
+
+extern "C" int srlz_convT_out_fwd_loss_u8(const float* x_nhwc, const float* w_ref, const float* bias, const uint8_t* target_u8,
+                                          const float* norm_lut, float* err_nchw, float* dec_nchw, const float* x_bnp,
+                                          double* loss_partial, const srlz_skinny_desc* d, srlz_stream_t stream) {
+  SRLZ_REQUIRE(norm_lut, SRLZ_ERR_NULL, "convT_out_fwd_loss_u8: null normalisation table");
+  return os_fwd_loss<uint8_t>(x_nhwc, w_ref, bias, target_u8, norm_lut, err_nchw, dec_nchw, x_bnp, loss_partial, d, stream);
+}
+
+extern "C" int srlz_convT_out_bwd_fused_supported(const srlz_skinny_desc* d) {
+  return d && d->kind == 1 && (d->c == 3 || d->c == 6) ? 1 : 0;
+}
+
+extern "C" int srlz_convT_out_bwd_fused_tiles(const srlz_skinny_desc* d) {
+  if (os_check(d, "convT_out_bwd_fused_tiles")) return -1;
+  return bwd_geo(d).njobs;
+}
+
+extern "C" size_t srlz_convT_out_bwd_fused_workspace(const srlz_skinny_desc* d) {
+  if (os_check(d, "convT_out_bwd_fused_workspace")) return 0;
+  const OsGeo g = bwd_geo(d);
+  return (size_t)g.grid * (d->c / 3) * 64 * 48 * sizeof(float) + (size_t)g.grid * d->c * sizeof(double);
+}
+
+extern "C" int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,
+                                        const float* x_bnp, float* bn_bwd_partial, float* dw_ref, float* dbias, void* ws,
+                                        size_t ws_bytes, const float* dy_gain_dev, float dy_gain_div, float dy_gain_coef,
+                                        const srlz_skinny_desc* d, srlz_stream_t stream) {
+  if (int rc = os_check(d, "convT_out_bwd_fused")) return rc;
+  SRLZ_REQUIRE(d->c == 3 || d->c == 6, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: 3 or 6 image channels (got %d)", d->c);
+  SRLZ_REQUIRE(dy_nchw && w_ref && dx_nhwc && x_raw && x_bnp && bn_bwd_partial && dw_ref && ws, SRLZ_ERR_NULL,
+               "convT_out_bwd_fused: null pointer");
+  SRLZ_REQUIRE(ws_bytes >= srlz_convT_out_bwd_fused_workspace(d), SRLZ_ERR_WORKSPACE,
+               "convT_out_bwd_fused: workspace too small (%zu)", ws_bytes);
+  SRLZ_REQUIRE(dy_gain_dev == nullptr || dy_gain_div != 0.f, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: dy_gain_div is zero");
+  hipStream_t st = as_stream(stream);
+  const OsGeo g = bwd_geo(d);
+  const int ncg = d->c / 3;
+  float* partial = (float*)ws;
+  double* bias_part = dbias ? (double*)((char*)ws + (size_t)g.grid * ncg * 64 * 48 * sizeof(float)) : nullptr;  // [C][grid]
+  SRLZ_REQUIRE((((uintptr_t)bias_part) & 7) == 0, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: unaligned workspace");
+#define SRLZ_OS_BWD(NCG)                                                                                                      \
+  do {                                                                                                                        \
+    size_t fl = (size_t)4 * ((NCG) * 3 * 8 * RP + 16 * OSP + 192) + ((NCG) > 1 ? (NCG) * 4 * 12 * 64 : 0);                          \
+    if (fl < 4 * 64 * 48) fl = 4 * 64 * 48;                                                                                   \
+    SRLZ_MAX_LDS((convT_out_os_bwd_kernel<NCG>), fl * 4);                                                                     \
+    hipLaunchKernelGGL((convT_out_os_bwd_kernel<NCG>), dim3(g.grid), dim3(256), fl * 4, st, dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, \
+                       partial, d->n, d->himg, d->wimg, d->hf, d->wf, x_raw, x_bnp, os_npg(d), bias_part, dy_gain_dev,        \
+                       dy_gain_div, dy_gain_coef, g.rows, g.nseg, g.nchunk);                                                  \
+  } while (0)
+  if (ncg == 1) SRLZ_OS_BWD(1); else SRLZ_OS_BWD(2);
+#undef SRLZ_OS_BWD
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(os_wgrad_reduce, dim3(ncg * 64 * 48 / 64), dim3(1024), 0, st, partial, g.grid, d->c, dw_ref);
+  SRLZ_LAUNCHED();
+  if (dbias) {
+    hipLaunchKernelGGL(os_chan_sum_final, dim3(d->c), dim3(64), 0, st, bias_part, g.grid, dbias);
+    SRLZ_LAUNCHED();
+  }
+  return 0;
+}

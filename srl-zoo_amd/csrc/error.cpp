@@ -17,7 +17,7 @@ int srlz_hip_fail(hipError_t e, const char* what) {
   return SRLZ_ERR_HIP;
 }
 
-extern "C" int srlz_version(void) { return 100; }
+extern "C" int srlz_version(void) { return SRLZ_ABI_VERSION; }
 
 extern "C" const char* srlz_last_error(void) { return g_err; }
 

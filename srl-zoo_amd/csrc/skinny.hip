@@ -497,14 +497,9 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
                                                              float* __restrict__ partial, int N, int C, int H, int W,
                                                              int HF, int WF, int tiles_y, int tiles_x,
                                                              const float* __restrict__ feat_bnp, const PoolFuse pf, int npg,
-                                                             int dephase, const float* __restrict__ lut = nullptr) {
+                                                             const float* __restrict__ lut = nullptr) {
   constexpr bool U8 = sizeof(PT) == 1;  // uint8 frames + the normalisation table (image_land)
   // FUSED (K = 7): the feature operand is rebuilt from (y, argmax, dpooled) by the BatchNorm + ReLU + MaxPool backward (PoolFuse)
-  // dephase: the second resident workgroup of every CU (blocks >= gridDim.x / 2 of the persistent grid) starts `dephase`
-  // x ~8k cycles late, so that its operand-staging phases fall into the other workgroup's MFMA phases instead of both
-  // staging (and then both multiplying) at the same time
-  if (dephase > 0 && blockIdx.x >= gridDim.x / 2)
-    for (int i = 0; i < dephase; ++i) __builtin_amdgcn_s_sleep(127);
   // npg = images per BatchNorm group: image n uses the records feat_bnp / pf.bnp [(n / npg) * 256 ..], pf.sums [(n / npg) * 128 ..]
   constexpr int KT = Geo<K>::KT;
   constexpr int NT = (KT + 31) / 32;
@@ -775,463 +770,6 @@ __global__ __launch_bounds__(1024) void skinny_wgrad_reduce(const float* __restr
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// ConvTranspose2d(64, 3, 4, stride 2) BACKWARD in one pass (C == 3, BatchNorm backward deferred into the producer: the
-// product path).  Per tile of 8 x 16 feature positions:
-//   dA   = the data gradient w.r.t. relu(bn(y))          [skinny_conv_kernel<4,0,true>: im2col(dy) . W]
-//   the two BatchNorm-backward sums of that tile          [its epilogue, from the prefetched y]
-//   dW  += relu(bn(y)) (x) im2col(dy)                     [skinny_wgrad_kernel<4,0> with the fused forward operand]
-// The two contractions consume the same two operands — the image window of dy (staged once in T) and the 8x16x64 tile of y
-// (read once into registers) — so y (1.6 GB at N = 512) and dy cross HBM once instead of twice; what is left is the
-// unavoidable 3.6 GB (y in, dA out, dy in).
-// Waves: data gradient — wave w owns tile rows 2w, 2w+1 (one 32-pixel M-tile) x 64 channels; weight gradient — wave
-// (mt = w & 1, sub = w >> 1) owns channels [32mt, 32mt+32) x 48 taps over tile rows [4 sub, 4 sub + 4).
-// The accumulators of the data gradient leave through a wave-private transposition buffer that is the wave's own 32 rows of
-// F; each lane then overwrites the 16 bytes it has just read with relu(bn(y)) — the weight gradient's feature operand.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int FTR = 8;  // tile rows of the fused kernel
-__global__ __launch_bounds__(256, 2) void convT_out_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w_ref,
-                                                              float* __restrict__ feat, float* __restrict__ stats_partial,
-                                                              float* __restrict__ wpartial, int N, int H, int W, int HF,
-                                                              int WF, int tiles_y, int tiles_x,
-                                                              const float* __restrict__ y_raw,
-                                                              const float* __restrict__ y_bnp, int npg,
-                                                              double* __restrict__ bias_partial,
-                                                              const float* __restrict__ gain_dev, float gain_div, float gain_coef) {
-  // gain_dev != NULL: `img` holds the reconstruction error dec - obs that convT_out_kernel<true> left behind, and
-  // d(loss)/d(dec) = ((upstream / div) * coef) * (dec - obs) — autograd's rounding order for sum(.)/numel — is formed while the
-  // window lands in LDS: the gradient tensor of the reconstruction / generation loss is never written.
-  const float gain = gain_dev ? (gain_dev[0] / gain_div) * gain_coef : 1.f;
-  constexpr int K = 4, PAD = 0, C = 3, TR = FTR;
-  using G = Geo<K, TR>;
-  constexpr int KT = G::KT, KS = G::KS, NT = 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* T = (float*)smem;               // image window of dy
-  float* Wl = T + G::TILE_FLOATS;        // [KS][2][64] data-gradient weights
-  float* red = Wl + KS * 128;            // [4][128]
-  float* F = red + 512;                  // [TR*16 pixels][64 channels]: transposition buffer, then relu(bn(y))
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int ntiles = N * tiles_y * tiles_x, tpi = tiles_y * tiles_x;
-
-  for (int idx = tid; idx < KS * 128; idx += 256) {
-    const int co = idx & 63, sh = idx >> 6;
-    const int k = (sh & 1) * KS + (sh >> 1);
-    Wl[idx] = (k < KT) ? w_ref[(size_t)co * C * (K * K) + k] : 0.f;  // [ci = co][c][ky][kx], k = (c*K+ky)*K+kx
-  }
-  // data gradient: this lane's pixel of the wave's M-tile and its weight column (keeping the 48 weights of a lane in registers
-  // instead was measured: same time, 50 more registers)
-  const int pb = 2 * (wave * 2 + (l31 >> 4)) * XP + (l31 & 15);
-  const float* wl0 = Wl + h * 64 + l31;
-  // weight gradient: operand columns (see skinny_wgrad_kernel)
-  const int mt = wave & 1, sub = __builtin_amdgcn_readfirstlane(wave >> 1);
-  const float* tb[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int k = j * 32 + l31;
-    const int kk = (k < KT) ? k : 0;
-    const int c = kk / (K * K), ky = (kk / K) % K, kx = kk % K;
-    tb[j] = T + ((c * 2 + (kx & 1)) * G::PP + ky * XP + (kx >> 1) + h);
-  }
-  // (taps 48..63 of N-tile 1 do not exist: they alias tap 0 and are dropped by skinny_wgrad_reduce, which reads KT columns)
-  const float* fcol = F + h * 64 + mt * 32 + l31;
-  f32x16 accw[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
-
-  const int eg = lane >> 4, eslot = lane & 15;
-  f32x4 bmean = {0.f, 0.f, 0.f, 0.f}, binv = bmean, bsc = bmean, bsh = bmean;
-  int cur_grp = -1;
-
-  // this lane's 8 x float4 of y: pixel eg + 4k of the wave's 32 (tile row 2w + (pix >> 4), column pix & 15), channels 4*eslot..
-  // Requested one tile ahead — right after the epilogue has consumed the previous set, so the same 32 registers carry them —
-  // and in flight during the weight-gradient pass, the barriers and the next tile's data-gradient MFMAs.
-  f32x4 yv[8];
-  unsigned yin = 0, yin_next = 0;
-  auto y_request = [&](int tile_) {
-    const int n_ = tile_ / tpi, trem_ = tile_ - n_ * tpi;
-    const int oy0_ = (trem_ / tiles_x) * TR, ox0_ = (trem_ % tiles_x) * 16;
-    yin_next = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int pix = eg + 4 * k;
-      const int oy = oy0_ + wave * 2 + (pix >> 4), ox = ox0_ + (pix & 15);
-      const bool ok = tile_ < ntiles && oy < HF && ox < WF;
-      yv[k] = *(const f32x4*)(y_raw + (ok ? ((size_t)(n_ * HF + oy) * WF + ox) * 64 : (size_t)0) + eslot * 4);
-      yin_next |= (ok ? 1u : 0u) << k;
-    }
-  };
-  ImgRegs<K, TR> nx;
-  image_index<K, TR>(nx);
-  // Bias gradient (the per-channel sum of dy) from the windows this kernel stages anyway — a separate pass would read dy a second
-  // time.  A tile OWNS rows [0, 2 TR) x columns [0, 32) of its (2 TR + 2) x 34 window, the last tile row / column also the tail,
-  // so every image pixel is counted exactly once; element j of a thread always belongs to the same channel, so one fp32
-  // accumulator per element suffices (<= ntiles / gridDim.x additions each) and the channels are only told apart at the end.
-  constexpr int PER = ImgRegs<K, TR>::PER;
-  float bsum[PER];
-  unsigned mrow = 0, mcol = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    int c, row, xl;
-    const bool live = image_decode<K, true, TR>(nx, j, c, row, xl);
-    bsum[j] = 0.f;
-    mrow |= (live && row < 2 * TR ? 1u : 0u) << j;
-    mcol |= (live && xl < 32 ? 1u : 0u) << j;
-  }
-  auto bias_accumulate = [&](int trem_) {
-    const bool last_y = trem_ / tiles_x == tiles_y - 1, last_x = trem_ % tiles_x == tiles_x - 1;
-    const unsigned own = nx.inside & (last_y ? ~0u : mrow) & (last_x ? ~0u : mcol);
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-      bsum[j] += __builtin_bit_cast(float, __builtin_bit_cast(unsigned, nx.v[j] * gain) & (unsigned)(-(int)((own >> j) & 1u)));
-  };
-  y_request(vtile(blockIdx.x, ntiles));
-  if ((int)blockIdx.x < ntiles) {
-    const int t0 = vtile(blockIdx.x, ntiles);
-    const int n = t0 / tpi, trem = t0 - n * tpi;
-    image_request<K, PAD, true, TR>(nx, img, n, C, 0, H, W, (trem / tiles_x) * TR, (trem % tiles_x) * 16, true);
-    image_land<K, true, TR>(T, nx, gain);
-    bias_accumulate(trem);
-  }
-  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-    const int tile = xcd_remap(v, ntiles);
-    const int n = tile / tpi, trem = tile - n * tpi;
-    const int oy0 = (trem / tiles_x) * TR, ox0 = (trem % tiles_x) * 16;
-    if (n / npg != cur_grp) {
-      cur_grp = n / npg;
-      const float* __restrict__ yb = y_bnp + cur_grp * 256;
-      bmean = *(const f32x4*)(yb + eslot * 4); binv = *(const f32x4*)(yb + 64 + eslot * 4);
-      bsc = *(const f32x4*)(yb + 128 + eslot * 4); bsh = *(const f32x4*)(yb + 192 + eslot * 4);
-      asm volatile("" : "+v"(bmean), "+v"(binv), "+v"(bsc), "+v"(bsh));  // (waited for here)
-    }
-    yin = yin_next;
-    __syncthreads();  // T of this tile has landed; the previous tile's weight-gradient pass is done with T and F
-    {
-      const int tile2 = vtile(v + gridDim.x, ntiles);
-      const int n2 = tile2 / tpi, trem2 = tile2 - n2 * tpi;
-      image_request<K, PAD, true, TR>(nx, img, n2, C, 0, H, W, (trem2 / tiles_x) * TR, (trem2 % tiles_x) * 16, tile2 < ntiles);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- data gradient: 32 pixels x 64 channels per wave, K = 48 taps
-    f32x16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-      const int ko = h ? koff<K, TR>(KS + s2) : koff<K, TR>(s2);
-      const float a = T[pb + ko];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl0[s2 * 128], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl0[s2 * 128 + 32], acc[1], 0, 0, 0);
-    }
-    // ---- epilogue: transpose, store dA, BatchNorm-backward partials, leave relu(bn(y)) behind
-    float* Ew = F + wave * 2048;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int pix = (r & 3) + 8 * (r >> 2) + 4 * h;
-      Ew[pix * 64 + l31] = acc[0][r];
-      Ew[pix * 64 + 32 + l31] = acc[1][r];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(yv[k]));  // all y loads waited for once, outside the branches below
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int pix = eg + 4 * k;
-      float* cell = Ew + pix * 64 + eslot * 4;
-      const f32x4 v = *(const f32x4*)cell;
-      const f32x4 yy = yv[k];
-      f32x4 act = {0.f, 0.f, 0.f, 0.f};
-      if ((yin >> k) & 1u) {
-        const int oy = oy0 + wave * 2 + (pix >> 4), ox = ox0 + (pix & 15);
-        *(f32x4*)(feat + ((size_t)(n * HF + oy) * WF + ox) * 64 + eslot * 4) = v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = yy[e] * bsc[e] + bsh[e];
-          if (z > 0.f) { act[e] = z; s1[e] += v[e]; s2v[e] += v[e] * ((yy[e] - bmean[e]) * binv[e]); }
-        }
-      }
-      *(f32x4*)cell = act;
-    }
-    y_request(vtile(v + gridDim.x, ntiles));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s1[e] += __shfl_xor(s1[e], 16, 64); s1[e] += __shfl_xor(s1[e], 32, 64);
-      s2v[e] += __shfl_xor(s2v[e], 16, 64); s2v[e] += __shfl_xor(s2v[e], 32, 64);
-    }
-    if (eg == 0) {
-      *(f32x4*)(red + wave * 128 + eslot * 4) = s1;
-      *(f32x4*)(red + wave * 128 + 64 + eslot * 4) = s2v;
-    }
-    __syncthreads();  // F = relu(bn(y)) of the whole tile; red complete
-    if (tid < 128) stats_partial[(size_t)tile * 128 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
-    // ---- weight gradient: 64 pixels (tile rows 4 sub .. 4 sub + 3) per wave in 8 blocks of 4 k-steps
-#pragma unroll 2
-    for (int blk = 0; blk < TR; ++blk) {
-      const int lrow = (TR / 2) * sub + (blk >> 1), tx0 = 8 * (blk & 1);
-      const float* fa = fcol + (lrow * 16 + tx0) * 64;
-      const int boff = 2 * lrow * XP + tx0;
-      float a[4], b[NT][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = fa[2 * i * 64];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) b[j][i] = tb[j][boff + 2 * i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j][i], accw[j], 0, 0, 0);
-    }
-    __syncthreads();  // every wave is done with T and F: the next window lands
-    image_land<K, true, TR>(T, nx, gain);
-    bias_accumulate(vtile(v + gridDim.x, ntiles) % tpi);  // (past the last tile nothing is inside: adds zeros)
-  }
-  if (bias_partial) {  // [3][gridDim.x] fp64, summed over workgroups in a fixed order by nchw_chan_sum_final
-    float cs[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      int c, row, xl;
-      image_decode<K, true, TR>(nx, j, c, row, xl);
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) cs[cc] += (c == cc) ? bsum[j] : 0.f;
-    }
-    __syncthreads();
-    double* bred = (double*)red;  // [3][4 waves]
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc) {
-      const double dsum = wave_sum_d((double)cs[cc]);
-      if (lane == 0) bred[cc * 4 + wave] = dsum;
-    }
-    __syncthreads();
-    if (tid < 3) bias_partial[(size_t)tid * gridDim.x + blockIdx.x] = (bred[tid * 4] + bred[tid * 4 + 1]) + (bred[tid * 4 + 2] + bred[tid * 4 + 3]);
-  }
-  float* out = wpartial + ((size_t)blockIdx.x * 2 + sub) * (64 * NT * 32);
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      out[row * (NT * 32) + j * 32 + l31] = accw[j][r];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// kind 1 forward: img[n,co,oy,ox] = bias[co] + sum_{ci,ky,kx: oy=2iy+ky, ox=2ix+kx} feat[n,iy,ix,ci]*w_ref[ci,co,ky,kx]
-// Tile: 16x16 positions of the (a,b) = (oy>>1, ox>>1) grid -> 32x32 output pixels x 3 channels; needs the 17x17 feature
-// pixels (a0-1.., b0-1..).  Step 1: Tt[p][co*16+tap] = feat[p][:] . W (M = 289 px in 19 M-tiles of 16, N = 48, K = 64)
-// with v_mfma_f32_16x16x4_f32, A fragments straight from global (each is used once), B held in 48 VGPRs.
-// Step 2: every output pixel sums its 2x2 contributing (pixel, tap) pairs from LDS and is stored NCHW.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int TP = 49;  // LDS pitch (floats) of one feature pixel's 48 products
-
-// LOSS (reconstruction / generation loss fused into the epilogue, /root/reference/losses/losses.py:172-214 — K11 / K12 of SURVEY.md
-// 8a'): the gather phase holds every output pixel in a register on its way to the NCHW store; with `target` (the observation the
-// decoder reconstructs) it stores the ERROR dec - target instead (`img`; the reconstruction itself only when `dec_out` is
-// given) and accumulates its square: one fp32 partial per thread and tile, fp64 across tiles, per LOSS group (images
-// [g*lpg, (g+1)*lpg): the two frames of a step) -> loss_partial[g][workgroup], summed in a fixed order by srlz_pair_loss_finalize.
-// The passes of srlz_sqdiff_pair_loss (read dec and obs) and srlz_sqdiff_grad_groups (read both again, write the gradient)
-// disappear; the gradient is the stored error times a scalar, applied where the backward kernel stages it (convT_out_bwd_kernel).
-// TT = uint8_t: `target` is the observation as the loader's bytes ([N,C,W,H]) and `lut` the normalisation table (image_land<U8>).
-template <bool LOSS, typename TT = float>
-__global__ __launch_bounds__(256, 2) void convT_out_kernel(const float* __restrict__ feat,
-                                                          const float* __restrict__ w_ref,
-                                                          const float* __restrict__ bias, float* __restrict__ img,
-                                                          int N, int C, int H, int W, int HF, int WF, int tiles_y,
-                                                          int tiles_x, const float* __restrict__ feat_bnp, int npg,
-                                                          const TT* __restrict__ target, float* __restrict__ dec_out,
-                                                          double* __restrict__ loss_partial, int lpg,
-                                                          const float* __restrict__ lut = nullptr) {
-  constexpr bool U8 = sizeof(TT) == 1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* Tt = (float*)smem;  // [304][TP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, kq = lane >> 4;
-  const int cg = blockIdx.y;
-  const int ntiles = N * tiles_y * tiles_x;
-  if constexpr (U8) {  // the normalisation table moves into LDS (published by the tile loop's first barrier)
-    float* L = Tt + 304 * TP;
-    for (int i = threadIdx.x; i < 768; i += 256) L[i] = lut[i];
-    lut = L;
-  }
-
-  // B fragments: breg[co][c][r] = w_ref[ci = 16c + 4kq + r][cg*3 + co][tap = li]
-  f32x4 breg[3][4];
-#pragma unroll
-  for (int co = 0; co < 3; ++co)
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        breg[co][c][r] = w_ref[((size_t)(16 * c + 4 * kq + r) * C + cg * 3 + co) * 16 + li];
-  float bs[3];
-#pragma unroll
-  for (int co = 0; co < 3; ++co) bs[co] = bias ? bias[cg * 3 + co] : 0.f;
-  // feat_bnp != NULL: the operand is relu(batchnorm(feat)); this lane's channels are 16c + 4kq + r.  The record is the one
-  // of the image's BatchNorm group (npg images per group), re-read when a workgroup's tile sequence crosses into the next group
-  f32x4 fsc[4], fsh[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { fsc[c] = f32x4{1.f, 1.f, 1.f, 1.f}; fsh[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  int cur_grp = -1;
-
-  // A fragments are requested DEPTH M-tiles ahead of the MFMAs that consume them, across tile boundaries: the queue runs over this
-  // wave's (tile, M-tile) sequence, so the loads of the next tile are in flight during this tile's gather phase and barriers.
-  // Loads only — the BatchNorm+ReLU of a fused operand is applied when the fragment is CONSUMED (activate); otherwise the affine
-  // would wait for the load right at the request and nothing would stay in flight behind the MFMAs.
-  constexpr int DEPTH = 4;
-  const int tpi = tiles_y * tiles_x;
-  auto load_a = [&](int vt, int mtile, f32x4 (&a)[4]) -> bool {
-    const int t = vtile(vt, ntiles);
-    const int n = t / tpi;
-    const int trem = t - n * tpi;
-    const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
-    const int p = mtile * 16 + li;
-    const int ia = p / 17, ib = p - ia * 17;
-    const int fy = a0 - 1 + ia, fx = b0 - 1 + ib;
-    const bool ok = t < ntiles && p < 289 && fy >= 0 && fy < HF && fx >= 0 && fx < WF;
-    const float* src = feat + (ok ? ((size_t)(n * HF + fy) * WF + fx) * 64 : (size_t)0) + 4 * kq;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a[c] = *(const f32x4*)(src + 16 * c);  // raw (clamped address when !ok): masked in activate
-    return ok;
-  };
-  auto activate = [&](f32x4 (&a)[4], bool ok) {
-    if (!ok) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) a[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else if (feat_bnp) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float z = a[c][e] * fsc[c][e] + fsh[c][e]; a[c][e] = z > 0.f ? z : 0.f; }
-    }
-  };
-  f32x4 q[DEPTH][4];
-  bool qok[DEPTH];
-  double lacc0 = 0.0, lacc1 = 0.0;  // LOSS: this thread's sum of squared errors per loss group
-  int nt = blockIdx.x, nm = wave;  // the next (tile, M-tile) to request
-  auto advance = [&]() { nm += 4; if (nm >= 19) { nm = wave; nt += gridDim.x; } };
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) { qok[d] = load_a(nt, nm, q[d]); advance(); }
-
-  for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-    const int tile = xcd_remap(v, ntiles);
-    const int n = tile / tpi;
-    if (feat_bnp && n / npg != cur_grp) {
-      cur_grp = n / npg;
-      const float* __restrict__ rec = feat_bnp + cur_grp * 256;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { fsc[c] = *(const f32x4*)(rec + 128 + 16 * c + 4 * kq); fsh[c] = *(const f32x4*)(rec + 192 + 16 * c + 4 * kq); }
-    }
-    const int trem = tile - n * tpi;
-    const int a0 = (trem / tiles_x) * 16, b0 = (trem % tiles_x) * 16;
-    // LOSS: this thread's 12 target pixels of the tile are requested here and travel under the MFMA phase (branch-free: a pixel
-    // outside the image reads a clamped address and is never used)
-    float tg[LOSS ? 12 : 1];
-    if (LOSS) {
-      const int oxl_ = tid & 31, rg_ = tid >> 5;
-#pragma unroll
-      for (int co = 0; co < 3; ++co)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int oy = 2 * a0 + rg_ + 8 * i, ox = 2 * b0 + oxl_;
-          const bool ok = oy < H && ox < W;
-          const TT raw = target[ok ? ((size_t)(n * C + cg * 3 + co) * H + oy) * W + ox : (size_t)0];
-          if constexpr (U8) tg[LOSS ? co * 4 + i : 0] = __uint_as_float((unsigned)raw); else tg[LOSS ? co * 4 + i : 0] = raw;
-        }
-      __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the requests next to their use, behind the MFMA phase)
-    }
-    __syncthreads();  // previous tile's gather is done with Tt
-    for (int mtile = wave; mtile < 19; mtile += 4) {
-      f32x4 a[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) a[c] = q[0][c];
-      const bool oka = qok[0];
-#pragma unroll
-      for (int d = 0; d + 1 < DEPTH; ++d) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) q[d][c] = q[d + 1][c];
-        qok[d] = qok[d + 1];
-      }
-      qok[DEPTH - 1] = load_a(nt, nm, q[DEPTH - 1]);
-      advance();
-      activate(a, oka);
-      f32x4 acc[3];
-#pragma unroll
-      for (int co = 0; co < 3; ++co) {
-        acc[co] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][r], breg[co][c][r], acc[co], 0, 0, 0);
-      }
-      // D layout: column (tap) = lane & 15, row (pixel) = (lane >> 4) * 4 + reg
-#pragma unroll
-      for (int co = 0; co < 3; ++co)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tt[(mtile * 16 + kq * 4 + r) * TP + co * 16 + li] = acc[co][r];
-    }
-    __syncthreads();
-    const int oxl = tid & 31, rg = tid >> 5;
-    const int bl = oxl >> 1, px = oxl & 1;
-    const int ox = 2 * b0 + oxl;
-    float lsum = 0.f;
-    if (LOSS) {  // every target load is waited for HERE, once, outside the branches that hold the stores
-#pragma unroll
-      for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(tg[LOSS ? j : 0]));
-      if constexpr (U8) {  // bytes -> normalised observation (all 12 look-ups requested together)
-#pragma unroll
-        for (int j = 0; j < 12; ++j) tg[LOSS ? j : 0] = lut[(j >> 2) * 256 + (int)__float_as_uint(tg[LOSS ? j : 0])];
-#pragma unroll
-        for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(tg[LOSS ? j : 0]));  // (and waited for, once, like the bytes above)
-      }
-    }
-#pragma unroll
-    for (int co = 0; co < 3; ++co) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int oyl = rg + 8 * i;
-        const int al = oyl >> 1, py = oyl & 1;
-        const int oy = 2 * a0 + oyl;
-        float v = bs[co];
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx)
-            v += Tt[((al + 1 - dy) * 17 + (bl + 1 - dx)) * TP + co * 16 + (py + 2 * dy) * 4 + (px + 2 * dx)];
-        if (oy < H && ox < W) {
-          const size_t o = ((size_t)(n * C + cg * 3 + co) * H + oy) * W + ox;
-          if (LOSS) {
-            const float d = v - tg[LOSS ? co * 4 + i : 0];
-            img[o] = d;
-            if (dec_out) dec_out[o] = v;
-            lsum += d * d;
-          } else {
-            img[o] = v;
-          }
-        }
-      }
-    }
-    if (LOSS) { if (n / lpg == 0) lacc0 += (double)lsum; else lacc1 += (double)lsum; }
-  }
-  if (LOSS) {
-    // [2 loss groups][workgroups of the launch] — every workgroup writes both slots (zeros included), fixed-order final sum
-    __syncthreads();
-    double* lred = (double*)smem;  // [2][4 waves]
-    const double w0 = wave_sum_d(lacc0), w1 = wave_sum_d(lacc1);
-    if (lane == 0) { lred[wave] = w0; lred[4 + wave] = w1; }
-    __syncthreads();
-    if (tid < 2) {
-      const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
-      loss_partial[(size_t)tid * nwg + wg] = (lred[tid * 4] + lred[tid * 4 + 1]) + (lred[tid * 4 + 2] + lred[tid * 4 + 3]);
-    }
-  }
-}
-
 // per-channel sum of an NCHW tensor (bias gradient of the last ConvTranspose): one block per (n, c) plane with float4
 // loads -> partial[c][n] (fp64), then one thread per channel sums over n in a fixed order.
 __global__ __launch_bounds__(256) void nchw_chan_sum_partial(const float* __restrict__ x, int C, int HW, double* __restrict__ partial,
@@ -1284,9 +822,8 @@ static size_t conv_lds(bool pipe) { return (size_t)(Geo<K>::TILE_FLOATS + Geo<K>
 
 static int images_per_group(const srlz_skinny_desc* d) { return d->n / (d->groups > 1 ? d->groups : 1); }
 
-static int persistent_grid(int ntiles, bool wgrad = false) {
-  static const int wgrad_per_cu = [] { const char* e = getenv("SRLZ_WGRAD_PER_CU"); return (e && atoi(e) == 1) ? 1 : 2; }();
-  int g = (wgrad ? wgrad_per_cu : 2) * srlz_device_cus();
+static int persistent_grid(int ntiles) {
+  const int g = 2 * srlz_device_cus();  // two persistent workgroups per CU
   return g > ntiles ? ntiles : g;
 }
 
@@ -1321,7 +858,7 @@ template <int K>
 static size_t wgrad_ws(const srlz_skinny_desc* d) {
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
-  const int g = persistent_grid(d->n * ty * tx, true);
+  const int g = persistent_grid(d->n * ty * tx);
   return (size_t)(d->c / 3) * g * 2 * 64 * NT * 32 * sizeof(float) + (size_t)d->n * d->c * sizeof(double);
 }
 
@@ -1331,23 +868,22 @@ static int launch_wgrad(const PT* img, const float* feat, float* dw, void* ws, s
   constexpr int NT = (Geo<K>::KT + 31) / 32;
   const int ty = (d->hf + 15) / 16, tx = (d->wf + 15) / 16;
   const int ntiles = d->n * ty * tx;
-  const int g = persistent_grid(ntiles, true);
+  const int g = persistent_grid(ntiles);
   SRLZ_REQUIRE(ws_bytes >= wgrad_ws<K>(d), SRLZ_ERR_WORKSPACE, "skinny wgrad: workspace too small (%zu)", ws_bytes);
   SRLZ_REQUIRE(K == 4 || feat_bnp == nullptr, SRLZ_ERR_BAD_DESC, "skinny wgrad: a fused forward operand exists for the 4x4 layer only");
   const size_t lds = (size_t)(Geo<K>::TILE_FLOATS + 128 * 64) * 4 + (sizeof(PT) == 1 ? 768 * 4 : 0);
   float* partial = (float*)ws;
   PoolFuse pf = {};
   if (pfuse) pf = *pfuse;
-  static const int dephase = [] { const char* e = getenv("SRLZ_DEPHASE"); return e ? atoi(e) : 0; }();
   bool launched = false;
   if constexpr (K == 7) if (pf.y) {
     hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD, true, PT>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase, lut);
+                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), lut);
     launched = true;
   }
   if (!launched)
     hipLaunchKernelGGL((skinny_wgrad_kernel<K, PAD, false, PT>), dim3(g, d->c / 3), dim3(256), lds, st, img, feat, partial, d->n, d->c,
-                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), dephase, lut);
+                       d->himg, d->wimg, d->hf, d->wf, ty, tx, feat_bnp, pf, images_per_group(d), lut);
   SRLZ_LAUNCHED();
   const int total = (d->c / 3) * 64 * Geo<K>::KT;
   hipLaunchKernelGGL(skinny_wgrad_reduce, dim3((total + WRED_OUTS - 1) / WRED_OUTS), dim3(1024), 0, st, partial, 2 * g, d->c, K * K, Geo<K>::KT,
@@ -1443,60 +979,6 @@ extern "C" int srlz_conv1_bwd_weight_fused_u8(const uint8_t* x_u8, const float* 
                                          stream);
 }
 
-extern "C" int srlz_convT_out_fwd(const float* x_nhwc, const float* w_ref, const float* bias, float* y_nchw,
-                                  const float* x_bnp, const srlz_skinny_desc* d, srlz_stream_t stream) {
-  if (int rc = check_skinny(d)) return rc;
-  SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_fwd: descriptor kind must be 1");
-  SRLZ_REQUIRE(x_nhwc && w_ref && y_nchw, SRLZ_ERR_NULL, "convT_out_fwd: null pointer");
-  const int ty = (d->himg / 2 + 15) / 16, tx = (d->wimg / 2 + 15) / 16;
-  const int ntiles = d->n * ty * tx;
-  const size_t lds = (size_t)304 * TP * 4;
-  hipLaunchKernelGGL(convT_out_kernel<false>, dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
-                     w_ref, bias, y_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp, images_per_group(d),
-                     (const float*)nullptr, (float*)nullptr, (double*)nullptr, d->n);
-  SRLZ_LAUNCHED();
-  return 0;
-}
-
-extern "C" int srlz_convT_out_fwd_loss_workgroups(const srlz_skinny_desc* d) {
-  if (check_skinny(d)) return -1;
-  const int ty = (d->himg / 2 + 15) / 16, tx = (d->wimg / 2 + 15) / 16;
-  return persistent_grid(d->n * ty * tx) * (d->c / 3);
-}
-
-template <typename TT>
-static int convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const TT* target_nchw, const float* lut,
-                              float* err_nchw, float* dec_nchw, const float* x_bnp, double* loss_partial,
-                              const srlz_skinny_desc* d, srlz_stream_t stream) {
-  if (int rc = check_skinny(d)) return rc;
-  SRLZ_REQUIRE(d->kind == 1, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: descriptor kind must be 1");
-  SRLZ_REQUIRE(x_nhwc && w_ref && target_nchw && err_nchw && loss_partial, SRLZ_ERR_NULL, "convT_out_fwd_loss: null pointer");
-  SRLZ_REQUIRE(d->n % 2 == 0, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: the batch is the two frames of a step (n = %d is odd)", d->n);
-  SRLZ_REQUIRE((((uintptr_t)loss_partial) & 7) == 0, SRLZ_ERR_BAD_DESC, "convT_out_fwd_loss: unaligned partial buffer");
-  const int ty = (d->himg / 2 + 15) / 16, tx = (d->wimg / 2 + 15) / 16;
-  const int ntiles = d->n * ty * tx;
-  const size_t lds = (size_t)304 * TP * 4 + (sizeof(TT) == 1 ? 768 * 4 : 0);
-  SRLZ_MAX_LDS((convT_out_kernel<true, TT>), lds);
-  hipLaunchKernelGGL((convT_out_kernel<true, TT>), dim3(persistent_grid(ntiles), d->c / 3), dim3(256), lds, as_stream(stream), x_nhwc,
-                     w_ref, bias, err_nchw, d->n, d->c, d->himg, d->wimg, d->hf, d->wf, ty, tx, x_bnp, images_per_group(d),
-                     target_nchw, dec_nchw, loss_partial, d->n / 2, lut);
-  SRLZ_LAUNCHED();
-  return 0;
-}
-
-extern "C" int srlz_convT_out_fwd_loss(const float* x_nhwc, const float* w_ref, const float* bias, const float* target_nchw,
-                                       float* err_nchw, float* dec_nchw, const float* x_bnp, double* loss_partial,
-                                       const srlz_skinny_desc* d, srlz_stream_t stream) {
-  return convT_out_fwd_loss<float>(x_nhwc, w_ref, bias, target_nchw, nullptr, err_nchw, dec_nchw, x_bnp, loss_partial, d, stream);
-}
-
-extern "C" int srlz_convT_out_fwd_loss_u8(const float* x_nhwc, const float* w_ref, const float* bias, const uint8_t* target_u8,
-                                          const float* norm_lut, float* err_nchw, float* dec_nchw, const float* x_bnp,
-                                          double* loss_partial, const srlz_skinny_desc* d, srlz_stream_t stream) {
-  SRLZ_REQUIRE(norm_lut, SRLZ_ERR_NULL, "convT_out_fwd_loss_u8: null normalisation table");
-  return convT_out_fwd_loss<uint8_t>(x_nhwc, w_ref, bias, target_u8, norm_lut, err_nchw, dec_nchw, x_bnp, loss_partial, d, stream);
-}
-
 extern "C" int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,
                                        const float* x_bnp, float* bn_bwd_partial, const srlz_skinny_desc* d,
                                        srlz_stream_t stream) {
@@ -1507,52 +989,6 @@ extern "C" int srlz_convT_out_bwd_data(const float* dy_nchw, const float* w_ref,
                "convT_out_bwd_data: x_raw, x_bnp and bn_bwd_partial go together");
   // dx[n,iy,ix,ci] = sum_{co,ky,kx} dy[n,co,2iy+ky,2ix+kx] * w_ref[ci,co,ky,kx]  == a 4x4 s2 p0 "conv" of dy
   return launch_conv<4, 0>(dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, d, as_stream(stream), x_raw, x_bnp);
-}
-
-static size_t fused_bwd_lds() { return (size_t)(Geo<4, FTR>::TILE_FLOATS + Geo<4, FTR>::KS * 128 + 512 + FTR * 16 * 64) * 4; }
-
-extern "C" int srlz_convT_out_bwd_fused_tiles(const srlz_skinny_desc* d) {
-  if (check_skinny(d)) return -1;
-  return d->n * ((d->hf + FTR - 1) / FTR) * ((d->wf + 15) / 16);
-}
-
-extern "C" size_t srlz_convT_out_bwd_fused_workspace(const srlz_skinny_desc* d) {
-  if (check_skinny(d)) return 0;
-  const int g = persistent_grid(srlz_convT_out_bwd_fused_tiles(d));
-  return (size_t)g * 2 * 64 * 64 * sizeof(float) + (size_t)g * 3 * sizeof(double);
-}
-
-extern "C" int srlz_convT_out_bwd_fused(const float* dy_nchw, const float* w_ref, float* dx_nhwc, const float* x_raw,
-                                        const float* x_bnp, float* bn_bwd_partial, float* dw_ref, float* dbias, void* ws,
-                                        size_t ws_bytes, const float* dy_gain_dev, float dy_gain_div, float dy_gain_coef,
-                                        const srlz_skinny_desc* d, srlz_stream_t stream) {
-  if (int rc = check_skinny(d)) return rc;
-  SRLZ_REQUIRE(d->kind == 1 && d->c == 3, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: kind 1, 3 image channels");
-  SRLZ_REQUIRE(dy_nchw && w_ref && dx_nhwc && x_raw && x_bnp && bn_bwd_partial && dw_ref && ws, SRLZ_ERR_NULL,
-               "convT_out_bwd_fused: null pointer");
-  SRLZ_REQUIRE(ws_bytes >= srlz_convT_out_bwd_fused_workspace(d), SRLZ_ERR_WORKSPACE,
-               "convT_out_bwd_fused: workspace too small (%zu)", ws_bytes);
-  SRLZ_REQUIRE(dy_gain_dev == nullptr || dy_gain_div != 0.f, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: dy_gain_div is zero");
-  hipStream_t st = as_stream(stream);
-  const int ty = (d->hf + FTR - 1) / FTR, tx = (d->wf + 15) / 16;
-  const int ntiles = d->n * ty * tx;
-  const int g = persistent_grid(ntiles);
-  const size_t lds = fused_bwd_lds();
-  float* partial = (float*)ws;
-  double* bias_part = dbias ? (double*)((char*)ws + (size_t)g * 2 * 64 * 64 * sizeof(float)) : nullptr;  // [3][g]
-  SRLZ_REQUIRE((((uintptr_t)bias_part) & 7) == 0, SRLZ_ERR_BAD_DESC, "convT_out_bwd_fused: unaligned workspace");
-  SRLZ_MAX_LDS(convT_out_bwd_kernel, lds);
-  hipLaunchKernelGGL(convT_out_bwd_kernel, dim3(g), dim3(256), lds, st, dy_nchw, w_ref, dx_nhwc, bn_bwd_partial, partial, d->n,
-                     d->himg, d->wimg, d->hf, d->wf, ty, tx, x_raw, x_bnp, images_per_group(d), bias_part, dy_gain_dev,
-                     dy_gain_div, dy_gain_coef);
-  SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(skinny_wgrad_reduce, dim3(64 * 48 / WRED_OUTS), dim3(1024), 0, st, partial, 2 * g, d->c, 16, 48, 64, dw_ref);
-  SRLZ_LAUNCHED();
-  if (dbias) {
-    hipLaunchKernelGGL(nchw_chan_sum_final, dim3(d->c), dim3(64), 0, st, bias_part, g, dbias);
-    SRLZ_LAUNCHED();
-  }
-  return 0;
 }
 
 extern "C" int srlz_convT_out_bwd_weight(const float* x_nhwc, const float* dy_nchw, float* dw_ref, float* dbias,

@@ -134,10 +134,18 @@ class BaseLearner(object):
             th.cuda.manual_seed(seed)
         self.device = th.device("cuda" if th.cuda.is_available() and cuda else "cpu")
 
-    @staticmethod
-    def _isPlanar(frames):
-        """uint8 frames [B, C, W, H] (DataLoader(raw_uint8="planar")) as opposed to [B, H, W, C] (raw_uint8=True)."""
-        return frames.dtype == th.uint8 and frames.dim() == 4 and frames.shape[1] in (3, 6, 9) and frames.shape[3] not in (3, 6, 9)
+    # Layout of the uint8 frames handed to _toDevice / _toDevicePair: "planar" = [B, C, W, H] (DataLoader(raw_uint8="planar"), what
+    # learn() builds its loaders with), "nhwc" = [B, H, W, C] (DataLoader(raw_uint8=True): the frames as decoded).  Stated by whoever
+    # builds the loader — never guessed from a shape (a 3 x 3 x 6 x 9 frame fits both).
+    frame_layout = "planar"
+
+    def _isPlanar(self, frames):
+        """uint8 frames in the reference's tensor layout [B, C, W, H] (see frame_layout)."""
+        if frames.dtype != th.uint8:
+            return False
+        if self.frame_layout not in ("planar", "nhwc"):
+            raise ValueError("frame_layout must be 'planar' or 'nhwc', got %r" % (self.frame_layout,))
+        return self.frame_layout == "planar"
 
     def _readsBytes(self):
         """Whether the training step can take the loader's bytes as they are (subclasses that own such a step say so)."""
@@ -267,20 +275,17 @@ class SRL4robotics(BaseLearner):
         self.model = self.model.to(self.device)
         self.rank, self.world_size = optim.world()
 
-        # SRLZ_TWO_STREAMS=1 (only meaningful with SRLZ_PAIR=0): the two frames of a step encoded / decoded / back-propagated on
-        # two HIP streams — round 1's way of overlapping them (16.7 vs 18.2 ms); superseded by the batched pair below.
         # SRLZ_GRAPH=1: hipGraph replay of the step body (see _graphStep).  Measured on MI355X: 3 % at bs = 32, nothing at
         # bs >= 64 — the small kernels of a step cost ~10 us each ON THE GPU whether they are enqueued one by one or replayed
         # from a graph, so the cure for small minibatches is fewer kernels (which is what the batched pair delivers).
         # The two frames of a step run as ONE batched model call with two BatchNorm groups (SRLModules.forwardPair): half the
         # launches, twice the grid of every small layer, per-call BatchNorm semantics intact.  SRLZ_PAIR=0 restores the two
-        # separate calls (A/B, parity tests).
+        # separate calls (A/B, parity tests).  (Round 1's two-HIP-stream form of the two calls is retired: DESIGN.md 5.1.)
         self._use_pair = os.environ.get("SRLZ_PAIR", "1") != "0"
         self._use_graph = os.environ.get("SRLZ_GRAPH", "0") == "1"
         self._graphs = {}
-        self._frame_streams = None
-        if os.environ.get("SRLZ_TWO_STREAMS", "0") != "0":
-            self._frame_streams = (th.cuda.Stream(device=self.device), th.cuda.Stream(device=self.device))
+        from srlz import ops as _ops
+        _ops.norm_lut(self.device)  # built eagerly: its first use must not fall inside a stream capture or on a side stream
 
         # one flat parameter / gradient buffer + fused Adam (torch.optim.Adam defaults)
         self.flat_params = optim.FlatParams(self.model)
@@ -355,7 +360,7 @@ class SRL4robotics(BaseLearner):
         (DAE noise, perceptual loss, triplets, the ResNet trunks, graph replay, the A/B switches that undo those fusions) gets the
         normalised float tensor (ops.frames_as_float)."""
         from srlz import hotpath
-        return (RAW_UINT8_INPUT and self.model_type == "custom_cnn" and self._use_pair and self._frame_streams is None
+        return (RAW_UINT8_INPUT and self.model_type == "custom_cnn" and self._use_pair
                 and not self._use_graph and not self.use_triplets and not self.use_dae
                 and not (self.use_vae and self.perceptual_similarity_loss)
                 and hotpath._FUSE_RECON and hotpath._FUSE_ENC_IN and hotpath.TAPS is None)
@@ -370,33 +375,23 @@ class SRL4robotics(BaseLearner):
         Minibatches above 574 samples (one launch takes at most 65535 / 57 = 1149 images — the pooling kernels' grid.y, DESIGN.md
         section 2) fall back to two separate model calls."""
         from srlz import hotpath, ops
-        if self._use_pair and self._frame_streams is None and x.shape == next_x.shape and 2 * x.shape[0] <= 1149 \
+        if self._use_pair and x.shape == next_x.shape and 2 * x.shape[0] <= 1149 \
                 and not self.use_triplets:
             target = ops.pair_of(recon[0], recon[1]) if recon is not None else None
             if target is not None:
                 with hotpath.recon_loss_into(target, recon[2]) as req:
                     out = self.model.forwardPair(x, next_x)
+                if req.loss is not None:
+                    # the decoder's last kernel kept the loss and stored dec - target in place of the reconstruction: the
+                    # "decoded frames" of the two outputs are NOT images — hand None to the caller so that a consumer fails loudly
+                    # (auto-encoders return (states, decoded), VAEs (decoded, mu, logvar): reference models.py:102-106,174-182)
+                    at = 0 if self.use_vae else 1
+                    out = tuple(tuple(None if j == at else t for j, t in enumerate(o)) for o in out)
                 return out[0], out[1], req.loss
             return self.model.forwardPair(x, next_x) + ((None,) if recon is not None else ())
         if recon is not None:
             return self._forwardPair(x, next_x) + (None,)
-        if self._frame_streams is None:
-            return self.model(x), self.model(next_x)
-        main = th.cuda.current_stream(self.device)
-        ready = th.cuda.Event()
-        ready.record(main)
-        outs = []
-        for inp, s in ((x, self._frame_streams[0]), (next_x, self._frame_streams[1])):
-            s.wait_event(ready)
-            inp.record_stream(s)
-            with th.cuda.stream(s):
-                out = self.model(inp)
-            for t in (out if isinstance(out, tuple) else (out,)):
-                t.record_stream(main)
-            outs.append(out)
-        for s in self._frame_streams:
-            main.wait_stream(s)
-        return outs[0], outs[1]
+        return self.model(x), self.model(next_x)
 
     def trainStep(self, obs, next_obs, actions_st, loss_manager, validation_mode=False, noisy_obs=None,
                   next_noisy_obs=None, rewards_st=None):
@@ -529,7 +524,7 @@ class SRL4robotics(BaseLearner):
             rewards_pred = self.model.rewardModel(states, next_states)
             rewardModelLoss(rewards_pred, rewards_st, weight=w['reward'], loss_manager=loss_manager)
         if (self.use_autoencoder or self.use_dae) and recon_loss is not None:
-            # (decoded_* hold the error dec - obs here, not the reconstruction: the loss came out of the decoder's last kernel)
+            # (decoded_* are None here: the loss came out of the decoder's last kernel and the reconstruction was never written)
             loss_manager.addToLosses('reconstruction_loss', w["dae" if self.use_dae else "autoencoder"], recon_loss)
         elif self.use_autoencoder or self.use_dae:
             autoEncoderLoss(ops.frames_as_float(obs), decoded_obs, ops.frames_as_float(next_obs), decoded_next_obs,

@@ -12,6 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrlz_hip.so")
 
 
+ABI_VERSION = 101  # include/srlz.h SRLZ_ABI_VERSION these prototypes were written for
+
+
 class SrlzError(RuntimeError):
     pass
 
@@ -98,6 +101,7 @@ _PROTOS = {
     "srlz_convT_out_bwd_data": (c_int, [P, P, P, P, P, P, _SK, P]),
     "srlz_bn_bwd_finalize_partials": (c_int, [P, c_int, c_int, P, P, P, P, c_size_t, P]),
     "srlz_convT_out_bwd_weight": (c_int, [P, P, P, P, P, P, c_size_t, _SK, P]),
+    "srlz_convT_out_bwd_fused_supported": (c_int, [_SK]),
     "srlz_convT_out_bwd_fused_tiles": (c_int, [_SK]),
     "srlz_convT_out_bwd_fused_workspace": (c_size_t, [_SK]),
     "srlz_convT_out_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, P, c_float, c_float, _SK, P]),
@@ -155,6 +159,7 @@ _PROTOS = {
 # entry points whose int return value is data, not a status
 _NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
                "srlz_convT_out_bwd_fused_tiles", "srlz_convT_out_fwd_loss_workgroups", "srlz_conv64_bwd_fused_supported",
+               "srlz_convT_out_bwd_fused_supported",
                "srlz_conv64_bwd_data_tiles",
                "srlz_conv64_debug_program", "srlz_comm_world"}
 
@@ -171,6 +176,10 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    got = lib.srlz_version()
+    if got != ABI_VERSION:  # a stale build next to newer bindings (or the reverse) would pass arguments in the wrong slots
+        raise SrlzError("libsrlz_hip.so at %s reports ABI version %d, these bindings are written for %d (include/srlz.h "
+                        "SRLZ_ABI_VERSION): rebuild with `make -C srl-zoo_amd/csrc`" % (LIB_PATH, got, ABI_VERSION))
     return lib
 
 

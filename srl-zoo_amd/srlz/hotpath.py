@@ -33,7 +33,8 @@ _DEFER_BN_BWD = os.environ.get("SRLZ_DEFER_BN_BWD", "1") != "0"
 # ---- the step's reconstruction / generation loss taken inside the last ConvTranspose (ops.DecOutLossFn) -------------------------
 # SRL4robotics._eagerStep opens `with recon_loss_into(target, mean) as req:` around the batched model call; decoder_forward then
 # ends in ONE node that yields the loss scalar (req.loss) and, in place of the reconstruction, the error tensor dec - target
-# (flagged `_srlz_recon_error`; the reconstruction itself is not written).  A/B switch: SRLZ_FUSED_RECON=0.
+# (the reconstruction itself is not written; SRL4robotics._forwardPair hands None to its caller in place of the decoded frames, so
+# nothing downstream can mistake the error for an image).  A/B switch: SRLZ_FUSED_RECON=0.
 _FUSE_RECON = os.environ.get("SRLZ_FUSED_RECON", "1") != "0"
 _RECON = None
 
@@ -123,8 +124,7 @@ def decoder_forward(seq, z, training):
     if req is not None and req.loss is None and TAPS is None and torch.is_grad_enabled() and y.shape[0] % 2 == 0 \
             and req.target.shape[0] == y.shape[0] and req.target.shape[1] == last.weight.shape[1] and not req.target.requires_grad:
         req.loss, err = ops.DecOutLossFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias, in_link, req.target, req.mean)
-        err._srlz_recon_error = True  # NOT the reconstruction: dec - target (the caller asked for the loss, not for the image)
-        return err
+        return err  # NOT the reconstruction: dec - target (the caller asked for the loss, not for the image)
     return _tap("decoder_conv", 12, ops.DecOutFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias, in_link))
 
 

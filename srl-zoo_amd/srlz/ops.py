@@ -116,6 +116,20 @@ def _conv64_flop(d):
     return 2.0 * 9 * 64 * 64 * pos
 
 
+def _convT_out_flop(d):
+    # ConvTranspose2d(64, C, 4, 2): 16 taps x 64 x C per feature position
+    return 2.0 * 16 * 64 * d.c * d.n * d.hf * d.wf
+
+
+def _conv1_flop(d):
+    # Conv2d(C, 64, 7, 2, 3): 49 taps x C x 64 per feature position
+    return 2.0 * 49 * 64 * d.c * d.n * d.hf * d.wf
+
+
+def _skinny_key(d, what):
+    return "%s n%d c%d %dx%d<->%dx%d %s" % ("conv1" if d.kind == 0 else "convT5", d.n, d.c, d.himg, d.wimg, d.hf, d.wf, what)
+
+
 def _conv64_key(d, what):
     return "%s s%d n%d %dx%d->%dx%d %s" % ("convT" if d.transposed else "conv", d.stride, d.n, d.hi, d.wi, d.ho, d.wo, what)
 
@@ -131,56 +145,7 @@ def _ws(nbytes, device, slot=0):
     return buf
 
 
-# ---- side stream (SRLZ_SIDE_STREAM=1, off by default): weight gradients are off the critical path of backward (nothing
-# downstream of a layer's dW until the optimiser), so they CAN run on a second HIP stream concurrently with the data-gradient
-# chain.  Measured on MI355X it loses: 18.7 vs 17.3 ms per step (round 2), 19.9 vs 18.2 (round 1) — both kernels of such a
-# pair fill the CUs' LDS, so they time-share the chip instead of overlapping.  Kept as an A/B switch only.
 import os as _os
-_USE_SIDE = _os.environ.get("SRLZ_SIDE_STREAM", "0") != "0"
-_side_streams = {}
-
-
-def _side_stream(device):
-    """The side stream paired with the CURRENT stream (each main stream gets its own)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    s = _side_streams.get(key)
-    if s is None:
-        s = torch.cuda.Stream(device=device)
-        _side_streams[key] = s
-    return s
-
-
-class _OnSide(object):
-    """with _OnSide(device, tensors...) as active: launches inside run on the side stream after everything already
-    enqueued on the current stream; join() makes the current stream wait for them."""
-
-    def __init__(self, device, *tensors):
-        self.device, self.tensors = device, [t for t in tensors if t is not None]
-        self.side = _side_stream(device) if _USE_SIDE else None
-
-    def __enter__(self):
-        if self.side is None:
-            return self
-        main = torch.cuda.current_stream(self.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self.side.wait_event(ev)
-        for t in self.tensors:
-            t.record_stream(self.side)
-        self.ctx = torch.cuda.stream(self.side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.side is not None:
-            self.ctx.__exit__(*exc)
-            self.done = torch.cuda.Event()
-            self.done.record(self.side)
-        return False
-
-    def join(self):
-        if self.side is not None and getattr(self, "done", None) is not None:
-            torch.cuda.current_stream(self.device).wait_event(self.done)
 
 
 def _check(t, name):
@@ -200,13 +165,20 @@ _NORM_LUT = {}
 
 
 def norm_lut(device):
-    """((v / 255) - mean[c]) / std[c] for v = 0..255, c = R, G, B (preprocessing/utils.py:20-32), one table per device."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    lut = _NORM_LUT.get(key)
+    """((v / 255) - mean[c]) / std[c] for v = 0..255, c = R, G, B (preprocessing/utils.py:20-32), one table per device.
+
+    Built ONCE and made visible to every stream before it is returned (the fill is followed by a device synchronisation), so a
+    later launch on another stream reads a finished table.  The first request must not fall inside a hipGraph capture — the fill
+    would be recorded instead of executed; SRL4robotics.__init__ asks for the table eagerly for that reason."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    lut = _NORM_LUT.get(index)
     if lut is None:
-        lut = torch.empty((3, 256), dtype=torch.float32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise C.SrlzError("norm_lut: first use inside a stream capture; call srlz.ops.norm_lut(device) once before capturing")
+        lut = torch.empty((3, 256), dtype=torch.float32, device=torch.device("cuda", index))
         C.normalize_lut(ptr(lut), stream())
-        _NORM_LUT[key] = lut
+        torch.cuda.synchronize(index)
+        _NORM_LUT[index] = lut
     return lut
 
 
@@ -232,7 +204,11 @@ def frames_as_float(frames, out=None):
         out = torch.empty(frames.shape, dtype=torch.float32, device=frames.device)
     elif tuple(out.shape) != tuple(frames.shape) or out.dtype != torch.float32 or not out.is_contiguous():
         raise C.SrlzError("frames_as_float: `out` must be a contiguous float32 tensor of the frames' shape")
-    C.normalize_u8_planar(ptr(frames), ptr(norm_lut(frames.device)), ptr(out), n, c, frames[0, 0].numel(), stream())
+    lut, plane = norm_lut(frames.device), frames[0, 0].numel()
+    per = max(1, 65535 // c)  # one launch takes n * c <= 65535 planes (grid.y)
+    for i in range(0, n, per):
+        m = min(per, n - i)
+        C.normalize_u8_planar(ptr(frames[i:i + m]), ptr(lut), ptr(out[i:i + m]), m, c, plane, stream())
     return out
 
 
@@ -344,16 +320,14 @@ class Conv64Fn(Function):
         d = ctx.desc
         dy = _check(dy, "conv64 dy")
         dw = db = None
-        side = _OnSide(x.device)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):  # (a frozen layer needs neither)
             dw = _gbuf(ctx.params[0])
             db = _gbuf(ctx.params[1]) if ctx.has_bias else None
             nbytes = C.conv64_bwd_weight_workspace(d)
             ws = _ws(nbytes, x.device, slot=1)
-            with _OnSide(x.device, x, dy, dw, db, ws) as side:
-                _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
-                        lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, None, ptr(ws), nbytes, d,
-                                                    stream()))
+            _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                    lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, None, ptr(ws), nbytes, d,
+                                                stream()))
         dx = None
         if ctx.needs_dx:
             dx = torch.empty_like(x)
@@ -370,7 +344,6 @@ class Conv64Fn(Function):
             else:
                 _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
                         lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), None, d, stream()))
-        side.join()
         return dx, _give(ctx.params[0], dw), _give(ctx.params[1], db), None, None, None, None, None
 
 
@@ -479,9 +452,12 @@ class EncInFn(Function):
         y = torch.empty((n, d.hf, d.wf, 64), dtype=torch.float32, device=x.device)
         stats = torch.empty((C.skinny_tiles(d), 128), dtype=torch.float32, device=x.device) if training else None
         if u8:
-            C.conv1_fwd_u8(ptr(x), ptr(norm_lut(x.device)), ptr(w), ptr(y), ptr(stats), d, stream())
+            lut = norm_lut(x.device)
+            _launch("skinny_conv_kernel", _skinny_key(d, "fwd u8"), _conv1_flop(d),
+                    lambda: C.conv1_fwd_u8(ptr(x), ptr(lut), ptr(w), ptr(y), ptr(stats), d, stream()))
         else:
-            C.conv1_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), d, stream())
+            _launch("skinny_conv_kernel", _skinny_key(d, "fwd"), _conv1_flop(d),
+                    lambda: C.conv1_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), d, stream()))
         hp, wp = (d.hf + 2 * pool_pad - 3) // 2 + 1, (d.wf + 2 * pool_pad - 3) // 2 + 1
         pd = PoolDesc(n, d.hf, d.wf, hp, wp, pool_pad, 0, cur_groups(training))
         bnp, batch_stat = _bn_params(stats, n * d.hf * d.wf, gamma, beta, running_mean, running_var, training, x.device)
@@ -523,11 +499,16 @@ class EncInFn(Function):
         nbytes = C.skinny_bwd_weight_workspace(ctx.desc)
         ws = _ws(nbytes, dev)
         if is_u8_frames(x):
-            C.conv1_bwd_weight_fused_u8(ptr(x), ptr(norm_lut(dev)), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums),
-                                        1 if ctx.training else 0, ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc, stream())
+            lut = norm_lut(dev)
+            _launch("skinny_wgrad_kernel", _skinny_key(ctx.desc, "wgrad fused u8"), _conv1_flop(ctx.desc),
+                    lambda: C.conv1_bwd_weight_fused_u8(ptr(x), ptr(lut), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums),
+                                                        1 if ctx.training else 0, ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc,
+                                                        stream()))
         else:
-            C.conv1_bwd_weight_fused(ptr(x), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums), 1 if ctx.training else 0,
-                                     ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc, stream())
+            _launch("skinny_wgrad_kernel", _skinny_key(ctx.desc, "wgrad fused"), _conv1_flop(ctx.desc),
+                    lambda: C.conv1_bwd_weight_fused(ptr(x), ptr(y), ptr(bnp), ptr(argmax), ptr(dpooled), ptr(sums),
+                                                     1 if ctx.training else 0, ptr(dw), ptr(ws), nbytes, ctx.desc, ctx.pdesc,
+                                                     stream()))
         return None, _give(w, dw), _give(ctx.params[0], dgamma), _give(ctx.params[1], dbeta), None, None, None, None, None, None
 
 
@@ -690,12 +671,10 @@ class DecBlockFn(Function):
         db = _gbuf(ctx.params[3], 64, dy.device)
         nbytes = C.conv64_bwd_weight_workspace(d)
         ws = _ws(nbytes, dy.device, slot=1)
-        with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
-            _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
-                    lambda: C.conv64_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), None, ptr(ws), nbytes, d,
-                                                stream()))
+        _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                lambda: C.conv64_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), None, ptr(ws), nbytes, d,
+                                            stream()))
         dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, gb=ctx.params[:2])
-        side.join()
         gp, bp, wp, cp = ctx.params
         return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(wp, dw), _give(cp, db), None, None, None
 
@@ -715,7 +694,8 @@ class DecOutFn(Function):
         c = w.shape[1]
         d = SkinnyDesc(n, c, (hf - 1) * 2 + 4, (wf - 1) * 2 + 4, hf, wf, 1, cur_groups(training))
         y = torch.empty((n, c, d.himg, d.wimg), dtype=torch.float32, device=y_prev.device)
-        C.convT_out_fwd(ptr(y_prev), ptr(w), ptr(bias), ptr(y), ptr(bnp), d, stream())
+        _launch("convT_out_os_kernel", _skinny_key(d, "fwd"), _convT_out_flop(d),
+                lambda: C.convT_out_fwd(ptr(y_prev), ptr(w), ptr(bias), ptr(y), ptr(bnp), d, stream()))
         ctx.save_for_backward(y_prev, bnp, w)
         ctx.desc, ctx.training, ctx.in_link = d, training, in_link
         ctx.params = (gamma, beta, bias)
@@ -735,15 +715,16 @@ def _dec_out_backward(ctx, y_prev, bnp, w, dy, gain):
     d = ctx.desc
     dw = _gbuf(w)
     db = _gbuf(ctx.params[2], d.c, dy.device)
-    if ctx.in_link is not None and d.c == 3 and _FUSED_OUT_BWD:
+    if ctx.in_link is not None and _FUSED_OUT_BWD and C.convT_out_bwd_fused_supported(d):
         # data gradient, its BatchNorm-backward partials and the weight / bias gradients in one pass over (dy, y_prev)
         da = torch.empty_like(y_prev)
         partial = torch.empty((C.convT_out_bwd_fused_tiles(d), 128), dtype=torch.float32, device=dy.device)
         nbytes = C.convT_out_bwd_fused_workspace(d)
         ws = _ws(nbytes, dy.device, slot=1)
         g_dev, g_div, g_coef = (ptr(gain[0]), gain[1], gain[2]) if gain is not None else (None, 1.0, 1.0)
-        C.convT_out_bwd_fused(ptr(dy), ptr(w), ptr(da), ptr(y_prev), ptr(bnp), ptr(partial), ptr(dw), ptr(db), ptr(ws), nbytes,
-                              g_dev, g_div, g_coef, d, stream())
+        _launch("convT_out_os_bwd_kernel", _skinny_key(d, "dgrad+wgrad"), 2.0 * _convT_out_flop(d),
+                lambda: C.convT_out_bwd_fused(ptr(dy), ptr(w), ptr(da), ptr(y_prev), ptr(bnp), ptr(partial), ptr(dw), ptr(db), ptr(ws),
+                                              nbytes, g_dev, g_div, g_coef, d, stream()))
         dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial, gb=ctx.params[:2])
         gp, bp, cp = ctx.params
         return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(w, dw), _give(cp, db)
@@ -751,8 +732,7 @@ def _dec_out_backward(ctx, y_prev, bnp, w, dy, gain):
         C.scale_by_scalar(ptr(dy), ptr(gain[0]), gain[1], gain[2], ptr(dy), dy.numel(), stream())
     nbytes = C.skinny_bwd_weight_workspace(d)
     ws = _ws(nbytes, dy.device, slot=1)
-    with _OnSide(dy.device, y_prev, dy, dw, db, bnp, ws) as side:
-        C.convT_out_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream())
+    C.convT_out_bwd_weight(ptr(y_prev), ptr(dy), ptr(dw), ptr(db), ptr(bnp), ptr(ws), nbytes, d, stream())
     da = torch.empty_like(y_prev)
     # with the BatchNorm backward deferred (in_link), its two sums come out of this kernel's epilogue
     partial = None
@@ -761,7 +741,6 @@ def _dec_out_backward(ctx, y_prev, bnp, w, dy, gain):
     C.convT_out_bwd_data(ptr(dy), ptr(w), ptr(da), ptr(y_prev) if partial is not None else None,
                          ptr(bnp) if partial is not None else None, ptr(partial), d, stream())
     dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial, gb=ctx.params[:2])
-    side.join()
     gp, bp, cp = ctx.params
     return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(w, dw), _give(cp, db)
 
@@ -789,10 +768,14 @@ class DecOutLossFn(Function):
         nwg = C.convT_out_fwd_loss_workgroups(d)
         part = _ws(2 * nwg * 8, y_prev.device, slot=2)
         if u8:
-            C.convT_out_fwd_loss_u8(ptr(y_prev), ptr(w), ptr(bias), ptr(target), ptr(norm_lut(y_prev.device)), ptr(err), None,
-                                    ptr(bnp), ptr(part), d, stream())
+            lut = norm_lut(y_prev.device)
+            _launch("convT_out_os_kernel", _skinny_key(d, "fwd+loss u8"), _convT_out_flop(d),
+                    lambda: C.convT_out_fwd_loss_u8(ptr(y_prev), ptr(w), ptr(bias), ptr(target), ptr(lut), ptr(err), None, ptr(bnp),
+                                                    ptr(part), d, stream()))
         else:
-            C.convT_out_fwd_loss(ptr(y_prev), ptr(w), ptr(bias), ptr(target), ptr(err), None, ptr(bnp), ptr(part), d, stream())
+            _launch("convT_out_os_kernel", _skinny_key(d, "fwd+loss"), _convT_out_flop(d),
+                    lambda: C.convT_out_fwd_loss(ptr(y_prev), ptr(w), ptr(bias), ptr(target), ptr(err), None, ptr(bnp), ptr(part), d,
+                                                 stream()))
         sums = torch.empty(2, dtype=torch.float32, device=y_prev.device)
         comb = torch.empty((), dtype=torch.float32, device=y_prev.device)
         per_frame = err.numel() // 2

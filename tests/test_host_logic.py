@@ -328,12 +328,12 @@ def test_which_steps_read_the_loaders_bytes(monkeypatch):
     from srlz import hotpath
 
     class Stub(object):
-        model_type, _use_pair, _frame_streams, _use_graph = "custom_cnn", True, None, False
+        model_type, _use_pair, _use_graph = "custom_cnn", True, False
         use_triplets = use_dae = use_vae = perceptual_similarity_loss = False
 
     reads = learner.SRL4robotics._readsBytes
     assert reads(Stub()) is True
-    for attr, value in (("model_type", "resnet"), ("_use_pair", False), ("_frame_streams", (1, 2)), ("_use_graph", True),
+    for attr, value in (("model_type", "resnet"), ("_use_pair", False), ("_use_graph", True),
                         ("use_triplets", True), ("use_dae", True)):
         s = Stub()
         setattr(s, attr, value)
@@ -348,7 +348,14 @@ def test_which_steps_read_the_loaders_bytes(monkeypatch):
     monkeypatch.setattr(hotpath, "_FUSE_RECON", True)
     monkeypatch.setattr(learner, "RAW_UINT8_INPUT", False)
     assert not reads(Stub())
-    # planar frames are recognised by their layout
-    is_planar = learner.BaseLearner._isPlanar
-    assert is_planar(torch.zeros(2, 3, 224, 224, dtype=torch.uint8)) and is_planar(torch.zeros(2, 9, 224, 224, dtype=torch.uint8))
-    assert not is_planar(torch.zeros(2, 224, 224, 3, dtype=torch.uint8)) and not is_planar(torch.zeros(2, 3, 224, 224))
+    # the layout of uint8 frames is STATED (frame_layout), never guessed from a shape: a [2, 3, 6, 9] byte tensor fits both readings
+    class Lay(learner.BaseLearner):
+        def __init__(self, layout):
+            self.frame_layout = layout
+    ambiguous = torch.zeros(2, 3, 6, 9, dtype=torch.uint8)
+    assert Lay("planar")._isPlanar(ambiguous) and not Lay("nhwc")._isPlanar(ambiguous)
+    assert Lay("planar")._isPlanar(torch.zeros(2, 9, 224, 224, dtype=torch.uint8))
+    assert not Lay("planar")._isPlanar(torch.zeros(2, 3, 224, 224))  # float observations are never "bytes"
+    with pytest.raises(ValueError):
+        Lay("chw")._isPlanar(ambiguous)
+    assert learner.BaseLearner.frame_layout == "planar"

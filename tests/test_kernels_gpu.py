@@ -141,7 +141,7 @@ def test_conv1(C, n, c, h):
     assert rel_err(dw, wr.grad) < 2e-5
 
 
-@pytest.mark.parametrize("n,c,hf", [(2, 3, 111), (1, 6, 111), (3, 3, 20), (1, 9, 30)])
+@pytest.mark.parametrize("n,c,hf", [(2, 3, 111), (1, 6, 111), (3, 3, 20), (1, 9, 30), (2, 3, 1), (1, 6, 16), (5, 3, 33)])
 def test_convT_out(C, n, c, hf):
     g = torch.Generator().manual_seed(c * 10 + hf)
     himg = (hf - 1) * 2 + 4
@@ -632,17 +632,18 @@ def test_convT_out_bwd_data_emits_bn_backward_sums(C, n, c, hf):
         assert rel_err(b, a) < 2e-5
 
 
-@pytest.mark.parametrize("n,hf,groups", [(2, 111, 1), (4, 37, 2), (3, 21, 1)])
-def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
+@pytest.mark.parametrize("n,c,hf,groups", [(2, 3, 111, 1), (4, 3, 37, 2), (3, 3, 21, 1), (2, 6, 111, 2), (3, 6, 18, 1), (1, 3, 5, 1)])
+def test_convT_out_bwd_fused_matches_the_two_launches(C, n, c, hf, groups):
     """srlz_convT_out_bwd_fused (one pass over dy and x_raw) == srlz_convT_out_bwd_data(x_raw, bnp, partial) followed by
-    srlz_convT_out_bwd_weight(bnp): identical dA (same contraction order), BatchNorm-backward sums / dgamma / dbeta from the
-    8x16 tiles, weight and bias gradients to rounding (different summation order; the bias gradient comes from the staged
-    windows of the fused kernel: every image pixel owned by exactly one tile)."""
+    srlz_convT_out_bwd_weight(bnp), for 3 and 6 image channels: dA, BatchNorm-backward sums / dgamma / dbeta (one record per strip
+    of the output-stationary kernel), weight and bias gradients to rounding (another contraction / summation order; the bias
+    gradient comes from the rows the fused kernel stages: every image pixel owned by exactly one strip), a second launch bit for
+    bit, and the fp64 torch oracle."""
     g = torch.Generator().manual_seed(71 + hf)
     himg = (hf - 1) * 2 + 4
     x_raw = (torch.randn(n, hf, hf, 64, generator=g) * 1.3 + 0.2).to(DEV)
-    w = (torch.randn(64, 3, 4, 4, generator=g) * 0.1).to(DEV)
-    dimg = torch.randn(n, 3, himg, himg, generator=g).to(DEV)
+    w = (torch.randn(64, c, 4, 4, generator=g) * 0.1).to(DEV)
+    dimg = torch.randn(n, c, himg, himg, generator=g).to(DEV)
     recs = []
     for gi in range(groups):
         xg = x_raw[gi * (n // groups):(gi + 1) * (n // groups)].double()
@@ -651,7 +652,8 @@ def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
         invstd = 1.0 / torch.sqrt(var + 1e-5)
         recs.append(torch.cat((mean, invstd, gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd)).float())
     bnp = torch.cat(recs).to(DEV)
-    d = C.SkinnyDesc(n, 3, himg, himg, hf, hf, 1, groups)
+    d = C.SkinnyDesc(n, c, himg, himg, hf, hf, 1, groups)
+    assert C.convT_out_bwd_fused_supported(d) == 1
     st = C.stream()
     nb = C.bn_bwd_workspace(0)
     wsb = torch.empty(nb, dtype=torch.uint8, device=DEV)
@@ -661,21 +663,26 @@ def test_convT_out_bwd_fused_matches_the_two_launches(C, n, hf, groups):
     C.convT_out_bwd_data(C.ptr(dimg), C.ptr(w), C.ptr(da0), C.ptr(x_raw), C.ptr(bnp), C.ptr(p0), d, st)
     n0 = C.skinny_bwd_weight_workspace(d)
     ws0 = torch.empty(n0, dtype=torch.uint8, device=DEV)
-    dw0, db0 = torch.empty(64, 3, 4, 4, device=DEV), torch.empty(3, device=DEV)
+    dw0, db0 = torch.empty(64, c, 4, 4, device=DEV), torch.empty(c, device=DEV)
     C.convT_out_bwd_weight(C.ptr(x_raw), C.ptr(dimg), C.ptr(dw0), C.ptr(db0), C.ptr(bnp), C.ptr(ws0), n0, d, st)
     # fused
     da1 = torch.full((n, hf, hf, 64), float("nan"), device=DEV)
     p1 = torch.full((C.convT_out_bwd_fused_tiles(d), 128), float("nan"), device=DEV)
     n1 = C.convT_out_bwd_fused_workspace(d)
     ws1 = torch.empty(n1, dtype=torch.uint8, device=DEV)
-    dw1, db1 = torch.full((64, 3, 4, 4), float("nan"), device=DEV), torch.full((3,), float("nan"), device=DEV)
+    dw1, db1 = torch.full((64, c, 4, 4), float("nan"), device=DEV), torch.full((c,), float("nan"), device=DEV)
     C.convT_out_bwd_fused(C.ptr(dimg), C.ptr(w), C.ptr(da1), C.ptr(x_raw), C.ptr(bnp), C.ptr(p1), C.ptr(dw1), C.ptr(db1), C.ptr(ws1),
+                          n1, None, 1.0, 1.0, d, st)
+    da2, p2 = torch.full_like(da1, float("nan")), torch.full_like(p1, float("nan"))
+    dw2, db2 = torch.full_like(dw1, float("nan")), torch.full_like(db1, float("nan"))
+    C.convT_out_bwd_fused(C.ptr(dimg), C.ptr(w), C.ptr(da2), C.ptr(x_raw), C.ptr(bnp), C.ptr(p2), C.ptr(dw2), C.ptr(db2), C.ptr(ws1),
                           n1, None, 1.0, 1.0, d, st)
     out = [[torch.empty(k, device=DEV) for k in (128 * groups, 64, 64)] for _ in range(2)]
     for p, o in ((p0, out[0]), (p1, out[1])):
         C.bn_bwd_finalize_partials(C.ptr(p), p.shape[0], groups, C.ptr(o[0]), C.ptr(o[1]), C.ptr(o[2]), C.ptr(wsb), nb, st)
     torch.cuda.synchronize()
-    assert torch.equal(da0, da1)
+    assert torch.isfinite(da1).all() and torch.isfinite(p1).all() and rel_err(da1, da0) < 5e-6
+    assert torch.equal(da2, da1) and torch.equal(p2, p1) and torch.equal(dw2, dw1) and torch.equal(db2, db1)  # deterministic
     for a, b in zip(out[0], out[1]):
         assert rel_err(b, a) < 2e-5
     assert rel_err(dw1, dw0) < 2e-5
@@ -918,8 +925,16 @@ def test_pipelined_fused_dgrad_is_the_synchronous_kernel_bit_for_bit(C, tmp_path
 def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
     """srlz_conv64_bwd_fused — data, weight and bias gradient of ConvTranspose2d(64,64,3,2) whose output went through
     BatchNorm2d + ReLU and whose input was relu(batchnorm(x)), from ONE staging of the rebuilt d(loss)/dy — against
-    (i) fp64 autograd through relu(bn(x)) -> conv_transpose2d -> batch_norm -> relu per BatchNorm group, and
-    (ii) the two-launch path srlz_conv64_bwd_data(dy_out) + srlz_conv64_bwd_weight: dx bit for bit, dw / db to rounding."""
+    (i) fp64 autograd through relu(bn(x)) -> conv_transpose2d -> batch_norm -> relu per BatchNorm group, EVERY element of dx
+    and dw to 1e-4 at every size, and
+    (ii) the two-launch path srlz_conv64_bwd_data(dy_out) + srlz_conv64_bwd_weight: dx bit for bit, dw / db to rounding.
+
+    The discrete decisions are taken out of the comparison the way tests/test_step_gpu.py does it for whole steps (two correct
+    evaluations decide a ReLU at |bn(.)| ~ 1e-7 differently, and one flipped decision moves ~256 dx values by 1e-2 of the
+    maximum): the INPUT activations are moved off the ReLU threshold of their record (the record is an input of the kernel), and
+    the incoming gradient dA is zeroed wherever the device's own bn(y) lies within 1e-4 of the output ReLU's threshold — there the
+    decision multiplies a zero in the data gradient, in the weight gradient and in both BatchNorm-backward sums, for either
+    evaluation; everywhere else the fp32 and fp64 decisions agree (the two evaluations of bn(y) differ by ~1e-6)."""
     assert n % groups == 0
     g = torch.Generator().manual_seed(77 * hi + n)
     ho = (hi - 1) * 2 + 3
@@ -930,26 +945,26 @@ def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
     rm, rv = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
     da = torch.randn(n, 64, ho, ho, generator=g)
     per = n // groups
-    # ---- fp64 reference, group by group (per-call BatchNorm statistics)
-    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
-    dx_ref, xrecs, yrecs, sums_l = [], [], [], []
+    # ---- the input's BatchNorm record per group (fp32, as the kernel receives it); x moved off its ReLU threshold
+    xrecs, recs64 = [], []
     for gi in range(groups):
         xs = x[gi * per:(gi + 1) * per].double()
         m, v = xs.mean((0, 2, 3)), xs.var((0, 2, 3), unbiased=False)
         inv = 1.0 / torch.sqrt(v + 1e-5)
-        sc, sh = gx.double() * inv, bx.double() - m * gx.double() * inv
-        xrecs.append(torch.cat((m, inv, sc, sh)).float())
-        a = torch.relu(xs * sc.view(1, 64, 1, 1) + sh.view(1, 64, 1, 1)).requires_grad_(True)
-        y = F.conv_transpose2d(a, wr, br, stride=2)
-        out = F.relu(F.batch_norm(y, rm.double().clone(), rv.double().clone(), gamma.double(), beta.double(), bool(training), 0.1, 1e-5))
-        out.backward(da[gi * per:(gi + 1) * per].double())
-        dx_ref.append(a.grad)
-    dx_ref = torch.cat(dx_ref)
+        rec = torch.cat((m, inv, gx.double() * inv, bx.double() - m * gx.double() * inv)).float()
+        xrecs.append(rec)
+        sc, sh = rec[128:192].double().view(1, 64, 1, 1), rec[192:256].double().view(1, 64, 1, 1)
+        recs64.append((sc, sh))
+        z = xs * sc + sh
+        near = z.abs() < 1e-3
+        xs = torch.where(near, (torch.where(z >= 0, 2e-3, -2e-3) - sh) / sc, xs)
+        x[gi * per:(gi + 1) * per] = xs.float()
+        assert float(((x[gi * per:(gi + 1) * per].double() * sc + sh).abs()).min()) > 5e-4
     # ---- device: forward through the C ABI to get y, its statistics and the backward sums
     st = C.stream()
     d = C.Conv64Desc(n, hi, hi, ho, ho, 3, 2, 0, 1, groups)
     assert C.conv64_bwd_fused_supported(d) == 1
-    xd, wd, bd, dad = nhwc(x).to(DEV), w.to(DEV), b.to(DEV), nhwc(da).to(DEV)
+    xd, wd, bd = nhwc(x).to(DEV), w.to(DEV), b.to(DEV)
     xbnp = torch.cat(xrecs).to(DEV)
     packs = torch.empty(2, C.conv64_packed_floats(), device=DEV)
     C.conv64_pack_weights(C.ptr(wd), C.ptr(packs[0]), C.ptr(packs[1]), d, st)
@@ -968,6 +983,27 @@ def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
         one = torch.empty(256, device=DEV)
         C.bn_eval_params(C.ptr(gd), C.ptr(bed), C.ptr(rmd), C.ptr(rvd), 1e-5, C.ptr(one), st)
         bnp = one.repeat(groups)
+    # ---- dA = 0 wherever the device's bn(y) is within 1e-4 of the output ReLU's threshold
+    torch.cuda.synchronize()
+    rec_y = bnp.view(groups, 256).double().cpu()
+    zy = nchw(y).double().cpu().view(groups, per, 64, ho, ho) * rec_y[:, 128:192].view(groups, 1, 64, 1, 1) \
+        + rec_y[:, 192:256].view(groups, 1, 64, 1, 1)
+    tie = (zy.abs() < 1e-4).view(n, 64, ho, ho)
+    da = torch.where(tie, torch.zeros(()), da)
+    dad = nhwc(da).to(DEV)
+    # ---- fp64 reference, group by group (per-call BatchNorm statistics)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    dx_ref = []
+    for gi in range(groups):
+        sc, sh = recs64[gi]
+        a = torch.relu(x[gi * per:(gi + 1) * per].double() * sc + sh).requires_grad_(True)
+        yr = F.conv_transpose2d(a, wr, br, stride=2)
+        zr = F.batch_norm(yr, rm.double().clone(), rv.double().clone(), gamma.double(), beta.double(), bool(training), 0.1, 1e-5)
+        # outside the zeroed ties both evaluations take the same decision
+        assert bool((((zr > 0) == (zy[gi] > 0)) | tie[gi * per:(gi + 1) * per]).all())
+        F.relu(zr).backward(da[gi * per:(gi + 1) * per].double())
+        dx_ref.append(a.grad)
+    dx_ref = torch.cat(dx_ref)
     sums, dgm, dbt = torch.empty(128 * groups, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
     C.bn_relu_bwd_sums(C.ptr(y), C.ptr(bnp), C.ptr(dad), C.ptr(sums), C.ptr(dgm), C.ptr(dbt), C.ptr(bws), nbn, n * ho * ho, groups, st)
     # ---- two launches
@@ -992,14 +1028,11 @@ def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
     torch.cuda.synchronize()
     assert torch.isfinite(dx1).all() and torch.equal(dx1, dx0)
     assert torch.equal(dx2, dx1) and torch.equal(dw2, dw1) and torch.equal(db2, db1)
-    # fp64 oracle: two correct evaluations decide a ReLU at |bn(y)| ~ 1e-7 differently a handful of times per few million
-    # elements, and one flipped decision moves the ~256 dx values it reaches by ~1e-2 of the tensor's maximum: all but a
-    # vanishing fraction of dx must agree to 5e-5 (small cases: every element)
+    # fp64 oracle with the decisions out of the way (docstring): EVERY element, every size
     dev_dx = (nchw(dx1).double().cpu() - dx_ref).abs() / float(dx_ref.abs().max())
-    assert float((dev_dx > 5e-5).double().mean()) <= (0.0 if n * ho * ho < 20000 else 3e-3), float(dev_dx.max())
+    assert float(dev_dx.max()) < 1e-4, float(dev_dx.max())
     assert rel_err(dw1, dw0) < 2e-5
-    if n * ho * ho < 20000:  # (one flipped ReLU decision moves a weight gradient by ~1e-2 of its maximum at these batch sizes)
-        assert rel_err(dw1, wr.grad) < 5e-5
+    assert rel_err(dw1, wr.grad) < 1e-4, rel_err(dw1, wr.grad)
     scale = float(da.abs().sum()) / 64
     assert float((db1 - db0).abs().max()) < 1e-5 * scale
     if training:  # the bias gradient of a convolution followed by train-mode BatchNorm is identically zero

@@ -287,3 +287,52 @@ def test_recon_loss_fusion_is_what_the_default_step_runs():
     finally:
         ops.DecOutLossFn.apply = real
     assert seen == [1] and lm.names == ["reconstruction_loss"]
+
+
+def test_separately_allocated_frames_take_the_unfused_route_in_the_default_environment():
+    """obs and next_obs that are NOT the two halves of one buffer (a caller outside learn()'s feed): no fused reconstruction loss is
+    possible (ops.pair_of finds no pair) — the step runs the batched model call on a concatenated copy, gets real decoded frames
+    and the separate pair loss.  Same environment, same weights, same inputs as the adjacent case: the loss agrees to fp32
+    rounding and the parameters after the step to summation order.  On the fused route the "decoded frames" never existed:
+    _forwardPair hands None to its caller (a consumer of a reconstruction must fail loudly, not read dec - target)."""
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from losses.losses import LossManager
+    from srlz import ops
+    pre.N_CHANNELS = 3
+    learner.BATCH_SIZE = 3
+    o, n, a = gu.golden_inputs(3, 3, 6, seed=77)
+    act = torch.from_numpy(a).view(-1, 1).cuda()
+
+    def one_step(adjacent):
+        srl = learner.SRL4robotics(24, model_type="custom_cnn", seed=5, learning_rate=1e-4, cuda=True,
+                                   losses=["autoencoder", "inverse"], n_actions=6, log_folder="/tmp")
+        lm = LossManager(srl.model, None)
+        if adjacent:
+            both = torch.from_numpy(np.concatenate((o, n), 0)).cuda()
+            obs, nxt = both[:3], both[3:]
+        else:
+            obs, nxt = torch.from_numpy(o).cuda(), torch.from_numpy(n).cuda()
+            assert ops.pair_of(obs, nxt) is None
+        calls = {"fused": 0, "plain": 0}
+        real_fused, real_plain = ops.DecOutLossFn.apply, ops.DecOutFn.apply
+        ops.DecOutLossFn.apply = lambda *args: (calls.__setitem__("fused", calls["fused"] + 1), real_fused(*args))[1]
+        ops.DecOutFn.apply = lambda *args: (calls.__setitem__("plain", calls["plain"] + 1), real_plain(*args))[1]
+        try:
+            srl.model.train()
+            out = srl._forwardPair(obs, nxt, (obs, nxt, True))
+            loss = srl.trainStep(obs, nxt, act, lm)
+        finally:
+            ops.DecOutLossFn.apply, ops.DecOutFn.apply = real_fused, real_plain
+        torch.cuda.synchronize()
+        return srl, out, calls, lm.lossValues() + [float(loss.detach())]
+
+    srl_a, out_a, calls_a, loss_a = one_step(True)
+    srl_s, out_s, calls_s, loss_s = one_step(False)
+    assert calls_a == {"fused": 2, "plain": 0} and calls_s == {"fused": 0, "plain": 2}
+    # fused route: (states, None) twice + the loss; plain route: real reconstructions, no loss
+    assert out_a[2] is not None and out_a[0][1] is None and out_a[1][1] is None and out_a[0][0].shape == (3, 24)
+    assert out_s[2] is None and tuple(out_s[0][1].shape) == (3, 3, 224, 224) and torch.isfinite(out_s[1][1]).all()
+    np.testing.assert_allclose(loss_s, loss_a, rtol=3e-6)
+    p_a, p_s = srl_a.flat_params.flat, srl_s.flat_params.flat
+    assert float((p_a - p_s).abs().max()) <= 2e-5 * float(p_a.abs().max())
