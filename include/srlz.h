@@ -436,6 +436,18 @@ int srlz_normalize_lut(float* norm_lut, srlz_stream_t stream);
  * tensor, through the table (for consumers that have no *_u8 form; bit-identical to srlz_normalize_u8 of the NHWC frames). */
 int srlz_normalize_u8_planar(const uint8_t* x_u8, const float* norm_lut, float* out, int n, int c, long long plane,
                              srlz_stream_t stream);
+/* The dataset resident in HBM (round 4): the loader process of /root/reference/preprocessing/data_loader.py:195-256
+ * decodes every frame of every epoch again; here a decoded frame is kept ([frames][C][W][H] uint8, 150 KB each: 100 k frames = 15 GB
+ * of the 288) and later epochs move frames BY INDEX.  Whole frames of frame_bytes (a multiple of 16) bytes:
+ *   dst[dst_index ? dst_index[i] + dst_shift : i] = src[src_index ? src_index[i] + src_shift : i],  i < n  (index arrays: int64, device)
+ * gather (next_obs = store[minibatch + 1]: src_shift = 1), scatter (store <- a freshly decoded minibatch), plain copy. */
+int srlz_copy_frames_u8(const uint8_t* src, const long long* src_index, long long src_shift, uint8_t* dst,
+                        const long long* dst_index, long long dst_shift, int n, long long frame_bytes, srlz_stream_t stream);
+/* The DAE loader's occluded copies (preprocessing/data_loader.py:100-111) made on the device from resident frames: out [n,C,W,H] fp32 =
+ * the normalised frame store[index[i] + shift] with the rectangle rects[i][view] = (h1, h2, w1, w2) set to 0, one rectangle per
+ * camera view (group of 3 channels); the rectangles are drawn by the loader process with the reference's np.random calls. */
+int srlz_occlude_frames_u8(const uint8_t* store, const long long* index, long long shift, const int* rects, const float* norm_lut,
+                           float* out, int n, int c, int w, int h, srlz_stream_t stream);
 
 /* SRLModulesSplit.detachSplit (models/modules.py:191-236): the state rebuilt from zero blocks and ONE kept slice is a
  * column mask: y[r][c] = x[r][c] for lo <= c < hi, else 0.  Its backward is the same call on the gradient. */

@@ -405,7 +405,9 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
     const f32x4 psc = *(const f32x4*)(rec + 128);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const bool zero = psc[e] == 0.f;
+      // |scale| tiny against |shift| (exactly 0 included): z - shift cancels — xhat = (z - shift) / scale ... would carry an error of
+      // ~ eps * |shift| / |scale| — so such a channel takes the cold loop, which computes xhat from the convolution output itself
+      const bool zero = fabsf(psc[e]) <= 1e-3f * fabsf(psh[e]) || psc[e] == 0.f;
       pz_zero |= (zero ? 1u : 0u) << e;
       pthr[e] = zero ? __builtin_inff() : 0.f;
       const float isc = zero ? 0.f : 1.f / psc[e];
@@ -507,11 +509,13 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
     }
     if constexpr (PSUM != 0) {
       if (pz_zero) {
-        // BatchNorm scale exactly 0 in one of this lane's channels: relu(bn(.)) is the constant max(shift, 0) there, every window's
-        // first position is the argmax, and xhat needs the convolution output under it.  Rare and slow on purpose: d(pooled) is read
-        // back from where this lane has just stored it.
+        // BatchNorm scale (almost) 0 in one of this lane's channels — exactly 0: relu(bn(.)) is the constant max(shift, 0), every
+        // window's first position is the argmax — xhat cannot be recovered from the pooled value: it is taken from the convolution
+        // output under the recorded argmax, and the ReLU decision is the forward's own expression on that output.  Rare and slow on
+        // purpose: d(pooled) is read back from where this lane has just stored it.
         const float* __restrict__ rec = ps.bnp + grp * 256 + eslot * 4;  // (the cold loop re-reads what it needs of the record)
-        const f32x4 mean = *(const f32x4*)rec, pinv = *(const f32x4*)(rec + 64), psh = *(const f32x4*)(rec + 192);
+        const f32x4 mean = *(const f32x4*)rec, pinv = *(const f32x4*)(rec + 64), psc = *(const f32x4*)(rec + 128),
+                    psh = *(const f32x4*)(rec + 192);
 #pragma unroll 1
         for (int hk = 0; hk < 8; ++hk) {
           if (!((pok >> hk) & 1u)) continue;
@@ -527,7 +531,7 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
               const int a = (packed >> (8 * e)) & 0xff;
               const int iy = y * 2 - ps.pad + a / 3, ix = x * 2 - ps.pad + a % 3;
               const float vy = ps.y[grp * ps.y_gstride + ((size_t)(n * ps.H + iy) * ps.W + ix) * 64 + eslot * 4 + e];
-              const float dz = psh[e] > 0.f ? v[e] : 0.f;
+              const float dz = vy * psc[e] + psh[e] > 0.f ? v[e] : 0.f;
               s4[e] += dz; q4[e] += dz * ((vy - mean[e]) * pinv[e]);
             }
         }

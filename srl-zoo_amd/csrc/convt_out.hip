@@ -28,6 +28,19 @@ namespace {
 
 __device__ __forceinline__ int xcd_wg(int b, int nb) { return xcd_remap(b, nb); }
 
+// Branch-free conditional stores (as conv64.hip's gp_buffer): a buffer resource over one image; a lane that must not write passes
+// OS_DROP and the hardware drops its store.  A store inside a branch makes hipcc's wait insertion give up at the next loop header
+// (everything is waited for: vmcnt is in-order and the path through the branch has an unknown number of stores in flight) — which
+// would empty the rows-in-flight queue of these kernels once per trip.  A NULL tensor becomes a zero-sized resource: all dropped.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t os_buffer(float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(p ? bytes : 0u), 0x00020000);
+}
+constexpr unsigned OS_DROP = 0xFFFFFF00u;
+__device__ __forceinline__ void os_store2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float a, float b) {
+  __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(a), __float_as_uint(b)}, r, byte_off, 0, 0);
+}
+
 constexpr int OSP = 68;            // LDS pitch (floats) of one staged 64-channel pixel: 8 consecutive pixels -> 8 distinct bank quads
 constexpr int OSROW = 18 * OSP;    // forward: 16 positions + the left halo pixel + one dummy pixel (branch-free tail of the landing)
 
@@ -36,8 +49,13 @@ constexpr int OSROW = 18 * OSP;    // forward: 16 positions + the left halo pixe
 // registers, NCG > 1 reads them per group from LDS (16 x ds_read_b128 per group and row).
 // LOSS: target != NULL; img receives dec - target, dec_out (optional) the reconstruction; loss_partial[2][workgroups] (fp64).
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef SRLZ_OS_DEPTH
+#define SRLZ_OS_DEPTH 3
+#endif
+constexpr int DEPTH = SRLZ_OS_DEPTH;  // rows in flight per wave of the forward kernel
+
 template <int NCG, bool LOSS, typename TT>
-__global__ __launch_bounds__(256, 3) void convT_out_os_kernel(const float* __restrict__ feat, const float* __restrict__ w_ref,
+__global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __restrict__ feat, const float* __restrict__ w_ref,
                                                              const float* __restrict__ bias, float* __restrict__ img, int N, int H,
                                                              int W, int HF, int WF, const float* __restrict__ feat_bnp, int npg,
                                                              const TT* __restrict__ target, float* __restrict__ dec_out,
@@ -104,45 +122,63 @@ __global__ __launch_bounds__(256, 3) void convT_out_os_kernel(const float* __res
       sh = *(const f32x4*)(rec + 192 + 4 * c4);
     }
     const float* __restrict__ fimg = feat + (size_t)n * HF * WF * 64 + 4 * c4;
-    f32x4 ld[5];
-    unsigned ldok = 0;
+    const __amdgpu_buffer_rsrc_t img_rs = os_buffer(img + (size_t)n * C * H * W, (unsigned)(C * H * W * 4));
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t dec_rs = os_buffer(dec_out ? dec_out + (size_t)n * C * H * W : nullptr,
+                                                                      (unsigned)(C * H * W * 4));
+    // Rows travel through a queue of DEPTH register sets: row r is requested DEPTH row-steps before it lands (one row in flight per
+    // wave covered ~1 us of the ~2.5 us an HBM round trip takes at this load; measured 563 us -> see DESIGN.md 5.4).  The queue slot
+    // of row r is (r - (a0 - 1)) % DEPTH; the row loop is unrolled by DEPTH so that every slot index is static.
+    f32x4 ld[DEPTH][5];
+    unsigned ldok[DEPTH];
     // row r of the input strip (pixels b0-1 .. b0+15) -> registers; a pixel outside the map reads a clamped address and lands as 0
-    auto request = [&](int r) {
+    auto request = [&](int r, f32x4 (&q)[5], unsigned& qok) {
       const bool rowok = (unsigned)r < (unsigned)HF;
-      ldok = 0;
+      qok = 0;
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         const int fx = b0 - 1 + pq + 4 * i;
         const bool ok = rowok && (i < 4 || pq == 0) && (unsigned)fx < (unsigned)WF;
         const unsigned off = ok ? (unsigned)((r * WF + fx) * 64) : 0u;
-        ld[i] = *(const f32x4*)(fimg + off);
-        ldok |= (ok ? 1u : 0u) << i;
+        q[i] = *(const f32x4*)(fimg + off);
+        qok |= (ok ? 1u : 0u) << i;
       }
     };
     // landing: relu(bn(.)) and the zero of a pixel outside the map are ONE v_med3 per element — med3(z, lo, hi) with (lo, hi) =
     // (0, +inf) for a live pixel of a BatchNorm+ReLU operand, (-inf, +inf) when there is no BatchNorm record, (0, 0) outside
-    auto land = [&](int r) {
+    auto land = [&](int r, const f32x4 (&q)[5], unsigned qok) {
       float* dst = S + (r & 1) * OSROW + 4 * c4;
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        const bool ok = (ldok >> i) & 1u;
+        const bool ok = (qok >> i) & 1u;
         const float lo = ok ? act_lo : 0.f, hi = ok ? __builtin_inff() : 0.f;
-        f32x4 v = ld[i];
+        f32x4 v = q[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * sc[e] + sh[e], lo, hi);
         const int pl = (i < 4 || pq == 0) ? pq + 4 * i : 17;  // (pixel 17: the dummy the idle lanes of the fifth load write)
         *(f32x4*)(dst + pl * OSP) = v;
       }
     };
-    request(a0 - 1);
-    land(a0 - 1);
-    request(a0);
-    for (int a = a0; a < a1; ++a) {
-      land(a);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) request(a0 - 1 + d, ld[d], ldok[d]);
+    land(a0 - 1, ld[0], ldok[0]);
+    request(a0 - 1 + DEPTH, ld[0], ldok[0]);
+    for (int ab = a0; ab < a1; ab += DEPTH) {
+#pragma unroll
+     for (int dd = 0; dd < DEPTH; ++dd) {
+      // (no exit in the middle of the unrolled body: with one, hipcc's wait insertion drains the whole queue at the loop header.
+      // A row past the strip's end — at most DEPTH - 1 per strip — is computed and dropped: its stores carry OS_DROP.)
+      const int a = ab + dd;
+      const bool arow = a < a1;
+      f32x4 (&slot)[5] = ld[(dd + 1) % DEPTH];
+      unsigned& slot_ok = ldok[(dd + 1) % DEPTH];
+      land(a, slot, slot_ok);
       // ---- targets of this row's 2x2 blocks (LOSS): requested BEFORE the next row — the memory counter is in-order, so waiting for
       // them in the epilogue must not also wait for the row that is meant to stay in flight until the next iteration
-      const bool live = kq < 3 && b0 + p <= WF;
+      const bool live = arow && kq < 3 && b0 + p <= WF;
+      // (raw loads only — a byte pair is unpacked in the epilogue: an instruction that consumes the loaded value HERE would wait for
+      // it here, and, the counter being in-order, would not need to wait for more, but would sit in front of the row request)
       [[maybe_unused]] float tg[NCG][4];
+      [[maybe_unused]] unsigned tgraw[NCG][2];
       if constexpr (LOSS) {
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg)
@@ -150,9 +186,9 @@ __global__ __launch_bounds__(256, 3) void convT_out_os_kernel(const float* __res
           for (int py = 0; py < 2; ++py) {
             const size_t o = live ? ((size_t)(n * C + cg * 3 + kq) * H + 2 * a + py) * W + 2 * (b0 + p) : (size_t)0;
             if constexpr (U8) {
-              const unsigned short raw = *(const unsigned short*)((const uint8_t*)target + o);
-              tg[cg][2 * py] = __uint_as_float((unsigned)(raw & 0xff));
-              tg[cg][2 * py + 1] = __uint_as_float((unsigned)(raw >> 8));
+              // the aligned dword that holds the two bytes (o is even; a 16-bit load would be zero-extended by an instruction that
+              // consumes it on the spot); which half is decided in the epilogue
+              tgraw[cg][py] = *(const unsigned*)((const uint8_t*)target + (o & ~(size_t)3));
             } else {
               const float2 raw = *(const float2*)((const float*)target + o);
               tg[cg][2 * py] = raw.x;
@@ -161,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void convT_out_os_kernel(const float* __res
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      request(a + 1);  // (past the strip's last row: clamped addresses, never landed)
+      request(a + DEPTH, slot, slot_ok);  // (past the strip's last row: clamped addresses, never landed)
       __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the requests below the MFMAs, next to their first use)
       float lsum = 0.f;
 #pragma unroll
@@ -206,32 +242,40 @@ __global__ __launch_bounds__(256, 3) void convT_out_os_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + bs[cg];
         if constexpr (LOSS) {
+          if constexpr (U8) { asm volatile("" : "+v"(tgraw[cg][0]), "+v"(tgraw[cg][1])); }
+          else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(tg[cg][r]));  // waited for once, outside the branch below
+            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(tg[cg][r]));
+          }
           if constexpr (U8) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tg[cg][r] = L[(kq < 3 ? kq : 0) * 256 + (int)__float_as_uint(tg[cg][r])];
+            for (int py = 0; py < 2; ++py) {
+              const float* Lc = L + (kq < 3 ? kq : 0) * 256;
+              // (W is even, so both rows' offsets have the parity of 2 (b0 + p): bit 1 of the byte offset = bit 0 of b0 + p)
+              const unsigned two = tgraw[cg][py] >> (((b0 + p) & 1) * 16);
+              tg[cg][2 * py] = Lc[two & 0xffu];
+              tg[cg][2 * py + 1] = Lc[(two >> 8) & 0xffu];
+            }
           }
         }
-        if (live) {
-          const size_t o = ((size_t)(n * C + cg * 3 + kq) * H + 2 * a) * W + 2 * (b0 + p);
-          if constexpr (LOSS) {
-            float d[4];
+        // (offsets inside image n: 32-bit; a dead lane's stores are dropped by the buffer hardware)
+        const unsigned ob = live ? (unsigned)((((cg * 3 + kq) * H + 2 * a) * W + 2 * (b0 + p)) * 4) : OS_DROP;
+        const unsigned ob2 = live ? ob + (unsigned)(W * 4) : OS_DROP;
+        if constexpr (LOSS) {
+          float d[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { d[r] = v[r] - tg[cg][r]; lsum += d[r] * d[r]; }
-            *(float2*)(img + o) = float2{d[0], d[1]};
-            *(float2*)(img + o + W) = float2{d[2], d[3]};
-            if (dec_out) {
-              *(float2*)(dec_out + o) = float2{v[0], v[1]};
-              *(float2*)(dec_out + o + W) = float2{v[2], v[3]};
-            }
-          } else {
-            *(float2*)(img + o) = float2{v[0], v[1]};
-            *(float2*)(img + o + W) = float2{v[2], v[3]};
-          }
+          for (int r = 0; r < 4; ++r) { d[r] = v[r] - tg[cg][r]; lsum += live ? d[r] * d[r] : 0.f; }
+          os_store2(img_rs, ob, d[0], d[1]);
+          os_store2(img_rs, ob2, d[2], d[3]);
+          os_store2(dec_rs, ob, v[0], v[1]);   // (zero-sized resource on the training path: nothing is written)
+          os_store2(dec_rs, ob2, v[2], v[3]);
+        } else {
+          os_store2(img_rs, ob, v[0], v[1]);
+          os_store2(img_rs, ob2, v[2], v[3]);
         }
       }
       if constexpr (LOSS) { if (n / lpg == 0) lacc0 += (double)lsum; else lacc1 += (double)lsum; }
+     }
     }
   }
   if constexpr (LOSS) {
@@ -254,10 +298,13 @@ __global__ __launch_bounds__(256, 3) void convT_out_os_kernel(const float* __res
 constexpr int RP = 40;  // ring row pitch (34 columns used)
 
 template <int NCG>
-__global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* __restrict__ err, const float* __restrict__ w_ref,
+// (err and y_raw are deliberately NOT __restrict__: hipcc treats loads through a `const __restrict__` kernel argument as invariant —
+// free of every ordering constraint — and sinks the requests of the software pipeline below the MFMAs they are meant to travel
+// under; as ordinary loads they stay in front of the memory clobber that follows them)
+__global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* err, const float* __restrict__ w_ref,
                                                                  float* __restrict__ dA, float* __restrict__ stats_partial,
                                                                  float* __restrict__ wpartial, int N, int H, int W, int HF, int WF,
-                                                                 const float* __restrict__ y_raw, const float* __restrict__ y_bnp,
+                                                                 const float* y_raw, const float* __restrict__ y_bnp,
                                                                  int npg, double* __restrict__ bias_partial,
                                                                  const float* __restrict__ gain_dev, float gain_div, float gain_coef,
                                                                  int R, int nseg, int nchunk) {
@@ -322,9 +369,9 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* _
       Bn[128 + lane] = rec[192 + lane];
     }
     const bool last_seg = seg == nseg - 1, last_chunk = a1 == HF;
-    const float* __restrict__ eimg = err + (size_t)n * C * H * W;
-    const float* __restrict__ yimg = y_raw + (size_t)n * HF * WF * 64 + 4 * kq;
-    float* __restrict__ dimg = dA + (size_t)n * HF * WF * 64 + 4 * kq;
+    const float* eimg = err + (size_t)n * C * H * W;
+    const float* yimg = y_raw + (size_t)n * HF * WF * 64 + 4 * kq;
+    const __amdgpu_buffer_rsrc_t dA_rs = os_buffer(dA + (size_t)n * HF * WF * 64, (unsigned)(HF * WF * 256));
     // ---- per strip: where each request slot reads (element offset of row 0) and lands, which slots exist, which are owned
     // (H and W are even and requests start at even rows / columns, so "row inside the image" and "row owned" are wave-uniform)
     unsigned e_off[NSLOT];
@@ -372,16 +419,36 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* _
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) yv[mt] = *(const f32x4*)(yimg + off + 16 * mt);
     };
-    req_err(2 * a0, true);
-    land_err(2 * a0);
-    req_err(2 * a0 + 2, true);
-    req_y(a0, true);
+    // Software pipeline of a strip (loop rotated by hand so that no loaded-but-not-yet-used register is live across the back edge —
+    // hipcc copies such registers at the loop header, which waits for them there):
+    //   iteration a:  request y(a) and the two err rows step a + 1 adds   |  weight gradient of step a - 1  |  data gradient of
+    //                 step a  |  epilogue (consumes y)  |  land the err rows
+    // so everything requested at the top of an iteration has the two MFMA phases to arrive (requested and landed around ONE
+    // phase, the err rows had ~1 us of the ~2.5 us an HBM round trip takes at this load).  The ring holds 8 rows and a step uses
+    // 4, so rows can land a step early.  The first iteration has no weight gradient, the last weight gradient follows the loop.
     f32x4 s1[4], s2[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) s1[mt] = s2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int a = a0; a < a1; ++a) {
-      land_err(2 * a + 2);
+    auto wgrad = [&](int a) {
+      // D[ci][(ky,kx)] per co, K = the 16 positions of the row (k-step s, quarter kq -> position 4 s + kq)
+      const int rrow = ((2 * a + ky_n) & 7) * RP + 2 * kq + kx_n;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float af[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = F[(4 * s + kq) * OSP + 16 * mt + p];
+#pragma unroll
+        for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+          for (int co = 0; co < 3; ++co) {
+            const float b = ring[(cg * 3 + co) * 8 * RP + rrow + 8 * s];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) accw[cg][mt][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], b, accw[cg][mt][co], 0, 0, 0);
+          }
+      }
+    };
+    auto dgrad_epilogue = [&](int a) {
       // ---- data gradient: D[ci][pos], K = (cg, co, ky, kx)
       f32x4 acc[4];
 #pragma unroll
@@ -400,8 +467,16 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* _
           }
         }
       // ---- epilogue: this lane holds dA[pos p][ci = 16 mt + 4 kq + e]; y of the same (pos, channels) is in yv
+      // The wait for y belongs HERE, behind both MFMA phases.  The MFMAs are pure operations: nothing but a data dependence keeps
+      // them in front of an `asm volatile`, so the statement that "touches" y (and makes hipcc wait for it once, outside what
+      // follows) also names the accumulators of both phases.
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(yv[2]), "+v"(yv[3]), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(yv[mt]));
+      for (int cg = 0; cg < NCG; ++cg)
+        asm volatile("" : "+v"(accw[cg][0][0]), "+v"(accw[cg][0][1]), "+v"(accw[cg][0][2]), "+v"(accw[cg][1][0]), "+v"(accw[cg][1][1]),
+                     "+v"(accw[cg][1][2]), "+v"(accw[cg][2][0]), "+v"(accw[cg][2][1]), "+v"(accw[cg][2][2]), "+v"(accw[cg][3][0]),
+                     "+v"(accw[cg][3][1]), "+v"(accw[cg][3][2]), "+v"(yv[0]));
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const f32x4 bmean = *(const f32x4*)(Bn + 16 * mt + 4 * kq), bsc = *(const f32x4*)(Bn + 64 + 16 * mt + 4 * kq),
@@ -418,34 +493,31 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* _
         }
         *(f32x4*)(F + p * OSP + 16 * mt + 4 * kq) = act;
       }
-      if (pvalid) {
-        const unsigned off = (unsigned)(a * WF * 64) + ypos;
+      const unsigned ob = ((unsigned)(a * WF * 64) + ypos + 4 * kq) * 4u;  // (branch-free, see os_buffer)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) *(f32x4*)(dimg + off + 16 * mt) = acc[mt];
-      }
-      // ---- the next row's operands travel under the weight-gradient MFMAs
+      for (int mt = 0; mt < 4; ++mt) __builtin_amdgcn_raw_buffer_store_b128(acc[mt], dA_rs, pvalid ? ob + 64u * mt : OS_DROP, 0, 0);
+    };
+    // requests of iteration a: the err rows step a + 1 adds (2a + 4, 2a + 5) and y(a); pinned in front of the MFMAs that follow
+    // (hipcc sinks a load towards its first use; a memory clobber is a point no load may be moved across)
+    auto requests = [&](int a) {
       req_err(2 * a + 4, a + 1 < a1);
-      req_y(a + 1, a + 1 < a1);
-      // (hipcc sinks a load whose only use is in the next iteration down to that use — behind the MFMAs it was meant to travel
-      // under; a memory clobber is a point no load may be moved across)
+      req_y(a, true);
       asm volatile("" ::: "memory");
-      // ---- weight gradient: D[ci][(ky,kx)] per co, K = the 16 positions of the row (k-step s, quarter kq -> position 4 s + kq)
-      const int rrow = ((2 * a + ky_n) & 7) * RP + 2 * kq + kx_n;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float af[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) af[mt] = F[(4 * s + kq) * OSP + 16 * mt + p];
-#pragma unroll
-        for (int cg = 0; cg < NCG; ++cg)
-#pragma unroll
-          for (int co = 0; co < 3; ++co) {
-            const float b = ring[(cg * 3 + co) * 8 * RP + rrow + 8 * s];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) accw[cg][mt][co] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], b, accw[cg][mt][co], 0, 0, 0);
-          }
-      }
+    };
+    req_err(2 * a0, true);
+    land_err(2 * a0);
+    req_err(2 * a0 + 2, true);
+    land_err(2 * a0 + 2);
+    requests(a0);
+    dgrad_epilogue(a0);
+    land_err(2 * a0 + 4);
+    for (int a = a0 + 1; a < a1; ++a) {
+      requests(a);
+      wgrad(a - 1);
+      dgrad_epilogue(a);
+      land_err(2 * a + 4);  // (zeros past the strip's last step: evin = 0)
     }
+    wgrad(a1 - 1);
     // ---- the strip's BatchNorm-backward record: [sum dz (64)] [sum dz * xhat (64)], summed over the 16 positions (lanes p)
     {
       const float* __restrict__ rec = y_bnp + cur_grp * 256;
@@ -511,8 +583,10 @@ int os_rows(const char* name, int dflt) {
   return r > 0 ? r : dflt;
 }
 // rows per strip (development knobs; the defaults are the measured-best values)
-int fwd_rows() { static const int r = os_rows("SRLZ_OS_FWD_ROWS", 16); return r; }
-int bwd_rows() { static const int r = os_rows("SRLZ_OS_BWD_ROWS", 16); return r; }
+// forward: a multiple of DEPTH (the row loop is unrolled by DEPTH; a ragged strip computes and drops up to DEPTH - 1 rows) near 28 —
+// 112 block rows = 30 + 30 + 30 + 22 (-> 24); backward: 111 = 28 + 28 + 28 + 27
+int fwd_rows() { static const int r = os_rows("SRLZ_OS_FWD_ROWS", DEPTH == 2 ? 28 : 30); return r; }
+int bwd_rows() { static const int r = os_rows("SRLZ_OS_BWD_ROWS", 28); return r; }
 
 int os_check(const srlz_skinny_desc* d, const char* who) {
   SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "%s: null descriptor", who);

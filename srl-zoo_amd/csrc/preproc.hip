@@ -62,7 +62,73 @@ __global__ __launch_bounds__(256) void normalize_u8_planar_kernel(const uint8_t*
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < plane; i += (long long)gridDim.x * 256) dst[i] = tab[src[i]];
 }
 
+// ---- the dataset resident in HBM (round 4): whole uint8 frames moved by index --------------------------------
+// dst frame (dst_index ? dst_index[i] : i) <- src frame (src_index ? src_index[i] + src_shift : i); one frame per blockIdx.y,
+// 16 bytes per thread and step.  Gather (minibatch <- store), scatter (store <- freshly decoded minibatch) and plain copy.
+__global__ __launch_bounds__(256) void copy_frames_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ src_index,
+                                                         long long src_shift, uint8_t* __restrict__ dst,
+                                                         const long long* __restrict__ dst_index, long long dst_shift,
+                                                         long long words) {
+  const long long i = blockIdx.y;
+  const long long sf = src_index ? src_index[i] + src_shift : i, df = dst_index ? dst_index[i] + dst_shift : i;
+  const uint4* __restrict__ s = (const uint4*)src + sf * words;
+  uint4* __restrict__ d = (uint4*)dst + df * words;
+  for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < words; w += (long long)gridDim.x * 256) d[w] = s[w];
+}
+
+// The DAE's occluded copy of a frame taken from the store (reference preprocessing/data_loader.py:100-111: the NORMALISED image
+// with a random rectangle set to 0): out[i][c][w][h] = (h1 <= h < h2 && w1 <= w < w2) ? 0 : lut[c % 3][store[index[i]+shift][c][w][h]],
+// one rectangle (h1, h2, w1, w2) per frame and camera view (group of 3 channels), drawn by the loader process.
+__global__ __launch_bounds__(256) void occlude_frames_kernel(const uint8_t* __restrict__ store, const long long* __restrict__ index,
+                                                            long long shift, const int* __restrict__ rects,
+                                                            const float* __restrict__ lut, float* __restrict__ out, int C, int Wd,
+                                                            int Hd) {
+  __shared__ float tab[256];
+  const long long i = blockIdx.y / C;
+  const int c = (int)(blockIdx.y % C);
+  tab[threadIdx.x] = lut[(c % 3) * 256 + threadIdx.x];
+  __syncthreads();
+  const int* r = rects + (i * (C / 3) + c / 3) * 4;
+  const int h1 = r[0], h2 = r[1], w1 = r[2], w2 = r[3];
+  const long long plane = (long long)Wd * Hd;
+  const uint8_t* __restrict__ src = store + ((index[i] + shift) * C + c) * plane;
+  float* __restrict__ dst = out + (size_t)blockIdx.y * plane;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < plane; k += (long long)gridDim.x * 256) {
+    const int w = (int)(k / Hd), h = (int)(k - (long long)w * Hd);
+    dst[k] = (h >= h1 && h < h2 && w >= w1 && w < w2) ? 0.f : tab[src[k]];
+  }
+}
+
 }  // namespace
+
+extern "C" int srlz_copy_frames_u8(const uint8_t* src, const long long* src_index, long long src_shift, uint8_t* dst,
+                                   const long long* dst_index, long long dst_shift, int n, long long frame_bytes,
+                                   srlz_stream_t stream) {
+  SRLZ_REQUIRE(src && dst, SRLZ_ERR_NULL, "copy_frames_u8: null pointer");
+  SRLZ_REQUIRE(n > 0 && n <= 65535 && frame_bytes > 0 && frame_bytes % 16 == 0, SRLZ_ERR_BAD_DESC,
+               "copy_frames_u8: 1..65535 frames of a multiple of 16 bytes (got %d x %lld)", n, frame_bytes);
+  SRLZ_REQUIRE((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, SRLZ_ERR_BAD_DESC, "copy_frames_u8: unaligned buffer");
+  const long long words = frame_bytes / 16;
+  int gx = (int)((words + 255) / 256);
+  if (gx > 16) gx = 16;
+  hipLaunchKernelGGL(copy_frames_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), src, src_index, src_shift, dst, dst_index,
+                     dst_shift, words);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_occlude_frames_u8(const uint8_t* store, const long long* index, long long shift, const int* rects,
+                                      const float* norm_lut, float* out, int n, int c, int w, int h, srlz_stream_t stream) {
+  SRLZ_REQUIRE(store && index && rects && norm_lut && out, SRLZ_ERR_NULL, "occlude_frames_u8: null pointer");
+  SRLZ_REQUIRE(n > 0 && c > 0 && c <= 9 && c % 3 == 0 && (long long)n * c <= 65535 && w > 0 && h > 0, SRLZ_ERR_BAD_DESC,
+               "occlude_frames_u8: channels must be 3, 6 or 9 (got %d) and n * c <= 65535", c);
+  int gx = (w * h + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(occlude_frames_kernel, dim3(gx, n * c), dim3(256), 0, as_stream(stream), store, index, shift, rects, norm_lut, out,
+                     c, w, h);
+  SRLZ_LAUNCHED();
+  return 0;
+}
 
 extern "C" int srlz_normalize_u8(const uint8_t* img_nhwc, float* out_ncwh, int n, int h, int w, int c,
                                  srlz_stream_t stream) {

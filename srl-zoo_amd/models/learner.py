@@ -40,8 +40,16 @@ VALIDATION_SIZE = 0.2
 BALANCED_SAMPLING = False
 # build-specific: ship decoded frames as uint8 and normalise on the GPU (bit-identical, 4x less PCIe traffic)
 RAW_UINT8_INPUT = True
+# build-specific: decode every frame ONCE — frames that arrived are kept in HBM and later epochs gather their minibatches by index
+# (preprocessing/resident.py); False restores the reference's re-decoding of every epoch (A/B, tests)
+RESIDENT_FRAMES = True
 
 SUPPORTED_LOSSES = {"autoencoder", "vae", "dae", "forward", "inverse", "reward", "perceptual", "random", "triplet"}
+
+
+def n_epochs_planned(losses):
+    """Epochs learn() will run (reference learner.py:346-350: none for the 'random' features)."""
+    return 0 if (len(losses) == 1 and losses[0] == 'random') else N_EPOCHS
 
 
 def _requireGpu(cuda):
@@ -623,16 +631,31 @@ class SRL4robotics(BaseLearner):
         if self.use_vae and self.perceptual_similarity_loss and self.path_to_dae is not None:
             self.loadDenoiser(th.load(self.path_to_dae, map_location=self.device))
 
+        # The decoded dataset stays resident (uint8 [frames, C, W, H], in HBM when it fits the budget): epoch 1 streams from the
+        # loader process as in the reference and is absorbed, later epochs receive INDICES from that same process (same per-epoch
+        # permutation from the same forked RNG, same end-of-epoch marker) and gather on the device.  Triplets keep streaming: their
+        # negative view is a fresh random draw per frame and epoch (reference data_loader.py:219-243).
+        use_bytes = bool(RAW_UINT8_INPUT)
+        resident = None
+        if RESIDENT_FRAMES and use_bytes and not self.use_triplets and n_epochs_planned(self.losses) > 1:
+            from preprocessing.resident import ResidentFrames
+            import preprocessing.preprocess as _pre
+            needed = np.concatenate([np.concatenate((mb, mb + 1)) for mb in minibatchlist])
+            resident = ResidentFrames(len(images_path), (_pre.getNChannels(), _pre.IMAGE_WIDTH, _pre.IMAGE_HEIGHT), self.device, needed)
+            if self.use_dae and not resident.on_device:
+                resident = None  # (the device-side occlusion reads the store in HBM)
+        self._resident = resident
         data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
                                  use_triplets=self.use_triplets, is_training=True, apply_occlusion=self.use_dae,
                                  occlusion_percentage=self.occlusion_percentage, rank=self.rank,
                                  world_size=self.world_size, val_indices=val_indices,
-                                 raw_uint8="planar" if RAW_UINT8_INPUT and not self.use_dae else False)
+                                 raw_uint8="planar" if use_bytes and (not self.use_dae or resident is not None) else False,
+                                 index_switch=resident is not None)
         test_data_loader = DataLoader(test_minibatchlist, images_path, n_workers=N_WORKERS,
                                       multi_view=self.multi_view, use_triplets=self.use_triplets, max_queue_len=1,
                                       is_training=False, apply_occlusion=self.use_dae,
                                       occlusion_percentage=self.occlusion_percentage,
-                                      raw_uint8="planar" if RAW_UINT8_INPUT and not self.use_dae else False)
+                                      raw_uint8="planar" if use_bytes and not self.use_dae else False)
 
         loss_history = defaultdict(list)
         loss_manager = LossManager(self.model, loss_history)
@@ -647,14 +670,31 @@ class SRL4robotics(BaseLearner):
             self.saveModel(best_model_path)
 
         val_set = set(int(i) for i in val_indices)
+        # build-specific record (train.py writes it to <log_folder>/epoch_stats.json): wall seconds, frames and index-only minibatches
+        # of every epoch — what shows epoch 1 decode-bound and the later epochs GPU-bound
+        self.epoch_stats = []
         for epoch in range(n_epochs):
             epoch_loss, epoch_batches, val_loss, val_batches = 0.0, 0, 0.0, 0
+            epoch_t0, epoch_gathers = time.time(), (resident.gathers if resident is not None else 0)
             feed = _DeviceFeed(data_loader, self.device)
             for minibatch_num, (minibatch_idx, obs, next_obs, noisy_obs, next_noisy_obs) in enumerate(feed):
                 validation_mode = int(minibatch_idx) in val_set
-                if self.use_dae:
-                    noisy_obs, next_noisy_obs = self._toDevicePair(noisy_obs, next_noisy_obs)
-                obs, next_obs = self._toDevicePair(obs, next_obs)
+                if obs is None:
+                    # an index-only minibatch: its frames are resident; gather [obs ; next_obs] (and the DAE's occluded copies, from
+                    # the rectangles the loader process drew) on the device
+                    mb = minibatchlist[minibatch_idx]
+                    if self.use_dae:
+                        noisy_obs, next_noisy_obs = resident.occluded_pair(mb, noisy_obs, next_noisy_obs)
+                    obs, next_obs = resident.pair(mb)
+                    obs, next_obs = self._toDevicePair(obs, next_obs)
+                else:
+                    if self.use_dae:
+                        noisy_obs, next_noisy_obs = self._toDevicePair(noisy_obs, next_noisy_obs)
+                    if resident is not None and obs.dtype == th.uint8:
+                        obs, next_obs = obs.to(self.device, non_blocking=True), next_obs.to(self.device, non_blocking=True)
+                        if resident.absorb(minibatchlist[minibatch_idx], obs, next_obs) and not data_loader.index_mode.is_set():
+                            data_loader.shipIndices()  # every frame a minibatch can ask for is home: no more pixels, no more decoding
+                    obs, next_obs = self._toDevicePair(obs, next_obs)
                 actions_st = th.from_numpy(actions[minibatchlist[minibatch_idx]]).view(-1, 1).to(self.device)
 
                 rewards_st = None
@@ -676,6 +716,10 @@ class SRL4robotics(BaseLearner):
                     epoch_loss += values[0]
                     epoch_batches += 1
 
+            steps = epoch_batches + val_batches
+            self.epoch_stats.append({"epoch": epoch + 1, "seconds": time.time() - epoch_t0, "minibatches": steps,
+                                     "images": 2 * steps * self.batch_size,
+                                     "index_minibatches": (resident.gathers - epoch_gathers) if resident is not None else 0})
             train_loss = epoch_loss / float(max(epoch_batches, 1))
             val_loss /= float(max(val_batches, 1)) if self.world_size > 1 else float(n_val_batches)
             loss_history = loss_manager.loss_history

@@ -86,12 +86,19 @@ def preprocessImage(image, convert_to_rgb=True, apply_occlusion=False, occlusion
             im = np.asarray(Image.fromarray(np.ascontiguousarray(im)).resize((IMAGE_WIDTH, IMAGE_HEIGHT), Image.BOX))
     im = preprocessInput(np.array(im, dtype=np.float32), mode="image_net")
     if apply_occlusion:
-        h_1 = np.random.randint(IMAGE_HEIGHT)
-        h_1, h_2 = sample_coordinates(h_1, IMAGE_HEIGHT, percentage=occlusion_percentage)
-        w_1 = np.random.randint(IMAGE_WIDTH)
-        w_1, w_2 = sample_coordinates(w_1, IMAGE_WIDTH, percentage=occlusion_percentage)
+        h_1, h_2, w_1, w_2 = drawOcclusion(occlusion_percentage)
         im[h_1:h_2, w_1:w_2, :] = 0.
     return im
+
+
+def drawOcclusion(occlusion_percentage):
+    """The DAE's random rectangle (h_1, h_2, w_1, w_2) of one frame: the four np.random draws of the reference
+    (preprocessing/data_loader.py:103-107), in its order."""
+    h_1 = np.random.randint(IMAGE_HEIGHT)
+    h_1, h_2 = sample_coordinates(h_1, IMAGE_HEIGHT, percentage=occlusion_percentage)
+    w_1 = np.random.randint(IMAGE_WIDTH)
+    w_1, w_2 = sample_coordinates(w_1, IMAGE_WIDTH, percentage=occlusion_percentage)
+    return h_1, h_2, w_1, w_2
 
 
 def _normalised(rgb, apply_occlusion, occlusion_percentage):
@@ -120,7 +127,7 @@ def shardOrder(order, rank, world_size, val_indices=None):
 class DataLoader(object):
     def __init__(self, minibatchlist, images_path, n_workers=1, multi_view=False, use_triplets=False,
                  infinite_loop=True, max_queue_len=4, is_training=False, apply_occlusion=False,
-                 occlusion_percentage=0.5, rank=0, world_size=1, val_indices=None, raw_uint8=False):
+                 occlusion_percentage=0.5, rank=0, world_size=1, val_indices=None, raw_uint8=False, index_switch=False):
         """
         :param minibatchlist: ([np.array]) observation indices grouped per minibatch
         :param images_path: (np.array) image paths (without the 'data/' prefix)
@@ -140,7 +147,13 @@ class DataLoader(object):
                           transposes on the GPU (srlz_normalize_u8, bit-identical).  "planar": [B, C, W, H], i.e. the
                           reference's transpose(0, 3, 2, 1) (data_loader.py:255) applied by the worker to the uint8 frame —
                           the first convolution and the reconstruction loss then read the bytes themselves (srlz_conv1_fwd_u8
-                          ...), no normalisation pass.  Not available with occlusion (DAE).
+                          ...), no normalisation pass.  With occlusion (DAE) only "planar" is available: the clean frames
+                          travel as bytes, the occluded copies as normalised float32.
+        :param index_switch: (bool, training loaders) create the switch shipIndices() flips: from then on the producer puts
+                          (minibatch_idx, None, None, rects, next_rects) — the SAME per-epoch permutation from the same forked RNG
+                          and the same end-of-epoch None, but no pixels: the consumer holds the decoded frames
+                          (preprocessing/resident.py) and gathers the minibatch by index.  rects / next_rects: with occlusion, the
+                          int32 [B, views, 4] rectangles (h_1, h_2, w_1, w_2) drawn with the reference's np.random calls; else None.
         :param val_indices: minibatch ids used for validation; with world_size > 1 training and validation
                             minibatches are sharded separately (train first) so all ranks stay in lock-step
         """
@@ -155,16 +168,25 @@ class DataLoader(object):
         self.images_path = images_path
         self.shuffle = is_training
         self.queue = Queue(max_queue_len)
+        self._max_queue_len, self._received, self._restarts = max_queue_len, 0, 0
         self.process = None
         self.multi_view = multi_view
         self.apply_occlusion = apply_occlusion
         self.occlusion_percentage = occlusion_percentage
         self.rank, self.world_size = rank, world_size
         self.val_indices = None if val_indices is None else set(int(i) for i in val_indices)
-        if raw_uint8 and apply_occlusion:
+        if raw_uint8 and raw_uint8 != "planar" and apply_occlusion:
             raise ValueError("raw_uint8 frames cannot carry the (normalised-space) occlusion of the DAE loader")
         self.raw_uint8 = raw_uint8
+        # (created BEFORE the fork: the producer sees the same flag)
+        self.index_mode = th.multiprocessing.Event() if (index_switch and is_training) else None
         self.startProcess()
+
+    def shipIndices(self):
+        """From the next minibatch the producer prepares: indices (and occlusion rectangles) instead of pixels."""
+        if self.index_mode is None:
+            raise ValueError("DataLoader(index_switch=True, is_training=True) creates the switch")
+        self.index_mode.set()
 
     @staticmethod
     def createTestMinibatchList(n_samples, batch_size):
@@ -198,6 +220,15 @@ class DataLoader(object):
             first = False
             for minibatch_idx in self._epochOrder():
                 idx = self.minibatchlist[minibatch_idx]
+                if self.index_mode is not None and self.index_mode.is_set():
+                    rects = next_rects = None
+                    if self.apply_occlusion:  # one rectangle per frame and camera view, frames of obs first, then of next_obs
+                        views = 2 if self.multi_view else 1
+                        draw = np.array([drawOcclusion(self.occlusion_percentage) for _ in range(2 * len(idx) * views)],
+                                        dtype=np.int32).reshape(2, len(idx), views, 4)
+                        rects, next_rects = draw[0], draw[1]
+                    self.queue.put((minibatch_idx, None, None, rects, next_rects))
+                    continue
                 if self.shuffle:
                     paths = np.concatenate((self.images_path[idx], self.images_path[idx + 1]))
                 else:
@@ -263,13 +294,36 @@ class DataLoader(object):
     def __iter__(self):
         return self
 
+    # A producer that never delivers its FIRST item is re-forked (fork() of a multi-threaded parent — HIP runtime, OpenMP pools — can
+    # leave the child behind a lock some other thread held at that instant; seen once on a GPU box as a training run waiting for
+    # ever).  The parent has drawn no random number since the first fork, so the new child starts from the same RNG state and
+    # produces the same permutations.  A producer that died is reported instead of waited for.
+    STARTUP_TIMEOUT = 90.0
+    MAX_RESTARTS = 2
+
     def __next__(self):
+        waited_since = time.time()
         while True:
             try:
                 val = self.queue.get_nowait()
                 break
             except queue.Empty:
                 time.sleep(0.001)
+                if time.time() - waited_since < 1.0:
+                    continue
+                if self.process is not None and not self.process.is_alive():
+                    raise RuntimeError("DataLoader: the producer process exited (code {}) without finishing the epoch".format(
+                        self.process.exitcode))
+                if self._received == 0 and time.time() - waited_since > self.STARTUP_TIMEOUT:
+                    if self._restarts >= self.MAX_RESTARTS:
+                        raise RuntimeError("DataLoader: the producer process delivered nothing in {} s, {} times".format(
+                            self.STARTUP_TIMEOUT, self._restarts + 1))
+                    self._restarts += 1
+                    self.process.terminate()
+                    self.queue = Queue(self._max_queue_len)
+                    self.startProcess()
+                    waited_since = time.time()
+        self._received += 1
         if val is None:
             raise StopIteration
         return val

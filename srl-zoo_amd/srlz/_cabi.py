@@ -92,6 +92,8 @@ _PROTOS = {
     "srlz_convT_out_fwd_loss_u8": (c_int, [P, P, P, P, P, P, P, P, P, _SK, P]),
     "srlz_normalize_lut": (c_int, [P, P]),
     "srlz_normalize_u8_planar": (c_int, [P, P, P, c_int, c_int, c_longlong, P]),
+    "srlz_copy_frames_u8": (c_int, [P, P, c_longlong, P, P, c_longlong, c_int, c_longlong, P]),
+    "srlz_occlude_frames_u8": (c_int, [P, P, c_longlong, P, P, P, c_int, c_int, c_int, c_int, P]),
     "srlz_skinny_bwd_weight_workspace": (c_size_t, [_SK]),
     "srlz_conv1_bwd_weight": (c_int, [P, P, P, P, c_size_t, _SK, P]),
     "srlz_conv1_bwd_data": (c_int, [P, P, P, _SK, P]),

@@ -9,6 +9,7 @@ SRL methods (priors, triplet, episode-prior, reward-prior), plots.
 from __future__ import print_function, division, absolute_import
 
 import argparse
+import json
 import os
 from collections import OrderedDict
 
@@ -186,6 +187,8 @@ if __name__ == '__main__':
         saveConfig(exp_config, print_config=True)
         srl.saveStates(learned_states, images_path, rewards, args.log_folder)
         np.savez('{}/loss_history.npz'.format(args.log_folder), **loss_history)
+        with open('{}/epoch_stats.json'.format(args.log_folder), 'w') as f:  # (build-specific: per-epoch wall time and frames)
+            json.dump(getattr(srl, "epoch_stats", []), f)
         correlationCall(exp_config, plot=False)
     if world_size > 1:
         optim.destroy_native_comm()  # (no-op unless SRLZ_COMM=rccl created the library's own communicator)

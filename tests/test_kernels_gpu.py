@@ -1045,6 +1045,7 @@ def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
     (4, 112, 1, 1, 2, True, False),   # block 1 -> conv2 (3x3 s1 p1 on the 56x56 pooled map), the pair's two BatchNorm groups
     (2, 56, 0, 2, 1, True, False),    # block 2 -> conv3 (3x3 s2 p1 on the 27x27 pooled map): a four-class scatter data gradient
     (6, 56, 0, 2, 2, True, True),     # a channel whose BatchNorm scale is exactly 0 (xhat from the convolution output under the argmax)
+    (4, 112, 1, 1, 2, True, "tiny"),  # gamma ~ 1e-6 against beta ~ 0.3: (z - shift) / scale would cancel (advisor, round 3)
     (2, 40, 1, 1, 1, False, False),   # eval mode (validation minibatches backpropagate too)
 ])
 def test_pool_block_bn_backward_sums_from_the_next_convs_data_gradient(C, n, h, pool_pad, stride, groups, training, zero_gamma):
@@ -1056,7 +1057,11 @@ def test_pool_block_bn_backward_sums_from_the_next_convs_data_gradient(C, n, h, 
     g = torch.Generator().manual_seed(31 * h + n)
     y0 = torch.randn(n, 64, h, h, generator=g) * 1.3 + 0.2
     gamma0, beta0 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
-    if zero_gamma:
+    if zero_gamma == "tiny":
+        gamma0[7], beta0[7] = 1e-6, 0.3      # relu(bn(.)) = 0.3 +- 1e-6 * xhat: every pooled value positive, xhat lost in its rounding
+        gamma0[21], beta0[21] = -3e-6, 0.2
+        gamma0[50], beta0[50] = 2e-6, -0.1   # nothing passes the ReLU
+    elif zero_gamma:
         gamma0[5] = 0.0
         beta0[5] = 0.25   # relu(bn(.)) = 0.25 everywhere in that channel: every window's first position is the argmax
         gamma0[40] = 0.0
@@ -1105,4 +1110,10 @@ def test_pool_block_bn_backward_sums_from_the_next_convs_data_gradient(C, n, h, 
     assert torch.equal(a[4], b[4]) and torch.equal(a[3], b[3])       # d(pooled), dW: the same launches' arithmetic
     for i, tol in ((0, 2e-5), (1, 2e-5), (2, 2e-5)):                  # dy of the block, dgamma, dbeta: summation order only
         assert rel_err(a[i], b[i]) < tol, (i, rel_err(a[i], b[i]))
-    assert rel_err(nchw(a[0]), yr.grad) < 1e-4 and rel_err(a[1], gr.grad) < 1e-4 and rel_err(a[2], br.grad) < 1e-4
+    keep = torch.ones(64, dtype=torch.bool)
+    if zero_gamma == "tiny":
+        # relu(bn(.)) = beta +- 1e-6 * xhat there: fp32 and fp64 break the max-pool's near-ties differently, so autograd routes a few
+        # per cent of that channel's gradient elsewhere; those channels are held by (i) above, whose separate pass takes xhat from y
+        keep[[7, 21, 50]] = False
+    assert rel_err(nchw(a[0]), yr.grad) < 1e-4
+    assert rel_err(a[1].cpu()[keep], gr.grad[keep]) < 1e-4 and rel_err(a[2].cpu()[keep], br.grad[keep]) < 1e-4

@@ -161,3 +161,56 @@ def test_triplet_stream(tmp_path):
             DataLoader([np.array([0])], paths, use_triplets=True)  # needs multi_view
     finally:
         os.chdir(cwd)
+
+
+def test_index_mode_keeps_the_iteration_contract(dataset):
+    """DataLoader(index_switch=True).shipIndices(): the SAME sequence of minibatch ids per epoch as a pixel-shipping loader forked
+    with the same RNG state (np.random.permutation per epoch in the child), the same end-of-epoch marker, no pixels; with occlusion
+    the items carry one int32 rectangle (h_1, h_2, w_1, w_2) per frame and view, inside the image and ordered."""
+    from preprocessing.data_loader import DataLoader
+    name, paths, *_ = dataset
+    ml = [np.array([0, 1, 2]), np.array([4, 5, 6]), np.array([8, 9, 10]), np.array([12, 13, 14]), np.array([16, 17, 18])]
+
+    def epochs(loader, count):
+        out = []
+        for _ in range(count):
+            out.append([item for item in loader])  # (StopIteration at the None marker; the producer goes on with the next epoch)
+        return out
+
+    np.random.seed(11)
+    pixels = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8="planar", max_queue_len=2)
+    np.random.seed(11)
+    indices = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8="planar", max_queue_len=2, index_switch=True)
+    indices.shipIndices()
+    a, b = epochs(pixels, 3), epochs(indices, 3)
+    assert [[int(i[0]) for i in e] for e in a] == [[int(i[0]) for i in e] for e in b]
+    assert all(sorted(int(i[0]) for i in e) == list(range(5)) for e in b)
+    flat = [i for e in b for i in e]
+    # (the producer may have prepared its first minibatches before the switch was flipped: pixels are legal, indices must follow)
+    first_idx = next(k for k, i in enumerate(flat) if i[1] is None)
+    assert first_idx <= 3 and all(i[1] is None and i[2] is None and i[3] is None and i[4] is None for i in flat[first_idx:])
+    del pixels, indices
+    with pytest.raises(ValueError):
+        DataLoader(ml, paths, is_training=True).shipIndices()
+    # DAE: clean frames as bytes + occluded copies as floats while streaming; rectangles once indices are shipped
+    np.random.seed(5)
+    dae = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8="planar", apply_occlusion=True, occlusion_percentage=0.4,
+                     max_queue_len=1, index_switch=True)
+    idx, obs, next_obs, noisy, next_noisy = next(iter(dae))
+    if obs is not None:
+        assert obs.dtype == torch.uint8 and noisy.dtype == torch.float32 and tuple(noisy.shape) == (3, 3, 224, 224)
+        assert (noisy == 0).any()
+    dae.shipIndices()
+    seen = 0
+    for _ in range(12):
+        try:
+            item = next(dae)
+        except StopIteration:
+            continue
+        if item[1] is None:
+            seen += 1
+            for r in (item[3], item[4]):
+                assert r.dtype == np.int32 and r.shape == (3, 1, 4)
+                assert (0 <= r[..., 0]).all() and (r[..., 0] <= r[..., 1]).all() and (r[..., 1] <= 224).all()
+                assert (0 <= r[..., 2]).all() and (r[..., 2] <= r[..., 3]).all() and (r[..., 3] <= 224).all()
+    assert seen >= 3
