@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
   const int n0 = blockIdx.y * N;
   // dz is non-zero only at a window's argmax and only if the pooled value is positive.  The pooled value IS
   // z = scale*v + shift at that position, so xhat = ((z - shift)/scale - mean)*invstd needs no access to y — unless
-  // `pooled` is not supplied or scale == 0, where v is gathered from y (one scattered 4-byte read per element).
+  // `pooled` is not supplied or scale is (almost) 0, where v is gathered from y (one scattered 4-byte read per element).
   const int c4 = threadIdx.x & 15;
   const f32x4 mean = *(const f32x4*)(bnp + c4 * 4);
   const f32x4 invstd = *(const f32x4*)(bnp + 64 + c4 * 4);
@@ -237,7 +237,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_reduce(const float* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v, z;
-        if (pooled && sc[j] != 0.f) {
+        // (|scale| tiny against |shift|: z - shift cancels, (z - shift) / scale would carry ~ eps * |shift| / |scale| — the
+        // same threshold as the epilogue form of these sums, conv64_dgrad_poolsum_kernel)
+        if (pooled && fabsf(sc[j]) > 1e-3f * fabsf(sh[j])) {
           z = pz[j];
           v = (z - sh[j]) / sc[j];
         } else {

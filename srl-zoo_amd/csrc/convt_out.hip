@@ -50,7 +50,7 @@ constexpr int OSROW = 18 * OSP;    // forward: 16 positions + the left halo pixe
 // LOSS: target != NULL; img receives dec - target, dec_out (optional) the reconstruction; loss_partial[2][workgroups] (fp64).
 // ------------------------------------------------------------------------------------------------------------------
 #ifndef SRLZ_OS_DEPTH
-#define SRLZ_OS_DEPTH 3
+#define SRLZ_OS_DEPTH 2
 #endif
 constexpr int DEPTH = SRLZ_OS_DEPTH;  // rows in flight per wave of the forward kernel
 
@@ -125,9 +125,10 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __res
     const __amdgpu_buffer_rsrc_t img_rs = os_buffer(img + (size_t)n * C * H * W, (unsigned)(C * H * W * 4));
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t dec_rs = os_buffer(dec_out ? dec_out + (size_t)n * C * H * W : nullptr,
                                                                       (unsigned)(C * H * W * 4));
-    // Rows travel through a queue of DEPTH register sets: row r is requested DEPTH row-steps before it lands (one row in flight per
-    // wave covered ~1 us of the ~2.5 us an HBM round trip takes at this load; measured 563 us -> see DESIGN.md 5.4).  The queue slot
-    // of row r is (r - (a0 - 1)) % DEPTH; the row loop is unrolled by DEPTH so that every slot index is static.
+    // Rows travel through a queue of DEPTH register sets: row r is requested DEPTH row-steps before it lands.  With ONE row in
+    // flight per wave a step waited ~1 us for HBM (563 us per launch at N = 512); with two the kernel is bound by instruction
+    // issue instead (DEPTH 2 and 3 measure the same, 567 / 574 us).  The queue slot of row r is
+    // (r - (a0 - 1)) % DEPTH; the row loop is unrolled by DEPTH so that every slot index is static.
     f32x4 ld[DEPTH][5];
     unsigned ldok[DEPTH];
     // row r of the input strip (pixels b0-1 .. b0+15) -> registers; a pixel outside the map reads a clamped address and lands as 0
