@@ -1969,12 +1969,9 @@ static int wgrad_grid(const ConvProg& P) {
   const int tk = wgrad_tk(P);
   const int nchunks = (P.total_q + tk - 1) / tk;  // per group
   int g = 2 * srlz_device_cus() / P.G;           // two persistent workgroups per CU; per group
-  // A workgroup leaves 9 x 64 x 64 partial sums (147 KB) behind for the second stage whatever it has accumulated into them: on the
-  // small layers (conv3: 900 chunks per group) 512 workgroups of 3-4 chunks each wrote and re-read 75 MB for 7.4 GFLOP — more
-  // time than the MFMAs.  At least WGRAD_MIN_CHUNKS chunks per workgroup: conv3 runs one workgroup per CU with 8 chunks (33 MB),
-  // the large layers (conv2: 102 chunks per workgroup) are unaffected.
-  constexpr int WGRAD_MIN_CHUNKS = 8;
-  if (g > nchunks / WGRAD_MIN_CHUNKS) g = nchunks / WGRAD_MIN_CHUNKS;
+  // (Fewer, longer-running workgroups on the small layers — at least 8 chunks each, to halve the 147 KB partial every workgroup
+  // leaves for the second stage — were measured in round 4 and lost: conv3's weight gradient 121 -> 172 us, ConvT1's 31 -> 102 us,
+  // the bs = 32 step 2.49 -> 2.70 ms.  These launches are bound by how many CUs work, not by the partials' traffic.)
   if (g > nchunks) g = nchunks;
   if (g < 1) g = 1;
   return g * P.G;

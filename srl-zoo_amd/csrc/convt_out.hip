@@ -22,7 +22,6 @@
 // (two 8-byte NCHW stores, the loss taken in registers); data gradient — four consecutive channels of one position (16-byte NHWC
 // stores, the same layout the BatchNorm-backward sums read y in).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -54,7 +53,7 @@ constexpr int OSROW = 18 * OSP;    // forward: 16 positions + the left halo pixe
 #endif
 constexpr int DEPTH = SRLZ_OS_DEPTH;  // rows in flight per wave of the forward kernel
 
-template <int NCG, bool LOSS, typename TT>
+template <int NCG, bool LOSS, typename TT, bool DEC = false>
 __global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __restrict__ feat, const float* __restrict__ w_ref,
                                                              const float* __restrict__ bias, float* __restrict__ img, int N, int H,
                                                              int W, int HF, int WF, const float* __restrict__ feat_bnp, int npg,
@@ -252,8 +251,9 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __res
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
               const float* Lc = L + (kq < 3 ? kq : 0) * 256;
-              // (W is even, so both rows' offsets have the parity of 2 (b0 + p): bit 1 of the byte offset = bit 0 of b0 + p)
-              const unsigned two = tgraw[cg][py] >> (((b0 + p) & 1) * 16);
+              // which half of the dword: bit 1 of the byte offset o = row * W + 2 (b0 + p), row = (plane * H + 2a + py).  H and W are
+              // even, so bit 1 of row * W is (row & 1) & (W / 2 & 1) = py & (W / 2 & 1); no carry reaches it from bit 0
+              const unsigned two = tgraw[cg][py] >> ((((py & (W >> 1)) ^ (b0 + p)) & 1) * 16);
               tg[cg][2 * py] = Lc[two & 0xffu];
               tg[cg][2 * py + 1] = Lc[(two >> 8) & 0xffu];
             }
@@ -268,8 +268,10 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __res
           for (int r = 0; r < 4; ++r) { d[r] = v[r] - tg[cg][r]; lsum += live ? d[r] * d[r] : 0.f; }
           os_store2(img_rs, ob, d[0], d[1]);
           os_store2(img_rs, ob2, d[2], d[3]);
-          os_store2(dec_rs, ob, v[0], v[1]);   // (zero-sized resource on the training path: nothing is written)
-          os_store2(dec_rs, ob2, v[2], v[3]);
+          if constexpr (DEC) {  // (the reconstruction itself: not on the training path)
+            os_store2(dec_rs, ob, v[0], v[1]);
+            os_store2(dec_rs, ob2, v[2], v[3]);
+          }
         } else {
           os_store2(img_rs, ob, v[0], v[1]);
           os_store2(img_rs, ob2, v[2], v[3]);
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* e
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* ring = (float*)smem + wave * PERW;
   float* F = ring + RING;
-  float* Bn = F + FSZ;                        // the BatchNorm record of the strip's group: mean[64], scale[64], shift[64]
+  float* Bn = F + FSZ;                        // the BatchNorm record of the strip's group: (unused), scale[64], shift[64]
   float* Wl = (float*)smem + 4 * PERW;        // NCG > 1: data-gradient A fragments [cg][mt][s][lane]
   const int p = lane & 15, kq = lane >> 4;
   const int ky_n = p >> 2, kx_n = p & 3;      // weight gradient: this lane's output column n = (ky, kx)
@@ -365,7 +367,6 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* e
     if (n / npg != cur_grp) {
       cur_grp = n / npg;
       const float* __restrict__ rec = y_bnp + cur_grp * 256;
-      Bn[lane] = rec[lane];
       Bn[64 + lane] = rec[128 + lane];
       Bn[128 + lane] = rec[192 + lane];
     }
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* e
       }
     };
     const bool pvalid = b0 + p < WF;
+    const float act_hi = pvalid ? __builtin_inff() : 0.f;
     const unsigned ypos = (unsigned)((b0 + p) * 64);
     f32x4 yv[4];
     auto req_y = [&](int a, bool any) {
@@ -480,17 +482,16 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* e
                      "+v"(accw[cg][3][1]), "+v"(accw[cg][3][2]), "+v"(yv[0]));
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 bmean = *(const f32x4*)(Bn + 16 * mt + 4 * kq), bsc = *(const f32x4*)(Bn + 64 + 16 * mt + 4 * kq),
-                    bsh = *(const f32x4*)(Bn + 128 + 16 * mt + 4 * kq);
+        const f32x4 bsc = *(const f32x4*)(Bn + 64 + 16 * mt + 4 * kq), bsh = *(const f32x4*)(Bn + 128 + 16 * mt + 4 * kq);
         f32x4 act;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float z = yv[mt][e] * bsc[e] + bsh[e];
           const bool on = z > 0.f && pvalid;
-          act[e] = on ? z : 0.f;
+          act[e] = __builtin_amdgcn_fmed3f(z, 0.f, act_hi);  // relu, and 0 for a position outside the map
           const float v = on ? acc[mt][e] : 0.f;
           s1[mt][e] += v;
-          s2[mt][e] += v * (yv[mt][e] - bmean[e]);
+          s2[mt][e] += v * yv[mt][e];  // (centred once per strip: sum dz (y - mean) = sum dz y - mean sum dz, in fp64)
         }
         *(f32x4*)(F + p * OSP + 16 * mt + 4 * kq) = act;
       }
@@ -524,14 +525,15 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* e
       const float* __restrict__ rec = y_bnp + cur_grp * 256;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 inv = *(const f32x4*)(rec + 64 + 16 * mt + 4 * kq);
+        const f32x4 inv = *(const f32x4*)(rec + 64 + 16 * mt + 4 * kq), mean = *(const f32x4*)(rec + 16 * mt + 4 * kq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float u = s1[mt][e], v = s2[mt][e];
 #pragma unroll
           for (int o = 1; o < 16; o <<= 1) { u += __shfl_xor(u, o, 64); v += __shfl_xor(v, o, 64); }
           s1[mt][e] = u;
-          s2[mt][e] = v * inv[e];
+          // sum dz * xhat = (sum dz y - mean sum dz) * invstd: the subtraction in fp64 (both sums are fp32 partials of <= 448 terms)
+          s2[mt][e] = (float)(((double)v - (double)mean[e] * (double)u) * (double)inv[e]);
         }
       }
       if (p == 0) {
@@ -578,16 +580,14 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* e
 
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
-int os_rows(const char* name, int dflt) {
-  const char* e = getenv(name);
-  const int r = e ? atoi(e) : 0;
-  return r > 0 ? r : dflt;
-}
-// rows per strip (development knobs; the defaults are the measured-best values)
-// forward: a multiple of DEPTH (the row loop is unrolled by DEPTH; a ragged strip computes and drops up to DEPTH - 1 rows) near 28 —
-// 112 block rows = 30 + 30 + 30 + 22 (-> 24); backward: 111 = 28 + 28 + 28 + 27
-int fwd_rows() { static const int r = os_rows("SRLZ_OS_FWD_ROWS", DEPTH == 2 ? 28 : 30); return r; }
-int bwd_rows() { static const int r = os_rows("SRLZ_OS_BWD_ROWS", 28); return r; }
+// Rows per strip.  Forward: a multiple of DEPTH (the row loop is unrolled by DEPTH; a ragged strip computes and drops up to DEPTH - 1
+// rows) — 112 block rows = 4 x 28; backward: 111 = 28 + 28 + 28 + 27.  Measured at N = 512 (tools/kb_convt_out.py, strips of 8 /
+// 16 / 28 / 56 rows): forward 569 / 563 / 545 / 584 us, backward 879 / 853 / 833 / 894 us — short strips pay their prologue (the
+// halo row, the weight fragments) more often, long ones leave the persistent waves unevenly loaded.
+constexpr int OS_FWD_ROWS = 28, OS_BWD_ROWS = 28;
+static_assert(OS_FWD_ROWS % DEPTH == 0, "forward strips are walked DEPTH rows at a time");
+int fwd_rows() { return OS_FWD_ROWS; }
+int bwd_rows() { return OS_BWD_ROWS; }
 
 int os_check(const srlz_skinny_desc* d, const char* who) {
   SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "%s: null descriptor", who);
@@ -631,9 +631,16 @@ int os_fwd_launch(const float* x, const float* w, const float* bias, float* out,
                   double* loss_partial, const float* lut, const srlz_skinny_desc* d, hipStream_t st) {
   const OsGeo g = fwd_geo(d);
   const size_t lds = (size_t)(4 * 2 * OSROW + (NCG > 1 ? NCG * 4096 : 0) + (sizeof(TT) == 1 ? 768 : 0)) * 4;
-  SRLZ_MAX_LDS((convT_out_os_kernel<NCG, LOSS, TT>), lds);
-  hipLaunchKernelGGL((convT_out_os_kernel<NCG, LOSS, TT>), dim3(g.grid), dim3(256), lds, st, x, w, bias, out, d->n, d->himg, d->wimg,
-                     d->hf, d->wf, bnp, os_npg(d), target, dec, loss_partial, d->n / 2 > 0 ? d->n / 2 : 1, lut, g.rows, g.nseg, g.nchunk);
+#define SRLZ_OS_FWD(DECV)                                                                                                       \
+  do {                                                                                                                        \
+    SRLZ_MAX_LDS((convT_out_os_kernel<NCG, LOSS, TT, DECV>), lds);                                                            \
+    hipLaunchKernelGGL((convT_out_os_kernel<NCG, LOSS, TT, DECV>), dim3(g.grid), dim3(256), lds, st, x, w, bias, out, d->n, d->himg, \
+                       d->wimg, d->hf, d->wf, bnp, os_npg(d), target, dec, loss_partial, d->n / 2 > 0 ? d->n / 2 : 1, lut, g.rows, \
+                       g.nseg, g.nchunk);                                                                                     \
+  } while (0)
+  if constexpr (LOSS) { if (dec) SRLZ_OS_FWD(true); else SRLZ_OS_FWD(false); }
+  else SRLZ_OS_FWD(false);
+#undef SRLZ_OS_FWD
   SRLZ_LAUNCHED();
   return 0;
 }

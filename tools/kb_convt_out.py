@@ -1,5 +1,5 @@
 """Micro-benchmark of the output-stationary ConvTranspose-5 kernels (csrc/convt_out.hip) at the bench shapes:
-    python tools/kb_convt_out.py [N] [C]     (SRLZ_OS_FWD_ROWS / SRLZ_OS_BWD_ROWS select the strip height)
+    python tools/kb_convt_out.py [N] [C]
 Prints one line per kernel: median us, algorithmic TFLOP/s, algorithmic GB/s."""
 import os
 import sys
@@ -15,7 +15,7 @@ d = C.SkinnyDesc(N, CH, 224, 224, 111, 111, 1, 2)
 st = C.stream()
 x, w, b = rnd(N, 111, 111, 64), rnd(64, CH, 4, 4) * 0.1, rnd(CH)
 bnp = torch.cat((torch.zeros(64), torch.ones(64), torch.ones(64), torch.zeros(64))).repeat(2).to("cuda")
-tag = "N=%d C=%d rows fwd %s bwd %s" % (N, CH, os.environ.get("SRLZ_OS_FWD_ROWS", "dflt"), os.environ.get("SRLZ_OS_BWD_ROWS", "dflt"))
+tag = "N=%d C=%d" % (N, CH)
 flop = 2.0 * 16 * CH * 64 * N * 111 * 111
 fbytes = 4.0 * N * (111 * 111 * 64 + CH * 224 * 224)
 
