@@ -265,7 +265,11 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __res
         if constexpr (LOSS) {
           float d[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { d[r] = v[r] - tg[cg][r]; lsum += live ? d[r] * d[r] : 0.f; }
+          for (int r = 0; r < 4; ++r) {
+            d[r] = v[r] - tg[cg][r];
+            const float dm = live ? d[r] : 0.f;
+            lsum = __builtin_fmaf(dm, dm, lsum);  // (an explicit fma: every instantiation rounds the partial sums alike)
+          }
           os_store2(img_rs, ob, d[0], d[1]);
           os_store2(img_rs, ob2, d[2], d[3]);
           if constexpr (DEC) {  // (the reconstruction itself: not on the training path)

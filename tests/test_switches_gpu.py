@@ -1,0 +1,103 @@
+"""Every environment switch that selects a non-default code path takes two training steps in a fresh process and must
+land where the default path lands: same losses, same parameters after Adam (to summation order — the switched paths run other
+kernels or other launch structures of the same arithmetic).  A switch nothing selects is a path the next kernel change breaks
+silently."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r"""
+import json, os, sys
+sys.path[:0] = [os.path.join(sys.argv[1], "srl-zoo_amd"), sys.argv[1], os.path.join(sys.argv[1], "tests")]
+import numpy as np, torch
+import golden_util as gu
+import models.learner as learner
+import preprocessing.preprocess as pre
+from losses.losses import LossManager
+pre.N_CHANNELS = 3
+learner.BATCH_SIZE = 3
+losses = sys.argv[2].split(",")
+srl = learner.SRL4robotics(24, model_type="custom_cnn", seed=7, learning_rate=1e-3, cuda=True, losses=losses, n_actions=6, log_folder="/tmp")
+lm = LossManager(srl.model, None)
+rows = []
+for step in range(2):
+    o, n, a = gu.golden_inputs(3, 3, 6, seed=500 + step)
+    both = torch.from_numpy(np.concatenate((o, n), 0)).cuda()
+    if "vae" in losses:
+        torch.manual_seed(90 + step)
+        it = iter([torch.randn(3, 24), torch.randn(3, 24)])
+        srl.model.model.eps_fn = lambda mu: next(it).to(mu.device)
+    loss = srl.trainStep(both[:3], both[3:], torch.from_numpy(a).view(-1, 1).cuda(), lm)
+    rows.append(lm.lossValues() + [float(loss.detach())])
+torch.cuda.synchronize()
+flat = srl.flat_params.flat.double().cpu().numpy()
+bufs = [float(b.double().sum()) for b in srl.model.buffers()]
+np.save(sys.argv[3], flat)
+print("RESULT " + json.dumps({"losses": rows, "names": list(lm.names), "bufs": bufs, "steps": srl.optimizer.steps()}))
+"""
+
+SWITCHES = [("SRLZ_DEFER_BN_BWD", "0"), ("SRLZ_FUSE_ENC_IN", "0"), ("SRLZ_DIRECT_GRADS", "0"), ("SRLZ_WGRAD_RING", "0"),
+            ("SRLZ_WGRAD_S2_TK32", "0"), ("SRLZ_PAIR", "0"), ("SRLZ_GRAPH", "1"), ("SRLZ_FUSED_TOTAL", "0"), ("SRLZ_FUSED_OUT_BWD", "0"),
+            ("SRLZ_FUSED_RECON", "0"), ("SRLZ_FUSED_CONVT_BWD", "0"), ("SRLZ_DGRAD_PIPE", "0"), ("SRLZ_POOL_BWD_IN_DGRAD", "0"),
+            ("SRLZ_SYNC", "1")]
+
+
+def _run_all(losses, tmp_path):
+    """Default + every switch, four processes at a time."""
+    jobs = [("default", {})] + [("%s=%s" % kv, dict([kv])) for kv in SWITCHES]
+    results, running = {}, []
+
+    def reap(block):
+        for item in list(running):
+            name, proc, path = item
+            if block:
+                proc.wait()
+            if proc.poll() is None:
+                continue
+            running.remove(item)
+            out = proc.stdout.read().decode("utf-8", "replace")
+            assert proc.returncode == 0, "%s: exit %d\n%s" % (name, proc.returncode, out[-3000:])
+            line = [l for l in out.splitlines() if l.startswith("RESULT ")][-1]
+            results[name] = (json.loads(line[7:]), np.load(path))
+    for name, extra in jobs:
+        while len(running) >= 4:
+            reap(False)
+            if len(running) >= 4:
+                running[0][1].wait()
+        env = dict(os.environ)
+        for k, _ in SWITCHES:
+            env.pop(k, None)
+        env.update(extra)
+        path = str(tmp_path / (name.replace("=", "_") + ".npy"))
+        proc = subprocess.Popen([sys.executable, "-c", _SCRIPT, REPO, ",".join(losses), path], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.STDOUT)
+        running.append((name, proc, path))
+    while running:
+        reap(True)
+    return results
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("losses", [["autoencoder", "inverse"], ["vae"]], ids=["ae_inverse", "vae"])
+def test_every_switch_lands_where_the_default_path_lands(losses, tmp_path):
+    res = _run_all(losses, tmp_path)
+    ref, pref = res["default"]
+    assert ref["steps"] == 2 and np.isfinite(ref["losses"]).all()
+    scale = float(np.abs(pref).max())
+    for name, (got, p) in sorted(res.items()):
+        if name == "default":
+            continue
+        assert got["names"] == ref["names"] and got["steps"] == 2, name
+        np.testing.assert_allclose(got["losses"], ref["losses"], rtol=3e-5, err_msg=name)
+        # Adam turns a 1e-6 gradient difference at a rounding-noise element into a +-lr step: bound the parameters by a few lr
+        assert float(np.abs(p - pref).max()) <= 4e-3 * scale, (name, float(np.abs(p - pref).max()), scale)
+        assert float(np.abs(p - pref).mean()) <= 2e-5 * scale, (name, float(np.abs(p - pref).mean()))
+        np.testing.assert_allclose(got["bufs"], ref["bufs"], rtol=1e-4, err_msg=name)
