@@ -16,9 +16,8 @@ HOT = ("conv64_fwd_kernel<4, false>", "conv64_fwd_kernel<4, true>", "conv64_wgra
        "skinny_conv_kernel<7, 3, false, false, float>",
        "skinny_conv_kernel<4, 0, true, false, float>", "skinny_wgrad_kernel<7, 3, true, float>",
        "skinny_wgrad_kernel<7, 3, true, unsigned char>", "skinny_wgrad_kernel<4, 0, false, float>",
-       "convT_out_os_kernel<1, false, float>", "convT_out_os_bwd_kernel<1>")
-# (the loss-taking instantiations of the ConvTranspose-5 forward keep 2-4 registers in scratch across the STRIP loop — reloaded once
-# per strip, outside the row loop that holds the MFMAs — so only the plain instantiation is held to "no scratch at all")
+       "convT_out_os_kernel<1, false, float, false>", "convT_out_os_kernel<1, true, float, false>",
+       "convT_out_os_kernel<1, true, unsigned char, false>", "convT_out_os_bwd_kernel<1>", "convT_out_os_bwd_kernel<2>")
 
 
 @pytest.mark.skipif(not os.path.exists(isa_audit.HIPCC) and shutil.which("hipcc") is None, reason="needs hipcc")
