@@ -294,12 +294,13 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
         if (!((okmask >> j) & 1u)) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         else if (bnp) {
           if (BWD) {
+            // (explicit fused multiply-adds: the same roundings in every kernel that rebuilds dy — as whole-vector operations, which
+            // hipcc issues as v_pk_fma_f32, two elements per instruction slot: every instruction next to the MFMAs costs matrix time)
+            const f32x4 z4 = __builtin_elementwise_fma(yv[j], sc4, sh4), t4 = __builtin_elementwise_fma(c1, yv[j], c0);
+            f32x4 dz4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {  // (explicit fused multiply-adds: the same roundings in every kernel that rebuilds dy)
-              const float z = __builtin_fmaf(yv[j][e], sc4[e], sh4[e]);
-              const float dz = z > 0.f ? v[j][e] : 0.f;
-              v[j][e] = __builtin_fmaf(sc4[e], dz, -__builtin_fmaf(c1[e], yv[j][e], c0[e]));
-            }
+            for (int e = 0; e < 4; ++e) dz4[e] = z4[e] > 0.f ? v[j][e] : 0.f;
+            v[j] = __builtin_elementwise_fma(sc4, dz4, -t4);
             if (f.dy_out && (unsigned)(R - core_lo) < (unsigned)core_n) *(f32x4*)(f.dy_out + (size_t)offs[j]) = v[j];
           } else {
 #pragma unroll
@@ -796,11 +797,13 @@ __device__ __forceinline__ void gather_land(float* __restrict__ lds, GatherRows&
     const bool ok = (r.ok >> j) & 1u;
     f32x4 v = r.v[j];
     const f32x4 yy = r.yv[j];
+    {  // (explicit fused multiply-adds: exactly stage_rows' roundings; vector form -> v_pk_fma_f32)
+      const f32x4 z4 = __builtin_elementwise_fma(yy, sc4, sh4), t4 = __builtin_elementwise_fma(c1, yy, c0);
+      f32x4 dz4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {  // (explicit fused multiply-adds: exactly stage_rows' roundings)
-      const float z = __builtin_fmaf(yy[e], sc4[e], sh4[e]);
-      const float dz = z > 0.f ? v[e] : 0.f;
-      v[e] = ok ? __builtin_fmaf(sc4[e], dz, -__builtin_fmaf(c1[e], yy[e], c0[e])) : 0.f;
+      for (int e = 0; e < 4; ++e) dz4[e] = z4[e] > 0.f ? v[e] : 0.f;
+      v = __builtin_elementwise_fma(sc4, dz4, -t4);
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (j < GP_CORE) {
       const bool core = ok && R < nrows && (unsigned)(R - core_lo) < (unsigned)core_n;
@@ -1054,10 +1057,11 @@ __device__ __forceinline__ void ytile_land(float* __restrict__ Ys, YRows& r, con
   for (int j = 0; j < 4; ++j) {
     const bool ok = (r.ok >> j) & 1u;
     f32x4 v = r.v[j];
+    {
+      const f32x4 z4 = __builtin_elementwise_fma(v, sc4, sh4);  // (v_pk_fma_f32; each element the same IEEE fma as before)
+      const float hi = ok ? __builtin_inff() : 0.f;              // relu, and 0 for a row outside the tensor: one v_med3 per element
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float z = __builtin_fmaf(v[e], sc4[e], sh4[e]);
-      v[e] = (ok && z > 0.f) ? z : 0.f;
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(z4[e], 0.f, hi);
     }
     *(f32x4*)(Ys + ((t >> 4) + GP_RP * j) * 64 + slot * 4) = v;
   }
@@ -1078,7 +1082,8 @@ __device__ __forceinline__ void gather_land_sum(float* __restrict__ lds, GatherR
     f32x4 v = r.v[j];
     const f32x4 yy = r.yv[j];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 4; ++e) {  // (scalar on purpose: the packed form needs aligned register pairs, and conv64_bwd_fused_kernel — at
+      // its 256-register limit — spills 8 registers with it instead of 2)
       const float z = __builtin_fmaf(yy[e], sc4[e], sh4[e]);
       const float dz = z > 0.f ? v[e] : 0.f;
       v[e] = ok ? __builtin_fmaf(sc4[e], dz, -__builtin_fmaf(c1[e], yy[e], c0[e])) : 0.f;

@@ -151,9 +151,9 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __res
       for (int i = 0; i < 5; ++i) {
         const bool ok = (qok >> i) & 1u;
         const float lo = ok ? act_lo : 0.f, hi = ok ? __builtin_inff() : 0.f;
-        f32x4 v = q[i];
+        f32x4 v = q[i] * sc + sh;  // (a vector expression: two v_pk_fma_f32; each element one IEEE fma as before)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * sc[e] + sh[e], lo, hi);
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
         const int pl = (i < 4 || pq == 0) ? pq + 4 * i : 17;  // (pixel 17: the dummy the idle lanes of the fifth load write)
         *(f32x4*)(dst + pl * OSP) = v;
       }
@@ -238,9 +238,7 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __res
           __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
         // ---- epilogue: this lane holds out[co = kq][2a + py][2(b0 + p) + px] in register py*2 + px
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + bs[cg];
+        const f32x4 v = (acc0 + acc1) + f32x4{bs[cg], bs[cg], bs[cg], bs[cg]};  // (vector expressions: v_pk_add_f32)
         if constexpr (LOSS) {
           if constexpr (U8) { asm volatile("" : "+v"(tgraw[cg][0]), "+v"(tgraw[cg][1])); }
           else {
@@ -263,13 +261,10 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_kernel(const float* __res
         const unsigned ob = live ? (unsigned)((((cg * 3 + kq) * H + 2 * a) * W + 2 * (b0 + p)) * 4) : OS_DROP;
         const unsigned ob2 = live ? ob + (unsigned)(W * 4) : OS_DROP;
         if constexpr (LOSS) {
-          float d[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            d[r] = v[r] - tg[cg][r];
-            const float dm = live ? d[r] : 0.f;
-            lsum = __builtin_fmaf(dm, dm, lsum);  // (an explicit fma: every instantiation rounds the partial sums alike)
-          }
+          const f32x4 d = v - f32x4{tg[cg][0], tg[cg][1], tg[cg][2], tg[cg][3]};
+          // (explicit fmas in a fixed order: every instantiation rounds the partial sums alike; a dead lane adds nothing)
+          const float sq = __builtin_fmaf(d[3], d[3], __builtin_fmaf(d[2], d[2], __builtin_fmaf(d[1], d[1], d[0] * d[0])));
+          lsum += live ? sq : 0.f;
           os_store2(img_rs, ob, d[0], d[1]);
           os_store2(img_rs, ob2, d[2], d[3]);
           if constexpr (DEC) {  // (the reconstruction itself: not on the training path)
@@ -487,16 +482,18 @@ __global__ __launch_bounds__(256, 2) void convT_out_os_bwd_kernel(const float* e
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const f32x4 bsc = *(const f32x4*)(Bn + 64 + 16 * mt + 4 * kq), bsh = *(const f32x4*)(Bn + 128 + 16 * mt + 4 * kq);
-        f32x4 act;
+        // (whole-vector expressions: hipcc turns them into v_pk_fma_f32 / v_pk_add_f32, two elements per issue slot — every
+        // instruction next to the MFMAs costs ~4.7 cycles of matrix time; each element is still one IEEE fma, the
+        // rounding of the forward kernel's relu(bn(y)))
+        const f32x4 z4 = yv[mt] * bsc + bsh;
+        f32x4 act, v4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float z = yv[mt][e] * bsc[e] + bsh[e];
-          const bool on = z > 0.f && pvalid;
-          act[e] = __builtin_amdgcn_fmed3f(z, 0.f, act_hi);  // relu, and 0 for a position outside the map
-          const float v = on ? acc[mt][e] : 0.f;
-          s1[mt][e] += v;
-          s2[mt][e] += v * yv[mt][e];  // (centred once per strip: sum dz (y - mean) = sum dz y - mean sum dz, in fp64)
+          act[e] = __builtin_amdgcn_fmed3f(z4[e], 0.f, act_hi);  // relu, and 0 for a position outside the map
+          v4[e] = (z4[e] > 0.f && pvalid) ? acc[mt][e] : 0.f;
         }
+        s1[mt] += v4;
+        s2[mt] = v4 * yv[mt] + s2[mt];  // (centred once per strip: sum dz (y - mean) = sum dz y - mean sum dz, in fp64)
         *(f32x4*)(F + p * OSP + 16 * mt + 4 * kq) = act;
       }
       const unsigned ob = ((unsigned)(a * WF * 64) + ypos + 4 * kq) * 4u;  // (branch-free, see os_buffer)
