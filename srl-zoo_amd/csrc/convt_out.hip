@@ -598,9 +598,9 @@ int os_check(const srlz_skinny_desc* d, const char* who) {
                "%s: image %dx%d inconsistent with feature map %dx%d", who, d->himg, d->wimg, d->hf, d->wf);
   SRLZ_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->n % d->groups == 0), SRLZ_ERR_BAD_DESC,
                "%s: n = %d is not a multiple of groups = %d", who, d->n, d->groups);
-  // per-image element offsets are 32-bit in the kernels
-  SRLZ_REQUIRE((long long)d->hf * d->wf * 64 < (1LL << 31) && (long long)d->c * d->himg * d->wimg < (1LL << 31), SRLZ_ERR_BAD_DESC,
-               "%s: one image of %dx%d exceeds the 32-bit per-image offsets", who, d->himg, d->wimg);
+  // offsets inside one image are 32-bit in the kernels — as BYTES in the buffer stores (a buffer resource spans one image)
+  SRLZ_REQUIRE((long long)d->hf * d->wf * 256 < (1LL << 31) && (long long)d->c * d->himg * d->wimg * 4 < (1LL << 31), SRLZ_ERR_BAD_DESC,
+               "%s: one image of %dx%d exceeds the 32-bit per-image byte offsets", who, d->himg, d->wimg);
   return 0;
 }
 
