@@ -214,7 +214,10 @@ class DataLoader(object):
         # forked child: the parent's intra-op (OpenMP) worker threads do not exist here, so torch must not try to use
         # them — the few tensor ops below (tensor(), cat) run single-threaded; decoding parallelism comes from the pool
         th.set_num_threads(1)
-        pool = ThreadPoolExecutor(max_workers=max(1, self.n_workers))
+        # ... and neither may the decoding threads: the OpenMP thread count is a per-thread setting, a pool thread starts with the
+        # default (all cores), and a tensor copy above ATen's grain size then opens a parallel region in this forked child, whose
+        # inherited OpenMP runtime has no threads — it hangs or crashes (seen on GPU boxes with the DAE loader, roughly one run in three)
+        pool = ThreadPoolExecutor(max_workers=max(1, self.n_workers), initializer=th.set_num_threads, initargs=(1,))
         first = True
         while first or self.infinite_loop:
             first = False
@@ -285,8 +288,9 @@ class DataLoader(object):
             return th.from_numpy(np.ascontiguousarray(im.transpose(2, 1, 0)).reshape((1, im.shape[2], im.shape[1], im.shape[0])))
         if raw_uint8:
             return th.from_numpy(np.ascontiguousarray(im).reshape((1,) + im.shape))
-        # channel first + batch dim; note the (W, H) order of the last two axes
-        return th.tensor(im.reshape((1,) + im.shape).transpose(0, 3, 2, 1))
+        # channel first + batch dim; note the (W, H) order of the last two axes.  (The copy is numpy's: th.tensor() of a strided view
+        # is an ATen copy kernel — an OpenMP parallel region in a pool thread of the forked producer, see _run.)
+        return th.from_numpy(np.ascontiguousarray(im.reshape((1,) + im.shape).transpose(0, 3, 2, 1)))
 
     def __len__(self):
         return self.n_minibatches
@@ -294,12 +298,24 @@ class DataLoader(object):
     def __iter__(self):
         return self
 
-    # A producer that never delivers its FIRST item is re-forked (fork() of a multi-threaded parent — HIP runtime, OpenMP pools — can
-    # leave the child behind a lock some other thread held at that instant; seen once on a GPU box as a training run waiting for
-    # ever).  The parent has drawn no random number since the first fork, so the new child starts from the same RNG state and
-    # produces the same permutations.  A producer that died is reported instead of waited for.
+    # A producer that never delivers its FIRST item — it hangs, or it dies (seen on GPU boxes as a segmentation fault of the freshly
+    # forked child in roughly one run out of three of the DAE loader) — is re-forked: fork() of a multi-threaded parent (HIP runtime,
+    # OpenMP pools) can leave the child behind a lock, or with state, some other thread owned at that instant.  The parent has drawn
+    # no random number since the first fork, so the new child starts from the same RNG state and produces the same permutations.
+    # A producer that dies AFTER it has delivered is reported instead of waited for: its epoch cannot be resumed.
     STARTUP_TIMEOUT = 90.0
-    MAX_RESTARTS = 2
+    MAX_RESTARTS = 3
+
+    def _restart(self, why):
+        if self._restarts >= self.MAX_RESTARTS:
+            raise RuntimeError("DataLoader: the producer process {} ({} attempts)".format(why, self._restarts + 1))
+        self._restarts += 1
+        try:
+            self.process.terminate()
+        except Exception:
+            pass
+        self.queue = Queue(self._max_queue_len)
+        self.startProcess()
 
     def __next__(self):
         waited_since = time.time()
@@ -309,19 +325,17 @@ class DataLoader(object):
                 break
             except queue.Empty:
                 time.sleep(0.001)
-                if time.time() - waited_since < 1.0:
+                if time.time() - waited_since < 0.25:
                     continue
                 if self.process is not None and not self.process.is_alive():
+                    if self._received == 0:
+                        self._restart("exited (code {}) before its first minibatch".format(self.process.exitcode))
+                        waited_since = time.time()
+                        continue
                     raise RuntimeError("DataLoader: the producer process exited (code {}) without finishing the epoch".format(
                         self.process.exitcode))
                 if self._received == 0 and time.time() - waited_since > self.STARTUP_TIMEOUT:
-                    if self._restarts >= self.MAX_RESTARTS:
-                        raise RuntimeError("DataLoader: the producer process delivered nothing in {} s, {} times".format(
-                            self.STARTUP_TIMEOUT, self._restarts + 1))
-                    self._restarts += 1
-                    self.process.terminate()
-                    self.queue = Queue(self._max_queue_len)
-                    self.startProcess()
+                    self._restart("delivered nothing in {} s".format(self.STARTUP_TIMEOUT))
                     waited_since = time.time()
         self._received += 1
         if val is None:

@@ -214,3 +214,43 @@ def test_index_mode_keeps_the_iteration_contract(dataset):
                 assert (0 <= r[..., 0]).all() and (r[..., 0] <= r[..., 1]).all() and (r[..., 1] <= 224).all()
                 assert (0 <= r[..., 2]).all() and (r[..., 2] <= r[..., 3]).all() and (r[..., 3] <= 224).all()
     assert seen >= 3
+
+
+def test_producer_that_dies_before_its_first_minibatch_is_reforked(dataset, tmp_path):
+    """fork() of a multi-threaded trainer occasionally yields a child that crashes at once (seen on GPU boxes with the DAE loader: exit
+    code -11).  A producer that dies before delivering anything is re-forked — same RNG state at fork, hence the same permutation —
+    and one that dies after having delivered raises instead of leaving the training loop waiting for ever."""
+    import os
+    import signal
+    from preprocessing.data_loader import DataLoader
+    name, paths, *_ = dataset
+    ml = [np.array([0, 1, 2]), np.array([4, 5, 6]), np.array([8, 9, 10])]
+    flag = str(tmp_path / "crash_once")
+    open(flag, "w").close()
+
+    class CrashOnce(DataLoader):
+        def _run(self):
+            if os.path.exists(flag):
+                os.remove(flag)
+                os.kill(os.getpid(), signal.SIGSEGV)
+            return DataLoader._run(self)
+
+    np.random.seed(21)
+    good = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8="planar")
+    order = [int(i[0]) for i in good]
+    del good
+    np.random.seed(21)
+    dl = CrashOnce(ml, paths, n_workers=2, is_training=True, raw_uint8="planar")
+    assert [int(i[0]) for i in dl] == order and dl._restarts == 1 and not os.path.exists(flag)
+
+    class DiesLater(DataLoader):
+        def _run(self):
+            self.queue.put((0, None, None, None, None))
+            time.sleep(0.3)
+            os.kill(os.getpid(), signal.SIGSEGV)
+
+    import time
+    late = DiesLater(ml, paths, is_training=True)
+    assert next(late)[0] == 0
+    with pytest.raises(RuntimeError, match="exited"):
+        next(late)

@@ -53,6 +53,20 @@ def test_planar_frames_as_float_is_normalize_u8(n, c):
         ops.frames_as_float(torch.zeros(2, 4, 8, 8, dtype=torch.uint8, device=DEV))
 
 
+def test_frames_as_float_chunks_calls_above_the_grid_limit():
+    """One srlz_normalize_u8_planar launch takes n * c <= 65535 planes (grid.y); frames_as_float splits larger calls (advisor, round 3):
+    22 000 tiny RGB frames = 66 000 planes, every value through the table."""
+    from srlz import ops
+    dev = torch.device(DEV, torch.cuda.current_device())
+    frames = torch.from_numpy(np.random.RandomState(8).randint(0, 256, (22000, 3, 4, 4)).astype(np.uint8)).to(dev)
+    out = ops.frames_as_float(frames)
+    lut = ops.norm_lut(dev)
+    ref = torch.stack([lut[c][frames[:, c].long()] for c in range(3)], dim=1)
+    assert out.shape == (22000, 3, 4, 4) and torch.equal(out, ref)
+    with pytest.raises(ops.C.SrlzError):  # the C entry point itself still states its limit
+        ops.C.normalize_u8_planar(ops.ptr(frames), ops.ptr(lut), ops.ptr(out), 22000, 3, 16, ops.stream())
+
+
 @pytest.mark.parametrize("n,c,w,h,training", [(4, 3, 224, 224, True), (2, 6, 224, 224, True), (2, 9, 224, 224, True),
                                               (3, 3, 70, 90, True), (2, 3, 64, 64, False)])
 def test_first_block_on_bytes_is_the_float_path_bit_for_bit(n, c, w, h, training):
