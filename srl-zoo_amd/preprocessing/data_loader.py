@@ -214,10 +214,13 @@ class DataLoader(object):
         # forked child: the parent's intra-op (OpenMP) worker threads do not exist here, so torch must not try to use
         # them — the few tensor ops below (tensor(), cat) run single-threaded; decoding parallelism comes from the pool
         th.set_num_threads(1)
-        # ... and neither may the decoding threads: the OpenMP thread count is a per-thread setting, a pool thread starts with the
-        # default (all cores), and a tensor copy above ATen's grain size then opens a parallel region in this forked child, whose
-        # inherited OpenMP runtime has no threads — it hangs or crashes (seen on GPU boxes with the DAE loader, roughly one run in three)
-        pool = ThreadPoolExecutor(max_workers=max(1, self.n_workers), initializer=th.set_num_threads, initargs=(1,))
+        # ... and the decoding threads must not run ATen kernels at all: the OpenMP thread count is a per-thread setting, a pool thread
+        # starts with the default (all cores), and a tensor copy above ATen's grain size opens a parallel region in this forked child,
+        # whose inherited OpenMP runtime has no threads — it hangs or crashes (seen on GPU boxes with the DAE loaders).  The workers
+        # therefore hand back numpy-made arrays wrapped by th.from_numpy (see _makeBatchElement); th.cat below runs on this thread.
+        # (Calling th.set_num_threads from the workers is no cure: it rebuilds a process-wide thread pool, and four threads doing that
+        # at once crashed the producer every time.)
+        pool = ThreadPoolExecutor(max_workers=max(1, self.n_workers))
         first = True
         while first or self.infinite_loop:
             first = False
