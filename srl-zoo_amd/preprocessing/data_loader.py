@@ -15,6 +15,7 @@ Image decoding is host-side I/O, not a kernel: OpenCV is used when importable (a
 """
 from __future__ import print_function, division, absolute_import
 
+import gc
 import glob
 import random
 import time
@@ -213,6 +214,12 @@ class DataLoader(object):
     def _run(self):
         # forked child: the parent's intra-op (OpenMP) worker threads do not exist here, so torch must not try to use
         # them — the few tensor ops below (tensor(), cat) run single-threaded; decoding parallelism comes from the pool
+        # forked child of a process that owns a GPU: everything alive at the fork — including cyclic garbage of earlier training runs
+        # that holds device tensors, streams and events — must stay untouched here.  Without the freeze this process's garbage
+        # collector finalises such objects (hipFree / hipEventDestroy in a child that has no GPU context) and dies of a segmentation
+        # fault while decoding, whenever a collection happens to fall into its first minibatch (found with faulthandler on a GPU box:
+        # "Current thread: Garbage-collecting"; it showed as a training run waiting for ever or, since the watchdog, as exit code -11).
+        gc.freeze()
         th.set_num_threads(1)
         # ... and the decoding threads must not run ATen kernels at all: the OpenMP thread count is a per-thread setting, a pool thread
         # starts with the default (all cores), and a tensor copy above ATen's grain size opens a parallel region in this forked child,
@@ -301,10 +308,10 @@ class DataLoader(object):
     def __iter__(self):
         return self
 
-    # A producer that never delivers its FIRST item — it hangs, or it dies (seen on GPU boxes as a segmentation fault of the freshly
-    # forked child in roughly one run out of three of the DAE loader) — is re-forked: fork() of a multi-threaded parent (HIP runtime,
-    # OpenMP pools) can leave the child behind a lock, or with state, some other thread owned at that instant.  The parent has drawn
-    # no random number since the first fork, so the new child starts from the same RNG state and produces the same permutations.
+    # A producer that never delivers its FIRST item — it hangs or it dies — is re-forked: fork() of a multi-threaded parent (HIP
+    # runtime, OpenMP pools) can leave the child behind a lock some other thread owned at that instant (the one crash that was
+    # actually found had another cause, see gc.freeze() in _run; this is the safety net).  The parent has drawn no random number
+    # since the first fork, so the new child starts from the same RNG state and produces the same permutations.
     # A producer that dies AFTER it has delivered is reported instead of waited for: its epoch cannot be resumed.
     STARTUP_TIMEOUT = 90.0
     MAX_RESTARTS = 3
