@@ -52,6 +52,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   return base + idx;
 }
 
+// a * b + c with a < 2^24 and a wave-uniform 0 <= b < 2^24, as the one full-rate instruction it is (hipcc turns the intrinsic form
+// __umul24(a, b) + c into a quarter-rate v_mad_u64_u32 whenever it cannot see the ranges, and plain 32-bit products are quarter-rate
+// v_mul_lo_u32): the pixel-offset arithmetic of the stagings, where every issue slot is paid for in matrix time
+__device__ __forceinline__ unsigned mad_u24(unsigned a, int b_uniform, unsigned c) {
+  unsigned r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -315,6 +315,85 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The row table of a forward tile.  stage_rows walks (image, row, column) per staged row and thread: with the bounds tests, the
+// pixel offset and the 64-bit address that is ~30 vector-ALU instructions per row (two of them quarter-rate 64-bit multiply-adds),
+// 16 rows per thread and tile — a sixth of everything conv64_fwd_kernel issues next to its MFMAs, each costing matrix time
+// (DESIGN.md 5.3).  Here every thread decomposes ONE row of the tile's range [qstart, qstart + nrows) into a table in LDS, once per
+// tile:   entry = pixel index of the row's class-(0,0) source pixel << 4 | bit k: source class k = (cy << 1) | cx is inside the image
+// (0: no class is), and a staging is then, per row: one quarter of a ds_read_b128, a bit-field extract, an add-shift, two ANDs and the
+// address add.  The four stagings of a stride-2 gather tile share the table.
+// Layout: entry of row R at (R & 15) * tpa + (R >> 4): the rows of thread t (R = (t >> 4) + 16 j) are consecutive words.
+// tpa = passes over the tile's rows rounded up to the batch (entries past nrows are 0: such a row reads pixel 0 and is dropped).
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int rowtab_passes(int nrows) { return ((nrows + 15) / 16 + SRLZ_BATCH_FWD - 1) / SRLZ_BATCH_FWD * SRLZ_BATCH_FWD; }
+
+__device__ __forceinline__ void rowtab_build(unsigned* __restrict__ tab, int tpa, const ConvProg& P, int qstart, int nrows) {
+  for (int R = threadIdx.x; R < 16 * tpa; R += blockDim.x) {
+    unsigned e = 0;
+    if (R < nrows) {
+      const int qq = qstart + R + P.PHW;  // shifted by one image: the first rows of the first tile (negative q) stay non-negative
+      const int n1 = fastdiv(qq, P.mPHW, P.sPHW);
+      const int rem = qq - n1 * P.PHW;
+      const int a = fastdiv(rem, P.mPW, P.sPW);
+      const int y0 = a * P.ss, x0 = (rem - a * P.PW) * P.ss;
+      if ((unsigned)(n1 - 1) < (unsigned)P.N) {
+        unsigned f = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f |= (y0 + (k >> 1) < P.Hs && x0 + (k & 1) < P.Ws) ? 1u << k : 0u;
+        e = ((unsigned)(((n1 - 1) * P.Hs + y0) * P.Ws + x0) << 4) | f;
+      }
+    }
+    tab[(R & 15) * tpa + (R >> 4)] = e;
+  }
+}
+
+// Rows of source class `cls` -> LDS (swizzled), through the table.  lrec != NULL: relu(batchnorm(.)) on the way in (scale, shift in LDS).
+template <int BATCH>
+__device__ __forceinline__ void stage_rows_tab(float* __restrict__ lds, const float* __restrict__ src,
+                                               const unsigned* __restrict__ tab, int tpa, int cls, int W, int nrows,
+                                               const float* __restrict__ lrec) {
+  const int t = threadIdx.x;
+  const int slot = t & 15, r = t >> 4;
+  const unsigned delta = (unsigned)((cls >> 1) * W + (cls & 1));
+  const float* __restrict__ base = src + slot * 4;
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (lrec) { sc4 = *(const f32x4*)(lrec + slot * 4); sh4 = *(const f32x4*)(lrec + 64 + slot * 4); }
+  for (int j0 = 0; j0 < tpa; j0 += BATCH) {
+    f32x4 v[BATCH];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int jj = 0; jj < BATCH; jj += 4) {  // (four entries at a time: all sixteen up front cost 12 registers the pooled-block kernel lacks)
+      const uint4 q = *(const uint4*)(tab + r * tpa + j0 + jj);
+      const unsigned e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = jj + i;
+        // branch-free (see stage_rows): m = all ones where the row's pixel of this class exists; any other row reads pixel 0
+        const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)e[i], (unsigned)cls, 1u);
+        const unsigned off = (((e[i] >> 4) + delta) << 6) & m;  // floats (a group's tensor has < 2^32: checked by the host)
+        v[j] = *(const f32x4*)(base + off);
+        okmask |= m & (1u << j);
+      }
+    }
+    // all loads of the batch are waited for here, once, in straight-line code (see stage_rows)
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) asm volatile("" : "+v"(v[j]));
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int R = r + 16 * (j0 + j);
+      if (R < nrows) {
+        if (!((okmask >> j) & 1u)) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (lrec) {
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) { const float z = v[j][e2] * sc4[e2] + sh4[e2]; v[j][e2] = z > 0.f ? z : 0.f; }
+        }
+        *(f32x4*)(lds + R * 64 + ((slot ^ (R & 15)) << 2)) = v[j];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Forward / data-gradient kernel.  NW = waves per workgroup: 4 (wave = 32 rows x 64 columns, two accumulators) or
 // 8 (wave = 32 rows x 32 columns, one accumulator; twice the waves per SIMD to hide barriers, LDS and staging latency).
 // ---------------------------------------------------------------------------------------------------------------
@@ -331,7 +410,8 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
                                                 const float* __restrict__ bias, float* __restrict__ dst,
                                                 float* __restrict__ stats_partial, const ConvProg& P, int ntiles,
                                                 const OpFuse& src_fuse_all, const PoolSum& ps) {
-  static_assert(PSUM == 0 || (NW == 4 && !BWD), "the pooled-block epilogue exists for the plain 4-wave kernel");
+  static_assert(NW == 4, "8 waves of 32 x 32 measured within +-3 % in rounds 1-3 and are not kept");
+  static_assert(PSUM == 0 || !BWD, "the pooled-block epilogue exists for the plain kernel");
   constexpr int NT = NW * 64;      // threads
   constexpr int NACC = 8 / NW;     // 32-column tiles per wave
   // rows (of 16 lanes) a thread requests per HBM round trip of the source staging: a stride-1 tile (244 rows = 15.25 passes) or a
@@ -340,7 +420,10 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* As = (float*)smem;                 // (TM + span) x 64, swizzled
   float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap, pre-swizzled in global
-  int* rowinfo = (int*)(Bs + 4096);         // [3][TM]: image index (or -1), a*ds, b*ds
+  const int tpa = rowtab_passes(TM + P.span);
+  unsigned* rowtab = (unsigned*)(Bs + 4096);  // [16][tpa]: the source-side row table (rowtab_build)
+  int* rowinfo = (int*)(rowtab + 16 * tpa);   // [TM]: the destination side of a grid position — pixel index of its class-(0,0) output
+                                              // << 2 | bit 0: the row below exists | bit 1: the column to the right exists; -1 = outside
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -358,18 +441,19 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
 
   if (tid < TM) {
     const int q = q0 + tid;
-    int n = -1, ya = 0, xb = 0;
+    int ri = -1;
     if (q < P.total_q) {
-      n = q / P.PHW;
+      const int n = fastdiv(q, P.mPHW, P.sPHW);
       const int rem = q - n * P.PHW;
-      const int a = rem / P.PW;
-      ya = a * P.ds;
-      xb = (rem - a * P.PW) * P.ds;
+      const int a = fastdiv(rem, P.mPW, P.sPW);
+      const int ya = a * P.ds, xb = (rem - a * P.PW) * P.ds;
+      if (ya < P.Hd && xb < P.Wd) ri = (((n * P.Hd + ya) * P.Wd + xb) << 2) | (ya + 1 < P.Hd ? 1 : 0) | (xb + 1 < P.Wd ? 2 : 0);
     }
-    rowinfo[tid] = n; rowinfo[TM + tid] = ya; rowinfo[2 * TM + tid] = xb;
+    rowinfo[tid] = ri;
   }
+  if constexpr (!BWD) rowtab_build(rowtab, tpa, P, q0 + P.min_off, TM + P.span);
   // coefficients of a fused operand, once per workgroup (visible after the first tap's barrier, which precedes the first staging)
-  float* frec = (float*)(rowinfo + 3 * TM);  // [4][64]: scale, shift, c0, c1
+  float* frec = (float*)(rowinfo + TM);  // [4][64]: scale, shift, c0, c1
   if (src_fuse.bnp && tid >= NT - 64) {
     const int c = tid - (NT - 64);
     const float sc = src_fuse.bnp[128 + c], sh = src_fuse.bnp[192 + c];
@@ -383,13 +467,9 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
   const float* lrec = src_fuse.bnp ? frec : nullptr;
 
   f32x16 acc[NACC];
-  float sum[NACC], sq[NACC];  // BatchNorm partials of this lane's columns
   float bcol[NACC];
 #pragma unroll
-  for (int j = 0; j < NACC; ++j) {
-    sum[j] = 0.f; sq[j] = 0.f;
-    bcol[j] = bias ? bias[(wcol * NACC + j) * 32 + l31] : 0.f;
-  }
+  for (int j = 0; j < NACC; ++j) bcol[j] = bias ? bias[(wcol * NACC + j) * 32 + l31] : 0.f;
 
   int cur_src = -1, cur_dst = -1;
 
@@ -426,20 +506,16 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
   // h = 0 / 1 of one ds_write_b32 (rows 4 apart, same column) hit different banks.
   f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 pz[PSUM ? 8 : 1];  // PSUM: the pooled values of this lane's eight rows of a flush (rows 16*(hk >> 2) + (lane >> 4) + 4*(hk & 3))
-  unsigned ppix[PSUM ? 8 : 1];  // ... their pixel index (n * Hd + y) * Wd + x in the group's tensor, kept for the flush's stores
-  unsigned pok = 0;             // ... and whether they are inside it
   auto pz_request = [&](int d) {  // branch-free, clamped: a row outside the tensor reads pixel 0 and is never used
-    const int dy = d >> 1, dx = d & 1;
-    pok = 0;
+    const int need = d >> 1 | (d & 1) << 1;  // destination class (dy, dx): the rowinfo bits it needs
+    const unsigned ddelta = (unsigned)((d >> 1) * P.Wd + (d & 1));
 #pragma unroll
-    for (int hk = 0; hk < 8; ++hk) {
+    for (int hk = 0; hk < 8; ++hk) {  // (the flush works the row's position out again: one LDS word and four instructions, against
+      // nine registers for the whole tile in a kernel that has none to spare)
       const int row = wrow * 32 + 16 * (hk >> 2) + (lane >> 4) + 4 * (hk & 3);
-      const int n = rowinfo[row];
-      const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
-      const bool ok = n >= 0 && y < P.Hd && x < P.Wd;
-      const unsigned pix = ok ? (unsigned)((n * P.Hd + y) * P.Wd + x) : 0u;
-      ppix[PSUM ? hk : 0] = pix;
-      pok |= (ok ? 1u : 0u) << hk;
+      const int ri = rowinfo[row];
+      const bool ok = ri >= 0 && (ri & need) == need;
+      const unsigned pix = ok ? (unsigned)(ri >> 2) + ddelta : 0u;
       pz[PSUM ? hk : 0] = *(const f32x4*)(ppool + (size_t)pix * 64 + (lane & 15) * 4);
     }
   };
@@ -450,7 +526,8 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
         return;
       }
     }
-    const int dy = d >> 1, dx = d & 1;
+    const int need = d >> 1 | (d & 1) << 1;
+    const unsigned ddelta = (unsigned)((d >> 1) * P.Wd + (d & 1));
     float* S = Bs + wave * 1024;
     const int eg = lane >> 4, eslot = lane & 15;
     // PSUM == 2: the pooled values are requested here, up front; PSUM == 1: they were requested before the tile's first tap.
@@ -471,22 +548,15 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
         const int rowl = eg + 4 * k;
         const int row = wrow * 32 + 16 * half + rowl;
         const f32x4 v = *(const f32x4*)(S + rowl * 64 + ((eslot ^ ((rowl & 4) << 1)) << 2));
-        int n = 0, y = 0, x = 0;
-        bool inside;
-        size_t pixel;
-        if constexpr (PSUM) {  // (position and validity of the row were worked out when its pooled value was requested)
+        if constexpr (PSUM) {
           if (half == 0 && k == 0) {
 #pragma unroll
             for (int hk = 0; hk < 8; ++hk) asm volatile("" : "+v"(pz[hk]));
           }
-          inside = (pok >> (half * 4 + k)) & 1u;
-          pixel = ppix[half * 4 + k];
-        } else {
-          n = rowinfo[row];
-          y = rowinfo[TM + row] + dy; x = rowinfo[2 * TM + row] + dx;
-          inside = n >= 0 && y < P.Hd && x < P.Wd;
-          pixel = (size_t)(n * P.Hd + y) * P.Wd + x;
         }
+        const int ri = rowinfo[row];
+        const bool inside = ri >= 0 && (ri & need) == need;
+        const size_t pixel = (unsigned)(ri >> 2) + ddelta;
         if (inside) {
           *(f32x4*)(dst + pixel * 64 + eslot * 4) = v;
           if constexpr (PSUM) {
@@ -519,11 +589,11 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
                     psh = *(const f32x4*)(rec + 192);
 #pragma unroll 1
         for (int hk = 0; hk < 8; ++hk) {
-          if (!((pok >> hk) & 1u)) continue;
-          const int row = wrow * 32 + 16 * (hk >> 2) + eg + 4 * (hk & 3);
-          const int n = rowinfo[row];
-          const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
-          const size_t pixel = ppix[hk];
+          const int ri = rowinfo[wrow * 32 + 16 * (hk >> 2) + eg + 4 * (hk & 3)];
+          if (!(ri >= 0 && (ri & need) == need)) continue;
+          const size_t pixel = (unsigned)(ri >> 2) + ddelta;  // (n * Hd + y) * Wd + x of the output this lane stored
+          const int n = (int)pixel / (P.Hd * P.Wd);
+          const int y = ((int)pixel - n * P.Hd * P.Wd) / P.Wd, x = (int)pixel - (n * P.Hd + y) * P.Wd;
           const uint32_t packed = *(const uint32_t*)(ps.argmax + (size_t)grp * P.dst_gstride + pixel * 64 + eslot * 4);
           const f32x4 v = *(const f32x4*)(dst + pixel * 64 + eslot * 4);
 #pragma unroll
@@ -535,29 +605,6 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
               const float dz = vy * psc[e] + psh[e] > 0.f ? v[e] : 0.f;
               s4[e] += dz; q4[e] += dz * ((vy - mean[e]) * pinv[e]);
             }
-        }
-      }
-    }
-  };
-
-  auto flush = [&](int d) {
-    if (P.dbg & 2) {  // ablation: keep the accumulators live, write nothing
-      if (acc[0][0] + acc[NACC - 1][5] == 123.456f) dst[tid] = acc[0][1];
-      return;
-    }
-    const int dy = d >> 1, dx = d & 1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int n = rowinfo[row];
-      const int y = rowinfo[TM + row] + dy, x = rowinfo[2 * TM + row] + dx;
-      if (n >= 0 && y < P.Hd && x < P.Wd) {
-        float* o = dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * 64 + wcol * NACC * 32 + l31;
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) {
-          const float v = acc[j][r] + bcol[j];
-          o[32 * j] = v;
-          sum[j] += v; sq[j] += v * v;
         }
       }
     }
@@ -583,13 +630,16 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
     __syncthreads();          // (rowinfo)
     pz_request(P.tdst[0]);
   }
-#pragma unroll
+  // Three taps per trip of the loop (the plain kernels; hipcc chose this by itself while the body was larger): 20 KB of code instead of
+  // 50 KB unrolled nine times — the instruction cache is 64 KB for two CUs.  (Everything tap-dependent comes from the program words.)
+  constexpr int TAP_UNROLL = BWD ? NTAPS : 3;
+#pragma unroll TAP_UNROLL
   for (int ti = 0; ti < NTAPS; ++ti) {
     const int w2 = P.tp[ti + 2];
     const int tsrc = (w0 >> 20) & 3, tdst = (w0 >> 22) & 3;
     __syncthreads();  // all waves are done with the previous tap's Bs (and with As if it is about to be replaced)
     if (tdst != cur_dst) {
-      if (cur_dst >= 0) { if constexpr (NW == 4) flush16(cur_dst); else flush(cur_dst); }
+      if (cur_dst >= 0) flush16(cur_dst);
 #pragma unroll
       for (int j = 0; j < NACC; ++j)
 #pragma unroll
@@ -602,8 +652,7 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
           stage_rows<true, (NW == 4 ? BATCH_BWD : 2), NT, true>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q,
                                                         q0 + P.min_off, TM + P.span, src_fuse, -P.min_off, TM, 64, 0, lrec);
         else
-          stage_rows<true, (NW == 4 ? BATCH_FWD : 4), NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off,
-                                                  TM + P.span, src_fuse, 0, 0, 64, 0, lrec);
+          stage_rows_tab<BATCH_FWD>(As, src, rowtab, tpa, tsrc, P.Ws, TM + P.span, lrec);
       }
       cur_src = tsrc;
     }
@@ -613,7 +662,9 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
       for (int i = 0; i < BV; ++i) wdst[bslot + i * 64] = breg[i];
     }
     __syncthreads();
-    if (ti + 1 < NTAPS) {  // (compile-time condition: a run-time one turns the requests into a branch the MFMAs get hoisted above)
+    if (BWD ? ti + 1 < NTAPS : true) {  // (never a run-time condition: behind the join of a branch with loads in it hipcc waits for
+      // everything at the next re-use of their registers — in the flush that was one full wait per store.  The plain kernels, whose
+      // loop is not unrolled nine times, therefore request a slab behind the last tap as well: word NTAPS of the program is 0 = slab 0)
       const f32x4* wsrc = (const f32x4*)(wpack + (size_t)((w1 >> 16) & 15) * 4096);
 #pragma unroll
       for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
@@ -652,38 +703,21 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
     }
     w0 = w1; w1 = w2;
   }
-  if constexpr (NW == 4) {
-    __syncthreads();  // every wave is done with the last tap's slab: Bs becomes scratch
-    flush16(cur_dst);
-  } else {
-    flush(cur_dst);
-  }
+  __syncthreads();  // every wave is done with the last tap's slab: Bs becomes scratch
+  flush16(cur_dst);
 
   if (stats_partial && !(P.dbg & 2)) {
-    // the lane groups (NW == 4: the 4 row groups g; else lanes l and l+32) hold the same columns; then the 4 row groups of
-    // waves are combined through LDS
+    // the 4 row groups g of a wave hold the same columns; then the 4 row groups of waves are combined through LDS
     __syncthreads();
     float* red = Bs;  // [4 row groups][128]
-    if constexpr (NW == 4) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s4[e] += __shfl_xor(s4[e], 16, 64); s4[e] += __shfl_xor(s4[e], 32, 64);
-        q4[e] += __shfl_xor(q4[e], 16, 64); q4[e] += __shfl_xor(q4[e], 32, 64);
-      }
-      if (lane < 16) {
-        *(f32x4*)(red + wrow * 128 + lane * 4) = s4;
-        *(f32x4*)(red + wrow * 128 + 64 + lane * 4) = q4;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NACC; ++j) {
-        sum[j] += __shfl_xor(sum[j], 32, 64);
-        sq[j] += __shfl_xor(sq[j], 32, 64);
-        if (h == 0) {
-          red[wrow * 128 + (wcol * NACC + j) * 32 + l31] = sum[j];
-          red[wrow * 128 + 64 + (wcol * NACC + j) * 32 + l31] = sq[j];
-        }
-      }
+    for (int e = 0; e < 4; ++e) {
+      s4[e] += __shfl_xor(s4[e], 16, 64); s4[e] += __shfl_xor(s4[e], 32, 64);
+      q4[e] += __shfl_xor(q4[e], 16, 64); q4[e] += __shfl_xor(q4[e], 32, 64);
+    }
+    if (lane < 16) {
+      *(f32x4*)(red + wrow * 128 + lane * 4) = s4;
+      *(f32x4*)(red + wrow * 128 + 64 + lane * 4) = q4;
     }
     __syncthreads();
     if (tid < 128) {
@@ -741,34 +775,57 @@ struct GatherRows {
   unsigned ok;              // bit j: row j lies inside the tensor
 };
 
-__device__ __forceinline__ void gather_request(GatherRows& r, const float* __restrict__ src, const float* __restrict__ y, int H,
-                                               int W, int cls, const ConvProg& P, int qstart, int nrows) {
+// The source-side row table of a gather tile (cf. rowtab_build): the walk over (image, row, column), the bounds tests and the pixel
+// offset of a tile's rows were redone by every thread for each of the tile's four classes (~22 vector-ALU instructions per row and
+// class); here the first 192 threads decompose one row each, once per tile:
+//   entry = pixel index of the row's class-(0,0) source pixel << 4 | bit k: class k = (cy << 1) | cx is inside the image  (0 = no row)
+// Layout: row R at (R & 31) * GT_P + (R >> 5): the six rows of thread t (R = (t >> 4) + 32 j) are consecutive words.
+// The tile starts at grid position q0 >= 0 (these programs have min_off == 0).
+constexpr int GT_P = 8;
+constexpr int GT_WORDS = GP_RP * GT_P;
+__device__ __forceinline__ void gtab_build(unsigned* __restrict__ tab, const ConvProg& P, int q0, int nrows) {
+  int R = threadIdx.x;
+  asm volatile("" : "+v"(R));  // opaque (as in gather_request): the word's address is not worth a register across the tile loop
+  if (R < GT_WORDS) {
+    unsigned e = 0;
+    if (R < nrows) {
+      const int qq = q0 + R;
+      const int n = fastdiv(qq, P.mPHW, P.sPHW);
+      const int rem = qq - n * P.PHW;
+      const int a = fastdiv(rem, P.mPW, P.sPW);
+      const int y0 = 2 * a, x0 = 2 * (rem - a * P.PW);
+      if (n < P.N) {
+        unsigned f = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f |= (y0 + (k >> 1) < P.Hs && x0 + (k & 1) < P.Ws) ? 1u << k : 0u;
+        e = ((unsigned)((n * P.Hs + y0) * P.Ws + x0) << 4) | f;
+      }
+    }
+    tab[(R & (GP_RP - 1)) * GT_P + (R >> 5)] = e;
+  }
+}
+
+__device__ __forceinline__ void gather_request(GatherRows& r, const float* __restrict__ src, const float* __restrict__ y,
+                                               const unsigned* __restrict__ tab, int cls, int W) {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));  // opaque: nothing derived from the thread index here is worth a register across the tile loop
   const int slot = t & 15;
-  const int cy = cls >> 1, cx = cls & 1;
-  const int PW = P.PW, PH = P.PH, PHW = P.PHW;
-  const int sa = fastdiv(GP_RP, P.mPW, P.sPW), sb = GP_RP - sa * PW;
-  const int qq = qstart + (t >> 4) + PHW;  // shifted by one image: the first rows of the first tile (negative q) stay non-negative
-  int n1 = fastdiv(qq, P.mPHW, P.sPHW);
-  const int rem = qq - n1 * PHW;
-  int a = fastdiv(rem, P.mPW, P.sPW);
-  int b = rem - a * PW;
-  const int N1max = P.N;
+  const unsigned delta = (unsigned)((cls >> 1) * W + (cls & 1));
+  const unsigned* __restrict__ tp = tab + (t >> 4) * GT_P;
+  const uint4 e03 = *(const uint4*)tp;
+  const uint2 e45 = *(const uint2*)(tp + 4);
+  const unsigned e[GP_BATCH] = {e03.x, e03.y, e03.z, e03.w, e45.x, e45.y};
+  static_assert(GP_BATCH == 6, "the table read above takes six rows");
   unsigned okmask = 0;
 #pragma unroll
   for (int j = 0; j < GP_BATCH; ++j) {
-    const int yy = a * 2 + cy, xx = b * 2 + cx;
-    const bool ok = (t >> 4) + GP_RP * j < nrows && n1 >= 1 && n1 <= N1max && yy < H && xx < W;
-    okmask |= (ok ? 1u : 0u) << j;
-    // branch-free: a padding row reads pixel 0 (always valid) and is zeroed when it lands
-    const unsigned off = (ok ? (unsigned)(((n1 - 1) * H + yy) * W + xx) * 64u : 0u) + slot * 4;
+    // branch-free: m = all ones where the row's pixel of this class exists; any other row reads pixel 0 and is zeroed when it lands
+    const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)e[j], (unsigned)cls, 1u);
+    const unsigned off = ((((e[j] >> 4) + delta) << 6) & m) + slot * 4;
     r.v[j] = *(const f32x4*)(src + off);
     r.yv[j] = *(const f32x4*)(y + off);
     if (j < GP_CORE) r.offs[j] = off;
-    b += sb; a += sa;
-    if (b >= PW) { b -= PW; ++a; }
-    if (a >= PH) { a -= PH; ++n1; }
+    okmask |= m & (1u << j);
   }
   r.ok = okmask;
 }
@@ -822,10 +879,10 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const 
   float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap
   int* rowinfo = (int*)(Bs + 4096);         // [2 (tile parity)][3][TM]: image index (or -1), a*ds, b*ds
   float* frec = (float*)(rowinfo + 6 * TM); // [G <= 2][4][64]: scale, shift, c0, c1 per BatchNorm group
+  unsigned* gtab = (unsigned*)(frec + 512); // the source-side row table of the tile whose rows are being requested (gtab_build)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wrow = wave & 3, wcol = wave >> 2;  // 32-row group, 32-column half
   const int nrows = TM + P.span;
   const int cls0 = P.tsrc[0], cls1 = P.tsrc[4], cls2 = P.tsrc[6], cls3 = P.tsrc[8];
 
@@ -871,8 +928,9 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const 
     const int tile = tbase + k;
     const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;  // (G <= 2, checked by the host)
     const int q0 = (tile - grp * P.tpg) * TM;
-    gather_request(rr, src_all + grp * P.src_gstride, fuse_all.y + grp * P.src_gstride, P.Hs, P.Ws, cls0, P, q0 + P.min_off, nrows);
-    __syncthreads();  // frec is complete
+    gtab_build(gtab, P, q0, nrows);
+    __syncthreads();  // the table and frec are complete
+    gather_request(rr, src_all + grp * P.src_gstride, fuse_all.y + grp * P.src_gstride, gtab, cls0, P.Ws);
     gather_land(As, rr, nrows, frec + grp * 256, gp_buffer(fuse_all.dy_out + grp * P.src_gstride, dy_bytes), -P.min_off, TM);
   }
   for (; k < tcnt; k += wpx, parity ^= 1) {
@@ -884,6 +942,10 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const 
     const __amdgpu_buffer_rsrc_t dyo = gp_buffer(fuse_all.dy_out + grp * P.src_gstride, dy_bytes);
     const __amdgpu_buffer_rsrc_t dst = gp_buffer(dst_all + grp * P.dst_gstride, dst_bytes);
     const float* lrec = frec + grp * 256;
+    const int k2 = k + wpx;  // this workgroup's next tile (past the end: this one again, with no rows)
+    const int tile2 = tbase + (k2 < tcnt ? k2 : k);
+    const int grp2 = (P.G > 1 && tile2 >= P.tpg) ? 1 : 0;
+    const int q02 = (tile2 - grp2 * P.tpg) * TM;
     int* ri = rowinfo + parity * (3 * TM);
     if (tid < TM) {  // (the other parity's copy may still be read by a wave that is flushing the previous tile)
       const int q = q0 + tid;
@@ -904,13 +966,15 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const 
     // (nine operand addresses, the slab offsets ...) in registers across the tile loop — which pushes the rows in flight into
     // scratch, and every scratch reload is a "s_waitcnt vmcnt(0)" in front of a tap's MFMAs, i.e. the end of the pipeline.  One
     // opaque copy of the lane index per tile keeps those few VALU instructions inside the loop instead.
-    int lane_t = lane;
-    asm volatile("" : "+v"(lane_t));
+    int tid_t = tid;  // (the thread index rather than the lane index: what derives from the wave index is kept — and spilled — too)
+    asm volatile("" : "+v"(tid_t));
+    const int lane_t = tid_t & 63, wave_t = tid_t >> 6;
+    const int wrow_t = wave_t & 3, wcol_t = wave_t >> 2;
     const int h_t = lane_t >> 5, l31_t = lane_t & 31;
-    const int arow0 = wrow * 32 + l31_t - P.min_off;
-    const float* brow = Bs + (wcol * 32 + l31_t) * 64;
+    const int arow0 = wrow_t * 32 + l31_t - P.min_off;
+    const float* brow = Bs + (wcol_t * 32 + l31_t) * 64;
     const int bkey = lane_t & 15;
-    const int bslot_t = wave * (BV * 64) + lane_t;  // (likewise: nine 64-bit slab addresses would be hoisted otherwise)
+    const int bslot_t = wave_t * (BV * 64) + lane_t;  // (likewise: nine 64-bit slab addresses would be hoisted otherwise)
 
 #pragma unroll
     for (int ti = 0; ti < NTAPS; ++ti) {
@@ -928,19 +992,16 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const 
         for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot_t + i * 64];
       }
       if (ti == 4 || ti == 6 || ti == 8) gather_land(As, rr, nrows, lrec, dyo, -P.min_off, TM);
+      // the NEXT tile's row table, between the last request of this tile (behind tap 6's second barrier) and the first of the next
+      // (tap 8); past the end: no rows -> every entry 0 -> every row reads pixel 0 and is dropped
+      if (ti == 7) gtab_build(gtab, P, q02, k2 < tcnt ? nrows : 0);
       __syncthreads();
       // the next class's rows
-      if (ti == 0) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls1, P, q0 + P.min_off, nrows);
-      if (ti == 4) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls2, P, q0 + P.min_off, nrows);
-      if (ti == 6) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls3, P, q0 + P.min_off, nrows);
-      if (ti == 8) {  // class 0 of this workgroup's NEXT tile (past the end: nrows = 0 -> every row reads pixel 0 and is dropped)
-        const int k2 = k + wpx;
-        const int tile2 = tbase + (k2 < tcnt ? k2 : k);
-        const int grp2 = (P.G > 1 && tile2 >= P.tpg) ? 1 : 0;
-        const int q02 = (tile2 - grp2 * P.tpg) * TM;
-        gather_request(rr, src_all + grp2 * P.src_gstride, fuse_all.y + grp2 * P.src_gstride, P.Hs, P.Ws, cls0, P, q02 + P.min_off,
-                       k2 < tcnt ? nrows : 0);
-      }
+      if (ti == 0) gather_request(rr, src, ysrc, gtab, cls1, P.Ws);
+      if (ti == 4) gather_request(rr, src, ysrc, gtab, cls2, P.Ws);
+      if (ti == 6) gather_request(rr, src, ysrc, gtab, cls3, P.Ws);
+      if (ti == 8)  // class 0 of this workgroup's NEXT tile
+        gather_request(rr, src_all + grp2 * P.src_gstride, fuse_all.y + grp2 * P.src_gstride, gtab, cls0, P.Ws);
       __builtin_amdgcn_sched_barrier(0);  // every request goes out HERE, ahead of the tap's MFMAs (the scheduler sinks them otherwise)
       const int R = arow0 + P.toff[ti];
       int abase = (R * 64 + ((h_t ^ (R & 15)) << 2)) * 4;  // bytes; slot (2kc + h) ^ (R & 15) is this XOR (kc << 5)
@@ -964,24 +1025,28 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const 
     }
     {  // flush through this wave's own 2 KB of the idle slab, 16 tile rows x 32 columns at a time: every global store is 16 bytes per
        // lane (lane = (row eg = lane >> 3, 4 channels at eslot = lane & 7); see conv64_fwd_kernel::flush16)
-      float* S = Bs + wave * 512;
-      const int eg = lane_t >> 3, eslot = lane_t & 7;
+      int tid_f = tid;  // (a fresh opaque copy: what the flush derives from the thread index does not live — in scratch — across the taps)
+      asm volatile("" : "+v"(tid_f));
+      const int lane_f = tid_f & 63, wave_f = tid_f >> 6;
+      const int wrow_f = wave_f & 3, wcol_f = wave_f >> 2, h_f = lane_f >> 5, l31_f = lane_f & 31;
+      float* S = Bs + wave_f * 512;
+      const int eg = lane_f >> 3, eslot = lane_f & 7;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
 #pragma unroll
         for (int rq = 0; rq < 8; ++rq) {
-          const int rowl = (rq & 3) + 8 * (rq >> 2) + 4 * h_t;
-          S[rowl * 32 + l31_t] = acc[8 * half + rq];
+          const int rowl = (rq & 3) + 8 * (rq >> 2) + 4 * h_f;
+          S[rowl * 32 + l31_f] = acc[8 * half + rq];
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int rowl = eg + 8 * kk;
-          const int row = wrow * 32 + 16 * half + rowl;
+          const int row = wrow_f * 32 + 16 * half + rowl;
           const f32x4 v = *(const f32x4*)(S + rowl * 32 + eslot * 4);
           const int n = ri[row];
           const int y = ri[TM + row], x = ri[2 * TM + row];
           const bool inside = n >= 0 && y < P.Hd && x < P.Wd;  // (branch-free store: see gp_buffer)
-          __builtin_amdgcn_raw_buffer_store_b128(v, dst, inside ? (unsigned)((n * P.Hd + y) * P.Wd + x) * 256u + wcol * 128 + eslot * 16 : GP_DROP,
+          __builtin_amdgcn_raw_buffer_store_b128(v, dst, inside ? (unsigned)((n * P.Hd + y) * P.Wd + x) * 256u + wcol_f * 128 + eslot * 16 : GP_DROP,
                                                  0, 0);
         }
       }
@@ -1022,27 +1087,34 @@ struct FusedBwd {
 
 struct YRows { f32x4 v[4]; unsigned ok; };  // the tile's 128 rows of y_prev: rows (t >> 4) + 32 j
 
-__device__ __forceinline__ void ytile_request(YRows& r, const float* __restrict__ x, const ConvProg& P, int q0, bool live) {
+// ... and of the tile's own 128 positions in the low-resolution tensor (y_prev): entry = pixel index << 1 | 1, 0 = outside;
+// row R at (R & 31) * 4 + (R >> 5).  Built by threads [256, 384).
+constexpr int YT_WORDS = GP_RP * 4;
+__device__ __forceinline__ void ytab_build(unsigned* __restrict__ tab, const ConvProg& P, int q0, bool live) {
+  int R = (int)threadIdx.x - 256;
+  asm volatile("" : "+v"(R));
+  if ((unsigned)R < (unsigned)YT_WORDS) {
+    const int qq = q0 + R;
+    const int n = fastdiv(qq, P.mPHW, P.sPHW);
+    const int rem = qq - n * P.PHW;
+    const int a = fastdiv(rem, P.mPW, P.sPW);
+    const int b = rem - a * P.PW;
+    const bool ok = live && n < P.N && a < P.Hd && b < P.Wd;
+    tab[(R & (GP_RP - 1)) * 4 + (R >> 5)] = ok ? ((unsigned)((n * P.Hd + a) * P.Wd + b) << 1) | 1u : 0u;
+  }
+}
+
+__device__ __forceinline__ void ytile_request(YRows& r, const float* __restrict__ x, const unsigned* __restrict__ tab) {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));
   const int slot = t & 15;
-  const int PW = P.PW, PH = P.PH, PHW = P.PHW;
-  const int sa = fastdiv(GP_RP, P.mPW, P.sPW), sb = GP_RP - sa * PW;
-  const int qq = q0 + (t >> 4);
-  int n = fastdiv(qq, P.mPHW, P.sPHW);
-  const int rem = qq - n * PHW;
-  int a = fastdiv(rem, P.mPW, P.sPW);
-  int b = rem - a * PW;
+  const uint4 q = *(const uint4*)(tab + (t >> 4) * 4);
+  const unsigned e[4] = {q.x, q.y, q.z, q.w};
   unsigned okmask = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const bool ok = live && n < P.N && a < P.Hd && b < P.Wd;
-    okmask |= (ok ? 1u : 0u) << j;
-    const unsigned off = (ok ? (unsigned)((n * P.Hd + a) * P.Wd + b) * 64u : 0u) + slot * 4;
-    r.v[j] = *(const f32x4*)(x + off);
-    b += sb; a += sa;
-    if (b >= PW) { b -= PW; ++a; }
-    if (a >= PH) { a -= PH; ++n; }
+    r.v[j] = *(const f32x4*)(x + ((e[j] >> 1) << 6) + slot * 4);  // (a row outside reads pixel 0; zeroed when it lands)
+    okmask |= (e[j] & 1u) << j;
   }
   r.ok = okmask;
 }
@@ -1083,7 +1155,7 @@ __device__ __forceinline__ void gather_land_sum(float* __restrict__ lds, GatherR
     const f32x4 yy = r.yv[j];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {  // (scalar on purpose: the packed form needs aligned register pairs, and conv64_bwd_fused_kernel — at
-      // its 256-register limit — spills 8 registers with it instead of 2)
+      // its 256-register limit — spills 14 registers with it instead of 4)
       const float z = __builtin_fmaf(yy[e], sc4[e], sh4[e]);
       const float dz = z > 0.f ? v[e] : 0.f;
       v[e] = ok ? __builtin_fmaf(sc4[e], dz, -__builtin_fmaf(c1[e], yy[e], c0[e])) : 0.f;
@@ -1139,6 +1211,8 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
   int* rowinfo = (int*)(Bs + 4096);         // [2 (tile parity)][3][TM]
   float* frec = (float*)(rowinfo + 6 * TM); // [G <= 2][4][64]: scale, shift, c0, c1 of this layer's BatchNorm backward
   float* xrec = frec + 512;                 // [G <= 2][2][64]: scale, shift of the previous layer's BatchNorm
+  unsigned* gtab = (unsigned*)(xrec + 256); // row tables of the tile whose rows are being requested: source side (gtab_build)
+  unsigned* ytab = gtab + GT_WORDS;         // ... and its own 128 positions in y_prev (ytab_build)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1192,9 +1266,11 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
     const int tile = tbase + k;
     const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;
     const int q0 = (tile - grp * P.tpg) * TM;
-    gather_request(rr, src_all + grp * P.src_gstride, fuse_all.y + grp * P.src_gstride, P.Hs, P.Ws, cls0, P, q0, nrows);
-    ytile_request(yr, fb.x + grp * P.dst_gstride, P, q0, true);
-    __syncthreads();  // frec / xrec are complete
+    gtab_build(gtab, P, q0, nrows);
+    ytab_build(ytab, P, q0, true);
+    __syncthreads();  // the tables, frec and xrec are complete
+    gather_request(rr, src_all + grp * P.src_gstride, fuse_all.y + grp * P.src_gstride, gtab, cls0, P.Ws);
+    ytile_request(yr, fb.x + grp * P.dst_gstride, ytab);
     gather_land_sum(As0, rr, nrows, frec + grp * 256, bs4);
     ytile_land(Ys, yr, xrec + grp * 128);
   }
@@ -1258,13 +1334,15 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
       if (ti == 6) gather_land_sum(As1, rr, nrows, lrec, bs4);
       if (ti == 8) gather_land_sum(As0, rr, nrows, frec + grp2 * 256, bs4);  // (past the last tile: every row masked off -> zeros; no
                                                                              // run-time branch around a landing, or its join costs a full vmcnt(0))
+      // the NEXT tile's row tables, between the last request of this tile (behind tap 4's second barrier) and the first of the next
+      // (tap 6); past the end: no rows -> every entry 0 -> every row reads pixel 0 and is dropped.  (Tap 5 has no landing.)
+      if (ti == 5) { gtab_build(gtab, P, q02, more ? nrows : 0); ytab_build(ytab, P, q02, more); }
       __syncthreads();
-      if (ti == 0) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls1, P, q0, nrows);
-      if (ti == 2) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls2, P, q0, nrows);
-      if (ti == 4) gather_request(rr, src, ysrc, P.Hs, P.Ws, cls3, P, q0, nrows);
-      if (ti == 6) gather_request(rr, src_all + grp2 * P.src_gstride, fuse_all.y + grp2 * P.src_gstride, P.Hs, P.Ws, cls0, P, q02,
-                                  more ? nrows : 0);
-      if (ti == 8) ytile_request(yr, fb.x + grp2 * P.dst_gstride, P, q02, more);
+      if (ti == 0) gather_request(rr, src, ysrc, gtab, cls1, P.Ws);
+      if (ti == 2) gather_request(rr, src, ysrc, gtab, cls2, P.Ws);
+      if (ti == 4) gather_request(rr, src, ysrc, gtab, cls3, P.Ws);
+      if (ti == 6) gather_request(rr, src_all + grp2 * P.src_gstride, fuse_all.y + grp2 * P.src_gstride, gtab, cls0, P.Ws);
+      if (ti == 8) ytile_request(yr, fb.x + grp2 * P.dst_gstride, ytab);
       __builtin_amdgcn_sched_barrier(0);
       {  // ---- data gradient: 32 positions x 32 channels of this wave
         const int R = arow0 + P.toff[ti];
@@ -1503,10 +1581,10 @@ __device__ __forceinline__ void rows64_load(f32x4 (&v)[NJ], unsigned& okmask, co
   for (int j = 0; j < J0 + NJ; ++j) {
     if (j >= J0) {
       v[j - J0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int y = a * stride + cy, x = b * stride + cx;
+      const int y = (a << (stride - 1)) + cy, x = (b << (stride - 1)) + cx;  // (stride is 1 or 2: a shift-add, not a quarter-rate multiply)
       const bool ok = (unsigned)(n1 - 1) < (unsigned)N1max && y < H && x < W;
       okmask |= (ok ? 1u : 0u) << j;
-      if (ok) v[j - J0] = *(const f32x4*)(src + ((((unsigned)(n1 - 1) * (unsigned)H + (unsigned)y) * (unsigned)W + (unsigned)x) * 64u + (unsigned)(slot * 4)));
+      if (ok) v[j - J0] = *(const f32x4*)(src + (mad_u24(mad_u24((unsigned)(n1 - 1), H, (unsigned)y), W, (unsigned)x) * 64u + (unsigned)(slot * 4)));
     }
     b += sb; a += sa;
     if (b >= PW) { b -= PW; ++a; }
@@ -1900,7 +1978,10 @@ static int program_for(ConvProg* P, const srlz_conv64_desc* d, int backward_data
   return 0;
 }
 
-static size_t fwd_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) * 256 + 16384 + 3 * TM * 4 + 256 * 4; }
+static size_t fwd_lds_bytes(const ConvProg& P) {  // source rows, slab, row table, rowinfo, fused-operand coefficients
+  return (size_t)(TM + P.span) * 256 + 16384 + (size_t)64 * rowtab_passes(TM + P.span) + TM * 4 + 256 * 4;
+}
+static size_t convn_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) * 256 + 16384 + 3 * TM * 4 + 256 * 4; }
 static size_t wgrad_lds_bytes(const ConvProg& P, int tk) { return (size_t)(tk + P.span + tk) * 256; }
 static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried: the extra staging registers spill
 
@@ -1909,6 +1990,11 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
   const int ntiles = P.G * P.tpg;
   const size_t lds = fwd_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64: tile needs %zu bytes of LDS", lds);
+  // the row table keeps pixel indices in 28 bits and the staging 32-bit float offsets; the fast divisions take dividends below 2^31
+  SRLZ_REQUIRE((long long)P.N * P.Hs * P.Ws * 64 < (1LL << 32) && (long long)P.N * P.Hd * P.Wd < (1LL << 29) &&
+                   (long long)P.total_q + P.PHW + TM + P.span < (1LL << 31),
+               SRLZ_ERR_BAD_DESC, "conv64: a group of %d images of %d x %d -> %d x %d is beyond the tile tables' 32-bit offsets", P.N, P.Hs,
+               P.Ws, P.Hd, P.Wd);
   if (psum) {  // data gradient whose epilogue takes the pooled block's BatchNorm-backward sums (its own instantiation)
     SRLZ_REQUIRE(!src_fuse.y && !src_fuse.bnp && stats && !bias, SRLZ_ERR_BAD_DESC, "conv64: the pooled-block epilogue takes a plain operand");
     bool one_class = true;
@@ -1943,7 +2029,7 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
     pgrid &= ~7;
     const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;  // buffer resources: 32-bit byte counts
     if (use_pipe && grouped && fits32 && !P.dbg && P.min_off == 0 && TM + P.span <= GP_RP * GP_BATCH && pgrid >= 8 && GP_RP <= P.PHW) {
-      const size_t plds = (size_t)(TM + P.span) * 256 + 16384 + 6 * TM * 4 + 2 * 256 * 4;
+      const size_t plds = (size_t)(TM + P.span) * 256 + 16384 + 6 * TM * 4 + 2 * 256 * 4 + GT_WORDS * 4;
       SRLZ_MAX_LDS(conv64_dgrad_pipe_kernel, plds);
       hipLaunchKernelGGL(conv64_dgrad_pipe_kernel, dim3(pgrid), dim3(GP_THREADS), plds, st, src, wpack, dst, P, ntiles, src_fuse);
       SRLZ_LAUNCHED();
@@ -2182,7 +2268,7 @@ extern "C" int srlz_convn_fwd(const float* x, const float* wpack, float* y, floa
   ConvProg P;
   if (int rc = convn_program(&P, d)) return rc;
   const int ntiles = P.tpg;
-  const size_t lds = fwd_lds_bytes(P);
+  const size_t lds = convn_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "convn: tile needs %zu bytes of LDS", lds);
   SRLZ_MAX_LDS(convN_fwd_kernel, lds);
   hipLaunchKernelGGL(convN_fwd_kernel, dim3(ntiles, d->cout / 64), dim3(256), lds, as_stream(stream), x, wpack, y, stats_partial, P,
@@ -2375,7 +2461,7 @@ extern "C" int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const f
   SRLZ_REQUIRE(ws_bytes >= (size_t)grid * (NTAPS * 4096 + 64) * sizeof(float), SRLZ_ERR_WORKSPACE,
                "conv64_bwd_fused: workspace too small (%zu bytes)", ws_bytes);
   hipStream_t st = as_stream(stream);
-  const size_t lds = (size_t)(TM + P.span) * 256 * 2 + (size_t)TM * 256 + 16384 + 6 * TM * 4 + 512 * 4 + 256 * 4;
+  const size_t lds = (size_t)(TM + P.span) * 256 * 2 + (size_t)TM * 256 + 16384 + 6 * TM * 4 + 512 * 4 + 256 * 4 + (GT_WORDS + YT_WORDS) * 4;
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64_bwd_fused: tile needs %zu bytes of LDS", lds);
   FusedBwd fb;
   fb.x = x; fb.x_bnp = x_bnp; fb.wpartial = (float*)ws;
