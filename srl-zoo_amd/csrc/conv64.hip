@@ -20,8 +20,8 @@
 // ds_read_b128: lanes 0-31 take k = 8c..8c+3 and lanes 32-63 k = 8c+4..8c+7 of a chunk (MFMA k-order is free as
 // long as A and B agree), so one 16-byte read feeds four MFMAs.  Rows are 256 B; the 16-byte slot index is XORed
 // with (row & 15) so a 16-lane ds_read_b128 group (consecutive rows, same k) covers all 64 banks.
-// LDS: (128+116)*256 + 16384 + 1536 + 1024 = 81408 B for conv2 (source rows, slab, row table, fused-operand coefficients) -> 2
-// workgroups per CU (81920 B each), which is what hides the staging.
+// LDS: (128+116)*256 + 16384 + 1024 + 512 + 1024 = 81408 B for conv2 (source rows, slab, the tile's row table, one word per output
+// position, fused-operand coefficients) -> 2 workgroups per CU (81920 B each), which is what hides the staging.
 // Epilogue: accumulators leave through a wave-private 4 KB transposition buffer (the wave's own quarter of the idle slab), so
 // that every global store is 16 bytes per lane (flush16).  See DESIGN.md 5.2 for what the generated ISA taught about this file.
 #include "common.h"

@@ -40,7 +40,8 @@ def out_size(hi, s, p, t):
 
 
 CONV64 = [(3, 56, 1, 1, 0), (3, 27, 2, 1, 0), (5, 6, 2, 0, 1), (3, 13, 2, 0, 1), (2, 27, 2, 0, 1), (2, 55, 2, 0, 1),
-          (1, 9, 1, 1, 0)]
+          (1, 9, 1, 1, 0),
+          (1, 80, 1, 1, 0)]  # 128 + 2 * 82 + 2 = 294 rows per tile: the row table's second batch of passes (rowtab_passes = 32)
 
 
 @pytest.mark.parametrize("n,hi,s,p,t", CONV64)
