@@ -5,8 +5,9 @@
 //   forward   : i=m, j=n, r=k : A = x  (sai=K, sar=1), B = w (sbr=1, sbj=K)
 //   data grad : i=m, j=k, r=n : A = dy (sai=N, sar=1), B = w (sbr=K, sbj=1)
 //   weight grad: i=n, j=k, r=m : A = dy (sai=1, sar=N), B = x (sbr=K, sbj=1)
-// 64x64 tile per workgroup, 4 waves = 4 quadrants of v_mfma_f32_32x32x2_f32, r-step 16 through LDS ([r][i] layout,
-// padded).  These GEMMs are tiny (M = batch); the kernel is deliberately simple.
+// 64x64 tile per workgroup, 4 waves = 4 quadrants of v_mfma_f32_32x32x2_f32.  Two kernels: gemm_vec_kernel (16-byte loads, r-steps
+// of 64, ds_read_b128 operands) for operands made of whole aligned float4s — the model's layers at their training shapes — and
+// gemm_strided_kernel (dword loads, r-steps of 32, [r][i] LDS layout) for everything else (e.g. K = 206 of the forward model).
 #include "common.h"
 
 namespace {
@@ -101,6 +102,119 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
   }
 }
 
+// The same GEMM for operands whose rows and leading dimensions are multiples of four floats (every nn.Linear of the model at its
+// training shapes; anything else takes gemm_strided_kernel): 16-byte global loads along whichever index is contiguous in memory,
+// r-steps of 64 (four 16-byte loads per thread and operand in flight while the previous step's 32 MFMAs per wave run — these GEMMs are
+// a handful of steps long, so what they wait for is memory latency, not the matrix pipe), and both LDS tiles kept [row][r] with r
+// contiguous so that one ds_read_b128 feeds four MFMAs (lanes 0-31 take r = 8c .. 8c+3, lanes 32-63 r = 8c+4 .. 8c+7 of a chunk:
+// the k-order of an MFMA is free as long as both operands agree — conv64.hip).  A row is 256 bytes; its 16-byte slot index is XORed with
+// key(row) = (row & 3) << 2 | (row >> 2) & 3, a permutation of row & 15: conflict-free for the readers (consecutive rows) and for the
+// transposing writers of an operand that is contiguous along its row index (rows 4 apart per lane).
+// AI / BI: operand A / B is contiguous along i / j (else along r).
+constexpr int TR = 64;
+__device__ __forceinline__ int tile_key(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <bool AI, bool BI>
+__global__ __launch_bounds__(256, 2) void gemm_vec_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
+                                                         long long ldb, const float* __restrict__ bias, float* __restrict__ C,
+                                                         int I, int J, int R, int relu, int rchunk) {
+  // lda / ldb: floats between two consecutive values of the operand's NON-contiguous index
+  __shared__ __attribute__((aligned(16))) float As[2][64 * TR];
+  __shared__ __attribute__((aligned(16))) float Bs[2][64 * TR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wi = wave & 1, wj = wave >> 1;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int rbeg = blockIdx.z * rchunk;
+  const int rend = (rbeg + rchunk < R) ? rbeg + rchunk : R;
+  C += (size_t)blockIdx.z * I * J;
+
+  f32x4 va[4], vb[4];
+  unsigned ina = 0, inb = 0;
+  // element u of a thread: e = tid + 256 u.  Contiguous along r: row = e >> 4, r = 4 (e & 15) .. + 3.  Contiguous along the row index:
+  // r = 4 (e >> 6) + (e & 3), rows 4 ((e >> 2) & 15) .. + 3 — four lanes take the same four rows at four consecutive r (their dword
+  // writes into the transposed tile then fall into different banks), sixteen lanes cover 64 contiguous bytes of four r.
+  auto fetch_one = [&](const float* __restrict__ P, long long ld, bool along_row, int row0, int nrow, int r0, f32x4 (&v)[4],
+                       unsigned& in) {
+    in = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      long long off;
+      bool ok;
+      if (!along_row) {
+        const int row = e >> 4, r = 4 * (e & 15);
+        ok = row0 + row < nrow && r0 + r < rend;
+        off = (long long)(row0 + row) * ld + (r0 + r);
+      } else {
+        const int r = 4 * (e >> 6) + (e & 3), row = 4 * ((e >> 2) & 15);
+        ok = row0 + row < nrow && r0 + r < rend;
+        off = (long long)(r0 + r) * ld + (row0 + row);
+      }
+      v[u] = *(const f32x4*)(P + (ok ? off : 0LL));  // branch-free: see gemm_strided_kernel
+      in |= (ok ? 1u : 0u) << u;
+    }
+  };
+  auto stash_one = [&](float* __restrict__ T, bool along_row, const f32x4 (&v)[4], unsigned in) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      const f32x4 x = ((in >> u) & 1u) ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!along_row) {
+        const int row = e >> 4, slot = e & 15;
+        *(f32x4*)(T + row * TR + ((slot ^ tile_key(row)) << 2)) = x;
+      } else {
+        const int r = 4 * (e >> 6) + (e & 3), row = 4 * ((e >> 2) & 15);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T[(row + c) * TR + ((((r >> 2) ^ tile_key(row + c)) << 2) | (r & 3))] = x[c];
+      }
+    }
+  };
+  fetch_one(A, lda, AI, i0, I, rbeg, va, ina);
+  fetch_one(B, ldb, BI, j0, J, rbeg, vb, inb);
+  stash_one(As[0], AI, va, ina);
+  stash_one(Bs[0], BI, vb, inb);
+  __syncthreads();
+  int buf = 0;
+  const int arow = wi * 32 + l31, brow = wj * 32 + l31;
+  const int akey = tile_key(arow), bkey = tile_key(brow);
+  for (int r0 = rbeg; r0 < rend; r0 += TR) {
+    // (past the last step the requests read element 0 and are dropped: no run-time branch around loads — see gemm_strided_kernel)
+    const int rn = (r0 + TR < rend) ? r0 + TR : rend;
+    fetch_one(A, lda, AI, i0, I, rn, va, ina);
+    fetch_one(B, ldb, BI, j0, J, rn, vb, inb);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* Ab = As[buf] + arow * TR;
+    const float* Bb = Bs[buf] + brow * TR;
+#pragma unroll
+    for (int c = 0; c < TR / 8; ++c) {
+      const f32x4 a = *(const f32x4*)(Ab + (((2 * c + h) ^ akey) << 2));
+      const f32x4 b = *(const f32x4*)(Bb + (((2 * c + h) ^ bkey) << 2));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m], acc, 0, 0, 0);
+    }
+    stash_one(As[buf ^ 1], AI, va, ina);  // nobody reads buf^1 during this step (the barrier below closed the previous one)
+    stash_one(Bs[buf ^ 1], BI, vb, inb);
+    __syncthreads();
+    buf ^= 1;
+  }
+  const int j = j0 + wj * 32 + l31;
+  float bj = bias ? bias[j < J ? j : 0] : 0.f;
+  asm volatile("" : "+v"(bj));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (i < I && j < J) {
+      float v = acc[r] + bj;
+      if (relu) v = v > 0.f ? v : 0.f;
+      C[(long long)i * J + j] = v;
+    }
+  }
+}
+
 // C[e] = sum_z partial[z][e] (+ bias[e % J]) (+ ReLU), fixed order
 __global__ void splitk_combine_kernel(const float* __restrict__ partial, int nsplit, const float* __restrict__ bias,
                                       float* __restrict__ C, int I, int J, int relu) {
@@ -142,35 +256,60 @@ __global__ void relu_bwd_kernel(const float* __restrict__ y, float* __restrict__
 
 // Few output tiles + a long reduction (e.g. Linear(2304, 200) at batch 256: 16 tiles, R = 2304) would leave most CUs
 // idle: split the reduction over blockIdx.z into `ws` and combine in a fixed order (deterministic, no atomics).
-static int choose_splits(int I, int J, int R, size_t ws_bytes) {
+static int choose_splits(int I, int J, int R, size_t ws_bytes, bool vec) {
   const int tiles = ((I + 63) / 64) * ((J + 63) / 64);
   if (tiles >= 96 || R < 512) return 1;
-  int s = 256 / tiles;
+  // (the vector kernel: two workgroups per CU and at least two of its 64-wide steps per split)
+  int s = (vec ? 512 : 256) / tiles;
   if (s > R / 128) s = R / 128;
   if (s > 16) s = 16;
   while (s > 1 && (size_t)s * I * J * sizeof(float) > ws_bytes) --s;
   return s < 1 ? 1 : s;
 }
 
+// gemm_vec_kernel takes the call when every 16-byte access it makes is aligned and whole
+static bool vec_ok(const float* P, long long s_row, long long s_r, int nrow, int R, bool* along_row, long long* ld) {
+  if (((uintptr_t)P & 15) != 0 || R % 4 != 0) return false;
+  if (s_r == 1 && s_row % 4 == 0) { *along_row = false; *ld = s_row; return true; }
+  if (s_row == 1 && s_r % 4 == 0 && nrow % 4 == 0) { *along_row = true; *ld = s_r; return true; }
+  return false;
+}
+
 static int launch(const float* A, long long sai, long long sar, const float* B, long long sbr, long long sbj,
                   const float* bias, float* C, int I, int J, int R, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
   SRLZ_REQUIRE(I > 0 && J > 0 && R > 0, SRLZ_ERR_BAD_DESC, "linear: empty GEMM %dx%dx%d", I, J, R);
-  const int splits = ws ? choose_splits(I, J, R, ws_bytes) : 1;
-  if (splits == 1) {
-    hipLaunchKernelGGL(gemm_strided_kernel, dim3((J + 63) / 64, (I + 63) / 64, 1), dim3(256), 0, st, A, sai, sar, B, sbr,
-                       sbj, bias, C, I, J, R, relu, R);
-    SRLZ_LAUNCHED();
-    return 0;
+  bool ai = false, bi = false;
+  long long lda = 0, ldb = 0;
+  const bool vec = vec_ok(A, sai, sar, I, R, &ai, &lda) && vec_ok(B, sbj, sbr, J, R, &bi, &ldb);
+  const int step = vec ? TR : BR;
+  int splits = ws ? choose_splits(I, J, R, ws_bytes, vec) : 1;
+  int rchunk = R, nz = 1;
+  if (splits > 1) {
+    rchunk = (R + splits - 1) / splits;
+    rchunk = (rchunk + step - 1) / step * step;
+    nz = (R + rchunk - 1) / rchunk;
   }
-  int rchunk = (R + splits - 1) / splits;
-  rchunk = (rchunk + BR - 1) / BR * BR;
-  const int nz = (R + rchunk - 1) / rchunk;
-  hipLaunchKernelGGL(gemm_strided_kernel, dim3((J + 63) / 64, (I + 63) / 64, nz), dim3(256), 0, st, A, sai, sar, B, sbr,
-                     sbj, (const float*)nullptr, (float*)ws, I, J, R, 0, rchunk);
+  const dim3 grid((J + 63) / 64, (I + 63) / 64, nz);
+  const float* kbias = nz > 1 ? nullptr : bias;
+  float* kC = nz > 1 ? (float*)ws : C;
+  const int krelu = nz > 1 ? 0 : relu;
+  if (vec) {
+#define SRLZ_VEC_LAUNCH(AIV, BIV) \
+    hipLaunchKernelGGL((gemm_vec_kernel<AIV, BIV>), grid, dim3(256), 0, st, A, lda, B, ldb, kbias, kC, I, J, R, krelu, rchunk)
+    if (ai && bi) SRLZ_VEC_LAUNCH(true, true);
+    else if (ai) SRLZ_VEC_LAUNCH(true, false);
+    else if (bi) SRLZ_VEC_LAUNCH(false, true);
+    else SRLZ_VEC_LAUNCH(false, false);
+#undef SRLZ_VEC_LAUNCH
+  } else {
+    hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, st, A, sai, sar, B, sbr, sbj, kbias, kC, I, J, R, krelu, rchunk);
+  }
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(splitk_combine_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, (const float*)ws, nz, bias, C, I, J,
-                     relu);
-  SRLZ_LAUNCHED();
+  if (nz > 1) {
+    hipLaunchKernelGGL(splitk_combine_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, (const float*)ws, nz, bias, C, I, J,
+                       relu);
+    SRLZ_LAUNCHED();
+  }
   return 0;
 }
 
