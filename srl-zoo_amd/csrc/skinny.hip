@@ -68,22 +68,26 @@ template <int K, int TR = 16>
 struct ImgRegs {
   static constexpr int TOT = 3 * Geo<K, TR>::ROWS * Geo<K, TR>::COLS;
   static constexpr int PER = (TOT + 255) / 256;
-  int pk[PER];       // (c << 12) | (row << 6) | xl, or -1 past the end of the window
+  int pk[PER];       // (LDS offset of the element << 14) | (c << 12) | (row << 6) | xl, or -1 past the end of the window
   float v[PER];      // raw loads (from a clamped address when the element is outside the image)
   unsigned inside;   // bit j: element j is inside the image; applied when the value LANDS — a select (or a branch merge) at the
                      // request would make the compiler wait for the load right there, and nothing would travel under the MFMAs
 };
 
-template <int K, int TR = 16>
+// XPV / PPV: row pitch and (channel, column-parity) plane pitch of the LDS tile the elements will land in (image_land): the element's
+// offset in it is tile-independent too and rides in the upper bits — one shift at the landing instead of eight instructions
+template <int K, int TR = 16, int XPV = XP, int PPV = Geo<K, TR>::PP>
 __device__ __forceinline__ void image_index(ImgRegs<K, TR>& r) {
   constexpr int ROWS = Geo<K, TR>::ROWS, COLS = Geo<K, TR>::COLS, TOT = ImgRegs<K, TR>::TOT;
+  static_assert(6 * PPV < (1 << 17), "the LDS offset has 17 bits in pk");
 #pragma unroll
   for (int j = 0; j < ImgRegs<K, TR>::PER; ++j) {
     const int idx = threadIdx.x + 256 * j;
     const int c = idx / (ROWS * COLS);
     const int rem = idx - c * (ROWS * COLS);
     const int row = rem / COLS, xl = rem - row * COLS;
-    r.pk[j] = idx < TOT ? ((c << 12) | (row << 6) | xl) : -1;
+    const int dst = (c * 2 + (xl & 1)) * PPV + row * XPV + (xl >> 1);
+    r.pk[j] = idx < TOT ? ((dst << 14) | (c << 12) | (row << 6) | xl) : -1;
   }
 }
 
@@ -102,7 +106,7 @@ __device__ __forceinline__ bool image_decode(const ImgRegs<K, TR>& r, int j, int
   }
   int pk = r.pk[j];
   asm volatile("" : "+v"(pk));
-  c = pk >> 12; row = (pk >> 6) & 63; xl = pk & 63;
+  c = (pk >> 12) & 3; row = (pk >> 6) & 63; xl = pk & 63;
   return pk >= 0;
 }
 
@@ -161,7 +165,10 @@ __device__ __forceinline__ void image_land(float* __restrict__ T, const ImgRegs<
     // (branch-free — elements past the end of the window go to a spare float of the first plane's padding: a wait inside a branch
     // leaves the compiler unsure, at the join, whether the load has landed, and it then waits for EVERYTHING at the next re-use
     // of the register, including the loads meant to stay in flight)
-    T[live ? (c * 2 + (xl & 1)) * PPV + row * XPV + (xl >> 1) : PPV - 1] = ((r.inside >> j) & 1u) ? val[j] : 0.f;
+    int dst;
+    if constexpr (HOIST) dst = (c * 2 + (xl & 1)) * PPV + row * XPV + (xl >> 1);
+    else { dst = r.pk[j]; asm volatile("" : "+v"(dst)); dst >>= 14; }  // (image_index was given this tile's pitches)
+    T[live ? dst : PPV - 1] = ((r.inside >> j) & 1u) ? val[j] : 0.f;
   }
 }
 
@@ -559,6 +566,9 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
   f32x4 dpv[FUSED ? 2 : 1][2];
   uint32_t am[FUSED ? 2 : 1][2];
   unsigned wmask = 0;  // bit 2wy+wx: window (wy, wx) exists
+  // (wave-uniform) every pooling window the requested stage looks at lies inside the pooled map — true for all but the last row and
+  // column of tiles, and then f_resolve skips their masking.  (The same for the pixel mask measured as nothing: hipcc if-converts it.)
+  bool all_win = false;
   // FUSED thread mapping: a thread owns a 2x2 block of pixels of the 4x16 stage — rows 2*brow + i, columns 2*bcol + j — and the
   // 2x2 pooling windows that can have picked them (3x3, stride 2, pad 1: window (R + wy, Cx + wx) sees pixel (2R + i, 2Cx + j) at
   // ky = i - 2wy + 1, kx = j - 2wx + 1), i.e. 9 membership tests with compile-time codes for 4 pixels on EVERY lane.  (One column
@@ -572,6 +582,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
     const float* __restrict__ fsrc = FUSED ? pf.y : feat;
     pmask = 0;
     if constexpr (FUSED) {
+      all_win = live && ((oy0_ + RPS * half_) >> 1) + RPS / 2 < pf.HP && (ox0_ >> 1) + 8 < pf.WP;
       const int oyb = oy0_ + RPS * half_ + 2 * brow, oxb = ox0_ + 2 * bcol;  // both even
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -610,7 +621,13 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
 #pragma unroll
       for (int wy = 0; wy < 2; ++wy)
 #pragma unroll
-        for (int wx = 0; wx < 2; ++wx) a[wy][wx] = ((wmask >> (2 * wy + wx)) & 1u) ? am[wy][wx] : 0xffffffffu;  // 0xff matches nothing
+        for (int wx = 0; wx < 2; ++wx) a[wy][wx] = am[wy][wx];
+      if (!all_win) {
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+          for (int wx = 0; wx < 2; ++wx) a[wy][wx] = ((wmask >> (2 * wy + wx)) & 1u) ? am[wy][wx] : 0xffffffffu;  // 0xff matches nothing
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_kernel(const PT* __restri
     }
   };
   ImgRegs<K> ir;  // the image window of the next tile, requested during the last stage of this one
-  image_index<K>(ir);
+  image_index<K, 16, WXP, WPP>(ir);
   auto i_request = [&](int tile_) {
     const int n_ = tile_ / tpi;
     const int trem_ = tile_ - n_ * tpi;
