@@ -103,4 +103,8 @@ def test_every_switch_lands_where_the_default_path_lands(losses, tmp_path):
         # Adam turns a 1e-6 gradient difference at a rounding-noise element into a +-lr step: bound the parameters by a few lr
         assert float(np.abs(p - pref).max()) <= 4e-3 * scale, (name, float(np.abs(p - pref).max()), scale)
         assert float(np.abs(p - pref).mean()) <= 2e-5 * scale, (name, float(np.abs(p - pref).mean()))
-        np.testing.assert_allclose(got["bufs"], ref["bufs"], rtol=1e-3, err_msg=name)
+        # (sums of |running_mean| / running_var over a layer's 64 channels, and the step counts.  The bias of a ConvTranspose in front of
+        # a training-mode BatchNorm has a gradient that is rounding noise — the normalisation removes the mean — so Adam moves it by
+        # +-lr per step on whichever side the noise falls, and the layer's batch means move with it: 64 channels x lr 1e-3 x momentum
+        # 0.1 x 2 steps bounds what two summation orders can differ by in such a sum, a few 1e-3 absolute)
+        np.testing.assert_allclose(got["bufs"], ref["bufs"], rtol=1e-3, atol=5e-3, err_msg=name)
