@@ -1536,6 +1536,192 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Weight-gradient kernel of the stride-2 GATHER programs (conv3: four source classes in tap groups {4, 2, 2, 1}, one destination
+// class), software-pipelined.  conv64_wgrad_kernel<true> stages each class synchronously between two barriers — four HBM round
+// trips per 64-position chunk in front of 128 / 64 / 64 / 32 MFMAs per wave — and walks (image, row, column) for every staged row
+// (~30 vector-ALU instructions per row, 24 rows per thread and chunk against 288 MFMAs).  Here
+//  * the rows of the NEXT group's class (the next chunk's class 0 and gradient rows behind the last group) are requested into
+//    registers right after the barrier that opens a group's MFMA loop and land in LDS behind the barrier that closes it;
+//  * a chunk's rows are decomposed once, into two small tables (source side: rowtab_build; gradient side below), rebuilt for the next
+//    chunk in the inter-barrier section of the last group, when nobody reads them.
+// Same chunks per workgroup, same MFMA order, same partial layout as conv64_wgrad_kernel<true, 64>: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WG_TK = 64;           // positions per chunk
+constexpr int WG_SROWS = 8;         // source rows per thread: WG_TK + span <= 128
+constexpr int WG_SWORDS = 16 * WG_SROWS, WG_GWORDS = 16 * 4;
+
+// gradient side: entry of row R of the chunk at (R & 15) * 4 + (R >> 4) = pixel index << 1 | 1 (0: outside the tensor)
+__device__ __forceinline__ void wg_gtab_build(unsigned* __restrict__ tab, const ConvProg& P, int q0) {
+  int R = (int)threadIdx.x - 128;  // (threads 128 .. 191; the source table is built by threads 0 .. 127)
+  asm volatile("" : "+v"(R));
+  if ((unsigned)R < (unsigned)WG_GWORDS) {
+    const int q = q0 + R;
+    unsigned e = 0;
+    if (q < P.total_q) {
+      const int n = fastdiv(q, P.mPHW, P.sPHW);
+      const int rem = q - n * P.PHW;
+      const int a = fastdiv(rem, P.mPW, P.sPW);
+      const int ya = a * P.ds, xb = (rem - a * P.PW) * P.ds;
+      if (ya < P.Hd && xb < P.Wd) e = ((unsigned)((n * P.Hd + ya) * P.Wd + xb) << 1) | 1u;
+    }
+    tab[(R & 15) * 4 + (R >> 4)] = e;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv64_wgrad_gather_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                    float* __restrict__ partial, const ConvProg P, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int srows = WG_TK + P.span;
+  float* Ss = (float*)smem;                    // (WG_TK + span) x 64: the rows of the current source class
+  float* Gs = Ss + srows * 64;                 // WG_TK x 64: the chunk's gradient rows
+  unsigned* stab = (unsigned*)(Gs + WG_TK * 64);  // [16][WG_SROWS]
+  unsigned* gtab = stab + WG_SWORDS;              // [16][4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mi = wave & 1, nj = wave >> 1;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  constexpr int GSTART[5] = {0, 4, 6, 8, 9};
+  const int cpg = nchunks / P.G;
+  f32x4 sv[WG_SROWS], gv[4];
+  unsigned sok = 0, gok = 0;
+
+  // rows of source class `cls` of the chunk whose table is in stab -> registers (branch-free; masks applied at the landing)
+  auto s_request = [&](const float* __restrict__ xg, int cls) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int slot = t & 15;
+    const unsigned delta = (unsigned)((cls >> 1) * P.Ws + (cls & 1));
+    const unsigned* __restrict__ tp = stab + (t >> 4) * WG_SROWS;
+    const uint4 e0 = *(const uint4*)tp, e1 = *(const uint4*)(tp + 4);
+    const unsigned e[WG_SROWS] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    sok = 0;
+#pragma unroll
+    for (int j = 0; j < WG_SROWS; ++j) {
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)e[j], (unsigned)cls, 1u);
+      sv[j] = *(const f32x4*)(xg + (((((e[j] >> 4) + delta) << 6) & m) + slot * 4));
+      sok |= m & (1u << j);
+    }
+  };
+  auto g_request = [&](const float* __restrict__ gg, bool live) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int slot = t & 15;
+    const uint4 q = *(const uint4*)(gtab + (t >> 4) * 4);
+    const unsigned e[4] = {q.x, q.y, q.z, q.w};
+    gok = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gv[j] = *(const f32x4*)(gg + (((e[j] >> 1) << 6) + slot * 4));
+      gok |= (live ? (e[j] & 1u) : 0u) << j;
+    }
+  };
+  auto s_land = [&]() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int slot = t & 15, r = t >> 4;
+#pragma unroll
+    for (int j = 0; j < WG_SROWS; ++j) {
+      const int R = r + 16 * j;
+      const f32x4 v = ((sok >> j) & 1u) ? sv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (R < srows) *(f32x4*)(Ss + R * 64 + slot * 4) = v;  // (an LDS write only: no vector-memory operation in a branch)
+    }
+  };
+  auto g_land = [&]() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int slot = t & 15, r = t >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)(Gs + (r + 16 * j) * 64 + slot * 4) = ((gok >> j) & 1u) ? gv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto tables = [&](int q0, bool live) {
+    // (no rows for a chunk past the end: every entry 0 -> every row reads pixel 0 and lands as zeros)
+    if (tid < 128) rowtab_build(stab, WG_SROWS, P, q0 + P.min_off, live ? srows : 0);
+    wg_gtab_build(gtab, P, live ? q0 : P.total_q);
+  };
+
+  int chunk = blockIdx.x;
+  if (chunk < nchunks) {  // the first chunk's class 0 and gradient rows are staged the plain way
+    const int grp = (P.G > 1) ? chunk / cpg : 0;
+    tables((chunk - grp * cpg) * WG_TK, true);
+    __syncthreads();
+    s_request(x + grp * P.src_gstride, P.tsrc[0]);
+    g_request(g + grp * P.dst_gstride, true);
+  }
+  for (; chunk < nchunks; chunk += gridDim.x) {
+    const int grp = (P.G > 1) ? chunk / cpg : 0;
+    const float* __restrict__ xg = x + grp * P.src_gstride;
+    const int chunk2 = chunk + (int)gridDim.x;
+    const bool more = chunk2 < nchunks;
+    const int grp2 = (P.G > 1 && more) ? chunk2 / cpg : grp;
+    const int q02 = ((more ? chunk2 : chunk) - grp2 * cpg) * WG_TK;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int t0 = GSTART[gi], t1 = GSTART[gi + 1];
+      __syncthreads();  // every wave is done with the previous group's Ss (and, at gi == 0, with the previous chunk's Gs)
+      s_land();
+      if (gi == 0) g_land();
+      if (gi == 3) tables(q02, more);  // (the last request through this chunk's tables went out behind the previous barrier)
+      __syncthreads();
+      if (gi < 3) s_request(xg, P.tsrc[GSTART[gi + 1]]);
+      else {
+        s_request(x + grp2 * P.src_gstride, P.tsrc[0]);
+        g_request(g + grp2 * P.dst_gstride, more);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the requests go out HERE, ahead of the group's MFMAs
+      if (gi == 0) {
+        const int col = tid & 63, part = tid >> 6;
+#pragma unroll
+        for (int r = 0; r < WG_TK / 4; ++r) bsum += Gs[(part * (WG_TK / 4) + r) * 64 + col];
+      }
+      const float* gcol = Gs + h * 64 + nj * 32 + l31;
+      const float* scol = Ss + h * 64 + mi * 32 + l31;
+#pragma unroll 2
+      for (int b = 0; b < WG_TK / 8; ++b) {
+        float bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = gcol[(8 * b + 2 * i) * 64];
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {
+          const float* ap = scol + (8 * b + P.toff[t] - P.min_off) * 64;
+          float af[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i] = ap[2 * i * 64];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * (NTAPS * 4096);
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t) {
+    float* o = out + (size_t)P.tw[t] * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      o[row * 64 + nj * 32 + l31] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  float* red = Ss;
+  red[tid] = bsum;
+  __syncthreads();
+  if (tid < 64) {
+    float* bout = partial + (size_t)gridDim.x * (NTAPS * 4096) + (size_t)blockIdx.x * 64;
+    bout[tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Weight-gradient kernel, ring version (programs with ONE source class: stride-1 conv, transposed conv).
 // Same GEMM as above, but
 //  * a workgroup walks a CONTIGUOUS range of chunks and keeps the source rows in a 256-row LDS ring: consecutive
@@ -2056,6 +2242,16 @@ static int make_bwd_fuse(OpFuse* f, const srlz_bn_bwd_operand* o, const char* wh
 }
 
 // workgroups of the weight-gradient kernels (all groups together); a multiple of P.G
+// conv64_wgrad_gather_kernel: four source classes in tap groups {4, 2, 2, 1}, one destination class, chunk + halo within its registers,
+// 32-bit offsets
+static bool wgrad_gather_ok(const ConvProg& P) {
+  static const int on = [] { const char* e = getenv("SRLZ_WGRAD_GATHER_PIPE"); return e ? atoi(e) : 1; }();
+  bool grouped = on && P.s2 && P.ss == 2 && !P.dbg;
+  for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
+  return grouped && WG_TK + P.span <= 16 * WG_SROWS && (long long)P.N * P.Hs * P.Ws * 64 < (1LL << 32) &&
+         (long long)P.N * P.Hd * P.Wd * 64 < (1LL << 32) && (long long)P.total_q + P.PHW + WG_TK + P.span < (1LL << 31);
+}
+
 static int wgrad_grid(const ConvProg& P) {
   const int tk = wgrad_tk(P);
   const int nchunks = (P.total_q + tk - 1) / tk;  // per group
@@ -2397,6 +2593,11 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
       SRLZ_MAX_LDS(conv64_wgrad_ring_kernel<false>, lds);
       hipLaunchKernelGGL((conv64_wgrad_ring_kernel<false>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, wpg, x_bnp);
     }
+  } else if (wgrad_gather_ok(P) && x_bnp == nullptr && gf.y == nullptr && tk == WG_TK) {
+    // stride-2 gather programs (conv3): the software-pipelined kernel; same grid, same partials as conv64_wgrad_kernel<true, 64>
+    const size_t lds = (size_t)(WG_TK + P.span + WG_TK) * 256 + (WG_SWORDS + WG_GWORDS) * 4;
+    SRLZ_MAX_LDS(conv64_wgrad_gather_kernel, lds);
+    hipLaunchKernelGGL(conv64_wgrad_gather_kernel, dim3(grid), dim3(256), lds, st, x, dy, partial, P, nchunks * P.G);
   } else {
     const size_t lds = wgrad_lds_bytes(P, tk);
     SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64 wgrad: chunk needs %zu bytes of LDS", lds);
