@@ -472,6 +472,7 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
   for (int j = 0; j < NACC; ++j) bcol[j] = bias ? bias[(wcol * NACC + j) * 32 + l31] : 0.f;
 
   int cur_src = -1, cur_dst = -1;
+  bool pz_new = false;  // (PSUM == 2) a destination class opened at this tap: its pooled values are still to be requested
 
   // PSUM: the pooled value z = relu(gamma * xhat + beta), so where it is positive xhat = (z - beta) / gamma = z * pA + pB with
   // pA = invstd / scale, pB = -(shift / scale + mean) * invstd — one fused multiply-add per element, for this lane's four channels of
@@ -530,9 +531,8 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
     const unsigned ddelta = (unsigned)((d >> 1) * P.Wd + (d & 1));
     float* S = Bs + wave * 1024;
     const int eg = lane >> 4, eslot = lane & 15;
-    // PSUM == 2: the pooled values are requested here, up front; PSUM == 1: they were requested before the tile's first tap.
-    // Either way they are waited for once, in straight-line code, before the first conditional store
-    if constexpr (PSUM == 2) pz_request(d);
+    // The pooled values were requested before the first tap of this destination class (PSUM == 1: the tile's only one) and have
+    // travelled under its MFMAs; they are waited for once, in straight-line code, before the first conditional store
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -644,6 +644,7 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
       for (int j = 0; j < NACC; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      if constexpr (PSUM == 2) pz_new = true;
       cur_dst = tdst;
     }
     if (tsrc != cur_src) {
@@ -660,6 +661,12 @@ __device__ __forceinline__ void conv64_fwd_body(const float* __restrict__ src, c
       f32x4* wdst = (f32x4*)Bs;
 #pragma unroll
       for (int i = 0; i < BV; ++i) wdst[bslot + i * 64] = breg[i];
+    }
+    if constexpr (PSUM == 2) {
+      // Several destination classes: the pooled values of the class that opens at this tap, for the flush that will close it.
+      // Requested inside that flush they were one exposed HBM round trip per class and tile; requested here — BEHIND the slab write,
+      // whose wait for the slab registers would otherwise wait for these younger loads too — they travel under the class's MFMAs.
+      if (pz_new) { pz_request(cur_dst); pz_new = false; }
     }
     __syncthreads();
     if (BWD ? ti + 1 < NTAPS : true) {  // (never a run-time condition: behind the join of a branch with loads in it hipcc waits for
