@@ -2252,8 +2252,7 @@ static int make_bwd_fuse(OpFuse* f, const srlz_bn_bwd_operand* o, const char* wh
 // conv64_wgrad_gather_kernel: four source classes in tap groups {4, 2, 2, 1}, one destination class, chunk + halo within its registers,
 // 32-bit offsets
 static bool wgrad_gather_ok(const ConvProg& P) {
-  static const int on = [] { const char* e = getenv("SRLZ_WGRAD_GATHER_PIPE"); return e ? atoi(e) : 1; }();
-  bool grouped = on && P.s2 && P.ss == 2 && !P.dbg;
+  bool grouped = P.s2 && P.ss == 2 && !P.dbg;
   for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
   return grouped && WG_TK + P.span <= 16 * WG_SROWS && (long long)P.N * P.Hs * P.Ws * 64 < (1LL << 32) &&
          (long long)P.N * P.Hd * P.Wd * 64 < (1LL << 32) && (long long)P.total_q + P.PHW + WG_TK + P.span < (1LL << 31);
