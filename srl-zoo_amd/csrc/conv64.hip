@@ -1745,7 +1745,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_gather_kernel(const float
 // not the matrix pipe, bounded the loop: 113 TF with every load and barrier removed.)
 // RING_ROWS >= TK + span + TK (the prefetched TK rows are written only after the readers' barrier).
 template <int V> struct IntC { static constexpr int value = V; };
-constexpr int RING_ROWS = 248, RING_MIRROR = 8, RING = RING_ROWS + RING_MIRROR;
+constexpr int RING_ROWS = 246, RING_MIRROR = 8, RING = RING_ROWS + RING_MIRROR;  // (246 + 8 + 64 rows + 2 rows of tables = 80 KB)
 // the stride-2 (ConvTranspose) kernel walks 32-position chunks: RING_ROWS_S2 >= 32 + span + 32, and 4 x 32 gradient rows next to it
 constexpr int RING_ROWS_S2 = 184, RING_S2 = RING_ROWS_S2 + RING_MIRROR;
 template <int ROWS = RING_ROWS>
@@ -1818,6 +1818,37 @@ __device__ __forceinline__ void rows64_store(float* __restrict__ lds, int rbase,
   }
 }
 
+// The 64 rows a chunk of conv64_wgrad_ring_kernel<false> requests per operand, decomposed ONCE (rows64_load does it per row and thread:
+// ~22 vector-ALU instructions per row, 8 rows per thread and chunk next to 288 MFMAs): entry of row R at (R & 15) * 4 + (R >> 4) =
+// pixel index << 1 | 1, 0 = outside the tensor.  One wave builds one table (lane = row).
+__device__ __forceinline__ void ring_tab_build(unsigned* __restrict__ tab, const ConvProg& P, int H, int W, int stride, int cls,
+                                               int qstart, int R) {
+  const int qq = qstart + R + P.PHW;  // shifted by one image: non-negative for the first rows of the first chunk
+  const int n1 = fastdiv(qq, P.mPHW, P.sPHW);
+  const int rem = qq - n1 * P.PHW;
+  const int a = fastdiv(rem, P.mPW, P.sPW);
+  const int y = (a << (stride - 1)) + (cls >> 1), x = ((rem - a * P.PW) << (stride - 1)) + (cls & 1);
+  const bool ok = (unsigned)(n1 - 1) < (unsigned)P.N && y < H && x < W;
+  tab[(R & 15) * 4 + (R >> 4)] = ok ? ((unsigned)(((n1 - 1) * H + y) * W + x) << 1) | 1u : 0u;
+}
+
+// rows64_load through such a table (same loads, same zeros for rows outside)
+__device__ __forceinline__ void rows64_load_tab(f32x4 (&v)[4], unsigned& okmask, const float* __restrict__ src,
+                                                const unsigned* __restrict__ tab) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const float* __restrict__ base = src + (t & 15) * 4;
+  const uint4 q = *(const uint4*)(tab + (t >> 4) * 4);
+  const unsigned e[4] = {q.x, q.y, q.z, q.w};
+  okmask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    okmask |= (e[j] & 1u) << j;
+    if (e[j] & 1u) v[j] = *(const f32x4*)(base + ((e[j] & ~1u) << 5));  // (pixel index * 64 floats)
+  }
+}
+
 template <bool S2>
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ g,
@@ -1829,11 +1860,21 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Ss = (float*)smem;        // ring: source row q lives at slot (q & 255)
   float* Gs = Ss + RING * 64;      // TK x 64: gradient rows of the current (chunk, destination class)
+  unsigned* tabx = (unsigned*)(Gs + TK * 64);  // (!S2) the 64 new source rows / the 64 gradient rows the current chunk requests
+  unsigned* tabg = tabx + 64;                  //       (ring_tab_build)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int mi = wave & 1, nj = wave >> 1;
+  // the tables of the requests chunk `c` makes: its successor's 64 new source rows and 64 gradient rows; waves 0 / 1 build one each
+  auto next_tables = [&](int c) {
+    if constexpr (!S2) {
+      const int q0 = c * TK;
+      if (wave == 0) ring_tab_build(tabx, P, P.Hs, P.Ws, P.ss, P.tsrc[0], q0 + P.min_off + TK + P.span, lane);
+      if (wave == 1) ring_tab_build(tabg, P, P.Hd, P.Wd, P.ds, P.tdst[0], q0 + TK, lane);
+    }
+  };
 
   f32x16 acc[NTAPS];
 #pragma unroll
@@ -1867,6 +1908,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
     rows64_load(v, ok, g, P.Hd, P.Wd, P.ds, P.tdst[0], P.PW, P.PH, P.total_q, q0, grid_div(P));
     rows64_store<false>(Gs, 0, v, ok, noq);
     bs4 += (v[0] + v[1]) + (v[2] + v[3]);  // (rows outside the tensor are zero)
+    next_tables(c_begin);
   }
   __syncthreads();
 
@@ -1892,9 +1934,13 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
         const int nq0 = last_group ? q0 + TK : q0;
         constexpr int ntap = last_group ? 0 : GSTART[gi + 1];  // first tap of the next class
         const int ncls = P.tdst[ntap];
-        rows64_load(pg, okg, g, P.Hd, P.Wd, P.ds, ncls, P.PW, P.PH, P.total_q, nq0, grid_div(P));
+        if constexpr (S2) rows64_load(pg, okg, g, P.Hd, P.Wd, P.ds, ncls, P.PW, P.PH, P.total_q, nq0, grid_div(P));
+        else rows64_load_tab(pg, okg, g, tabg);  // (one group per chunk: nq0 = q0 + TK, what next_tables(chunk) decomposed)
       }
-      if (want_s) rows64_load<SJ0, SNJ>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span, grid_div(P));
+      if (want_s) {
+        if constexpr (S2) rows64_load<SJ0, SNJ>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span, grid_div(P));
+        else rows64_load_tab(ps, oks, x, tabx);
+      }
       // ---- this group's work
       // 8 blocks of 4 k-steps; k-step i of block b multiplies grid rows q0 + 8b + 2i + h.  Per tap the ring slot of row
       // q0 + toff + 8b is wave-uniform (u[t], wrapped with scalar instructions); the 4 rows of a lane are u + h + {0,2,4,6}
@@ -1932,6 +1978,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
         bs4 += (pg[0] + pg[1]) + (pg[2] + pg[3]);
       }
       if (want_s) rows64_store<true, SJ0, SNJ>(Ss, q0 + P.min_off + TK + P.span, ps, oks, xq);
+      if (!last_chunk) next_tables(chunk + 1);  // (this chunk's requests have been issued — and their table reads returned — long ago)
       __syncthreads();
     };
     group(IntC<0>{});
@@ -2585,13 +2632,15 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
     const size_t lds = (size_t)(RING_S2 + 4 * 32) * 256;
     SRLZ_MAX_LDS(conv64_wgrad_ring_s2_kernel, lds);
     hipLaunchKernelGGL(conv64_wgrad_ring_s2_kernel, dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nch, cpw, wpg, x_bnp);
-  } else if (use_ring && single_src && gf.y == nullptr && tk + P.span + tk <= RING_ROWS && tk == 64) {
+  } else if (use_ring && single_src && gf.y == nullptr && tk + P.span + tk <= RING_ROWS && tk == 64 &&
+             (long long)P.N * P.Hs * P.Ws * 64 < (1LL << 32) && (long long)P.N * P.Hd * P.Wd * 64 < (1LL << 32) &&
+             (long long)P.total_q + 2 * P.PHW < (1LL << 31)) {  // (the row tables of the stride-1 kernel: 32-bit offsets)
     // contiguous chunk ranges per workgroup (ring re-use of the source rows), group by group
     const int gpg = grid / P.G;
     const int cpw = (nchunks + gpg - 1) / gpg;
     const int wpg = (nchunks + cpw - 1) / cpw;
     launched_grid = wpg * P.G;
-    const size_t lds = (size_t)(RING + 64) * 256;
+    const size_t lds = (size_t)(RING + 64) * 256 + 2 * 64 * 4;  // ring + gradient rows + the two row tables = 80 KB
     if (P.s2) {
       SRLZ_MAX_LDS(conv64_wgrad_ring_kernel<true>, lds);
       hipLaunchKernelGGL((conv64_wgrad_ring_kernel<true>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, wpg, x_bnp);
