@@ -36,11 +36,13 @@ class LossManager:
             return []
         return th.stack([l.detach().reshape(()) for l in self.losses]).tolist()
 
-    def updateLossHistory(self, values=None):
+    def updateLossHistory(self, values=None, names=None, weights=None):
+        # (names / weights: those of the step the values belong to, when they are booked a step later — learn() reads a step's scalars
+        # after it has launched the next one)
         if self.loss_history is not None:
             if values is None:
                 values = self.lossValues()
-            for name, w, value in zip(self.names, self.weights, values):
+            for name, w, value in zip(self.names if names is None else names, self.weights if weights is None else weights, values):
                 if w > 0:
                     if len(self.loss_history[name]) > 0:
                         self.loss_history[name][-1] += w * value

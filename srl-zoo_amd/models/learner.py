@@ -675,6 +675,7 @@ class SRL4robotics(BaseLearner):
         self.epoch_stats = []
         for epoch in range(n_epochs):
             epoch_loss, epoch_batches, val_loss, val_batches = 0.0, 0, 0.0, 0
+            pending = None  # the previous step's scalars: (ticket, validation?, loss names, loss weights)
             epoch_t0, epoch_gathers = time.time(), (resident.gathers if resident is not None else 0)
             feed = _DeviceFeed(data_loader, self.device)
             for minibatch_num, (minibatch_idx, obs, next_obs, noisy_obs, next_noisy_obs) in enumerate(feed):
@@ -706,15 +707,31 @@ class SRL4robotics(BaseLearner):
                 loss = self.trainStep(obs, next_obs, actions_st, loss_manager, validation_mode, noisy_obs,
                                       next_noisy_obs, rewards_st)
                 feed.advance()  # next minibatch's H2D copy overlaps this step (issued before the host waits below)
-                # one D2H copy for every scalar of this step (total first; the mean over the ranks when there are several)
-                values = self.flat_params.read_scalars(1 + len(loss_manager.losses))
-                loss_manager.updateLossHistory(values[1:])
-                if validation_mode:
+                # one D2H copy for every scalar of this step (total first; the mean over the ranks when there are several) — queued,
+                # and booked once the NEXT step has been launched: the host stays a step ahead of the GPU (same values, same order)
+                ticket = (self.flat_params.read_scalars_async(1 + len(loss_manager.losses)), validation_mode,
+                          list(loss_manager.names), list(loss_manager.weights))
+                for done in ([pending] if pending is not None else []):
+                    values = self.flat_params.scalars(done[0])
+                    loss_manager.updateLossHistory(values[1:], done[2], done[3])
+                    if done[1]:
+                        val_loss += values[0]
+                        val_batches += 1
+                    else:
+                        epoch_loss += values[0]
+                        epoch_batches += 1
+                pending = ticket
+
+            for done in ([pending] if pending is not None else []):  # the epoch's last step
+                values = self.flat_params.scalars(done[0])
+                loss_manager.updateLossHistory(values[1:], done[2], done[3])
+                if done[1]:
                     val_loss += values[0]
                     val_batches += 1
                 else:
                     epoch_loss += values[0]
                     epoch_batches += 1
+            pending = None
 
             steps = epoch_batches + val_batches
             self.epoch_stats.append({"epoch": epoch + 1, "seconds": time.time() - epoch_t0, "minibatches": steps,

@@ -87,6 +87,33 @@ class FlatParams(object):
         values = self.tail[:count].tolist()
         return values if size == 1 else [v / size for v in values]
 
+    def read_scalars_async(self, count):
+        """read_scalars without the wait: the copy of the first `count` tail slots into pinned host memory is queued behind the step
+        that wrote them and a ticket comes back; `scalars(ticket)` waits for THAT copy only.  learn() redeems a step's ticket after it
+        has launched the next step, so the host runs one step ahead and the GPU never idles while ~100 launches are being issued
+        (a blocking read per step cost 0.4-0.8 ms of a 2.4 / 13 ms step).  Two host buffers alternate: at most one ticket is
+        outstanding when the next one is taken."""
+        if not self.tail.is_cuda:
+            return (self.tail[:count].clone(), count, None)
+        if getattr(self, "_host", None) is None:
+            self._host = [torch.empty(self.TAIL, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._host_i = 0
+        buf = self._host[self._host_i]
+        self._host_i ^= 1
+        buf[:count].copy_(self.tail[:count], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.tail.device))
+        return (buf, count, ev)
+
+    def scalars(self, ticket):
+        """The values of a read_scalars_async ticket as Python floats (mean over the ranks, like read_scalars)."""
+        buf, count, ev = ticket
+        if ev is not None:
+            ev.synchronize()
+        _, size = world()
+        values = buf[:count].tolist()
+        return values if size == 1 else [v / size for v in values]
+
     def zero_grad(self):
         self.grad.zero_()
         if self._dirty:  # a backward pass whose gradients were neither delivered nor discarded
