@@ -115,35 +115,103 @@ def test_program_tap_grouping(cabi, hi, s, p, t):
         assert sorted(w for (_, _, _, w) in P["taps"]) == list(range(9))
 
 
+RING_ROWS, RING_MIRROR = 246, 8  # csrc/conv64.hip (the ring shrank from 248 rows when the two row tables moved into its 80 KB)
+
+
 @pytest.mark.parametrize("hi,s,p,t", [(56, 1, 1, 0), (6, 2, 0, 1), (13, 2, 0, 1), (27, 2, 0, 1), (55, 2, 0, 1), (9, 1, 1, 0)])
 def test_wgrad_ring_schedule_never_aliases(cabi, hi, s, p, t):
-    """conv64_wgrad_ring_kernel keeps source row q in LDS slot q & 255 and, per 64-position chunk, lands only the 64 new
+    """conv64_wgrad_ring_kernel keeps source row q in LDS slot q mod RING_ROWS (the first RING_MIRROR slots a second time behind
+    the ring, so a reader that starts at slot u goes on to u + 7 without wrapping) and, per 64-position chunk, lands only the 64 new
     rows of the NEXT chunk after the current chunk's last MFMA.  Replay that schedule for the forward program of every
-    single-source-class layer: whenever a tap reads slot (q0 + row + off) & 255 it must still hold row q0 + row + off."""
+    single-source-class layer: whenever a tap reads row q0 + row + off through its block's start slot it must find that row."""
     P = get_program(cabi, 2, hi, s, p, t, 0)
     assert len(set(c for (c, _, _, _) in P["taps"])) == 1, "ring kernel is only used for single-source-class programs"
-    RING, TK = 256, 64
+    TK = 64
     span, min_off = P["span"], P["min_off"]
-    assert TK + span <= RING
+    assert TK + span + TK <= RING_ROWS, "the launch condition of the ring kernel"
     total = P["N"] * P["PH"] * P["PW"]
     nchunks = (total + TK - 1) // TK
     offs = sorted(set(off for (_, _, off, _) in P["taps"]))
     assert offs[0] == min_off and offs[-1] - offs[0] == span
+
+    def land(lds, q):  # rows64_store<RINGED>
+        r = q % RING_ROWS
+        lds[r] = q
+        if r < RING_MIRROR:
+            lds[r + RING_ROWS] = q
+
     for (c_begin, c_end) in ((0, nchunks), (3, min(nchunks, 9))):  # a workgroup's contiguous chunk range
-        slot = {}
+        lds = {}
         q0 = c_begin * TK
         for r in range(0, TK + span, 64):  # prologue: passes of 64 rows, may run past TK + span
             for q in range(q0 + min_off + r, q0 + min_off + r + 64):
-                slot[q & (RING - 1)] = q
+                land(lds, q)
         for chunk in range(c_begin, c_end):
             q0 = chunk * TK
-            for row in range(TK):
-                for off in offs:
-                    q = q0 + row + off
-                    assert slot.get(q & (RING - 1)) == q, (chunk, row, off)
+            for off in offs:
+                for b in range(TK // 8):  # a block of 4 k-steps reads rows u .. u + 7 from ONE wrapped start slot
+                    u = (q0 + off + 8 * b) % RING_ROWS
+                    for k in range(8):
+                        assert lds.get(u + k) == q0 + off + 8 * b + k, (chunk, off, b, k)
             if chunk + 1 < c_end:  # landed after the barrier that follows this chunk's MFMA loop
                 for q in range(q0 + min_off + TK + span, q0 + min_off + TK + span + 64):
-                    slot[q & (RING - 1)] = q
+                    land(lds, q)
+
+
+def _rowtab_entry(P, q):
+    """rowtab_build / gtab_build of csrc/conv64.hip for grid position q of one BatchNorm group: pixel index of the row's class-(0,0)
+    source pixel << 4 | bit k: source class k = (cy << 1) | cx lies inside the image; 0 = no image."""
+    PHW = P["PH"] * P["PW"]
+    n1 = (q + PHW) // PHW  # (shifted by one image, as the kernel does for the negative q of the first tile)
+    rem = (q + PHW) - n1 * PHW
+    a, b = rem // P["PW"], rem % P["PW"]
+    y0, x0 = a * P["ss"], b * P["ss"]
+    if not 0 <= n1 - 1 < P["N"]:
+        return 0
+    f = sum(1 << k for k in range(4) if y0 + (k >> 1) < P["Hs"] and x0 + (k & 1) < P["Ws"])
+    return ((((n1 - 1) * P["Hs"] + y0) * P["Ws"] + x0) << 4) | f
+
+
+@pytest.mark.parametrize("hi,s,p,t", LAYERS)
+def test_row_tables_address_the_rows_the_program_means(cabi, hi, s, p, t):
+    """The per-tile row tables (round 4): for every staged row of every 128-position tile and every source class of the program,
+    the pixel the table-driven staging loads — ((entry >> 4) + cy * Ws + cx) masked by the entry's class bit — is the pixel the
+    program's definition S_c(q) = src[n, a * ss + cy, b * ss + cx] names, and rows outside the image are masked off; the packed
+    destination word (rowinfo) does the same for D_d(q).  Entries must fit their bit fields at the network's largest batch."""
+    TM = 128
+    for backward in (0, 1):
+        P = get_program(cabi, 3, hi, s, p, t, backward)
+        PH, PW, N = P["PH"], P["PW"], P["N"]
+        total = N * PH * PW
+        classes = sorted(set(c for (c, _, _, _) in P["taps"]))
+        for q0 in range(0, total, TM):
+            for R in range(TM + P["span"]):
+                q = q0 + P["min_off"] + R
+                e = _rowtab_entry(P, q)
+                n, rem = divmod(q, PH * PW) if q >= 0 else (-1, 0)
+                a, b = rem // PW, rem % PW
+                for c in classes:
+                    y, x = a * P["ss"] + (c >> 1), b * P["ss"] + (c & 1)
+                    inside = 0 <= q < total and y < P["Hs"] and x < P["Ws"]
+                    assert bool((e >> c) & 1) == inside, (backward, q, c)
+                    if inside:
+                        assert (e >> 4) + (c >> 1) * P["Ws"] + (c & 1) == (n * P["Hs"] + y) * P["Ws"] + x, (backward, q, c)
+        # destination side: pixel index of the class-(0,0) output << 2 | row below exists | column to the right exists << 1
+        for q in range(total):
+            n, rem = divmod(q, PH * PW)
+            ya, xb = (rem // PW) * P["ds"], (rem % PW) * P["ds"]
+            ri = -1 if not (ya < P["Hd"] and xb < P["Wd"]) else \
+                (((n * P["Hd"] + ya) * P["Wd"] + xb) << 2) | (1 if ya + 1 < P["Hd"] else 0) | (2 if xb + 1 < P["Wd"] else 0)
+            for d in sorted(set(dd for (_, dd, _, _) in P["taps"])):
+                need = (d >> 1) | ((d & 1) << 1)
+                inside = ya + (d >> 1) < P["Hd"] and xb + (d & 1) < P["Wd"]
+                assert (ri >= 0 and (ri & need) == need) == inside, (backward, q, d)
+                if inside:
+                    assert (ri >> 2) + (d >> 1) * P["Wd"] + (d & 1) == (n * P["Hd"] + ya + (d >> 1)) * P["Wd"] + xb + (d & 1)
+    # bit budget at the largest call the kernels accept (1149 images of the widest layer): 28-bit pixel indices, 32-bit float offsets
+    P = get_program(cabi, 1149, hi, s, p, t, 0)
+    assert P["N"] * P["Hs"] * P["Ws"] < 1 << 28 and P["N"] * P["Hs"] * P["Ws"] * 64 < 1 << 32
+    assert P["N"] * P["Hd"] * P["Wd"] < 1 << 29
 
 
 def test_programs_for_random_shapes(cabi):
