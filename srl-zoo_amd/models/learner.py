@@ -636,15 +636,22 @@ class SRL4robotics(BaseLearner):
         # permutation from the same forked RNG, same end-of-epoch marker) and gather on the device.  Triplets keep streaming: their
         # negative view is a fresh random draw per frame and epoch (reference data_loader.py:219-243).
         use_bytes = bool(RAW_UINT8_INPUT)
-        resident = None
+        resident = fill = None
         if RESIDENT_FRAMES and use_bytes and not self.use_triplets and n_epochs_planned(self.losses) > 1:
             from preprocessing.resident import ResidentFrames
             import preprocessing.preprocess as _pre
-            needed = np.concatenate([np.concatenate((mb, mb + 1)) for mb in minibatchlist])
-            resident = ResidentFrames(len(images_path), (_pre.getNChannels(), _pre.IMAGE_WIDTH, _pre.IMAGE_HEIGHT), self.device, needed)
-            if self.use_dae and not resident.on_device:
-                resident = None  # (the device-side occlusion reads the store in HBM)
-        self._resident = resident
+            frame_shape = (_pre.getNChannels(), _pre.IMAGE_WIDTH, _pre.IMAGE_HEIGHT)
+            # (the DAE's device-side occlusion reads the store in HBM: no store at all when it would not fit there)
+            if not self.use_dae or ResidentFrames.fits_device(len(images_path), frame_shape, self.device):
+                needed = np.concatenate([np.concatenate((mb, mb + 1)) for mb in minibatchlist])
+                resident = ResidentFrames(len(images_path), frame_shape, self.device, needed, rank=self.rank,
+                                          world_size=self.world_size)
+            if resident is not None and self.world_size > 1:
+                # several ranks: the epoch-1 stream of a rank carries a random 1/W of the minibatches, so the store is NOT completed
+                # by absorbing it — every rank decodes its own fixed slice of the dataset beside the first epoch (a second loader
+                # process, in order, bytes only) and the slices are exchanged at the epoch boundary (ResidentFrames.exchange)
+                from preprocessing.resident import FillPass
+                fill = FillPass(resident, images_path, n_workers=N_WORKERS, multi_view=self.multi_view)
         data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
                                  use_triplets=self.use_triplets, is_training=True, apply_occlusion=self.use_dae,
                                  occlusion_percentage=self.occlusion_percentage, rank=self.rank,
@@ -693,7 +700,8 @@ class SRL4robotics(BaseLearner):
                         noisy_obs, next_noisy_obs = self._toDevicePair(noisy_obs, next_noisy_obs)
                     if resident is not None and obs.dtype == th.uint8:
                         obs, next_obs = obs.to(self.device, non_blocking=True), next_obs.to(self.device, non_blocking=True)
-                        if resident.absorb(minibatchlist[minibatch_idx], obs, next_obs) and not data_loader.index_mode.is_set():
+                        if self.world_size == 1 and resident.absorb(minibatchlist[minibatch_idx], obs, next_obs) \
+                                and not data_loader.index_mode.is_set():
                             data_loader.shipIndices()  # every frame a minibatch can ask for is home: no more pixels, no more decoding
                     obs, next_obs = self._toDevicePair(obs, next_obs)
                 actions_st = th.from_numpy(actions[minibatchlist[minibatch_idx]]).view(-1, 1).to(self.device)
@@ -707,6 +715,8 @@ class SRL4robotics(BaseLearner):
                 loss = self.trainStep(obs, next_obs, actions_st, loss_manager, validation_mode, noisy_obs,
                                       next_noisy_obs, rewards_st)
                 feed.advance()  # next minibatch's H2D copy overlaps this step (issued before the host waits below)
+                if fill is not None:
+                    fill.drain()  # whatever chunks of the own slice are decoded by now
                 # one D2H copy for every scalar of this step (total first; the mean over the ranks when there are several) — queued,
                 # and booked once the NEXT step has been launched: the host stays a step ahead of the GPU (same values, same order)
                 ticket = (self.flat_params.read_scalars_async(1 + len(loss_manager.losses)), validation_mode,
@@ -733,10 +743,21 @@ class SRL4robotics(BaseLearner):
                     epoch_batches += 1
             pending = None
 
+            fill_stats = {}
+            if fill is not None:
+                # the first epoch boundary, on every rank (all ranks run the same number of steps per epoch): the rest of the own
+                # slice, then the exchange — and the loaders of ALL ranks switch to indices here, or none does
+                if not fill.finish(data_loader):
+                    printYellow("resident frames: a rank could not complete its slice; every rank keeps decoding")
+                fill_stats, fill = fill.stats, None
+            elif resident is not None and epoch == 0 and not data_loader.index_mode.is_set():
+                data_loader.keepPixels()
+
             steps = epoch_batches + val_batches
-            self.epoch_stats.append({"epoch": epoch + 1, "seconds": time.time() - epoch_t0, "minibatches": steps,
-                                     "images": 2 * steps * self.batch_size,
-                                     "index_minibatches": (resident.gathers - epoch_gathers) if resident is not None else 0})
+            self.epoch_stats.append(dict({"epoch": epoch + 1, "seconds": time.time() - epoch_t0, "minibatches": steps,
+                                          "images": 2 * steps * self.batch_size,
+                                          "index_minibatches": (resident.gathers - epoch_gathers) if resident is not None else 0},
+                                         **fill_stats))
             train_loss = epoch_loss / float(max(epoch_batches, 1))
             val_loss /= float(max(val_batches, 1)) if self.world_size > 1 else float(n_val_batches)
             loss_history = loss_manager.loss_history

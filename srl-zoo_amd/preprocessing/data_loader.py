@@ -17,6 +17,7 @@ from __future__ import print_function, division, absolute_import
 
 import gc
 import glob
+import os
 import random
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -28,7 +29,13 @@ except ImportError:  # python 2
 
 import numpy as np
 import torch as th
-from torch.multiprocessing import Queue, Process
+import torch.multiprocessing as _tmp
+
+# The producer is a FORKED child by contract: it inherits the parent's np.random / random state (every rank forks from the same state
+# and therefore draws the same per-epoch permutations, of which it takes its shard) and the loader object itself.  Whatever start
+# method the host program has made the default (a process started by multiprocessing "spawn" inherits "spawn"), this module forks.
+_mp = _tmp.get_context("fork")
+Queue, Process, Event = _mp.Queue, _mp.Process, _mp.Event
 
 from .preprocess import IMAGE_WIDTH, IMAGE_HEIGHT
 from .utils import preprocessInput
@@ -155,6 +162,11 @@ class DataLoader(object):
                           and the same end-of-epoch None, but no pixels: the consumer holds the decoded frames
                           (preprocessing/resident.py) and gathers the minibatch by index.  rects / next_rects: with occlusion, the
                           int32 [B, views, 4] rectangles (h_1, h_2, w_1, w_2) drawn with the reference's np.random calls; else None.
+                          Such a producer also PAUSES behind the end-of-epoch marker of its first epoch until the consumer has said
+                          what epoch 2 is made of — shipIndices() or keepPixels(); coming back for the next item without a decision
+                          counts as keepPixels() — so the epoch after the decision is index-only from its first minibatch (the
+                          producer runs max_queue_len + 1 minibatches ahead otherwise).  With several ranks the decision falls at
+                          that boundary on every rank at once (preprocessing/resident.py::ResidentFrames.exchange).
         :param val_indices: minibatch ids used for validation; with world_size > 1 training and validation
                             minibatches are sharded separately (train first) so all ranks stay in lock-step
         """
@@ -180,7 +192,9 @@ class DataLoader(object):
             raise ValueError("raw_uint8 frames cannot carry the (normalised-space) occlusion of the DAE loader")
         self.raw_uint8 = raw_uint8
         # (created BEFORE the fork: the producer sees the same flag)
-        self.index_mode = th.multiprocessing.Event() if (index_switch and is_training) else None
+        self.index_mode = Event() if (index_switch and is_training) else None
+        self.epoch_gate = Event() if self.index_mode is not None else None
+        self._epochs_received = 0
         self.startProcess()
 
     def shipIndices(self):
@@ -188,6 +202,12 @@ class DataLoader(object):
         if self.index_mode is None:
             raise ValueError("DataLoader(index_switch=True, is_training=True) creates the switch")
         self.index_mode.set()
+        self.epoch_gate.set()
+
+    def keepPixels(self):
+        """The consumer's other answer at the first epoch boundary: keep decoding (the producer waits there for one of the two)."""
+        if self.epoch_gate is not None:
+            self.epoch_gate.set()
 
     @staticmethod
     def createTestMinibatchList(n_samples, batch_size):
@@ -263,6 +283,8 @@ class DataLoader(object):
                     item = batch
                 self.queue.put(item)
             self.queue.put(None)  # end-of-epoch sentinel
+            if self.epoch_gate is not None:
+                self.epoch_gate.wait()  # (first epoch only: the event stays set) pixels or indices from here on?
         # one-shot loader: stay alive until terminated — tensors travel through the queue as shared-memory handles and
         # the sender must outlive their reception
         while True:
@@ -308,13 +330,16 @@ class DataLoader(object):
     def __iter__(self):
         return self
 
-    # A producer that never delivers its FIRST item — it hangs or it dies — is re-forked: fork() of a multi-threaded parent (HIP
-    # runtime, OpenMP pools) can leave the child behind a lock some other thread owned at that instant (the one crash that was
-    # actually found had another cause, see gc.freeze() in _run; this is the safety net).  The parent has drawn no random number
+    # A producer that DIES before its first item is re-forked (one that merely hangs: only with STARTUP_TIMEOUT > 0): fork() of a
+    # multi-threaded parent (HIP runtime, OpenMP pools) can leave the child behind a lock some other thread owned at that instant
+    # (the one crash that was actually found had another cause, see gc.freeze() in _run; this is the safety net).  The parent has drawn no random number
     # since the first fork, so the new child starts from the same RNG state and produces the same permutations.
     # A producer that dies AFTER it has delivered is reported instead of waited for: its epoch cannot be resumed.
-    STARTUP_TIMEOUT = 90.0
+    # Seconds a live producer may take for its first item before it is re-forked; 0 (the default) = never: only a DEAD producer is
+    # replaced — a first minibatch can legitimately take minutes (cold network storage, bs = 256 pairs, the DAE decoding twice).
+    STARTUP_TIMEOUT = float(os.environ.get("SRLZ_LOADER_STARTUP_TIMEOUT", "0"))
     MAX_RESTARTS = 3
+    EMPTY = object()  # tryNext(): nothing ready yet
 
     def _restart(self, why):
         if self._restarts >= self.MAX_RESTARTS:
@@ -322,12 +347,44 @@ class DataLoader(object):
         self._restarts += 1
         try:
             self.process.terminate()
+            self.process.join(5)
+        except Exception:
+            pass
+        try:  # the abandoned queue's feeder thread and pipe
+            self.queue.close()
+            self.queue.cancel_join_thread()
         except Exception:
             pass
         self.queue = Queue(self._max_queue_len)
         self.startProcess()
 
+    def _book(self, val):
+        self._received += 1
+        if val is None:
+            self._epochs_received += 1
+            raise StopIteration
+        return val
+
+    def _deadProducer(self):
+        """The producer is gone.  One last look into the queue (it may have put its item and exited between our two checks), then:
+        re-fork if nothing was ever delivered, report otherwise.  Returns an item or EMPTY (after a restart)."""
+        try:
+            return self.queue.get(timeout=0.05)
+        except queue.Empty:
+            pass
+        if self._received == 0:
+            self._restart("exited (code {}) before its first minibatch".format(self.process.exitcode))
+            return self.EMPTY
+        raise RuntimeError("DataLoader: the producer process exited (code {}) without finishing the epoch".format(
+            self.process.exitcode))
+
+    def _openGateIfUndecided(self):
+        # the consumer is back for epoch 2 and has not said shipIndices() / keepPixels(): it wants what it had
+        if self.epoch_gate is not None and self._epochs_received >= 1 and not self.epoch_gate.is_set():
+            self.epoch_gate.set()
+
     def __next__(self):
+        self._openGateIfUndecided()
         waited_since = time.time()
         while True:
             try:
@@ -338,19 +395,29 @@ class DataLoader(object):
                 if time.time() - waited_since < 0.25:
                     continue
                 if self.process is not None and not self.process.is_alive():
-                    if self._received == 0:
-                        self._restart("exited (code {}) before its first minibatch".format(self.process.exitcode))
-                        waited_since = time.time()
-                        continue
-                    raise RuntimeError("DataLoader: the producer process exited (code {}) without finishing the epoch".format(
-                        self.process.exitcode))
-                if self._received == 0 and time.time() - waited_since > self.STARTUP_TIMEOUT:
+                    val = self._deadProducer()
+                    if val is not self.EMPTY:
+                        break
+                    waited_since = time.time()
+                    continue
+                if self._received == 0 and self.STARTUP_TIMEOUT > 0 and time.time() - waited_since > self.STARTUP_TIMEOUT:
                     self._restart("delivered nothing in {} s".format(self.STARTUP_TIMEOUT))
                     waited_since = time.time()
-        self._received += 1
-        if val is None:
-            raise StopIteration
-        return val
+        return self._book(val)
+
+    def tryNext(self):
+        """next() without the wait: an item, DataLoader.EMPTY when none is ready, StopIteration at the end-of-epoch marker."""
+        self._openGateIfUndecided()
+        try:
+            val = self.queue.get_nowait()
+        except queue.Empty:
+            if self.process is not None and not self.process.is_alive():
+                val = self._deadProducer()
+                if val is self.EMPTY:
+                    return val
+            else:
+                return self.EMPTY
+        return self._book(val)
 
     next = __next__
 

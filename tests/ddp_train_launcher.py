@@ -57,6 +57,9 @@ if digest_dir:
                       param_sum=float(flat.sum()), param_abs_sum=float(flat.abs().sum()),
                       log_folder=self.log_folder, world=self.world_size, adam_steps=self.optimizer.steps(),
                       states_shape=list(states.shape), states_finite=bool(np.isfinite(states).all()),
+                      epoch_stats=list(getattr(self, "epoch_stats", [])),
+                      resident_complete=bool(self._resident is not None and self._resident.complete()
+                                             and self._resident.have.all()),
                       backend=torch.distributed.get_backend() if self.world_size > 1 else None)
         with open(os.path.join(digest_dir, "rank%d.json" % RANK), "w") as f:
             json.dump(record, f)

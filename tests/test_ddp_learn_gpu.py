@@ -8,7 +8,8 @@ bucket bounces through host memory, every kernel still runs on the GPU), so the 
 
 Checked: ONE log folder (rank 0's timestamped choice, broadcast), identical loss_history / parameters on both ranks, lock-step
 validation, the checkpoint's BatchNorm running statistics = the ranks' average, learn() returns on every rank and rank 0 writes
-the reference's output files; a NaN injected on rank 1 makes BOTH ranks exit with pipeline.NAN_ERROR (11) together.
+the reference's output files; the resident dataset completed by the ranks' slice exchange after epoch 1 (epoch 2 index-only on
+both ranks); a NaN injected on rank 1 makes BOTH ranks exit with pipeline.NAN_ERROR (11) together.
 """
 import glob
 import json
@@ -100,6 +101,14 @@ def test_two_rank_train_cli(dataset):
     assert ranks[0]["adam_steps"] == ranks[1]["adam_steps"] == 10
     for d in ranks:
         assert d["states_shape"] == [104, 10] and d["states_finite"]
+    # ---- the resident dataset is rank-aware: each rank decoded its slice beside epoch 1, the slices were exchanged at the epoch
+    # boundary over the process group, and BOTH ranks train epoch 2 from indices only, from its first minibatch on
+    for d in ranks:
+        e1, e2 = d["epoch_stats"]
+        assert d["resident_complete"]
+        assert e1["minibatches"] == e2["minibatches"] == 6 and e1["index_minibatches"] == 0
+        assert e2["index_minibatches"] == e2["minibatches"]
+        assert e1["exchange"]["bytes"] == 104 * 3 * 224 * 224 and e1["exchange"]["backend"] == backend
     # ---- checkpoints: every save averaged the ranks' LOCAL running statistics (they differ: different minibatches)
     assert len(ranks[0]["saves"]) == len(ranks[1]["saves"]) >= 1
     for s0, s1 in zip(ranks[0]["saves"], ranks[1]["saves"]):

@@ -254,3 +254,62 @@ def test_producer_that_dies_before_its_first_minibatch_is_reforked(dataset, tmp_
     assert next(late)[0] == 0
     with pytest.raises(RuntimeError, match="exited"):
         next(late)
+
+
+def test_epoch_gate_makes_the_second_epoch_index_only_from_its_first_minibatch(dataset):
+    """DataLoader(index_switch=True): the producer pauses behind its first end-of-epoch marker until the consumer has decided —
+    shipIndices(): every minibatch of epoch 2 is an index item (no look-ahead pixels); keepPixels() or simply coming back for more:
+    pixels as before.  The sequence of minibatch ids is the ungated loader's either way."""
+    from preprocessing.data_loader import DataLoader
+    name, paths, *_ = dataset
+    ml = [np.array([0, 1, 2]), np.array([4, 5, 6]), np.array([8, 9, 10]), np.array([12, 13, 14]), np.array([16, 17, 18])]
+    np.random.seed(3)
+    plain = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8="planar", max_queue_len=4)
+    want = [[int(i[0]) for i in plain] for _ in range(3)]
+    del plain
+
+    np.random.seed(3)
+    gated = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8="planar", max_queue_len=4, index_switch=True)
+    first = [i for i in gated]
+    assert all(i[1] is not None for i in first)
+    import time
+    time.sleep(0.5)  # a producer running ahead would have queued epoch-2 pixels by now
+    assert gated.queue.empty() and not gated.epoch_gate.is_set()
+    gated.shipIndices()
+    second, third = [i for i in gated], [i for i in gated]
+    assert all(i[1] is None and i[2] is None for i in second + third)
+    assert [[int(i[0]) for i in e] for e in (first, second, third)] == want
+    del gated
+
+    for decide in ("keep", "undecided"):
+        np.random.seed(3)
+        dl = DataLoader(ml, paths, n_workers=2, is_training=True, raw_uint8="planar", max_queue_len=4, index_switch=True)
+        a = [i for i in dl]
+        if decide == "keep":
+            dl.keepPixels()
+        b = [i for i in dl]  # (undecided: asking for the next item opens the gate)
+        assert dl.epoch_gate.is_set() and all(i[1] is not None for i in a + b)
+        assert [[int(i[0]) for i in e] for e in (a, b)] == want[:2]
+        del dl
+
+
+def test_try_next_never_waits(dataset):
+    from preprocessing.data_loader import DataLoader
+    name, paths, *_ = dataset
+    ranges = [np.arange(0, 3), np.arange(3, 5), np.arange(5, 5)]
+    dl = DataLoader(ranges, paths, n_workers=2, is_training=False, infinite_loop=False, raw_uint8="planar", max_queue_len=4)
+    import time
+    got, empties, t0 = [], 0, time.time()
+    while time.time() - t0 < 60:
+        try:
+            item = dl.tryNext()
+        except StopIteration:
+            break
+        if item is DataLoader.EMPTY:
+            empties += 1
+            time.sleep(0.005)
+            continue
+        got.append(item)
+    assert [tuple(g.shape) for g in got] == [(3, 3, 224, 224), (2, 3, 224, 224), (0,)] and empties >= 1
+    assert torch.equal(got[1][0], DataLoader._makeBatchElement(paths[3], raw_uint8="planar")[0])
+    assert DataLoader.STARTUP_TIMEOUT == 0.0  # a live producer is never re-forked unless SRLZ_LOADER_STARTUP_TIMEOUT says so

@@ -115,8 +115,9 @@ def test_learn_with_resident_frames_is_learn_with_redecoding(workdir, losses):
     h1, s1, store = run(True)
     h0, s0, none = run(False)
     assert none is None and store is not None and store.complete() and store.on_device
-    # 12 minibatches per epoch, 4 epochs: epoch 1 streams (and the few minibatches the producer had prepared ahead), the rest gathers
-    assert 24 <= store.gathers <= 36, store.gathers
+    # 12 minibatches per epoch, 4 epochs: epoch 1 streams; the producer waits at the first epoch boundary for the decision, so epochs
+    # 2-4 are index-only from their first minibatch (at most the tail of epoch 1 too, when the store completed before its last step)
+    assert 36 <= store.gathers <= 40, store.gathers
     assert sorted(h1) == sorted(h0)
     if losses == ["dae"]:
         # the occlusion rectangles are random draws of the loader process, raced between its decoding threads in the reference
