@@ -234,6 +234,13 @@ def main():
     ap.add_argument("--u8-resident", action="store_true",
                     help="the resident synthetic batch is the loader's uint8 frames [B,C,W,H] instead of the normalised float tensor "
                          "(what learn() feeds the step; conv1 and the fused loss read the bytes)")
+    ap.add_argument("--no-vae-leg", action="store_true",
+                    help="skip the second leg of the headline metric (BASELINE.json configs[2]: --losses vae on the same shapes), which the "
+                         "default --losses autoencoder run measures in the same process right after the AE leg and reports as `vae`")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="with --gpus N > 1: skip the strong-scaling leg (global batch = --batch-size, i.e. bs / N per GPU) reported as `strong`")
+    ap.add_argument("--allow-short", action="store_true",
+                    help="print the line even when the timed region is shorter than 0.2 s (functional tests on tiny batches)")
     ap.add_argument("--host-input-nhwc", action="store_true",
                     help="with --host-input: frames as decoded ([B,H,W,C]) + the separate srlz_normalize_u8 pass (A/B)")
     args = ap.parse_args()
@@ -334,22 +341,30 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    totals = []
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.time()
-    for _ in range(args.steps):
-        totals.append(step().detach())
-    sync()
-    dt = time.time() - t0
-    last_losses = torch.stack(totals).tolist()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        if torch.distributed.get_backend() != "gloo":
-            t = t.to(device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(step_fn, warmup, steps):
+        """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize.  Returns (seconds: max over the
+        ranks, seconds on this rank's own clock, the steps' total losses)."""
+        for _ in range(warmup):
+            step_fn()
+        sync()
+        t0 = time.time()
+        totals = [step_fn().detach() for _ in range(steps)]
+        sync()
+        own = time.time() - t0
+        worst = own
+        if world > 1:
+            t = torch.tensor([own], dtype=torch.float64)
+            if torch.distributed.get_backend() != "gloo":
+                t = t.to(device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            worst = float(t.item())
+        return worst, own, torch.stack(totals).tolist()
+
+    dt, own_dt, last_losses = timed(step, args.warmup, args.steps)
+    rank_ms = None
+    if world > 1:  # every rank's own clock around the same K steps: skew between the ranks shows here
+        rank_ms = [None] * world
+        torch.distributed.all_gather_object(rank_ms, round(1e3 * own_dt / args.steps, 3))
     # the roofline's per-launch HIP-event times: the SAME steps, instrumented, after the clock has stopped
     # (two instrumented steps are discarded first: the first ~200 event pairs are created cold and their launches measured
     # 3-4 % long — 448 vs 432 us for the dominant kernel against rocprofv3's 434)
@@ -357,26 +372,112 @@ def main():
     for phase, count in (("settle", 2 if timer_steps else 0), ("measure", timer_steps)):
         if count and rank == 0:
             ops.timers_enable(True)  # (clears what the settling steps recorded)
+        if count and world > 1:
+            _optim.comm_timing(True)
         for _ in range(count):  # (every rank runs them: the steps hold collectives)
             step()
         sync()
     ops.timers_enable(False)
+    comm = None
+    if world > 1:
+        # the step's ONE collective, timed with HIP events on the launch stream in the instrumented steps (every rank; rank 0 reports
+        # its own average and the fastest / slowest rank's)
+        mine = _optim.comm_timing_report()
+        _optim.comm_timing(False)
+        avg_us = float(np.mean([u for u, _ in mine])) if mine else None
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, avg_us)
+        if mine:
+            nbytes = mine[0][1]
+            comm = {"collective": "all_reduce(sum) of the flat gradient bucket (gradients + 16 loss scalars), one per step",
+                    "backend": torch.distributed.get_backend(), "native_rccl_comm": bool(_optim.native_comm_requested()),
+                    "bucket_bytes": nbytes, "calls_timed": len(mine), "avg_us": round(avg_us, 1),
+                    "avg_us_per_rank_min_max": [round(min(per_rank), 1), round(max(per_rank), 1)],
+                    "algbw_GBps": round(nbytes / (avg_us * 1e-6) / 1e9, 2),
+                    "busbw_GBps": round(nbytes / (avg_us * 1e-6) / 1e9 * 2.0 * (world - 1) / world, 2),
+                    "share_of_step": round(avg_us * 1e-3 / (1e3 * dt / args.steps), 4),
+                    "timing": "HIP events on the launch stream around the collective, %d instrumented steps" % timer_steps}
+
+    # ---- the other leg of the headline metric ("AE+VAE train step"): BASELINE.json configs[2], --losses vae (beta = 1) on the same
+    # shapes and batch, measured in this process right after the AE leg with the same warm-up / step counts
+    vae = None
+    if (list(args.losses) == ["autoencoder"] and channels == 3 and host_frames is None and not args.u8_resident
+            and not args.no_vae_leg):
+        stdout, sys.stdout = sys.stdout, quiet
+        try:
+            srl_vae = SRL4robotics(args.state_dim, model_type="custom_cnn", seed=1, learning_rate=0.005, cuda=True, losses=["vae"],
+                                   n_actions=6, beta=1.0, log_folder="/tmp")
+        finally:
+            sys.stdout = stdout
+        lm_vae = LossManager(srl_vae.model, None)
+        v_dt, _, v_losses = timed(lambda: srl_vae.trainStep(obs, next_obs, actions, lm_vae), args.warmup, args.steps)
+        v_tf = 2320.0e6 * 2 * B / (v_dt / args.steps) / 1e12
+        vae = {"workload": "synthetic 224x224x3 obs, --losses vae (beta=1), custom_cnn, state-dim %d, bs=%d per GPU" % (args.state_dim, B),
+               "ms_per_step": round(1e3 * v_dt / args.steps, 3), "images_per_s": round(2 * B * world * args.steps / v_dt, 1),
+               "steps": args.steps, "warmup": args.warmup, "timed_region_s": round(v_dt, 4), "final_loss": round(v_losses[-1], 6),
+               "step_roofline": {"algorithmic_tflop_per_step": round(2320.0e6 * 2 * B / 1e12, 4), "achieved_tflops": round(v_tf, 2),
+                                 "frac_of_fp32_mfma_peak": round(v_tf / PEAK_FP32_MFMA_TFLOPS, 4)}}
+        del srl_vae, lm_vae
+
+    # ---- strong scaling beside weak (N > 1): the SAME global batch as the 1-GPU run, bs / N samples per GPU
+    strong = None
+    if world > 1 and B % world == 0 and host_frames is None and not args.no_strong_leg:
+        b = B // world
+        pair = torch.cat((obs[:b], next_obs[:b]), 0)  # the two frames as the halves of one buffer, like the full batch
+        s_obs, s_next, s_act = pair[:b], pair[b:], actions[:b].contiguous()
+        s_rew = None if rewards is None else rewards[:b].contiguous()
+
+        def s_step():
+            return srl.trainStep(s_obs, s_next, s_act, loss_manager, rewards_st=s_rew)
+        probe, _, _ = timed(s_step, 3, 3)
+        k = max(args.steps, int(np.ceil(0.25 / max(probe / 3, 1e-6))))
+        if world > 1:  # (the step count must be the same on every rank)
+            box = [k]
+            torch.distributed.broadcast_object_list(box, src=0)
+            k = box[0]
+        s_dt, _, _ = timed(s_step, 0, k)
+        strong = {"scaling": "strong", "global_batch": B, "per_gpu_batch": b, "steps": k, "ms_per_step": round(1e3 * s_dt / k, 3),
+                  "images_per_s": round(2 * B * k / s_dt, 1), "timed_region_s": round(s_dt, 4)}
 
     if rank == 0:
         images = 2 * B * world * args.steps
+        if host_frames is not None:
+            where = "uint8 frames [B,%s] in pinned host memory every step, H2D copy inside the timed region (PCIe-inclusive)" % (
+                "H,W,C" if args.host_input_nhwc else "C,W,H")
+        elif args.u8_resident:
+            where = "the loader's uint8 frames [B,C,W,H] resident in HBM"
+        else:
+            where = "normalised fp32 observations resident in HBM"
+        if dt < 0.2 and not args.allow_short:
+            raise SystemExit("bench.py: the timed region was %.3f s (< 0.2 s: %d steps of %.3f ms) — too short to be a measurement; "
+                             "raise --steps (or pass --allow-short for a functional check)" % (dt, args.steps, 1e3 * dt / args.steps))
         out = {
             "metric": "images/sec (224x224x3) AE+VAE train step", "value": round(images / dt, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "timed_region_s": round(dt, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": ("synthetic, uint8 frames resident in HBM" if args.u8_resident else "synthetic") if host_frames is None else "synthetic, uint8 frames in pinned host memory every step (PCIe-inclusive)",
             "samples_per_s": round(B * world * args.steps / dt, 1),
+            "value_is": "the --losses %s leg (BASELINE.json configs[1] when autoencoder at bs=256)%s" % (
+                " ".join(args.losses), "; the VAE leg of the metric (configs[2]) is the `vae` object, same process, same step counts"
+                if vae is not None else ""),
             "config": {"workload": "synthetic 224x224x%d obs, --losses %s, custom_cnn, state-dim %d, bs=%d per GPU "
-                                   "(%d frames fwd+bwd per step per GPU), Adam lr 0.005, data resident in HBM"
-                                   % (channels, " ".join(args.losses), args.state_dim, B, 2 * B),
+                                   "(%d frames fwd+bwd per step per GPU), Adam lr 0.005, %s"
+                                   % (channels, " ".join(args.losses), args.state_dim, B, 2 * B, where),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "final_loss": round(last_losses[-1], 6)},
         }
+        if vae is not None:
+            out["vae"] = vae
+        if world > 1:
+            out["ranks"] = {"ms_per_step_per_rank": rank_ms, "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms),
+                            "backend": torch.distributed.get_backend(),
+                            "note": "each rank's own clock around the same K steps (barrier + synchronize on both sides)"}
+            if comm is not None:
+                out["allreduce"] = comm
+            if strong is not None:
+                out["strong"] = strong
         # whole-step arithmetic intensity check (2317.3 MFLOP per 224x224x3 image and train step for the AE,
         # 2320.0 for the VAE; heads are negligible): algorithmic FLOP of the step / wall time, against the same fp32-matrix peak
         if channels == 3 and "triplet" not in args.losses:

@@ -226,7 +226,37 @@ def local_device_index():
     return local_rank % n
 
 
+# bench.py --gpus N: HIP-event pairs around every exchange of the instrumented steps (on the launch stream: torch.distributed's
+# collective makes the current stream wait for RCCL's, so the second event completes behind the all-reduce)
+_comm_events = None
+
+
+def comm_timing(on):
+    """Start (True) / stop (False) recording one HIP-event pair per collective of the data path."""
+    global _comm_events
+    _comm_events = [] if on else None
+
+
+def comm_timing_report():
+    """[(microseconds, bytes)] of the collectives recorded since comm_timing(True) (synchronises)."""
+    if not _comm_events:
+        return []
+    torch.cuda.synchronize()
+    return [(1e3 * a.elapsed_time(b), nbytes) for a, b, nbytes in _comm_events]
+
+
 def _sum_across_ranks(t):
+    if _comm_events is not None and t.is_cuda:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(t.device))
+        _sum_across_ranks_impl(t)
+        b.record(torch.cuda.current_stream(t.device))
+        _comm_events.append((a, b, t.numel() * t.element_size()))
+        return
+    _sum_across_ranks_impl(t)
+
+
+def _sum_across_ranks_impl(t):
     if _native_ready:
         from . import _cabi as C
         C.comm_allreduce_f32(C.ptr(t), t.numel(), C.stream())

@@ -145,7 +145,7 @@ def test_bench_self_launches_its_ranks():
         env.pop(k, None)
     env["SRLZ_DIST_BACKEND"] = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                           "--batch-size", "8", "--timer-steps", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           "--batch-size", "8", "--timer-steps", "2", "--allow-short"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                           timeout=500)
     assert proc.returncode == 0, proc.stderr.decode("utf-8", "replace")[-3000:]
     lines = [l for l in proc.stdout.decode().splitlines() if l.startswith("{")]
@@ -154,3 +154,12 @@ def test_bench_self_launches_its_ranks():
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["global_batch"] == 16
     assert out["value"] > 0 and out["scaling"] == "weak" and "cpu_baseline" not in out
     assert np.isfinite(out["config"]["final_loss"])
+    # what makes a first multi-GPU run readable: every rank's own step time, the all-reduce timed by HIP events, a strong-scaling leg
+    assert len(out["ranks"]["ms_per_step_per_rank"]) == 2 and 0 < out["ranks"]["ms_per_step_min"] <= out["ranks"]["ms_per_step_max"]
+    ar = out["allreduce"]
+    assert ar["calls_timed"] == 2 and ar["avg_us"] > 0 and ar["bucket_bytes"] > 4 * 1e6 and ar["backend"] == env["SRLZ_DIST_BACKEND"]
+    assert ar["busbw_GBps"] == pytest.approx(ar["algbw_GBps"], rel=1e-2)  # 2 (W - 1) / W = 1 at W = 2
+    st = out["strong"]
+    assert st["global_batch"] == 8 and st["per_gpu_batch"] == 4 and st["timed_region_s"] >= 0.2 and st["images_per_s"] > 0
+    # the headline is both legs of the metric: the VAE step measured in the same process
+    assert out["vae"]["ms_per_step"] > 0 and np.isfinite(out["vae"]["final_loss"]) and out["timed_region_s"] > 0

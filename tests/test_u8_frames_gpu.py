@@ -236,7 +236,7 @@ def test_bench_input_modes(flag):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     proc = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "3", "--warmup", "1", "--batch-size", "8",
-                           "--no-cpu-baseline", "--no-kernel-timers", flag], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           "--no-cpu-baseline", "--no-kernel-timers", "--allow-short", flag], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                           timeout=500)
     assert proc.returncode == 0, proc.stderr.decode("utf-8", "replace")[-3000:]
     lines = [l for l in proc.stdout.decode().splitlines() if l.startswith("{")]
@@ -245,3 +245,7 @@ def test_bench_input_modes(flag):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["unit"] == "images/s" and out["dtype"] == "f32"
     assert np.isfinite(out["config"]["final_loss"])
     assert ("uint8" in out["data"]) and out["data"].startswith("synthetic")
+    # the workload string says where the frames of a step come from (and never "resident" for the PCIe-inclusive modes)
+    w = out["config"]["workload"]
+    assert ("pinned host memory" in w and "resident" not in w) if flag != "--u8-resident" else "uint8 frames [B,C,W,H] resident in HBM" in w
+    assert out["timed_region_s"] > 0 and "vae" not in out
