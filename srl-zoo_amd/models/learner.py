@@ -652,6 +652,7 @@ class SRL4robotics(BaseLearner):
                 # process, in order, bytes only) and the slices are exchanged at the epoch boundary (ResidentFrames.exchange)
                 from preprocessing.resident import FillPass
                 fill = FillPass(resident, images_path, n_workers=N_WORKERS, multi_view=self.multi_view)
+        self._resident = resident
         data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
                                  use_triplets=self.use_triplets, is_training=True, apply_occlusion=self.use_dae,
                                  occlusion_percentage=self.occlusion_percentage, rank=self.rank,

@@ -15,6 +15,20 @@ from . import ops
 TAPS = None
 
 
+# Test hook that does NOT change the route: when set to a dict, the forwards leave REFERENCES to the tensors the default route produces
+# anyway — the pooled maps (whose autograd nodes hold y, the BatchNorm record and the argmax bytes) and the decoder blocks' outputs
+# (whose nodes hold the raw input and its BatchNorm record) — so a test can read the ReLU / max-pool decisions of exactly the step the
+# product runs (PoolLink, deferred BatchNorm backward, fused block backward, loss in the last ConvTranspose), which TAPS switches off.
+OBSERVE = None
+
+
+def _observe(prefix, idx, t):
+    if OBSERVE is not None:
+        # (the node's saved tensors are taken NOW: backward frees them)
+        OBSERVE["%s.%d" % (prefix, idx)] = (t.detach(), tuple(t.grad_fn.saved_tensors) if t.grad_fn is not None else ())
+    return t
+
+
 def _tap(prefix, idx, t):
     if TAPS is not None and t.requires_grad:
         t.retain_grad()
@@ -74,16 +88,18 @@ def encoder_forward(seq, x, training, stat_sink=None, name="encoder_conv"):
         p, y = ops.EncInFn.apply(x, conv1.weight, *_bn_args(bn1), training, 1, stat_sink, link1)
         _tap(name, 0, y)
         _tap(name, 3, p)
+        _observe(name, 3, p)
     else:
         y, st = ops.Conv1Fn.apply(x, conv1.weight, training)
         _tap(name, 0, y)
         p = _tap(name, 3, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn1), training, 1, False, stat_sink, link1))
+        _observe(name, 3, p)
     y, st = ops.Conv64Fn.apply(p, conv2.weight, None, 1, 1, False, training, link1)
     _tap(name, 4, y)
-    p = _tap(name, 7, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn2), training, 0, False, stat_sink, link2))
+    p = _observe(name, 7, _tap(name, 7, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn2), training, 0, False, stat_sink, link2)))
     y, st = ops.Conv64Fn.apply(p, conv3.weight, None, 2, 1, False, training, link2)
     _tap(name, 8, y)
-    return _tap(name, 11, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn3), training, 0, True, stat_sink))
+    return _observe(name, 11, _tap(name, 11, ops.BNReLUPoolFn.apply(y, st, *_bn_args(bn3), training, 0, True, stat_sink)))
 
 
 def replay_encoder_bn(seq, stats, group=0):
@@ -117,6 +133,7 @@ def decoder_forward(seq, z, training):
         y, st = ops.DecBlockFn.apply(y, st, *_bn_args(bn), training, conv.weight, conv.bias, training, in_link, out_link)
         in_link = out_link
         _tap("decoder_conv", ci, y)
+        _observe("decoder_conv", ci, y)
     bn, last = seq[10], seq[12]
     if TAPS is not None:
         _record_activation(11, y, st, bn, training)
@@ -124,8 +141,10 @@ def decoder_forward(seq, z, training):
     if req is not None and req.loss is None and TAPS is None and torch.is_grad_enabled() and y.shape[0] % 2 == 0 \
             and req.target.shape[0] == y.shape[0] and req.target.shape[1] == last.weight.shape[1] and not req.target.requires_grad:
         req.loss, err = ops.DecOutLossFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias, in_link, req.target, req.mean)
+        _observe("decoder_conv", 12, req.loss)  # (err carries no node: the loss scalar's node holds (y_prev, bnp, w, err))
         return err  # NOT the reconstruction: dec - target (the caller asked for the loss, not for the image)
-    return _tap("decoder_conv", 12, ops.DecOutFn.apply(y, st, *_bn_args(bn), training, last.weight, last.bias, in_link))
+    return _observe("decoder_conv", 12, _tap("decoder_conv", 12, ops.DecOutFn.apply(y, st, *_bn_args(bn), training, last.weight,
+                                                                                      last.bias, in_link)))
 
 
 def _record_activation(idx, y, st, bn, training):
