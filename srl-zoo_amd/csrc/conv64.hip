@@ -1818,7 +1818,7 @@ __device__ __forceinline__ void rows64_store(float* __restrict__ lds, int rbase,
   }
 }
 
-// The 64 rows a chunk of conv64_wgrad_ring_kernel<false> requests per operand, decomposed ONCE (rows64_load does it per row and thread:
+// The 64 rows a chunk of conv64_wgrad_ring_kernel requests per operand, decomposed ONCE (rows64_load does it per row and thread:
 // ~22 vector-ALU instructions per row, 8 rows per thread and chunk next to 288 MFMAs): entry of row R at (R & 15) * 4 + (R >> 4) =
 // pixel index << 1 | 1, 0 = outside the tensor.  One wave builds one table (lane = row).
 __device__ __forceinline__ void ring_tab_build(unsigned* __restrict__ tab, const ConvProg& P, int H, int W, int stride, int cls,
@@ -1849,7 +1849,8 @@ __device__ __forceinline__ void rows64_load_tab(f32x4 (&v)[4], unsigned& okmask,
   }
 }
 
-template <bool S2>
+// (Stride-1 programs only: the stride-2 form of this kernel, which walked a 64-position chunk class by class, was superseded by
+// conv64_wgrad_ring_s2_kernel in round 2 and removed in round 5 — every program it took, span <= 118, the s2 kernel takes too.)
 __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ g,
                                                                   float* __restrict__ partial, const ConvProg P,
@@ -1860,7 +1861,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Ss = (float*)smem;        // ring: source row q lives at slot (q & 255)
   float* Gs = Ss + RING * 64;      // TK x 64: gradient rows of the current (chunk, destination class)
-  unsigned* tabx = (unsigned*)(Gs + TK * 64);  // (!S2) the 64 new source rows / the 64 gradient rows the current chunk requests
+  unsigned* tabx = (unsigned*)(Gs + TK * 64);  // the 64 new source rows / the 64 gradient rows the current chunk requests
   unsigned* tabg = tabx + 64;                  //       (ring_tab_build)
 
   const int tid = threadIdx.x;
@@ -1869,11 +1870,9 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   const int mi = wave & 1, nj = wave >> 1;
   // the tables of the requests chunk `c` makes: its successor's 64 new source rows and 64 gradient rows; waves 0 / 1 build one each
   auto next_tables = [&](int c) {
-    if constexpr (!S2) {
-      const int q0 = c * TK;
-      if (wave == 0) ring_tab_build(tabx, P, P.Hs, P.Ws, P.ss, P.tsrc[0], q0 + P.min_off + TK + P.span, lane);
-      if (wave == 1) ring_tab_build(tabg, P, P.Hd, P.Wd, P.ds, P.tdst[0], q0 + TK, lane);
-    }
+    const int q0 = c * TK;
+    if (wave == 0) ring_tab_build(tabx, P, P.Hs, P.Ws, P.ss, P.tsrc[0], q0 + P.min_off + TK + P.span, lane);
+    if (wave == 1) ring_tab_build(tabg, P, P.Hd, P.Wd, P.ds, P.tdst[0], q0 + TK, lane);
   };
 
   f32x16 acc[NTAPS];
@@ -1885,9 +1884,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   // way into Gs, so the sums are taken there (channels [4*slot, 4*slot+4) of this thread's rows) instead of re-reading Gs
   f32x4 bs4 = {0.f, 0.f, 0.f, 0.f};
 
-  constexpr int NG = S2 ? 4 : 1;
-  constexpr int GSTART[5] = {0, S2 ? 4 : 9, 6, 8, 9};
-  const int cs = P.tsrc[0];  // the single source class
+  const int cs = P.tsrc[0];  // the single source class (and a single destination class: one tap group of nine per chunk)
 
   const int grp = (P.G > 1) ? blockIdx.x / wgs_per_group : 0;
   x += grp * P.src_gstride;
@@ -1916,31 +1913,15 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int q0 = chunk * TK;
     const bool last_chunk = chunk + 1 >= c_end;
-    auto group = [&](auto GI) {
-      constexpr int gi = decltype(GI)::value;
-      constexpr int t0 = GSTART[gi], t1 = GSTART[gi + 1];
-      constexpr bool last_group = gi == NG - 1;
-      // ---- requests for what the NEXT step needs: the next class's gradient rows; at the last group of a chunk also the
-      //      64 new source rows of the next chunk (they overwrite ring slots nobody reads after this chunk)
-      // (stride 2: the 64 new source rows come in two halves, during the two 2-tap groups — with the next class's gradient rows
-      //  also in flight, a full set of both does not fit in the registers the 144 accumulators leave.  New source rows may land at
-      //  any point of the chunk: RING_ROWS >= TK + span + TK keeps their slots outside the window the chunk still reads.)
-      constexpr int SJ0 = S2 ? (gi == 2 ? 2 : 0) : 0, SNJ = S2 ? 2 : 4;
-      f32x4 pg[4], ps[SNJ];
+    {
+      constexpr int t0 = 0, t1 = NTAPS;
+      // ---- requests for what the NEXT chunk needs: its gradient rows and its 64 new source rows (they overwrite ring slots nobody
+      //      reads after this chunk: RING_ROWS >= TK + span + TK keeps them outside the window the chunk still reads)
+      f32x4 pg[4], ps[4];
       unsigned okg = 0;
-      const bool want_g = !(last_group && last_chunk);
-      const bool want_s = (S2 ? (gi == 1 || gi == 2) : last_group) && !last_chunk;
-      if (want_g) {
-        const int nq0 = last_group ? q0 + TK : q0;
-        constexpr int ntap = last_group ? 0 : GSTART[gi + 1];  // first tap of the next class
-        const int ncls = P.tdst[ntap];
-        if constexpr (S2) rows64_load(pg, okg, g, P.Hd, P.Wd, P.ds, ncls, P.PW, P.PH, P.total_q, nq0, grid_div(P));
-        else rows64_load_tab(pg, okg, g, tabg);  // (one group per chunk: nq0 = q0 + TK, what next_tables(chunk) decomposed)
-      }
-      if (want_s) {
-        if constexpr (S2) rows64_load<SJ0, SNJ>(ps, oks, x, P.Hs, P.Ws, P.ss, cs, P.PW, P.PH, P.total_q, q0 + P.min_off + TK + P.span, grid_div(P));
-        else rows64_load_tab(ps, oks, x, tabx);
-      }
+      const bool want_g = !last_chunk, want_s = !last_chunk;
+      if (want_g) rows64_load_tab(pg, okg, g, tabg);  // (rows q0 + TK ..: what next_tables(chunk) decomposed)
+      if (want_s) rows64_load_tab(ps, oks, x, tabx);
       // ---- this group's work
       // 8 blocks of 4 k-steps; k-step i of block b multiplies grid rows q0 + 8b + 2i + h.  Per tap the ring slot of row
       // q0 + toff + 8b is wave-uniform (u[t], wrapped with scalar instructions); the 4 rows of a lane are u + h + {0,2,4,6}
@@ -1977,12 +1958,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
         rows64_store<false>(Gs, 0, pg, okg, noq);
         bs4 += (pg[0] + pg[1]) + (pg[2] + pg[3]);
       }
-      if (want_s) rows64_store<true, SJ0, SNJ>(Ss, q0 + P.min_off + TK + P.span, ps, oks, xq);
+      if (want_s) rows64_store<true, 0, 4>(Ss, q0 + P.min_off + TK + P.span, ps, oks, xq);
       if (!last_chunk) next_tables(chunk + 1);  // (this chunk's requests have been issued — and their table reads returned — long ago)
       __syncthreads();
-    };
-    group(IntC<0>{});
-    if constexpr (NG > 1) { group(IntC<1>{}); group(IntC<2>{}); group(IntC<3>{}); }
+    }
   }
   // partial[wg][9 (reference tap index)][64 ci][64 co] + [wg][64] bias sums after all workgroups' tap blocks
   float* out = partial + (size_t)blockIdx.x * (NTAPS * 4096);
@@ -2011,7 +1990,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_ring_kernel(const float* 
 
 // ---------------------------------------------------------------------------------------------------------------
 // The same for stride-2 scatter programs (ConvTranspose weight gradients: one source class, four destination classes with
-// 4 / 2 / 2 / 1 taps).  conv64_wgrad_ring_kernel<true> walks a 64-position chunk class by class — four barrier pairs per chunk,
+// 4 / 2 / 2 / 1 taps).  (Its predecessor walked a 64-position chunk class by class — four barrier pairs per chunk,
 // the last of them around 32 MFMAs per wave.  Here a chunk is 32 positions and carries the gradient rows of ALL four classes
 // (4 x 8 KB) next to a 184 + 8 row source ring (48 KB): one barrier pair per 144 MFMAs, every tap of a k-block shares the block's
 // loads, and the prefetch (8 gradient + 2 source float4 per thread) travels under a whole chunk.
@@ -2619,10 +2598,12 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
   float* partial = (float*)ws;
   bool single_src = true;
   for (int t = 1; t < NTAPS; ++t) single_src = single_src && P.tsrc[t] == P.tsrc[0];
-  static const int use_ring = [] { const char* e = getenv("SRLZ_WGRAD_RING"); return e ? atoi(e) : 1; }();
   int launched_grid = grid;
-  static const int s2_tk32 = [] { const char* e = getenv("SRLZ_WGRAD_S2_TK32"); return e ? atoi(e) : 1; }();
-  if (use_ring && s2_tk32 && single_src && gf.y == nullptr && P.s2 && 32 + P.span + 32 <= RING_ROWS_S2) {
+  // The chain below is a chain of SHAPE fallbacks (no environment switches): ConvTranspose programs whose span fits the 184-row ring
+  // (PW <= 119) -> conv64_wgrad_ring_s2_kernel; stride-1 programs whose span fits the 246-row ring (PW <= 58) with 32-bit offsets ->
+  // conv64_wgrad_ring_kernel; stride-2 gather programs (conv3) -> conv64_wgrad_gather_kernel; anything else (wider images, operands
+  // rebuilt from (dA, y)) -> the chunk-at-a-time conv64_wgrad_kernel.
+  if (single_src && gf.y == nullptr && P.s2 && 32 + P.span + 32 <= RING_ROWS_S2) {
     // 32-position chunks carrying all four destination classes (conv64_wgrad_ring_s2_kernel)
     const int nch = (P.total_q + 31) / 32;
     const int gpg = grid / P.G;
@@ -2632,7 +2613,7 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
     const size_t lds = (size_t)(RING_S2 + 4 * 32) * 256;
     SRLZ_MAX_LDS(conv64_wgrad_ring_s2_kernel, lds);
     hipLaunchKernelGGL(conv64_wgrad_ring_s2_kernel, dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nch, cpw, wpg, x_bnp);
-  } else if (use_ring && single_src && gf.y == nullptr && tk + P.span + tk <= RING_ROWS && tk == 64 &&
+  } else if (single_src && gf.y == nullptr && !P.s2 && tk + P.span + tk <= RING_ROWS && tk == 64 &&
              (long long)P.N * P.Hs * P.Ws * 64 < (1LL << 32) && (long long)P.N * P.Hd * P.Wd * 64 < (1LL << 32) &&
              (long long)P.total_q + 2 * P.PHW < (1LL << 31)) {  // (the row tables of the stride-1 kernel: 32-bit offsets)
     // contiguous chunk ranges per workgroup (ring re-use of the source rows), group by group
@@ -2641,13 +2622,8 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
     const int wpg = (nchunks + cpw - 1) / cpw;
     launched_grid = wpg * P.G;
     const size_t lds = (size_t)(RING + 64) * 256 + 2 * 64 * 4;  // ring + gradient rows + the two row tables = 80 KB
-    if (P.s2) {
-      SRLZ_MAX_LDS(conv64_wgrad_ring_kernel<true>, lds);
-      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<true>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, wpg, x_bnp);
-    } else {
-      SRLZ_MAX_LDS(conv64_wgrad_ring_kernel<false>, lds);
-      hipLaunchKernelGGL((conv64_wgrad_ring_kernel<false>), dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, wpg, x_bnp);
-    }
+    SRLZ_MAX_LDS(conv64_wgrad_ring_kernel, lds);
+    hipLaunchKernelGGL(conv64_wgrad_ring_kernel, dim3(launched_grid), dim3(256), lds, st, x, dy, partial, P, nchunks, cpw, wpg, x_bnp);
   } else if (wgrad_gather_ok(P) && x_bnp == nullptr && gf.y == nullptr && tk == WG_TK) {
     // stride-2 gather programs (conv3): the software-pipelined kernel; same grid, same partials as conv64_wgrad_kernel<true, 64>
     const size_t lds = (size_t)(WG_TK + P.span + WG_TK) * 256 + (WG_SWORDS + WG_GWORDS) * 4;

@@ -59,10 +59,6 @@ def _requireGpu(cuda):
                            % (cuda, th.cuda.is_available()))
 
 
-# A/B switch: total loss + scalar tail as one launch (0: LossManager.computeTotalLoss() on 0-dim tensors + torch.stack)
-_FUSED_TOTAL = os.environ.get("SRLZ_FUSED_TOTAL", "1") != "0"
-
-
 class _DeviceFeed(object):
     """One-minibatch look-ahead between the loader process and the GPU: the H2D copy of minibatch i+1 is issued on a copy
     stream right after step i has been enqueued (advance()), i.e. BEFORE the host blocks on step i's loss scalars, so it
@@ -287,9 +283,8 @@ class SRL4robotics(BaseLearner):
         # bs >= 64 — the small kernels of a step cost ~10 us each ON THE GPU whether they are enqueued one by one or replayed
         # from a graph, so the cure for small minibatches is fewer kernels (which is what the batched pair delivers).
         # The two frames of a step run as ONE batched model call with two BatchNorm groups (SRLModules.forwardPair): half the
-        # launches, twice the grid of every small layer, per-call BatchNorm semantics intact.  SRLZ_PAIR=0 restores the two
-        # separate calls (A/B, parity tests).  (Round 1's two-HIP-stream form of the two calls is retired: DESIGN.md 5.1.)
-        self._use_pair = os.environ.get("SRLZ_PAIR", "1") != "0"
+        # launches, twice the grid of every small layer, per-call BatchNorm semantics intact.
+        self._use_pair = True  # (False: two model calls per step — what minibatches above 574 samples fall back to; tests set it)
         self._use_graph = os.environ.get("SRLZ_GRAPH", "0") == "1"
         self._graphs = {}
         from srlz import ops as _ops
@@ -559,7 +554,7 @@ class SRL4robotics(BaseLearner):
             # (the step's scalars — total first — ride in the TAIL slots behind the gradients, whichever branch runs below)
             raise ValueError("a training step carries at most {} loss terms (got {}: {})".format(
                 self.flat_params.TAIL - 1, len(loss_manager.losses), loss_manager.names))
-        if _FUSED_TOTAL and len(loss_manager.losses) >= 1:
+        if len(loss_manager.losses) >= 1:
             loss = ops.TotalLossFn.apply(tuple(loss_manager.weights), self.flat_params.tail, *loss_manager.losses)
             loss.backward()  # the reference backpropagates on validation minibatches too (learner.py:487-489)
         else:

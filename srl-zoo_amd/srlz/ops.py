@@ -84,9 +84,10 @@ def timers_report():
 
 # Direct gradient delivery (srlz.optim.FlatParams.grad_buffer / deliver): a parameter re-homed into the flat bucket
 # carries `_srlz_flat`; its weight-gradient kernel writes straight into a staging copy of the bucket and autograd gets
-# None, which removes one tiny `grad += new` launch per parameter and contribution.  SRLZ_DIRECT_GRADS=0 restores the
-# classic path (A/B, tests).
-_DIRECT_GRADS = __import__("os").environ.get("SRLZ_DIRECT_GRADS", "1") != "0"
+# None, which removes one tiny `grad += new` launch per parameter and contribution.  Parameters that are not re-homed (a bare module
+# without FlatParams) or whose stages are used up (a fourth contribution in one pass) take autograd's classic accumulation; tests
+# clear _DIRECT_GRADS in-process to compare the two.
+_DIRECT_GRADS = True
 
 
 def _gbuf(param, shape=None, device=None):
@@ -285,7 +286,7 @@ class PoolLink:
         return p
 
 
-_POOL_LINK = _os.environ.get("SRLZ_POOL_BWD_IN_DGRAD", "1") != "0"
+_POOL_LINK = True  # (the route without it — hotpath.TAPS on, link = None — runs srlz_bn_relu_pool_bwd_sums in the producer instead)
 
 
 class Conv64Fn(Function):
@@ -679,8 +680,8 @@ class DecBlockFn(Function):
         return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(wp, dw), _give(cp, db), None, None, None
 
 
-# A/B switch: the last ConvTranspose's backward as one fused launch (0: data gradient and weight gradient as two launches)
-_FUSED_OUT_BWD = _os.environ.get("SRLZ_FUSED_OUT_BWD", "1") != "0"
+# The last ConvTranspose's backward is ONE fused launch whenever the BatchNorm backward in front of it is deferred (in_link) and the
+# shape is supported (C = 3 / 6); the two-launch form serves hotpath.TAPS (no link) and is the reference of the fused kernel's tests.
 
 
 class DecOutFn(Function):
@@ -715,7 +716,7 @@ def _dec_out_backward(ctx, y_prev, bnp, w, dy, gain):
     d = ctx.desc
     dw = _gbuf(w)
     db = _gbuf(ctx.params[2], d.c, dy.device)
-    if ctx.in_link is not None and _FUSED_OUT_BWD and C.convT_out_bwd_fused_supported(d):
+    if ctx.in_link is not None and C.convT_out_bwd_fused_supported(d):
         # data gradient, its BatchNorm-backward partials and the weight / bias gradients in one pass over (dy, y_prev)
         da = torch.empty_like(y_prev)
         partial = torch.empty((C.convT_out_bwd_fused_tiles(d), 128), dtype=torch.float32, device=dy.device)

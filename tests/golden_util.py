@@ -141,3 +141,39 @@ def endpoint_errors(sd, g, lr, n_steps, eval_states):
     ref = g["eval_states/full"]
     worst["eval_states"] = float(_np.abs(_np.asarray(eval_states, dtype=_np.float64) - ref).max() / _np.abs(ref).max())
     return worst, table
+
+
+def pins_from_observed(observed, B):
+    """(decisions of obs, decisions of next_obs) of ONE batched step: pool argmax (flat H*W index per window) + positivity of the
+    pooled value, decoder ReLU masks — the `pins` format of oracle.torch_twin.train_step.  The batch is [obs ; next_obs] (N = 2 B)."""
+    import torch
+    from srlz import ops
+    full = {}
+    for name, pad in (("encoder_conv.3", 1), ("encoder_conv.7", 0), ("encoder_conv.11", 0)):
+        pooled, saved = observed[name]
+        y, _bnp, arg = saved[:3]
+        n, h, w, _ = y.shape
+        a = arg.long().cpu().permute(0, 3, 1, 2)  # [n, c, hp, wp]: window index ky * 3 + kx
+        hp, wp = a.shape[2], a.shape[3]
+        py, px = torch.arange(hp).view(1, 1, hp, 1), torch.arange(wp).view(1, 1, 1, wp)
+        idx = (py * 2 - pad + a // 3) * w + (px * 2 - pad + a % 3)
+        pooled = pooled.cpu()
+        if pooled.shape != a.shape:
+            pooled = pooled.permute(0, 3, 1, 2)
+        full[name] = (idx, pooled > 0)
+    for node, relu in ((3, 2), (6, 5), (9, 8), (12, 11)):
+        key = "decoder_conv.%d" % node
+        if key not in observed:
+            continue
+        y_prev, bnp = observed[key][1][:2]
+        groups = bnp.numel() // 256
+        per = y_prev.shape[0] // groups
+        act = torch.cat([ops.bn_relu_materialise(y_prev[g * per:(g + 1) * per].contiguous(), bnp[256 * g:256 * (g + 1)].contiguous())
+                         for g in range(groups)], 0)
+        full["decoder_conv.%d" % relu] = act.cpu().permute(0, 3, 1, 2) > 0
+    halves = ({}, {})
+    for k, v in full.items():
+        for i in range(2):
+            sl = slice(i * B, (i + 1) * B)
+            halves[i][k] = (v[0][sl], v[1][sl]) if isinstance(v, tuple) else v[sl]
+    return halves

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
 import isa_audit  # noqa: E402
 
-HOT = ("conv64_fwd_kernel<4, false>", "conv64_fwd_kernel<4, true>", "conv64_wgrad_ring_kernel<false>", "conv64_wgrad_gather_kernel",
+HOT = ("conv64_fwd_kernel<4, false>", "conv64_fwd_kernel<4, true>", "conv64_wgrad_ring_kernel", "conv64_wgrad_gather_kernel",
        "conv64_dgrad_poolsum_kernel<1>", "conv64_dgrad_poolsum_kernel<2>",
        "conv64_wgrad_ring_s2_kernel", "conv64_dgrad_pipe_kernel",
        "skinny_conv_kernel<7, 3, false, false, float>",

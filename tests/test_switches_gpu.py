@@ -44,10 +44,13 @@ np.save(sys.argv[3], flat)
 print("RESULT " + json.dumps({"losses": rows, "names": list(lm.names), "bufs": bufs, "steps": srl.optimizer.steps()}))
 """
 
-SWITCHES = [("SRLZ_DEFER_BN_BWD", "0"), ("SRLZ_FUSE_ENC_IN", "0"), ("SRLZ_DIRECT_GRADS", "0"), ("SRLZ_WGRAD_RING", "0"),
-            ("SRLZ_WGRAD_S2_TK32", "0"), ("SRLZ_PAIR", "0"), ("SRLZ_GRAPH", "1"), ("SRLZ_FUSED_TOTAL", "0"), ("SRLZ_FUSED_OUT_BWD", "0"),
-            ("SRLZ_FUSED_RECON", "0"), ("SRLZ_FUSED_CONVT_BWD", "0"), ("SRLZ_DGRAD_PIPE", "0"), ("SRLZ_POOL_BWD_IN_DGRAD", "0"),
-            ("SRLZ_SYNC", "1")]
+# Round 5 retired the A/B residue (ten variables; DESIGN.md 5.1): what is left selects a feature (hipGraph replay), a debugging aid
+# (synchronise after every call) and the two-launch form of a ConvTranspose block's backward (pipelined data gradient + ring weight
+# gradient) with its synchronous predecessor.  The fallback ROUTES the retired variables used to select are reached the way the
+# product reaches them — by shape or by what the step needs — in tests/test_pair_gpu.py, test_step_gpu.py, test_trajectory_gpu.py.
+SWITCHES = [("SRLZ_GRAPH", "1"), ("SRLZ_FUSED_CONVT_BWD", "0"), ("SRLZ_DGRAD_PIPE", "0"), ("SRLZ_SYNC", "1")]
+RETIRED = ["SRLZ_DEFER_BN_BWD", "SRLZ_FUSE_ENC_IN", "SRLZ_DIRECT_GRADS", "SRLZ_WGRAD_RING", "SRLZ_WGRAD_S2_TK32", "SRLZ_PAIR",
+           "SRLZ_FUSED_TOTAL", "SRLZ_FUSED_OUT_BWD", "SRLZ_FUSED_RECON", "SRLZ_POOL_BWD_IN_DGRAD"]
 
 
 def _run_all(losses, tmp_path):
@@ -108,3 +111,15 @@ def test_every_switch_lands_where_the_default_path_lands(losses, tmp_path):
         # +-lr per step on whichever side the noise falls, and the layer's batch means move with it: 64 channels x lr 1e-3 x momentum
         # 0.1 x 2 steps bounds what two summation orders can differ by in such a sum, a few 1e-3 absolute)
         np.testing.assert_allclose(got["bufs"], ref["bufs"], rtol=1e-3, atol=5e-3, err_msg=name)
+
+
+def test_retired_switches_are_gone_from_the_sources():
+    """No source file reads a retired variable any more (a variable that is read but untested is a path the next change breaks)."""
+    import glob
+    files = [f for pat in ("srl-zoo_amd/**/*.py", "srl-zoo_amd/csrc/*", "bench.py") for f in glob.glob(os.path.join(REPO, pat), recursive=True)
+             if os.path.isfile(f) and not f.endswith((".o", ".so", ".pyc"))]
+    assert len(files) > 20
+    for f in files:
+        text = open(f, errors="replace").read()
+        for name in RETIRED:
+            assert ('"%s"' % name) not in text, (f, name)
