@@ -45,7 +45,7 @@ enum srlz_status {
  * 101 (round 4): srlz_convT_out_bwd_fused carries three gain arguments (added in round 3 without a bump); its partial records and
  *                workspace follow the strip geometry of csrc/convt_out.hip; srlz_convT_out_fwd_loss_workgroups counts those strips'
  *                workgroups. */
-#define SRLZ_ABI_VERSION 101
+#define SRLZ_ABI_VERSION 102
 int srlz_version(void);
 const char* srlz_last_error(void);
 /* Number of CUs of the current device (used by callers to size persistent grids / workspaces). */
@@ -443,6 +443,14 @@ int srlz_normalize_u8_planar(const uint8_t* x_u8, const float* norm_lut, float* 
  * gather (next_obs = store[minibatch + 1]: src_shift = 1), scatter (store <- a freshly decoded minibatch), plain copy. */
 int srlz_copy_frames_u8(const uint8_t* src, const long long* src_index, long long src_shift, uint8_t* dst,
                         const long long* dst_index, long long dst_shift, int n, long long frame_bytes, srlz_stream_t stream);
+/* The same between frames of different pitch, for a byte range inside the frame:
+ *   dst[df][dst_offset .. dst_offset + copy_bytes) = src[sf][src_offset .. src_offset + copy_bytes),  frames src_frame_bytes / dst_frame_bytes apart.
+ * The time-contrastive triplets of /root/reference/preprocessing/data_loader.py:219-243 are [view 1 ; view 2 ; view 1 of ANOTHER time step
+ * of the same record] = 9 channels; the store keeps the two views of every time step (6 channels), so a triplet minibatch is two
+ * gathers by index — the frame's own two views, and the negative's first — and no pixel of it is decoded again (round 5). */
+int srlz_copy_frames_u8_strided(const uint8_t* src, const long long* src_index, long long src_shift, long long src_frame_bytes,
+                                long long src_offset_bytes, uint8_t* dst, const long long* dst_index, long long dst_shift,
+                                long long dst_frame_bytes, long long dst_offset_bytes, int n, long long copy_bytes, srlz_stream_t stream);
 /* The DAE loader's occluded copies (preprocessing/data_loader.py:100-111) made on the device from resident frames: out [n,C,W,H] fp32 =
  * the normalised frame store[index[i] + shift] with the rectangle rects[i][view] = (h1, h2, w1, w2) set to 0, one rectangle per
  * camera view (group of 3 channels); the rectangles are drawn by the loader process with the reference's np.random calls. */

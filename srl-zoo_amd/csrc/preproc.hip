@@ -76,6 +76,22 @@ __global__ __launch_bounds__(256) void copy_frames_kernel(const uint8_t* __restr
   for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < words; w += (long long)gridDim.x * 256) d[w] = s[w];
 }
 
+// The same with different frame pitches on the two sides and a byte offset inside the frame: `words` 16-byte words of
+// src frame sf (pitch src_pitch words, starting src_off words in) -> dst frame df (pitch dst_pitch, starting dst_off).  What assembles the
+// 9-channel triplet observation [view 1 ; view 2 ; view 1 of the negative] from a store of 6-channel frames, and what keeps the
+// first two views of a freshly decoded 9-channel minibatch.
+__global__ __launch_bounds__(256) void copy_frames_strided_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ src_index,
+                                                                 long long src_shift, long long src_pitch, long long src_off,
+                                                                 uint8_t* __restrict__ dst, const long long* __restrict__ dst_index,
+                                                                 long long dst_shift, long long dst_pitch, long long dst_off,
+                                                                 long long words) {
+  const long long i = blockIdx.y;
+  const long long sf = src_index ? src_index[i] + src_shift : i, df = dst_index ? dst_index[i] + dst_shift : i;
+  const uint4* __restrict__ s = (const uint4*)src + sf * src_pitch + src_off;
+  uint4* __restrict__ d = (uint4*)dst + df * dst_pitch + dst_off;
+  for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < words; w += (long long)gridDim.x * 256) d[w] = s[w];
+}
+
 // The DAE's occluded copy of a frame taken from the store (reference preprocessing/data_loader.py:100-111: the NORMALISED image
 // with a random rectangle set to 0): out[i][c][w][h] = (h1 <= h < h2 && w1 <= w < w2) ? 0 : lut[c % 3][store[index[i]+shift][c][w][h]],
 // one rectangle (h1, h2, w1, w2) per frame and camera view (group of 3 channels), drawn by the loader process.
@@ -113,6 +129,29 @@ extern "C" int srlz_copy_frames_u8(const uint8_t* src, const long long* src_inde
   if (gx > 16) gx = 16;
   hipLaunchKernelGGL(copy_frames_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), src, src_index, src_shift, dst, dst_index,
                      dst_shift, words);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_copy_frames_u8_strided(const uint8_t* src, const long long* src_index, long long src_shift,
+                                           long long src_frame_bytes, long long src_offset_bytes, uint8_t* dst,
+                                           const long long* dst_index, long long dst_shift, long long dst_frame_bytes,
+                                           long long dst_offset_bytes, int n, long long copy_bytes, srlz_stream_t stream) {
+  SRLZ_REQUIRE(src && dst, SRLZ_ERR_NULL, "copy_frames_u8_strided: null pointer");
+  SRLZ_REQUIRE(n > 0 && n <= 65535 && copy_bytes > 0 && copy_bytes % 16 == 0 && src_frame_bytes % 16 == 0 && dst_frame_bytes % 16 == 0 &&
+                   src_offset_bytes % 16 == 0 && dst_offset_bytes % 16 == 0,
+               SRLZ_ERR_BAD_DESC, "copy_frames_u8_strided: 1..65535 frames; sizes, pitches and offsets in multiples of 16 bytes (got %d x %lld)",
+               n, copy_bytes);
+  SRLZ_REQUIRE(src_offset_bytes >= 0 && dst_offset_bytes >= 0 && src_offset_bytes + copy_bytes <= src_frame_bytes &&
+                   dst_offset_bytes + copy_bytes <= dst_frame_bytes,
+               SRLZ_ERR_BAD_DESC, "copy_frames_u8_strided: [offset, offset + %lld) must lie inside a frame (%lld+ of %lld -> %lld+ of %lld)",
+               copy_bytes, src_offset_bytes, src_frame_bytes, dst_offset_bytes, dst_frame_bytes);
+  SRLZ_REQUIRE((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, SRLZ_ERR_BAD_DESC, "copy_frames_u8_strided: unaligned buffer");
+  const long long words = copy_bytes / 16;
+  int gx = (int)((words + 255) / 256);
+  if (gx > 16) gx = 16;
+  hipLaunchKernelGGL(copy_frames_strided_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), src, src_index, src_shift, src_frame_bytes / 16,
+                     src_offset_bytes / 16, dst, dst_index, dst_shift, dst_frame_bytes / 16, dst_offset_bytes / 16, words);
   SRLZ_LAUNCHED();
   return 0;
 }

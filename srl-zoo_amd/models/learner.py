@@ -628,14 +628,16 @@ class SRL4robotics(BaseLearner):
 
         # The decoded dataset stays resident (uint8 [frames, C, W, H], in HBM when it fits the budget): epoch 1 streams from the
         # loader process as in the reference and is absorbed, later epochs receive INDICES from that same process (same per-epoch
-        # permutation from the same forked RNG, same end-of-epoch marker) and gather on the device.  Triplets keep streaming: their
-        # negative view is a fresh random draw per frame and epoch (reference data_loader.py:219-243).
+        # permutation from the same forked RNG, same end-of-epoch marker) and gather on the device.  Triplets too: the negative view of a
+        # frame is camera 1 of ANOTHER time step of the same record (reference data_loader.py:219-243) — an index into the same store,
+        # which keeps the two views of every time step; the loader process keeps drawing it with the reference's random.randint.
         use_bytes = bool(RAW_UINT8_INPUT)
         resident = fill = None
-        if RESIDENT_FRAMES and use_bytes and not self.use_triplets and n_epochs_planned(self.losses) > 1:
+        if RESIDENT_FRAMES and use_bytes and n_epochs_planned(self.losses) > 1 \
+                and (not self.use_triplets or DataLoader.negativesIndexable(images_path)):
             from preprocessing.resident import ResidentFrames
             import preprocessing.preprocess as _pre
-            frame_shape = (_pre.getNChannels(), _pre.IMAGE_WIDTH, _pre.IMAGE_HEIGHT)
+            frame_shape = (6 if self.use_triplets else _pre.getNChannels(), _pre.IMAGE_WIDTH, _pre.IMAGE_HEIGHT)
             # (the DAE's device-side occlusion reads the store in HBM: no store at all when it would not fit there)
             if not self.use_dae or ResidentFrames.fits_device(len(images_path), frame_shape, self.device):
                 needed = np.concatenate([np.concatenate((mb, mb + 1)) for mb in minibatchlist])
@@ -687,9 +689,13 @@ class SRL4robotics(BaseLearner):
                     # an index-only minibatch: its frames are resident; gather [obs ; next_obs] (and the DAE's occluded copies, from
                     # the rectangles the loader process drew) on the device
                     mb = minibatchlist[minibatch_idx]
-                    if self.use_dae:
-                        noisy_obs, next_noisy_obs = resident.occluded_pair(mb, noisy_obs, next_noisy_obs)
-                    obs, next_obs = resident.pair(mb)
+                    if self.use_triplets:  # (the loader process drew the negatives: frame indices in the two trailing slots)
+                        obs, next_obs = resident.triplet_pair(mb, noisy_obs, next_noisy_obs)
+                        noisy_obs = next_noisy_obs = None
+                    else:
+                        if self.use_dae:
+                            noisy_obs, next_noisy_obs = resident.occluded_pair(mb, noisy_obs, next_noisy_obs)
+                        obs, next_obs = resident.pair(mb)
                     obs, next_obs = self._toDevicePair(obs, next_obs)
                 else:
                     if self.use_dae:

@@ -161,7 +161,8 @@ class DataLoader(object):
                           (minibatch_idx, None, None, rects, next_rects) — the SAME per-epoch permutation from the same forked RNG
                           and the same end-of-epoch None, but no pixels: the consumer holds the decoded frames
                           (preprocessing/resident.py) and gathers the minibatch by index.  rects / next_rects: with occlusion, the
-                          int32 [B, views, 4] rectangles (h_1, h_2, w_1, w_2) drawn with the reference's np.random calls; else None.
+                          int32 [B, views, 4] rectangles (h_1, h_2, w_1, w_2) drawn with the reference's np.random calls; with triplets,
+                          the int64 [B] frame indices of the negative observations (the reference's random.randint draws); else None.
                           Such a producer also PAUSES behind the end-of-epoch marker of its first epoch until the consumer has said
                           what epoch 2 is made of — shipIndices() or keepPixels(); coming back for the next item without a decision
                           counts as keepPixels() — so the epoch after the decision is index-only from its first minibatch (the
@@ -194,6 +195,7 @@ class DataLoader(object):
         # (created BEFORE the fork: the producer sees the same flag)
         self.index_mode = Event() if (index_switch and is_training) else None
         self.epoch_gate = Event() if self.index_mode is not None else None
+        self._index_of = None  # image stem -> frame index (built on first use by the triplet index path)
         self._epochs_received = 0
         self.startProcess()
 
@@ -255,6 +257,8 @@ class DataLoader(object):
                 idx = self.minibatchlist[minibatch_idx]
                 if self.index_mode is not None and self.index_mode.is_set():
                     rects = next_rects = None
+                    if self.use_triplets:  # the negatives of the frames of obs, then of next_obs: indices into images_path
+                        rects, next_rects = self._negativeIndices(idx), self._negativeIndices(idx + 1)
                     if self.apply_occlusion:  # one rectangle per frame and camera view, frames of obs first, then of next_obs
                         views = 2 if self.multi_view else 1
                         draw = np.array([drawOcclusion(self.occlusion_percentage) for _ in range(2 * len(idx) * views)],
@@ -290,6 +294,54 @@ class DataLoader(object):
         while True:
             time.sleep(0.05)
 
+    # ---- time-contrastive triplets (reference data_loader.py:219-243): the negative observation of a frame is camera 1 of a random
+    # OTHER time step of the same record.  The draw — a glob of the record's camera-1 files, the current step removed, one
+    # random.randint — is kept in one place: the streaming path decodes the file it names, the index path (the dataset resident in
+    # HBM) ships the INDEX of that time step in images_path instead.
+    _record_steps = {}  # record prefix -> time steps in the order glob returned them (a fork inherits what the parent has seen)
+
+    @classmethod
+    def _negativeStep(cls, stem):
+        """The time step (int) of the negative observation of 'data/<...>/frameNNNNNN' — the reference's draw, in its order."""
+        extra_chars = '_1.jpg'
+        prefix = stem[:-6]
+        steps = cls._record_steps.get(prefix)
+        if steps is None:
+            digits_path = glob.glob(prefix + '[0-9]*' + extra_chars)
+            steps = [int(k[:-len(extra_chars)][-6:]) for k in digits_path]
+            cls._record_steps[prefix] = steps
+        all_frame_steps = list(steps)
+        all_frame_steps.remove(int(stem[-6:]))
+        return all_frame_steps[random.randint(0, len(all_frame_steps) - 1)]
+
+    @staticmethod
+    def _stem(image_path):
+        return 'data/' + image_path.split('.jpg')[0]
+
+    @classmethod
+    def negativesIndexable(cls, images_path):
+        """True when every negative the reference could draw is itself an entry of images_path (every camera-1 file of every record is
+        a listed time step): then a triplet is (index, negative index) into a store of the listed frames, and nothing else."""
+        listed = {}
+        for p in images_path:
+            stem = cls._stem(p)
+            listed.setdefault(stem[:-6], set()).add(int(stem[-6:]))
+        for prefix, steps in listed.items():
+            on_disk = set(int(k[:-len('_1.jpg')][-6:]) for k in glob.glob(prefix + '[0-9]*' + '_1.jpg'))
+            if not on_disk or not on_disk <= steps:
+                return False
+        return True
+
+    def _negativeIndices(self, idx):
+        """Frame index (into images_path) of the negative observation of every frame in idx, drawn in order."""
+        if self._index_of is None:
+            self._index_of = {self._stem(p): i for i, p in enumerate(self.images_path)}
+        out = np.empty(len(idx), dtype=np.int64)
+        for k, i in enumerate(idx):
+            stem = self._stem(self.images_path[i])
+            out[k] = self._index_of['{}{:06d}'.format(stem[:-6], self._negativeStep(stem))]
+        return out
+
     @classmethod
     def _makeBatchElement(cls, image_path, multi_view=False, use_triplets=False, apply_occlusion=False,
                           occlusion_percentage=None, raw_uint8=False):
@@ -301,13 +353,7 @@ class DataLoader(object):
         if multi_view and use_triplets:
             # negative observation (reference data_loader.py:219-243): camera 1 of a random OTHER time step of the same
             # record, drawn with Python's `random` as the reference does; it is never occluded
-            extra_chars = '_1.jpg'
-            digits_path = glob.glob(stem[:-6] + '[0-9]*' + extra_chars)
-            current = int(stem[-6:])
-            all_frame_steps = [int(k[:-len(extra_chars)][-6:]) for k in digits_path]
-            all_frame_steps.remove(current)
-            negative = all_frame_steps[random.randint(0, len(all_frame_steps) - 1)]
-            names.append('{}{:06d}_1.jpg'.format(stem[:-6], negative))
+            names.append('{}{:06d}_1.jpg'.format(stem[:-6], cls._negativeStep(stem)))
             occlude.append(False)
         views = []
         for name, occ in zip(names, occlude):

@@ -184,9 +184,15 @@ class ResidentFrames(object):
                 n = len(idx)
                 for frames, shift in ((obs, 0), (next_obs, 1)):
                     frames = frames if frames.is_contiguous() else frames.contiguous()
-                    self.C.copy_frames_u8(ptr(frames), None, 0, ptr(self.store), ptr(di), shift, n, self.frame_bytes, stream())
+                    got = int(frames[0].numel())  # (triplet minibatches carry a third view behind the two the store keeps)
+                    if got == self.frame_bytes:
+                        self.C.copy_frames_u8(ptr(frames), None, 0, ptr(self.store), ptr(di), shift, n, self.frame_bytes, stream())
+                    else:
+                        self.C.copy_frames_u8_strided(ptr(frames), None, 0, got, 0, ptr(self.store), ptr(di), shift, self.frame_bytes, 0,
+                                                      n, self.frame_bytes, stream())
             else:
-                host0, host1 = obs.cpu(), next_obs.cpu()
+                c = self.frame_shape[0]
+                host0, host1 = obs[:, :c].cpu(), next_obs[:, :c].cpu()
                 self.store[th.from_numpy(idx)] = host0
                 self.store[th.from_numpy(idx + 1)] = host1
             self._mark(idx[new0])
@@ -286,6 +292,46 @@ class ResidentFrames(object):
             stage = self._stage[k][:2 * n]
             th.index_select(self.store, 0, hi, out=stage[:n])
             th.index_select(self.store, 0, hi + 1, out=stage[n:])
+            both.copy_(stage, non_blocking=True)
+            if self.device.type == "cuda":
+                self._stage_ev[k] = th.cuda.Event()
+                self._stage_ev[k].record(th.cuda.current_stream(self.device))
+        return both[:n], both[n:]
+
+    def triplet_pair(self, idx, negatives, next_negatives):
+        """The time-contrastive triplet observations of a minibatch (reference preprocessing/data_loader.py:219-243) from a store of
+        two-view frames [n_frames, 6, W, H]: (obs, next_obs), each [B, 9, W, H] = [view 1 ; view 2 ; view 1 of the negative time step],
+        as the halves of one buffer.  negatives / next_negatives: int64 [B] frame indices drawn by the loader process."""
+        idx = np.asarray(idx, dtype=np.int64)
+        n = len(idx)
+        c, w, h = self.frame_shape
+        if c != 6:
+            raise ValueError("triplet_pair reads a store of two-view frames (6 channels), not %d" % c)
+        view = 3 * w * h
+        both = th.empty((2 * n, 9, w, h), dtype=th.uint8, device=self.device)
+        self.gathers += 1
+        if self.on_device:
+            from srlz.ops import stream, ptr
+            di = self._index(idx)
+            for half, (shift, neg) in enumerate(((0, negatives), (1, next_negatives))):
+                out = both[half * n:(half + 1) * n]
+                dn = self._index(neg)
+                self.C.copy_frames_u8_strided(ptr(self.store), ptr(di), shift, 2 * view, 0, ptr(out), None, 0, 3 * view, 0, n, 2 * view,
+                                              stream())
+                self.C.copy_frames_u8_strided(ptr(self.store), ptr(dn), 0, 2 * view, 0, ptr(out), None, 0, 3 * view, 2 * view, n, view,
+                                              stream())
+        else:
+            k = self._stage_i
+            self._stage_i ^= 1
+            if self._stage_ev[k] is not None:
+                self._stage_ev[k].synchronize()
+            if self._stage[k] is None or self._stage[k].numel() < both.numel():
+                self._stage[k] = th.empty(both.numel(), dtype=th.uint8, pin_memory=th.cuda.is_available())
+            stage = self._stage[k][:both.numel()].view(both.shape)
+            for half, (shift, neg) in enumerate(((0, negatives), (1, next_negatives))):
+                out = stage[half * n:(half + 1) * n]
+                out[:, :6] = self.store[th.from_numpy(idx + shift)]
+                out[:, 6:] = self.store[th.from_numpy(np.asarray(neg, dtype=np.int64))][:, :3]
             both.copy_(stage, non_blocking=True)
             if self.device.type == "cuda":
                 self._stage_ev[k] = th.cuda.Event()

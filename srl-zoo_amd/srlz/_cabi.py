@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrlz_hip.so")
 
 
-ABI_VERSION = 101  # include/srlz.h SRLZ_ABI_VERSION these prototypes were written for
+ABI_VERSION = 102  # include/srlz.h SRLZ_ABI_VERSION these prototypes were written for
 
 
 class SrlzError(RuntimeError):
@@ -93,6 +93,8 @@ _PROTOS = {
     "srlz_normalize_lut": (c_int, [P, P]),
     "srlz_normalize_u8_planar": (c_int, [P, P, P, c_int, c_int, c_longlong, P]),
     "srlz_copy_frames_u8": (c_int, [P, P, c_longlong, P, P, c_longlong, c_int, c_longlong, P]),
+    "srlz_copy_frames_u8_strided": (c_int, [P, P, c_longlong, c_longlong, c_longlong, P, P, c_longlong, c_longlong, c_longlong, c_int,
+                                            c_longlong, P]),
     "srlz_occlude_frames_u8": (c_int, [P, P, c_longlong, P, P, P, c_int, c_int, c_int, c_int, P]),
     "srlz_skinny_bwd_weight_workspace": (c_size_t, [_SK]),
     "srlz_conv1_bwd_weight": (c_int, [P, P, P, P, c_size_t, _SK, P]),

@@ -191,5 +191,8 @@ if __name__ == '__main__':
             json.dump(getattr(srl, "epoch_stats", []), f)
         correlationCall(exp_config, plot=False)
     if world_size > 1:
+        # (every rank's own per-epoch record: wall seconds, minibatches served from the resident store, the slice exchange)
+        with open('{}/epoch_stats_rank{}.json'.format(args.log_folder, rank), 'w') as f:
+            json.dump(getattr(srl, "epoch_stats", []), f)
         optim.destroy_native_comm()  # (no-op unless SRLZ_COMM=rccl created the library's own communicator)
         th.distributed.destroy_process_group()
