@@ -313,3 +313,55 @@ def test_try_next_never_waits(dataset):
     assert [tuple(g.shape) for g in got] == [(3, 3, 224, 224), (2, 3, 224, 224), (0,)] and empties >= 1
     assert torch.equal(got[1][0], DataLoader._makeBatchElement(paths[3], raw_uint8="planar")[0])
     assert DataLoader.STARTUP_TIMEOUT == 0.0  # a live producer is never re-forked unless SRLZ_LOADER_STARTUP_TIMEOUT says so
+
+
+def test_triplet_index_mode_names_the_negatives_the_streaming_loader_decodes(tmp_path):
+    """The triplets of the resident store (round 5): with indices shipped, an item carries the FRAME INDEX of every negative observation
+    — drawn by the loader process with the reference's glob + random.randint (data_loader.py:219-243).
+    (a) the two code paths make the same draw: for the same state of Python's `random`, the element builder of the streaming path decodes
+        camera 1 of exactly the frame the index path names;
+    (b) through the loader processes (whose `random` is re-seeded by Python at fork — in the reference as here — so the draws of two
+        processes cannot be compared): same minibatch order as a streaming loader forked from the same np.random state, negatives are
+        other time steps of the frame's own record, obs and next_obs draws are separate."""
+    import random
+    from preprocessing.data_loader import DataLoader
+    name, paths, *_ = make_dataset(str(tmp_path), name="tiny_tri", n_episodes=2, ep_len=7, multi_view=True)
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        assert DataLoader.negativesIndexable(paths)
+        assert not DataLoader.negativesIndexable(paths[:5])  # a listed subset: negatives on disk that are not frames of the dataset
+        ml = [np.array([0, 1, 2]), np.array([3, 4, 5]), np.array([7, 8, 9]), np.array([10, 11, 12])]
+        np.random.seed(3)
+        stream = DataLoader(ml, paths, n_workers=1, multi_view=True, use_triplets=True, is_training=True, raw_uint8="planar",
+                            infinite_loop=False)
+        np.random.seed(3)
+        index = DataLoader(ml, paths, n_workers=1, multi_view=True, use_triplets=True, is_training=True, raw_uint8="planar",
+                           infinite_loop=False, index_switch=True)
+        index.shipIndices()
+        # (a) in this process, on the loader object itself
+        for seed in range(6):
+            frames = np.array([1, 4, 9, 12])
+            random.seed(seed)
+            named = index._negativeIndices(frames)
+            random.seed(seed)
+            for k, f in enumerate(frames):
+                el = DataLoader._makeBatchElement(paths[f], multi_view=True, use_triplets=True, raw_uint8="planar")
+                view1 = DataLoader._makeBatchElement(paths[named[k]], multi_view=True, raw_uint8="planar")[0, :3]
+                assert torch.equal(el[0, 6:], view1) and named[k] != f
+        # (b) through the processes
+        a, b = list(stream), list(index)
+        assert [int(i[0]) for i in a] == [int(i[0]) for i in b] and len(a) == 4
+        assert sum(1 for i in b if i[1] is None) >= 3  # (the producer may have prepared its first minibatch before the switch was flipped)
+        assert all(tuple(i[1].shape) == (3, 9, 224, 224) for i in a)
+        for i_item in b:
+            if i_item[1] is not None:
+                continue
+            mb = ml[int(i_item[0])]
+            neg, next_neg = i_item[3], i_item[4]
+            assert neg.dtype == np.int64 and neg.shape == (3,) and next_neg.shape == (3,)
+            for k in range(3):
+                for idx, nn in ((mb[k], neg[k]), (mb[k] + 1, next_neg[k])):
+                    assert nn != idx and paths[nn].rsplit("/", 1)[0] == paths[idx].rsplit("/", 1)[0]  # another step of the same record
+    finally:
+        os.chdir(cwd)

@@ -53,6 +53,37 @@ def test_store_scatter_gather_round_trip(budget):
     assert store.gathers == 3
 
 
+@pytest.mark.parametrize("budget", [None, 0], ids=["hbm", "pinned_host"])
+def test_triplet_pair_from_a_two_view_store(budget):
+    """Time-contrastive triplets (reference preprocessing/data_loader.py:219-243) from the resident store: the store keeps the two
+    camera views of every time step (6 channels); a streamed 9-channel minibatch leaves its first two views there (strided scatter),
+    and a triplet minibatch is [views of frame idx ; view 1 of the frame the loader named as negative] (two strided gathers)."""
+    from preprocessing.resident import ResidentFrames
+    rs = np.random.RandomState(11)
+    n_frames = 24
+    two = torch.from_numpy(rs.randint(0, 256, (n_frames, 6, 224, 224)).astype(np.uint8))
+    ml = [np.array([0, 1, 2, 5]), np.array([8, 9, 20, 21]), np.array([12, 13, 14, 16])]
+    needed = np.concatenate([np.concatenate((m, m + 1)) for m in ml])
+    store = ResidentFrames(n_frames, (6, 224, 224), torch.device(DEV, torch.cuda.current_device()), needed, budget=budget)
+    for m in ml:  # what the streaming epoch delivers: 9 channels, the third view a negative that is NOT kept
+        junk = torch.from_numpy(rs.randint(0, 256, (len(m), 3, 224, 224)).astype(np.uint8))
+        obs = torch.cat((two[m], junk), 1).to(DEV)
+        nxt = torch.cat((two[m + 1], junk), 1).to(DEV)
+        store.absorb(m, obs, nxt)
+    assert store.complete()
+    for m in ml:
+        neg, next_neg = rs.choice(np.unique(needed), len(m)), rs.choice(np.unique(needed), len(m))
+        obs, nxt = store.triplet_pair(m, neg, next_neg)
+        torch.cuda.synchronize()
+        assert tuple(obs.shape) == (4, 9, 224, 224) and obs.dtype == torch.uint8 and obs.is_cuda
+        assert torch.equal(obs[:, :6].cpu(), two[m]) and torch.equal(obs[:, 6:].cpu(), two[neg][:, :3])
+        assert torch.equal(nxt[:, :6].cpu(), two[m + 1]) and torch.equal(nxt[:, 6:].cpu(), two[next_neg][:, :3])
+        assert nxt.storage_offset() == obs.storage_offset() + obs.numel()  # the halves of one buffer
+    with pytest.raises(ValueError):
+        ResidentFrames(4, (3, 224, 224), torch.device(DEV, torch.cuda.current_device()), np.arange(4)).triplet_pair(
+            np.array([0]), np.array([1]), np.array([2]))
+
+
 @pytest.mark.parametrize("c", [3, 6])
 def test_device_occlusion_is_the_loaders(c):
     """srlz_occlude_frames_u8 on resident frames == preprocessInput(frame) with im[h_1:h_2, w_1:w_2, :] = 0 per camera view, in the

@@ -187,3 +187,6 @@ def test_train_cli_multi_view_triplet(tmp_path):
     assert "triplet_loss" in hist.files and np.isfinite(hist["triplet_loss"]).all()
     cfg = json.load(open(os.path.join(log, "exp_config.json")))
     assert cfg["losses"] == ["triplet"] and cfg["multi-view"] is True
+    # round 5: the triplet stream is resident too — epoch 1 decodes, epoch 2 gathers [view 1 ; view 2 ; negative's view 1] by index
+    e1, e2 = json.load(open(os.path.join(log, "epoch_stats.json")))
+    assert e1["index_minibatches"] == 0 and e2["minibatches"] >= 2 and e2["index_minibatches"] == e2["minibatches"]
