@@ -345,6 +345,14 @@ size_t srlz_linear_workspace(int M, int N, int K);
 int srlz_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu,
                     void* ws, size_t ws_bytes, srlz_stream_t stream);
 /* dx[M,K] = dy[M,N] . w[N,K] */
+/* The forward model's residual (forward_inverse.py:27-37: next_state = state + Linear([state ; onehot(action)])) in the GEMM's
+ * epilogue: y = (x . w^T + b) + res with res [M, N] — two separately rounded fp32 adds, as the reference rounds them — and its data
+ * gradient restricted to the first Kout input columns (the state part of the concatenation) with the residual branch's gradient
+ * added: dx[M, Kout] = (dy . w)[:, :Kout] + res, res [M, Kout] (res = dy for the residual above: N == Kout). */
+int srlz_linear_fwd_res(const float* x, const float* w, const float* b, const float* res, float* y, int M, int N, int K, int relu,
+                        void* ws, size_t ws_bytes, srlz_stream_t stream);
+int srlz_linear_bwd_data_res(const float* dy, const float* w, const float* res, float* dx, int M, int N, int K, int Kout, void* ws,
+                             size_t ws_bytes, srlz_stream_t stream);
 int srlz_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, void* ws, size_t ws_bytes,
                          srlz_stream_t stream);
 /* dw[N,K] = dy^T . x ; db[N] = column sums of dy (may be NULL) */
@@ -396,6 +404,9 @@ int srlz_weighted_total(const float* const* scalars, const float* weights, int n
                         srlz_stream_t stream);
 int srlz_weighted_total_bwd(const float* dout, const float* weights, int n, float* g, srlz_stream_t stream);
 /* out[0] = -0.5*sum(1 + logvar - mu^2 - exp(logvar))      kullbackLeiblerLoss 239-256 */
+/* out[0] = fp32(sum((a-b)^2)) / div      reconstructionLoss 172-181 (div = numel): the fp32 division behind the sum's rounding */
+int srlz_sqdiff_mean(const float* a, const float* b, long long n, float div, float* out, void* ws, size_t ws_bytes,
+                     srlz_stream_t stream);
 int srlz_kl_sum(const float* mu, const float* logvar, long long n, float* out, void* ws, size_t ws_bytes,
                 srlz_stream_t stream);
 /* dmu += g*mu ; dlogvar += g*0.5*(exp(logvar)-1)   with g = coef_dev[0]*coef */
@@ -421,6 +432,14 @@ int srlz_triplet_fwd(const float* s, const float* p, const float* n, int B, int 
 int srlz_triplet_bwd(const float* s, const float* p, const float* n, const float* hinge, const float* g, int B, int S,
                      float* ds, float* dp, float* dn, srlz_stream_t stream);
 /* cat[b,:] = [s[b,:S], onehot(a[b])]          forwardModel forward_inverse.py:21-31 + encodeOneHot models.py:229-237 */
+/* th.cat((state, next_state), dim=1) of the inverse / reward heads (forward_inverse.py:62,78-95) and the split of its gradient
+ * (a or b may be NULL: that half is not wanted); out / in: [rows, ca + cb], a: [rows, ca], b: [rows, cb]. */
+int srlz_cat_cols(const float* a, const float* b, float* out, int rows, int ca, int cb, srlz_stream_t stream);
+int srlz_split_cols(const float* in, float* a, float* b, int rows, int ca, int cb, srlz_stream_t stream);
+/* out = ((t0 + t1) + t2) + t3 over nterms (1..4) tensors of n floats, left to right in fp32: the gradient of a tensor with several
+ * consumers (states feed the decoder, the forward / inverse / reward heads and the forward loss: models/learner.py:392-449) summed
+ * by ONE launch in a fixed order instead of one accumulation kernel per extra consumer.  terms: HOST array of device pointers. */
+int srlz_sum_terms(const float* const* terms, int nterms, float* out, long long n, srlz_stream_t stream);
 int srlz_concat_onehot(const float* s, const int64_t* a, float* cat, int B, int S, int A, srlz_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -1062,6 +1062,246 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The stride-2 gather programs with a PLAIN operand — conv3's forward (27x27 -> 14x14, with the BatchNorm statistics of its output)
+// and the data gradient of the decoder's first ConvTranspose — software-pipelined like conv64_dgrad_pipe_kernel (round 5).
+// In conv64_fwd_kernel<4, false> such a tile stages its four source classes in four synchronous HBM round trips between barriers,
+// and conv3 has only 900 tiles of them for 512 workgroup slots: 102 us for 47 us of matrix work.  Here, as in the fused kernel above:
+// persistent workgroups (2 per CU) walk their XCD's tiles, class c + 1 is requested behind the barrier that opens class c and lands
+// behind its last tap, class 0 of the next tile travels under the single tap of class 3 and the epilogue; branch-free requests and
+// stores.  Differences: no BatchNorm-backward rebuild, no dy_out; the programs of a convolution with padding start their staged range
+// at a NEGATIVE grid offset (min_off < 0: the row table is built with rowtab_build's one-image shift); the epilogue takes the
+// per-tile BatchNorm partial sums (sum y, sum y^2 over the tile's valid rows) like conv64_fwd_kernel's, in this kernel's own
+// (fixed) summation order.  Same tiles, same accumulation order of the contraction: y is bit-identical to conv64_fwd_kernel's.
+// ---------------------------------------------------------------------------------------------------------------
+struct PlainRows {
+  f32x4 v[GP_BATCH];
+  unsigned ok;
+};
+
+// gtab_build for a staged range [qstart, qstart + nrows) that may begin before grid position 0 (qstart >= -PHW)
+__device__ __forceinline__ void gtab_build_shifted(unsigned* __restrict__ tab, const ConvProg& P, int qstart, int nrows) {
+  int R = threadIdx.x;
+  asm volatile("" : "+v"(R));
+  if (R < GT_WORDS) {
+    unsigned e = 0;
+    if (R < nrows) {
+      const int qq = qstart + R + P.PHW;  // shifted by one image: stays non-negative
+      const int n1 = fastdiv(qq, P.mPHW, P.sPHW);
+      const int rem = qq - n1 * P.PHW;
+      const int a = fastdiv(rem, P.mPW, P.sPW);
+      const int y0 = 2 * a, x0 = 2 * (rem - a * P.PW);
+      if ((unsigned)(n1 - 1) < (unsigned)P.N) {
+        unsigned f = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f |= (y0 + (k >> 1) < P.Hs && x0 + (k & 1) < P.Ws) ? 1u << k : 0u;
+        e = ((unsigned)(((n1 - 1) * P.Hs + y0) * P.Ws + x0) << 4) | f;
+      }
+    }
+    tab[(R & (GP_RP - 1)) * GT_P + (R >> 5)] = e;
+  }
+}
+
+__device__ __forceinline__ void plain_request(PlainRows& r, const float* __restrict__ src, const unsigned* __restrict__ tab, int cls,
+                                              int W) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int slot = t & 15;
+  const unsigned delta = (unsigned)((cls >> 1) * W + (cls & 1));
+  const unsigned* __restrict__ tp = tab + (t >> 4) * GT_P;
+  const uint4 e03 = *(const uint4*)tp;
+  const uint2 e45 = *(const uint2*)(tp + 4);
+  const unsigned e[GP_BATCH] = {e03.x, e03.y, e03.z, e03.w, e45.x, e45.y};
+  unsigned okmask = 0;
+#pragma unroll
+  for (int j = 0; j < GP_BATCH; ++j) {
+    const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)e[j], (unsigned)cls, 1u);  // all ones where the row's pixel of this class exists
+    const unsigned off = ((((e[j] >> 4) + delta) << 6) & m) + slot * 4;                // (any other row reads pixel 0; zeroed at the landing)
+    r.v[j] = *(const f32x4*)(src + off);
+    okmask |= m & (1u << j);
+  }
+  r.ok = okmask;
+}
+
+__device__ __forceinline__ void plain_land(float* __restrict__ lds, PlainRows& r, int nrows) {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int slot = t & 15;
+#pragma unroll
+  for (int j = 0; j < GP_BATCH; ++j) {
+    const int R = (t >> 4) + GP_RP * j;
+    const f32x4 v = ((r.ok >> j) & 1u) ? r.v[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (R < nrows) *(f32x4*)(lds + R * 64 + ((slot ^ (R & 15)) << 2)) = v;
+  }
+}
+
+__global__ __launch_bounds__(GP_THREADS, 4) void conv64_gather_pipe_kernel(const float* __restrict__ src_all,
+                                                                          const float* __restrict__ wpack,
+                                                                          float* __restrict__ dst_all,
+                                                                          float* __restrict__ stats_partial, const ConvProg P,
+                                                                          int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* As = (float*)smem;                 // (TM + span) x 64, swizzled: the rows of the current class
+  float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap
+  int* rowinfo = (int*)(Bs + 4096);         // [2 (tile parity)][3][TM]: image index (or -1), a*ds, b*ds
+  unsigned* gtab = (unsigned*)(rowinfo + 6 * TM);  // the source-side row table of the tile whose rows are being requested
+  float* red = (float*)(gtab + GT_WORDS);   // [8 waves][sum 32 | sum of squares 32]: the tile's BatchNorm partials on their way out
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int nrows = TM + P.span;
+  const int cls0 = P.tsrc[0], cls1 = P.tsrc[4], cls2 = P.tsrc[6], cls3 = P.tsrc[8];
+
+  const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int tbase = (xcd < tr) ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int tcnt = tq + (xcd < tr ? 1 : 0);
+
+  constexpr int BV = 1024 / GP_THREADS;
+  const int bslot = wave * (BV * 64) + lane;
+  f32x4 breg[BV];
+  {
+    const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[0] * 4096);
+#pragma unroll
+    for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
+  }
+  const unsigned dst_bytes = (unsigned)P.dst_gstride * 4u;
+
+  PlainRows rr;
+  int k = wi;
+  int parity = 0;
+  if (k < tcnt) {  // the first tile's class 0 is staged the plain way
+    const int tile = tbase + k;
+    const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;  // (G <= 2, checked by the host)
+    const int q0 = (tile - grp * P.tpg) * TM;
+    gtab_build_shifted(gtab, P, q0 + P.min_off, nrows);
+    __syncthreads();
+    plain_request(rr, src_all + grp * P.src_gstride, gtab, cls0, P.Ws);
+    plain_land(As, rr, nrows);
+  }
+  for (; k < tcnt; k += wpx, parity ^= 1) {
+    const int tile = tbase + k;
+    const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;
+    const int q0 = (tile - grp * P.tpg) * TM;
+    const float* __restrict__ src = src_all + grp * P.src_gstride;
+    const __amdgpu_buffer_rsrc_t dst = gp_buffer(dst_all + grp * P.dst_gstride, dst_bytes);
+    const int k2 = k + wpx;  // this workgroup's next tile (past the end: this one again, with no rows)
+    const int tile2 = tbase + (k2 < tcnt ? k2 : k);
+    const int grp2 = (P.G > 1 && tile2 >= P.tpg) ? 1 : 0;
+    const int q02 = (tile2 - grp2 * P.tpg) * TM;
+    int* ri = rowinfo + parity * (3 * TM);
+    if (tid < TM) {  // (the other parity's copy may still be read by a wave that is flushing the previous tile)
+      const int q = q0 + tid;
+      int n = -1, ya = 0, xb = 0;
+      if (q < P.total_q) {
+        n = fastdiv(q, P.mPHW, P.sPHW);
+        const int rem = q - n * P.PHW;
+        const int a = fastdiv(rem, P.mPW, P.sPW);
+        ya = a * P.ds;
+        xb = (rem - a * P.PW) * P.ds;
+      }
+      ri[tid] = n; ri[TM + tid] = ya; ri[2 * TM + tid] = xb;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int tid_t = tid;  // (one opaque copy of the thread index per tile: see conv64_dgrad_pipe_kernel)
+    asm volatile("" : "+v"(tid_t));
+    const int lane_t = tid_t & 63, wave_t = tid_t >> 6;
+    const int wrow_t = wave_t & 3, wcol_t = wave_t >> 2;
+    const int h_t = lane_t >> 5, l31_t = lane_t & 31;
+    const int arow0 = wrow_t * 32 + l31_t - P.min_off;
+    const float* brow = Bs + (wcol_t * 32 + l31_t) * 64;
+    const int bkey = lane_t & 15;
+    const int bslot_t = wave_t * (BV * 64) + lane_t;
+
+#pragma unroll
+    for (int ti = 0; ti < NTAPS; ++ti) {
+      __syncthreads();  // all waves are done with the previous tap's Bs — and with As when this tap opens a new class
+      {
+        f32x4* wdst = (f32x4*)Bs;
+#pragma unroll
+        for (int i = 0; i < BV; ++i) wdst[bslot_t + i * 64] = breg[i];
+      }
+      {  // the next tap's slab (tap 0 of the next tile behind tap 8: same weights)
+        const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[(ti + 1) % NTAPS] * 4096);
+#pragma unroll
+        for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot_t + i * 64];
+      }
+      if (ti == 4 || ti == 6 || ti == 8) plain_land(As, rr, nrows);
+      if (ti == 7) gtab_build_shifted(gtab, P, q02 + P.min_off, k2 < tcnt ? nrows : 0);
+      __syncthreads();
+      if (ti == 0) plain_request(rr, src, gtab, cls1, P.Ws);
+      if (ti == 4) plain_request(rr, src, gtab, cls2, P.Ws);
+      if (ti == 6) plain_request(rr, src, gtab, cls3, P.Ws);
+      if (ti == 8) plain_request(rr, src_all + grp2 * P.src_gstride, gtab, cls0, P.Ws);  // class 0 of this workgroup's NEXT tile
+      __builtin_amdgcn_sched_barrier(0);  // every request goes out HERE, ahead of the tap's MFMAs
+      const int R = arow0 + P.toff[ti];
+      int abase = (R * 64 + ((h_t ^ (R & 15)) << 2)) * 4;  // bytes; slot (2kc + h) ^ (R & 15) is this XOR (kc << 5)
+      asm volatile("" : "+v"(abase));
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const f32x4 a = *(const f32x4*)((const char*)As + (abase ^ (kc << 5)));
+        const f32x4 b = *(const f32x4*)(brow + (((kc * 2 + h_t) ^ bkey) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave is done with the last tap's slab and with As: Bs becomes scratch, As takes the next tile
+    if (k + wpx < tcnt) plain_land(As, rr, nrows);  // (the landing first: it waits for its rows only)
+    {  // flush through this wave's own 2 KB of the idle slab, 16 tile rows x 32 columns at a time: 16-byte stores, branch-free
+      int tid_f = tid;
+      asm volatile("" : "+v"(tid_f));
+      const int lane_f = tid_f & 63, wave_f = tid_f >> 6;
+      const int wrow_f = wave_f & 3, wcol_f = wave_f >> 2, h_f = lane_f >> 5, l31_f = lane_f & 31;
+      float* S = Bs + wave_f * 512;
+      const int eg = lane_f >> 3, eslot = lane_f & 7;
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int rq = 0; rq < 8; ++rq) {
+          const int rowl = (rq & 3) + 8 * (rq >> 2) + 4 * h_f;
+          S[rowl * 32 + l31_f] = acc[8 * half + rq];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int rowl = eg + 8 * kk;
+          const int row = wrow_f * 32 + 16 * half + rowl;
+          const f32x4 v = *(const f32x4*)(S + rowl * 32 + eslot * 4);
+          const int n = ri[row];
+          const int y = ri[TM + row], x = ri[2 * TM + row];
+          const bool inside = n >= 0 && y < P.Hd && x < P.Wd;
+          __builtin_amdgcn_raw_buffer_store_b128(v, dst, inside ? (unsigned)((n * P.Hd + y) * P.Wd + x) * 256u + wcol_f * 128 + eslot * 16 : GP_DROP,
+                                                 0, 0);
+          const f32x4 vv = inside ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+          s4 += vv;
+          q4 += vv * vv;
+        }
+      }
+      if (stats_partial) {
+        // this lane's four channels (32 wcol + 4 eslot ..) over its four rows; the eight row groups of the wave (lane bits 3-5), then
+        // the four row-waves of a column half through LDS; fixed order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s4[e] += __shfl_xor(s4[e], 8, 64); s4[e] += __shfl_xor(s4[e], 16, 64); s4[e] += __shfl_xor(s4[e], 32, 64);
+          q4[e] += __shfl_xor(q4[e], 8, 64); q4[e] += __shfl_xor(q4[e], 16, 64); q4[e] += __shfl_xor(q4[e], 32, 64);
+        }
+        if (lane_f < 8) {
+          *(f32x4*)(red + wave_f * 64 + lane_f * 4) = s4;
+          *(f32x4*)(red + wave_f * 64 + 32 + lane_f * 4) = q4;
+        }
+        __syncthreads();
+        if (tid_f < 128) {
+          const int c = tid_f & 63, which = tid_f >> 6;  // [0, 64): sum, [64, 128): sum of squares
+          const float* base = red + ((c >> 5) * 4) * 64 + which * 32 + (c & 31);  // waves 4 wcol + wrow
+          stats_partial[(size_t)tile * 128 + tid_f] = (base[0] + base[64]) + (base[128] + base[192]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The WHOLE backward of a decoder block's ConvTranspose2d(64, 64, 3, stride 2) in one launch: data gradient, weight gradient and
 // bias gradient from ONE staging of the rebuilt d(loss)/dy.
 // conv64_dgrad_pipe_kernel reads (dA, y) = 3.2 GB at the 111x111 layer, rebuilds dy and — only so that the weight-gradient
@@ -2256,6 +2496,23 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
     }
     SRLZ_FWD_LAUNCH(4, true);
   } else {
+    // plain stride-2 gather programs (conv3 forward, ConvT1 data gradient): the software-pipelined persistent kernel.  The choice
+    // depends on the program's geometry only — never on the number of tiles — so one BatchNorm group alone and the batched pair of
+    // a step take the same kernel (their statistics are compared bit for bit).
+    bool grouped = P.s2 && P.ss == 2 && P.G <= 2 && !src_fuse.bnp && !bias && !P.dbg;
+    for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
+    const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;
+    if (grouped && fits32 && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && -P.min_off <= P.PHW) {
+      int pgrid = 2 * srlz_device_cus();
+      if (pgrid > ntiles) pgrid = ntiles;
+      pgrid &= ~7;
+      if (pgrid < 8) pgrid = 8;  // (the XCD walk wants a multiple of 8 workgroups; those without a tile leave at once)
+      const size_t plds = (size_t)(TM + P.span) * 256 + 16384 + 6 * TM * 4 + GT_WORDS * 4 + 8 * 64 * 4;
+      SRLZ_MAX_LDS(conv64_gather_pipe_kernel, plds);
+      hipLaunchKernelGGL(conv64_gather_pipe_kernel, dim3(pgrid), dim3(GP_THREADS), plds, st, src, wpack, dst, stats, P, ntiles);
+      SRLZ_LAUNCHED();
+      return 0;
+    }
     SRLZ_FWD_LAUNCH(4, false);
   }
 #undef SRLZ_FWD_LAUNCH

@@ -1,7 +1,9 @@
 // linear.hip — nn.Linear forward / backward as one strided fp32-MFMA GEMM.
 // Replaces nn.Linear of /root/reference/models/autoencoders.py:94-100, models/vae.py:52-57,
 // models/forward_inverse.py:16,48-55 (and their autograd backward).
-//   C[i][j] = sum_r A(i,r) * B(r,j)  (+ bias[j]) (+ ReLU),  A(i,r) = A[i*sai + r*sar],  B(r,j) = B[r*sbr + j*sbj]
+//   C[i][j] = sum_r A(i,r) * B(r,j)  (+ bias[j]) (+ ReLU) (+ res[i*ldr + j]),  A(i,r) = A[i*sai + r*sar],  B(r,j) = B[r*sbr + j*sbj]
+//   (res: the residual of the forward model, next_state = state + Linear([state ; onehot(action)]), forward_inverse.py:27-37 — a
+//    separately rounded fp32 add behind bias and ReLU, as `state + self.forward_net(concat)` rounds it)
 //   forward   : i=m, j=n, r=k : A = x  (sai=K, sar=1), B = w (sbr=1, sbj=K)
 //   data grad : i=m, j=k, r=n : A = dy (sai=N, sar=1), B = w (sbr=K, sbj=1)
 //   weight grad: i=n, j=k, r=m : A = dy (sai=1, sar=N), B = x (sbr=K, sbj=1)
@@ -20,7 +22,8 @@ constexpr int LD = 68;  // 64 + 4 padding floats
 __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restrict__ A, long long sai, long long sar,
                                                           const float* __restrict__ B, long long sbr, long long sbj,
                                                           const float* __restrict__ bias, float* __restrict__ C, int I,
-                                                          int J, int R, int relu, int rchunk) {
+                                                          int J, int R, int relu, int rchunk, const float* __restrict__ res,
+                                                          long long ldr) {
   // Double-buffered LDS tiles; the next r-step's global loads are issued before the current step's MFMAs and land in the
   // other buffer after them: one barrier per step and the load latency sits behind the matrix work.
   __shared__ float As[2][BR][LD];
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
     if (i < I && j < J) {
       float v = acc[r] + bj;
       if (relu) v = v > 0.f ? v : 0.f;
+      if (res) v = __fadd_rn(v, res[(long long)i * ldr + j]);
       C[(long long)i * J + j] = v;
     }
   }
@@ -117,7 +121,8 @@ __device__ __forceinline__ int tile_key(int row) { return ((row & 3) << 2) | ((r
 template <bool AI, bool BI>
 __global__ __launch_bounds__(256, 2) void gemm_vec_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B,
                                                          long long ldb, const float* __restrict__ bias, float* __restrict__ C,
-                                                         int I, int J, int R, int relu, int rchunk) {
+                                                         int I, int J, int R, int relu, int rchunk, const float* __restrict__ res,
+                                                         long long ldr) {
   // lda / ldb: floats between two consecutive values of the operand's NON-contiguous index
   __shared__ __attribute__((aligned(16))) float As[2][64 * TR];
   __shared__ __attribute__((aligned(16))) float Bs[2][64 * TR];
@@ -210,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_vec_kernel(const float* __restric
     if (i < I && j < J) {
       float v = acc[r] + bj;
       if (relu) v = v > 0.f ? v : 0.f;
+      if (res) v = __fadd_rn(v, res[(long long)i * ldr + j]);
       C[(long long)i * J + j] = v;
     }
   }
@@ -217,13 +223,14 @@ __global__ __launch_bounds__(256, 2) void gemm_vec_kernel(const float* __restric
 
 // C[e] = sum_z partial[z][e] (+ bias[e % J]) (+ ReLU), fixed order
 __global__ void splitk_combine_kernel(const float* __restrict__ partial, int nsplit, const float* __restrict__ bias,
-                                      float* __restrict__ C, int I, int J, int relu) {
+                                      float* __restrict__ C, int I, int J, int relu, const float* __restrict__ res, long long ldr) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= I * J) return;
   float s = 0.f;
   for (int z = 0; z < nsplit; ++z) s += partial[(size_t)z * I * J + e];
   if (bias) s += bias[e % J];
   if (relu) s = s > 0.f ? s : 0.f;
+  if (res) s = __fadd_rn(s, res[(long long)(e / J) * ldr + e % J]);
   C[e] = s;
 }
 
@@ -276,7 +283,8 @@ static bool vec_ok(const float* P, long long s_row, long long s_r, int nrow, int
 }
 
 static int launch(const float* A, long long sai, long long sar, const float* B, long long sbr, long long sbj,
-                  const float* bias, float* C, int I, int J, int R, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
+                  const float* bias, float* C, int I, int J, int R, int relu, void* ws, size_t ws_bytes, hipStream_t st,
+                  const float* res = nullptr, long long ldr = 0) {
   SRLZ_REQUIRE(I > 0 && J > 0 && R > 0, SRLZ_ERR_BAD_DESC, "linear: empty GEMM %dx%dx%d", I, J, R);
   bool ai = false, bi = false;
   long long lda = 0, ldb = 0;
@@ -293,21 +301,22 @@ static int launch(const float* A, long long sai, long long sar, const float* B, 
   const float* kbias = nz > 1 ? nullptr : bias;
   float* kC = nz > 1 ? (float*)ws : C;
   const int krelu = nz > 1 ? 0 : relu;
+  const float* kres = nz > 1 ? nullptr : res;
   if (vec) {
 #define SRLZ_VEC_LAUNCH(AIV, BIV) \
-    hipLaunchKernelGGL((gemm_vec_kernel<AIV, BIV>), grid, dim3(256), 0, st, A, lda, B, ldb, kbias, kC, I, J, R, krelu, rchunk)
+    hipLaunchKernelGGL((gemm_vec_kernel<AIV, BIV>), grid, dim3(256), 0, st, A, lda, B, ldb, kbias, kC, I, J, R, krelu, rchunk, kres, ldr)
     if (ai && bi) SRLZ_VEC_LAUNCH(true, true);
     else if (ai) SRLZ_VEC_LAUNCH(true, false);
     else if (bi) SRLZ_VEC_LAUNCH(false, true);
     else SRLZ_VEC_LAUNCH(false, false);
 #undef SRLZ_VEC_LAUNCH
   } else {
-    hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, st, A, sai, sar, B, sbr, sbj, kbias, kC, I, J, R, krelu, rchunk);
+    hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, st, A, sai, sar, B, sbr, sbj, kbias, kC, I, J, R, krelu, rchunk, kres, ldr);
   }
   SRLZ_LAUNCHED();
   if (nz > 1) {
     hipLaunchKernelGGL(splitk_combine_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, (const float*)ws, nz, bias, C, I, J,
-                       relu);
+                       relu, res, ldr);
     SRLZ_LAUNCHED();
   }
   return 0;
@@ -327,6 +336,20 @@ extern "C" int srlz_linear_fwd(const float* x, const float* w, const float* b, f
                                void* ws, size_t ws_bytes, srlz_stream_t stream) {
   SRLZ_REQUIRE(x && w && y, SRLZ_ERR_NULL, "linear_fwd: null pointer");
   return launch(x, K, 1, w, 1, K, b, y, M, N, K, relu, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int srlz_linear_fwd_res(const float* x, const float* w, const float* b, const float* res, float* y, int M, int N, int K,
+                                   int relu, void* ws, size_t ws_bytes, srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && w && y && res, SRLZ_ERR_NULL, "linear_fwd_res: null pointer");
+  return launch(x, K, 1, w, 1, K, b, y, M, N, K, relu, ws, ws_bytes, as_stream(stream), res, N);
+}
+
+extern "C" int srlz_linear_bwd_data_res(const float* dy, const float* w, const float* res, float* dx, int M, int N, int K, int Kout,
+                                        void* ws, size_t ws_bytes, srlz_stream_t stream) {
+  SRLZ_REQUIRE(dy && w && dx && res, SRLZ_ERR_NULL, "linear_bwd_data_res: null pointer");
+  SRLZ_REQUIRE(Kout >= 1 && Kout <= K, SRLZ_ERR_BAD_DESC, "linear_bwd_data_res: %d of %d input columns", Kout, K);
+  // the first Kout columns of dy . W, plus the residual branch's gradient (res: [M, Kout])
+  return launch(dy, N, 1, w, K, 1, nullptr, dx, M, Kout, N, 0, ws, ws_bytes, as_stream(stream), res, Kout);
 }
 
 extern "C" int srlz_linear_bwd_data(const float* dy, const float* w, float* dx, int M, int N, int K, void* ws,

@@ -44,13 +44,14 @@ __global__ __launch_bounds__(256) void reduce_partial(const float* __restrict__ 
   if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-__global__ void reduce_final(const double* __restrict__ partial, int nb, float* __restrict__ out) {
-  // one wave per group (blockIdx.x)
+__global__ void reduce_final(const double* __restrict__ partial, int nb, float* __restrict__ out, float div) {
+  // one wave per group (blockIdx.x); div: the fp32 division of reconstructionLoss (losses.py:181: sum / numel) behind the sum's own
+  // rounding to fp32 — 1 elsewhere (x / 1 is x)
   partial += (size_t)blockIdx.x * nb;
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
   s = wave_sum_d(s);
-  if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
+  if (threadIdx.x == 0) out[blockIdx.x] = __fdiv_rn((float)s, div);
 }
 
 __global__ __launch_bounds__(256) void sqdiff_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -328,7 +329,7 @@ constexpr int MAX_GROUPS = 8;
 // geometry and summation order of a single-group call (bit-identical results).
 template <int OP>
 static int reduce_launch(const float* a, const float* b, long long n, int groups, float* out, void* ws, size_t ws_bytes,
-                         hipStream_t st) {
+                         hipStream_t st, float div = 1.f) {
   SRLZ_REQUIRE(a && b && out && ws, SRLZ_ERR_NULL, "reduce: null pointer");
   SRLZ_REQUIRE(groups >= 1 && groups <= MAX_GROUPS, SRLZ_ERR_BAD_DESC, "reduce: groups = %d", groups);
   SRLZ_REQUIRE(ws_bytes >= (size_t)groups * RED_BLOCKS * sizeof(double), SRLZ_ERR_WORKSPACE, "reduce: workspace too small");
@@ -337,7 +338,7 @@ static int reduce_launch(const float* a, const float* b, long long n, int groups
   const int nb = blocks_for((n + 3) / 4, RED_BLOCKS);
   hipLaunchKernelGGL(reduce_partial<OP>, dim3(nb, groups), dim3(256), 0, st, a, b, n, (double*)ws);
   SRLZ_LAUNCHED();
-  hipLaunchKernelGGL(reduce_final, dim3(groups), dim3(64), 0, st, (const double*)ws, nb, out);
+  hipLaunchKernelGGL(reduce_final, dim3(groups), dim3(64), 0, st, (const double*)ws, nb, out, div);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -368,6 +369,33 @@ __global__ __launch_bounds__(256) void join2_kernel(const float* __restrict__ a,
   for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// cat([a, b], dim 1) of two row-major matrices with the same number of rows (inverse / reward heads: [state ; next_state],
+// forward_inverse.py:62,78) and its backward, the split of the gradient's columns
+__global__ void cat_cols_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int rows, int ca, int cb) {
+  const long long n = (long long)rows * (ca + cb);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / (ca + cb)), c = (int)(e - (long long)r * (ca + cb));
+    out[e] = c < ca ? a[(long long)r * ca + c] : b[(long long)r * cb + (c - ca)];
+  }
+}
+__global__ void split_cols_kernel(const float* __restrict__ in, float* __restrict__ a, float* __restrict__ b, int rows, int ca, int cb) {
+  const long long n = (long long)rows * (ca + cb);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / (ca + cb)), c = (int)(e - (long long)r * (ca + cb));
+    if (c < ca) { if (a) a[(long long)r * ca + c] = in[e]; }
+    else if (b) b[(long long)r * cb + (c - ca)] = in[e];
+  }
+}
+// out = ((g0 + g1) + g2) + g3 over the non-null terms, left to right in fp32: what autograd's accumulation of the gradients of a
+// tensor with several consumers computes (one add per extra consumer), as ONE launch in a fixed order
+struct TermList { const float* p[4]; int n; };
+__global__ void sum_terms_kernel(const TermList L, float* __restrict__ out, long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    float t = L.p[0][e];
+    for (int i = 1; i < L.n; ++i) t = __fadd_rn(t, L.p[i][e]);
+    out[e] = t;
+  }
+}
 // total = (((0 + w0*l0) + w1*l1) + ...) in fp32 with separately rounded products — exactly Python's sum([w_i * l_i]) over 0-dim
 // fp32 tensors (reference losses/losses.py:55-56) — plus the step's scalars into the gradient bucket's tail: [total, l_0, l_1, ...]
 struct ScalarList {
@@ -420,6 +448,39 @@ extern "C" int srlz_weighted_total_bwd(const float* dout, const float* weights, 
   return 0;
 }
 
+extern "C" int srlz_cat_cols(const float* a, const float* b, float* out, int rows, int ca, int cb, srlz_stream_t stream) {
+  SRLZ_REQUIRE(a && b && out, SRLZ_ERR_NULL, "cat_cols: null pointer");
+  SRLZ_REQUIRE(rows > 0 && ca > 0 && cb > 0, SRLZ_ERR_BAD_DESC, "cat_cols: %d rows of %d + %d columns", rows, ca, cb);
+  hipLaunchKernelGGL(cat_cols_kernel, dim3(blocks_for((long long)rows * (ca + cb), 1024)), dim3(256), 0, as_stream(stream), a, b, out,
+                     rows, ca, cb);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_split_cols(const float* in, float* a, float* b, int rows, int ca, int cb, srlz_stream_t stream) {
+  SRLZ_REQUIRE(in && (a || b), SRLZ_ERR_NULL, "split_cols: null pointer");
+  SRLZ_REQUIRE(rows > 0 && ca > 0 && cb > 0, SRLZ_ERR_BAD_DESC, "split_cols: %d rows of %d + %d columns", rows, ca, cb);
+  hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for((long long)rows * (ca + cb), 1024)), dim3(256), 0, as_stream(stream), in, a, b,
+                     rows, ca, cb);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
+extern "C" int srlz_sum_terms(const float* const* terms, int nterms, float* out, long long n, srlz_stream_t stream) {
+  SRLZ_REQUIRE(terms && out, SRLZ_ERR_NULL, "sum_terms: null pointer");
+  SRLZ_REQUIRE(nterms >= 1 && nterms <= 4 && n > 0, SRLZ_ERR_BAD_DESC, "sum_terms: %d terms (1..4) of %lld elements", nterms, n);
+  TermList L;
+  for (int i = 0; i < 4; ++i) L.p[i] = nullptr;
+  for (int i = 0; i < nterms; ++i) {
+    SRLZ_REQUIRE(terms[i], SRLZ_ERR_NULL, "sum_terms: null term %d", i);
+    L.p[i] = terms[i];
+  }
+  L.n = nterms;
+  hipLaunchKernelGGL(sum_terms_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, as_stream(stream), L, out, n);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
 extern "C" size_t srlz_reduce_workspace(long long n) {
   (void)n;
   return (size_t)MAX_GROUPS * RED_BLOCKS * sizeof(double);
@@ -428,6 +489,12 @@ extern "C" size_t srlz_reduce_workspace(long long n) {
 extern "C" int srlz_sqdiff_sum(const float* a, const float* b, long long n, float* out, void* ws, size_t ws_bytes,
                                srlz_stream_t stream) {
   return reduce_launch<0>(a, b, n, 1, out, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int srlz_sqdiff_mean(const float* a, const float* b, long long n, float div, float* out, void* ws, size_t ws_bytes,
+                                srlz_stream_t stream) {
+  SRLZ_REQUIRE(div != 0.f, SRLZ_ERR_BAD_DESC, "sqdiff_mean: division by zero");
+  return reduce_launch<0>(a, b, n, 1, out, ws, ws_bytes, as_stream(stream), div);
 }
 
 extern "C" int srlz_sqdiff_sum_groups(const float* a, const float* b, long long n_per_group, int groups, float* out, void* ws,

@@ -79,7 +79,7 @@ def rewardModelLoss(rewards_pred, rewards_st, weight, loss_manager):
 
 def reconstructionLoss(input_image, target_image):
     """sum((a-b)^2) / numel  (reference losses.py:172-181)."""
-    return ops.SqDiffSumFn.apply(input_image, target_image) / input_image.numel()
+    return ops.SqDiffSumFn.apply(input_image, target_image, True)
 
 
 def forwardModelLoss(next_states_pred, next_states, weight, loss_manager):
@@ -110,7 +110,7 @@ def autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs, weight, loss_m
     """reconstruction error of both frames (reference losses.py:184-196)."""
     ae_loss = _pairSqDiff(obs, next_obs, decoded_obs, decoded_next_obs, True)
     if ae_loss is None:
-        ae_loss = reconstructionLoss(obs, decoded_obs) + reconstructionLoss(next_obs, decoded_next_obs)
+        ae_loss = ops.add_scalars(reconstructionLoss(obs, decoded_obs), reconstructionLoss(next_obs, decoded_next_obs))
     loss_manager.addToLosses('reconstruction_loss', weight, ae_loss)
     return weight * ae_loss
 
@@ -119,7 +119,7 @@ def generationLoss(decoded, next_decoded, obs, next_obs, weight, loss_manager):
     """pixel-wise summed squared error of both frames (reference losses.py:199-214)."""
     generation_loss = _pairSqDiff(decoded, next_decoded, obs, next_obs, False)
     if generation_loss is None:
-        generation_loss = ops.SqDiffSumFn.apply(decoded, obs) + ops.SqDiffSumFn.apply(next_decoded, next_obs)
+        generation_loss = ops.add_scalars(ops.SqDiffSumFn.apply(decoded, obs), ops.SqDiffSumFn.apply(next_decoded, next_obs))
     loss_manager.addToLosses('generation_loss', weight, generation_loss)
     return weight * generation_loss
 
@@ -128,15 +128,15 @@ def perceptualSimilarityLoss(encoded_real, encoded_prediction, next_encoded_real
                              weight, loss_manager):
     """DARLA's perceptual similarity: summed squared distance between the frozen denoiser's encodings of the real frames
     and of the VAE's reconstructions, both frames (reference losses.py:217-236)."""
-    pretrained_dae_encoding_loss = ops.SqDiffSumFn.apply(encoded_real, encoded_prediction) + \
-        ops.SqDiffSumFn.apply(next_encoded_real, next_encoded_prediction)
+    pretrained_dae_encoding_loss = ops.add_scalars(ops.SqDiffSumFn.apply(encoded_real, encoded_prediction),
+                                                   ops.SqDiffSumFn.apply(next_encoded_real, next_encoded_prediction))
     loss_manager.addToLosses("denoising perceptual similarity", weight, pretrained_dae_encoding_loss)
     return weight * pretrained_dae_encoding_loss
 
 
 def kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager, beta=1):
     """KL(q(z|x) || N(0, I)) summed over elements and batch, both frames (reference losses.py:239-256)."""
-    kl_divergence = ops.KLSumFn.apply(mu, logvar) + ops.KLSumFn.apply(next_mu, next_logvar)
+    kl_divergence = ops.add_scalars(ops.KLSumFn.apply(mu, logvar), ops.KLSumFn.apply(next_mu, next_logvar))
     loss_manager.addToLosses('kl_loss', beta, kl_divergence)
     return beta * kl_divergence
 

@@ -1,7 +1,6 @@
 """Forward / inverse / reward heads on top of the learned state (reference models/forward_inverse.py:8-95)."""
 from __future__ import print_function, division, absolute_import
 
-import torch as th
 import torch.nn as nn
 
 from .models import BaseModelSRL
@@ -38,8 +37,7 @@ class BaseForwardModel(BaseModelSRL):
 
     def forwardModel(self, state, action):
         """next-state prediction: state + W [state ; onehot(action)] + b (predicts the delta)."""
-        concat = ops.ConcatOneHotFn.apply(state, action.view(-1), self.action_dim)
-        return state + hotpath.linear(self.forward_net, concat)
+        return ops.ForwardModelFn.apply(state, action.view(-1), self.forward_net.weight, self.forward_net.bias, self.action_dim)
 
 
 class BaseInverseModel(BaseModelSRL):
@@ -59,7 +57,7 @@ class BaseInverseModel(BaseModelSRL):
 
     def inverseModel(self, state, next_state):
         """action logits from [state ; next_state]."""
-        return _run_head(self.inverse_net, th.cat((state, next_state), dim=1))
+        return _run_head(self.inverse_net, ops.CatColsFn.apply(state, next_state))
 
 
 class BaseRewardModel(BaseModelSRL):
@@ -75,4 +73,4 @@ class BaseRewardModel(BaseModelSRL):
 
     def rewardModel(self, state, next_state):
         """reward logits from [state ; next_state] (reference forward_inverse.py:87-95)."""
-        return _run_head(self.reward_net, th.cat((state, next_state), dim=1))
+        return _run_head(self.reward_net, ops.CatColsFn.apply(state, next_state))

@@ -512,19 +512,23 @@ class SRL4robotics(BaseLearner):
             states, next_states = self._forwardPair(obs, next_obs)
 
         w = self.losses_weights_dict
+        # the states feed several heads (and, as next_states, the forward loss): explicit fan-outs, one alias per consumer, so that the
+        # gradients coming back are summed by one launch each (ops.FanOutFn) instead of one accumulation kernel per extra consumer
+        n_heads = int(self.use_forward_loss) + int(self.use_inverse_loss) + int(self.use_reward_loss)
+        states_fan, next_states_fan = ops.Fan(states, n_heads + int(self.use_triplets)), ops.Fan(next_states, n_heads)
         # same order as the reference's loop body (learner.py:420-449): regularisers, forward, inverse, reward, AE, VAE
         if w['l1_reg'] > 0:
             l1Loss(loss_manager.reg_params, w['l1_reg'], loss_manager)
         if w['l2_reg'] > 0:
             l2Loss(loss_manager.reg_params, w['l2_reg'], loss_manager)
         if self.use_forward_loss:
-            next_states_pred = self.model.forwardModel(states, actions_st)
-            forwardModelLoss(next_states_pred, next_states, weight=w['forward'], loss_manager=loss_manager)
+            next_states_pred = self.model.forwardModel(states_fan.take(), actions_st)
+            forwardModelLoss(next_states_pred, next_states_fan.take(), weight=w['forward'], loss_manager=loss_manager)
         if self.use_inverse_loss:
-            actions_pred = self.model.inverseModel(states, next_states)
+            actions_pred = self.model.inverseModel(states_fan.take(), next_states_fan.take())
             inverseModelLoss(actions_pred, actions_st, weight=w['inverse'], loss_manager=loss_manager)
         if self.use_reward_loss:
-            rewards_pred = self.model.rewardModel(states, next_states)
+            rewards_pred = self.model.rewardModel(states_fan.take(), next_states_fan.take())
             rewardModelLoss(rewards_pred, rewards_st, weight=w['reward'], loss_manager=loss_manager)
         if (self.use_autoencoder or self.use_dae) and recon_loss is not None:
             # (decoded_* are None here: the loss came out of the decoder's last kernel and the reconstruction was never written)
@@ -545,7 +549,7 @@ class SRL4robotics(BaseLearner):
                                weight=w['vae'], loss_manager=loss_manager)
 
         if self.use_triplets:
-            tripletLoss(states, positive_states, negative_states, weight=w['triplet'], loss_manager=loss_manager, alpha=0.2)
+            tripletLoss(states_fan.take(), positive_states, negative_states, weight=w['triplet'], loss_manager=loss_manager, alpha=0.2)
 
         # LossManager.computeTotalLoss() as one launch, which also drops the step's scalars [total, l_0, l_1, ...] into the tail
         # of the gradient bucket: with several GPUs every rank reads the SAME (mean) losses back, so the NaN exit and the

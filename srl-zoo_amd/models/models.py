@@ -101,8 +101,10 @@ class BaseModelAutoEncoder(BaseModelSRL):
 
     def forward(self, x):
         input_shape = x.size()
-        encoded = self.encode(x)
-        decoded = self.decode(encoded).view(input_shape)
+        # the state feeds the decoder AND whatever the caller does with it (forward / inverse / reward heads): an explicit fan-out,
+        # whose backward sums the returning gradients in one launch (ops.FanOutFn)
+        encoded, to_decoder = ops.fan_out(self.encode(x), 2)
+        decoded = self.decode(to_decoder).view(input_shape)
         return encoded, decoded
 
 
@@ -175,9 +177,13 @@ class BaseModelVAE(BaseModelAutoEncoder):
         input_shape = x.size()
         sink = [] if self.training else None
         mu, logvar = self.encode(x, stat_sink=sink)
+        # mu: sampled from, returned (the KL term) and remembered for getStates (the heads); logvar: sampled from and returned —
+        # explicit fan-outs (ops.FanOutFn sums the returning gradients in one launch)
+        mu, mu_z, mu_states = ops.fan_out(mu, 3)
+        logvar, logvar_z = ops.fan_out(logvar, 2)
         if self.training:
-            self._remember(x, mu, sink)
-        z = self.reparameterize(mu, logvar)
+            self._remember(x, mu_states, sink)
+        z = self.reparameterize(mu_z, logvar_z)
         decoded = self.decode(z).view(input_shape)
         return decoded, mu, logvar
 

@@ -128,6 +128,12 @@ _PROTOS = {
     "srlz_linear_workspace": (c_size_t, [c_int, c_int, c_int]),
     "srlz_linear_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "srlz_linear_bwd_data": (c_int, [P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "srlz_linear_fwd_res": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "srlz_linear_bwd_data_res": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "srlz_cat_cols": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "srlz_split_cols": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "srlz_sum_terms": (c_int, [P, c_int, P, c_longlong, P]),
+    "srlz_sqdiff_mean": (c_int, [P, P, c_longlong, c_float, P, P, c_size_t, P]),
     "srlz_linear_bwd_weight": (c_int, [P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     "srlz_relu_bwd_inplace": (c_int, [P, P, c_longlong, P]),
     "srlz_reduce_workspace": (c_size_t, [c_longlong]),

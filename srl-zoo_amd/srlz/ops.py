@@ -969,17 +969,22 @@ class ToNHWCFn(Function):
 # losses — losses/losses.py
 # ----------------------------------------------------------------------------------------------------------------
 class SqDiffSumFn(Function):
-    """sum((a-b)^2) — the reduction inside reconstructionLoss (losses.py:181) and F.mse_loss(sum) (losses.py:210)."""
+    """sum((a-b)^2) — F.mse_loss(sum) (losses.py:210) — or, with mean=True, sum((a-b)^2) / numel — reconstructionLoss (losses.py:181):
+    the fp32 division behind the sum's own rounding, in the reduction's last launch, and (g / numel) formed inside the gradient kernel."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, mean=False):
         a, b = _check(a, "loss input"), _check(b, "loss target")
         assert a.shape == b.shape
         out = torch.empty((), dtype=torch.float32, device=a.device)
         nbytes = C.reduce_workspace(a.numel())
         ws = _ws(nbytes, a.device)
-        C.sqdiff_sum(ptr(a), ptr(b), a.numel(), ptr(out), ptr(ws), nbytes, stream())
+        if mean:
+            C.sqdiff_mean(ptr(a), ptr(b), a.numel(), float(a.numel()), ptr(out), ptr(ws), nbytes, stream())
+        else:
+            C.sqdiff_sum(ptr(a), ptr(b), a.numel(), ptr(out), ptr(ws), nbytes, stream())
         ctx.save_for_backward(a, b)
+        ctx.div = float(a.numel()) if mean else None
         return out
 
     @staticmethod
@@ -987,13 +992,138 @@ class SqDiffSumFn(Function):
         a, b = ctx.saved_tensors
         g = g.contiguous()
         da = db = None
-        if ctx.needs_input_grad[0]:
-            da = torch.empty_like(a)
-            C.sqdiff_grad(ptr(a), ptr(b), ptr(g), 2.0, ptr(da), a.numel(), stream())
-        if ctx.needs_input_grad[1]:
-            db = torch.empty_like(b)
-            C.sqdiff_grad(ptr(a), ptr(b), ptr(g), -2.0, ptr(db), a.numel(), stream())
+        for k, coef in ((0, 2.0), (1, -2.0)):
+            if not ctx.needs_input_grad[k]:
+                continue
+            d = torch.empty_like(a)
+            if ctx.div is None:
+                C.sqdiff_grad(ptr(a), ptr(b), ptr(g), coef, ptr(d), a.numel(), stream())
+            else:
+                C.sqdiff_grad_groups(ptr(a), ptr(b), ptr(g), 0, ctx.div, coef, ptr(d), a.numel(), 1, stream())
+            if k == 0:
+                da = d
+            else:
+                db = d
+        return da, db, None
+
+
+def add_scalars(a, b):
+    """a + b of two 0-dim loss tensors as one HIP launch (srlz_weighted_total with weights 1, 1: (0 + 1 * a) + 1 * b is exactly a + b)."""
+    return TotalLossFn.apply((1.0, 1.0), None, a, b)
+
+
+class FanOutFn(Function):
+    """A tensor with several consumers, made explicit: n aliases go out, and the backward sums the gradients that come back with ONE
+    launch in a fixed order (srlz_sum_terms: ((g0 + g1) + g2) + g3) — what autograd would otherwise do with one accumulation kernel
+    per extra consumer.  An alias nobody differentiates through contributes nothing."""
+
+    @staticmethod
+    def forward(ctx, t, n):
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        terms = [_check(g, "fan-out gradient") for g in grads if g is not None]
+        if not terms:
+            return None, None
+        if len(terms) == 1:
+            return terms[0], None
+        out = torch.empty_like(terms[0])
+        while len(terms) > 1:  # (at most four terms per launch)
+            head, terms = terms[:4], terms[4:]
+            ptrs = (ctypes.c_void_p * len(head))(*[g.data_ptr() for g in head])
+            C.sum_terms(ptrs, len(head), ptr(out), out.numel(), stream())
+            terms = [out] + terms
+            if len(terms) > 1:
+                out = torch.empty_like(out)
+        return terms[0], None
+
+
+def fan_out(t, n):
+    """n aliases of t whose gradients are summed by one launch (FanOutFn); t itself n times when it carries no gradient."""
+    if n <= 1 or not (torch.is_tensor(t) and t.requires_grad and torch.is_grad_enabled()):
+        return (t,) * n
+    return FanOutFn.apply(t, n)
+
+
+class Fan(object):
+    """Hands out the aliases of a FanOutFn one consumer at a time: Fan(t, n).take() n times.  n <= 1 (or a tensor without gradient):
+    the tensor itself."""
+
+    def __init__(self, t, n):
+        self.parts = list(fan_out(t, n)) if n > 1 else None
+        self.t = t
+
+    def take(self):
+        return self.parts.pop() if self.parts else self.t
+
+
+class CatColsFn(Function):
+    """th.cat((a, b), dim=1) of two [B, *] matrices — the input of the inverse / reward heads (forward_inverse.py:62,78-95) — and the
+    split of its gradient, one launch each."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _check(a, "cat input"), _check(b, "cat input")
+        assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
+        out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), dtype=torch.float32, device=a.device)
+        C.cat_cols(ptr(a), ptr(b), ptr(out), a.shape[0], a.shape[1], b.shape[1], stream())
+        ctx.cols = (a.shape[1], b.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = _check(d, "cat gradient")
+        ca, cb = ctx.cols
+        da = torch.empty((d.shape[0], ca), dtype=torch.float32, device=d.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty((d.shape[0], cb), dtype=torch.float32, device=d.device) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            C.split_cols(ptr(d), ptr(da), ptr(db), d.shape[0], ca, cb, stream())
         return da, db
+
+
+class ForwardModelFn(Function):
+    """next-state prediction as ONE node (forward_inverse.py:27-37): state + Linear([state ; onehot(action)]).  The concatenation is
+    one launch, the residual add sits in the GEMM's epilogue (separately rounded, as `state + self.forward_net(concat)` rounds it);
+    backward: d state = dy + (dy . W)[:, :S] — the residual branch's gradient in the data-gradient GEMM's epilogue, only the state
+    columns computed — and the weight / bias gradients of the linear layer."""
+
+    @staticmethod
+    def forward(ctx, state, action, w, b, n_actions):
+        state, w = _check(state, "state"), _check(w, "forward model weight")
+        action = action.contiguous()
+        assert action.dtype == torch.int64 and action.device == state.device
+        m, sdim = state.shape
+        k = sdim + n_actions
+        assert tuple(w.shape) == (sdim, k)
+        cat = torch.empty((m, k), dtype=torch.float32, device=state.device)
+        C.concat_onehot(ptr(state), ptr(action), ptr(cat), m, sdim, n_actions, stream())
+        y = torch.empty((m, sdim), dtype=torch.float32, device=state.device)
+        nbytes = C.linear_workspace(m, sdim, k)
+        ws = _ws(nbytes, state.device)
+        C.linear_fwd_res(ptr(cat), ptr(w), ptr(b), ptr(state), ptr(y), m, sdim, k, 0, ptr(ws), nbytes, stream())
+        ctx.save_for_backward(cat, w)
+        ctx.params = (b,)
+        ctx.dims = (m, sdim, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cat, w = ctx.saved_tensors
+        dy = _check(dy, "forward model dy")
+        m, sdim, k = ctx.dims
+        nbytes = C.linear_workspace(m, sdim, k)
+        ws = _ws(nbytes, dy.device)
+        dstate = None
+        if ctx.needs_input_grad[0]:
+            dstate = torch.empty((m, sdim), dtype=torch.float32, device=dy.device)
+            C.linear_bwd_data_res(ptr(dy), ptr(w), ptr(dy), ptr(dstate), m, sdim, k, sdim, ptr(ws), nbytes, stream())
+        dw = _gbuf(w)
+        db = _gbuf(ctx.params[0]) if ctx.params[0] is not None else None
+        C.linear_bwd_weight(ptr(dy), ptr(cat), ptr(dw), ptr(db), m, sdim, k, ptr(ws), nbytes, stream())
+        return dstate, None, _give(w, dw), _give(ctx.params[0], db), None
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -214,6 +214,12 @@ def test_bench_line_contract_on_committed_profile():
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e3) < 0.01 * r["achieved"]
     c = line["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    if os.path.basename(files[-1]) >= "r05":  # round 5: both legs of the headline metric, and the length of the timed region
+        assert line["timed_region_s"] >= 0.2 and abs(line["timed_region_s"] - line["ms_per_step"] * 1e-3 * line["steps"]) < 1e-3
+        v = line["vae"]
+        assert v["ms_per_step"] > 0 and v["steps"] == line["steps"] and "--losses vae" in v["workload"]
+        assert abs(v["images_per_s"] - 2 * line["config"]["global_batch"] / (v["ms_per_step"] * 1e-3)) < 1e-3 * v["images_per_s"]
+        assert "resident in HBM" in line["config"]["workload"]
 
 
 def test_device_feed_protocol(monkeypatch):
