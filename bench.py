@@ -489,8 +489,8 @@ def main():
         # every instrumented kernel symbol (the MFMA launches of the step): launches, average, achieved rate, share of their time
         SYMBOL = {"conv64_fwd_kernel": "conv64_fwd_kernel<4, false>", "conv64_bwd_fused_kernel": "conv64_bwd_fused_kernel",
                   "conv64_dgrad_poolsum_kernel": "conv64_dgrad_poolsum_kernel<1>",
-                  "conv64_fwd_kernel<bn-bwd operand>": "conv64_dgrad_pipe_kernel"}
-        NOTE = {"conv64_fwd_kernel": "3x3 64->64 conv / convT forward and ConvT1 data gradient, 7 launches per step",
+                  "conv64_fwd_kernel<bn-bwd operand>": "conv64_fwd_kernel<4, true>", "conv64_gather_pipe_kernel": "conv64_gather_pipe_kernel"}
+        NOTE = {"conv64_fwd_kernel": "3x3 64->64 conv / convT forward, 5 launches per step (conv3 forward and ConvT1 data gradient: conv64_gather_pipe_kernel)",
                 "conv64_bwd_fused_kernel": "data + weight + bias gradient of a ConvTranspose block in one launch (ConvT2-4); flop = 2 x the "
                                            "layer's forward flop",
                 "conv64_dgrad_poolsum_kernel": "conv2 / conv3 data gradient with the pooled block's BatchNorm-backward sums in its epilogue"}

@@ -125,6 +125,11 @@ int srlz_conv64_bwd_data_pool_sums(const float* dy, const float* wpack_bwd, floa
  * srlz_conv64_bwd_data's; dw_ref / dbias are deterministic (per-workgroup partials in `ws`, fixed-order fp64 second stage).
  * Only where srlz_conv64_bwd_fused_supported(d) != 0 (stride-2 transposed layers with at least 8 tiles; groups <= 2). */
 int srlz_conv64_bwd_fused_supported(const srlz_conv64_desc* d);
+/* != 0: srlz_conv64_fwd (backward_data = 0) / srlz_conv64_bwd_data (1) of this layer with a plain operand and no bias run as
+ * conv64_gather_pipe_kernel — the software-pipelined persistent kernel of the stride-2 gather programs (conv3's forward,
+ * /root/reference/models/models.py:59, and the first ConvTranspose's data gradient) — rather than conv64_fwd_kernel: what a profile
+ * will list the launch under. */
+int srlz_conv64_gather_pipe_supported(const srlz_conv64_desc* d, int backward_data);
 size_t srlz_conv64_bwd_fused_workspace(const srlz_conv64_desc* d);
 int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const float* dy, const srlz_bn_bwd_operand* dy_bn,
                           const float* wpack_bwd, float* dx, float* dw_ref, float* dbias /* may be NULL */, void* ws, size_t ws_bytes,

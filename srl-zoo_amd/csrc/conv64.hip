@@ -756,19 +756,18 @@ __global__ __launch_bounds__(256, 2) void conv64_dgrad_poolsum_kernel(const floa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The fused data gradient of the ConvTranspose blocks (what conv64_fwd_kernel<4, true> computes), software-pipelined.
-// A stride-2 gather tile stages its source FOUR times (one class of 128 + span rows of (dA, y) per tap group 4 / 2 / 2 / 1), and
-// in conv64_fwd_kernel every one of those stagings is a synchronous HBM round trip between two barriers: at the 111x111 layer
-// the kernel moves 5.5 GB in 1.5 ms — neither the matrix pipe (52 % busy) nor HBM (3.7 TB/s) is busy, they take turns.  Here
+// Software-pipelined, persistent kernels of the stride-2 gather programs (conv64_bwd_fused_kernel: the whole backward of a
+// ConvTranspose block; conv64_gather_pipe_kernel: plain operands).  A stride-2 gather tile stages its source FOUR times (one class of
+// 128 + span rows per tap group 4 / 2 / 2 / 1), and in conv64_fwd_kernel every one of those stagings is a synchronous HBM round trip
+// between two barriers.  Here
 //  * the rows of class c+1 are REQUESTED into registers right after the barrier that opens the first tap of class c and LAND
-//    in LDS (BatchNorm+ReLU backward rebuilt, dy_out stored) after the barrier that closes its last tap: they travel under
-//    4 / 2 / 2 taps of MFMAs; the requests are branch-free (clamped addresses, masks applied at the landing), so hipcc's wait
-//    insertion keeps them in flight (DESIGN.md 5.2 — the round-2 attempt at this, tools/experiments/gather_pipe_kernel.patch, had
-//    its requests inside branches);
-//  * workgroups are persistent (2 per CU) and walk a contiguous run of their XCD's tiles, so class 0 of the NEXT tile travels
-//    under the single tap of class 3 and the epilogue, and the weight slab of tap 0 under tap 8;
+//    in LDS after the barrier that closes its last tap: they travel under 4 / 2 / 2 taps of MFMAs; the requests are branch-free
+//    (clamped addresses, masks applied at the landing), so hipcc's wait insertion keeps them in flight;
+//  * workgroups are persistent and walk a contiguous run of their XCD's tiles, so class 0 of the NEXT tile travels under the single
+//    tap of class 3 and the epilogue, and the weight slab of tap 0 under tap 8;
 //  * the tap structure is compile-time (groups {0..3}, {4, 5}, {6, 7}, {8}): no run-time class switch inside the pipeline.
-// Same arithmetic, same accumulation order and same tiles as conv64_fwd_kernel<4, true>: results are bit-identical.
+// (Round 3's conv64_dgrad_pipe_kernel — the fused data gradient alone, with the rebuilt gradient stored for a separate weight-gradient
+// launch — was the first of this family; conv64_bwd_fused_kernel took over every shape it served and it was removed in round 5.)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int GP_THREADS = 512;                 // 8 waves: wave = 32 rows x 32 columns, one accumulator (the rows of a class in
 constexpr int GP_RP = GP_THREADS / 16;          // flight cost 376 bytes per thread at 256 threads — with the 4-wave kernel's 64
@@ -846,224 +845,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gp_buffer(float* p, unsigned b
 }
 constexpr unsigned GP_DROP = 0xFFFFFF00u;
 
-// lrec: [4][64] in LDS — scale, shift, c0, c1 of the rows' BatchNorm group (see stage_rows); dy_rsrc: the group's dy_out tensor
-// (zero-sized when the rebuilt gradient is not to be stored)
-__device__ __forceinline__ void gather_land(float* __restrict__ lds, GatherRows& r, int nrows, const float* __restrict__ lrec,
-                                            __amdgpu_buffer_rsrc_t dy_rsrc, int core_lo, int core_n) {
-  int t = threadIdx.x;
-  asm volatile("" : "+v"(t));
-  const int slot = t & 15;
-  const f32x4 sc4 = *(const f32x4*)(lrec + slot * 4), sh4 = *(const f32x4*)(lrec + 64 + slot * 4);
-  const f32x4 c0 = *(const f32x4*)(lrec + 128 + slot * 4), c1 = *(const f32x4*)(lrec + 192 + slot * 4);
-#pragma unroll
-  for (int j = 0; j < GP_BATCH; ++j) {
-    const int R = (t >> 4) + GP_RP * j;
-    const bool ok = (r.ok >> j) & 1u;
-    f32x4 v = r.v[j];
-    const f32x4 yy = r.yv[j];
-    {  // (explicit fused multiply-adds: exactly stage_rows' roundings; vector form -> v_pk_fma_f32)
-      const f32x4 z4 = __builtin_elementwise_fma(yy, sc4, sh4), t4 = __builtin_elementwise_fma(c1, yy, c0);
-      f32x4 dz4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dz4[e] = z4[e] > 0.f ? v[e] : 0.f;
-      v = __builtin_elementwise_fma(sc4, dz4, -t4);
-      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (j < GP_CORE) {
-      const bool core = ok && R < nrows && (unsigned)(R - core_lo) < (unsigned)core_n;
-      __builtin_amdgcn_raw_buffer_store_b128(v, dy_rsrc, core ? r.offs[j < GP_CORE ? j : 0] * 4u : GP_DROP, 0, 0);
-    }
-    if (R < nrows) *(f32x4*)(lds + R * 64 + ((slot ^ (R & 15)) << 2)) = v;  // (an LDS write only: no vector-memory op in a branch)
-  }
-}
-
-__global__ __launch_bounds__(GP_THREADS, 4) void conv64_dgrad_pipe_kernel(const float* __restrict__ src_all,
-                                                                         const float* __restrict__ wpack,
-                                                                         float* __restrict__ dst_all, const ConvProg P, int ntiles,
-                                                                         const OpFuse fuse_all) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* As = (float*)smem;                 // (TM + span) x 64, swizzled: the rows of the current class
-  float* Bs = As + (TM + P.span) * 64;      // 64 x 64 weight slab of the current tap
-  int* rowinfo = (int*)(Bs + 4096);         // [2 (tile parity)][3][TM]: image index (or -1), a*ds, b*ds
-  float* frec = (float*)(rowinfo + 6 * TM); // [G <= 2][4][64]: scale, shift, c0, c1 per BatchNorm group
-  unsigned* gtab = (unsigned*)(frec + 512); // the source-side row table of the tile whose rows are being requested (gtab_build)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int nrows = TM + P.span;
-  const int cls0 = P.tsrc[0], cls1 = P.tsrc[4], cls2 = P.tsrc[6], cls3 = P.tsrc[8];
-
-  // this workgroup's tiles: a strided walk over the contiguous run of tiles that belongs to its XCD (block b runs on XCD b % 8;
-  // concurrently running workgroups of an XCD therefore work on neighbouring tiles, which share halo rows in that XCD's L2)
-  const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, wpx = gridDim.x >> 3;
-  const int tq = ntiles >> 3, tr = ntiles & 7;
-  const int tbase = (xcd < tr) ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-  const int tcnt = tq + (xcd < tr ? 1 : 0);
-
-  // BatchNorm-backward coefficients of every group, once per workgroup
-  if (tid < 64 * P.G) {
-    const int g = tid >> 6, c = tid & 63;
-    const float* bnp = fuse_all.bnp + g * 256;
-    const float* sums = fuse_all.sums + g * 128;
-    const float sc = bnp[128 + c], sh = bnp[192 + c];
-    float c0 = 0.f, c1 = 0.f;
-    if (fuse_all.training) {
-      c1 = sc * bnp[64 + c] * sums[64 + c] * fuse_all.inv_count;
-      c0 = sc * sums[c] * fuse_all.inv_count - c1 * bnp[c];
-    }
-    float* fr = frec + g * 256;
-    fr[c] = sc; fr[64 + c] = sh; fr[128 + c] = c0; fr[192 + c] = c1;
-  }
-
-  constexpr int BV = 1024 / GP_THREADS;  // 16-byte vectors of the 16 KB slab per thread; wave w moves (and may scribble on) its own 2 KB
-  const int bslot = wave * (BV * 64) + lane;
-  f32x4 breg[BV];
-  {
-    const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[0] * 4096);
-#pragma unroll
-    for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
-  }
-
-  // bytes of one group's dy_out / dst tensor (< 2^32: checked by the host); a zero-sized dy_out drops every store
-  const unsigned dy_bytes = fuse_all.dy_out ? (unsigned)P.src_gstride * 4u : 0u;
-  const unsigned dst_bytes = (unsigned)P.dst_gstride * 4u;
-
-  GatherRows rr;
-  int k = wi;
-  int parity = 0;
-  if (k < tcnt) {  // the first tile's class 0 is staged the plain way
-    const int tile = tbase + k;
-    const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;  // (G <= 2, checked by the host)
-    const int q0 = (tile - grp * P.tpg) * TM;
-    gtab_build(gtab, P, q0, nrows);
-    __syncthreads();  // the table and frec are complete
-    gather_request(rr, src_all + grp * P.src_gstride, fuse_all.y + grp * P.src_gstride, gtab, cls0, P.Ws);
-    gather_land(As, rr, nrows, frec + grp * 256, gp_buffer(fuse_all.dy_out + grp * P.src_gstride, dy_bytes), -P.min_off, TM);
-  }
-  for (; k < tcnt; k += wpx, parity ^= 1) {
-    const int tile = tbase + k;
-    const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;
-    const int q0 = (tile - grp * P.tpg) * TM;
-    const float* __restrict__ src = src_all + grp * P.src_gstride;
-    const float* __restrict__ ysrc = fuse_all.y + grp * P.src_gstride;
-    const __amdgpu_buffer_rsrc_t dyo = gp_buffer(fuse_all.dy_out + grp * P.src_gstride, dy_bytes);
-    const __amdgpu_buffer_rsrc_t dst = gp_buffer(dst_all + grp * P.dst_gstride, dst_bytes);
-    const float* lrec = frec + grp * 256;
-    const int k2 = k + wpx;  // this workgroup's next tile (past the end: this one again, with no rows)
-    const int tile2 = tbase + (k2 < tcnt ? k2 : k);
-    const int grp2 = (P.G > 1 && tile2 >= P.tpg) ? 1 : 0;
-    const int q02 = (tile2 - grp2 * P.tpg) * TM;
-    int* ri = rowinfo + parity * (3 * TM);
-    if (tid < TM) {  // (the other parity's copy may still be read by a wave that is flushing the previous tile)
-      const int q = q0 + tid;
-      int n = -1, ya = 0, xb = 0;
-      if (q < P.total_q) {
-        n = fastdiv(q, P.mPHW, P.sPHW);
-        const int rem = q - n * P.PHW;
-        const int a = fastdiv(rem, P.mPW, P.sPW);
-        ya = a * P.ds;
-        xb = (rem - a * P.PW) * P.ds;
-      }
-      ri[tid] = n; ri[TM + tid] = ya; ri[2 * TM + tid] = xb;
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // Everything the nine taps derive from the lane index is tile-independent, and left to itself the compiler keeps all of it
-    // (nine operand addresses, the slab offsets ...) in registers across the tile loop — which pushes the rows in flight into
-    // scratch, and every scratch reload is a "s_waitcnt vmcnt(0)" in front of a tap's MFMAs, i.e. the end of the pipeline.  One
-    // opaque copy of the lane index per tile keeps those few VALU instructions inside the loop instead.
-    int tid_t = tid;  // (the thread index rather than the lane index: what derives from the wave index is kept — and spilled — too)
-    asm volatile("" : "+v"(tid_t));
-    const int lane_t = tid_t & 63, wave_t = tid_t >> 6;
-    const int wrow_t = wave_t & 3, wcol_t = wave_t >> 2;
-    const int h_t = lane_t >> 5, l31_t = lane_t & 31;
-    const int arow0 = wrow_t * 32 + l31_t - P.min_off;
-    const float* brow = Bs + (wcol_t * 32 + l31_t) * 64;
-    const int bkey = lane_t & 15;
-    const int bslot_t = wave_t * (BV * 64) + lane_t;  // (likewise: nine 64-bit slab addresses would be hoisted otherwise)
-
-#pragma unroll
-    for (int ti = 0; ti < NTAPS; ++ti) {
-      __syncthreads();  // all waves are done with the previous tap's Bs — and with As when this tap opens a new class
-      {  // the slab first: its loads are older than the rows in flight and are waited for with those still pending
-        f32x4* wdst = (f32x4*)Bs;
-#pragma unroll
-        for (int i = 0; i < BV; ++i) wdst[bslot_t + i * 64] = breg[i];
-      }
-      {  // the next tap's slab (tap 0 of the next tile behind tap 8: same weights) — requested BEFORE the landing's dy_out stores:
-         // vmcnt is in-order and counts stores, so the next tap's slab wait lets everything issued after these loads (the stores,
-         // the next class's rows) stay in flight, and a store's HBM round trip travels under two taps like the rows do
-        const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[(ti + 1) % NTAPS] * 4096);
-#pragma unroll
-        for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot_t + i * 64];
-      }
-      if (ti == 4 || ti == 6 || ti == 8) gather_land(As, rr, nrows, lrec, dyo, -P.min_off, TM);
-      // the NEXT tile's row table, between the last request of this tile (behind tap 6's second barrier) and the first of the next
-      // (tap 8); past the end: no rows -> every entry 0 -> every row reads pixel 0 and is dropped
-      if (ti == 7) gtab_build(gtab, P, q02, k2 < tcnt ? nrows : 0);
-      __syncthreads();
-      // the next class's rows
-      if (ti == 0) gather_request(rr, src, ysrc, gtab, cls1, P.Ws);
-      if (ti == 4) gather_request(rr, src, ysrc, gtab, cls2, P.Ws);
-      if (ti == 6) gather_request(rr, src, ysrc, gtab, cls3, P.Ws);
-      if (ti == 8)  // class 0 of this workgroup's NEXT tile
-        gather_request(rr, src_all + grp2 * P.src_gstride, fuse_all.y + grp2 * P.src_gstride, gtab, cls0, P.Ws);
-      __builtin_amdgcn_sched_barrier(0);  // every request goes out HERE, ahead of the tap's MFMAs (the scheduler sinks them otherwise)
-      const int R = arow0 + P.toff[ti];
-      int abase = (R * 64 + ((h_t ^ (R & 15)) << 2)) * 4;  // bytes; slot (2kc + h) ^ (R & 15) is this XOR (kc << 5)
-      asm volatile("" : "+v"(abase));
-      // (no register double-buffering of the fragments here: four waves per SIMD hide the LDS latency, and the 8 registers are
-      // needed for the rows in flight)
-#pragma unroll
-      for (int kc = 0; kc < 8; ++kc) {
-        const f32x4 a = *(const f32x4*)((const char*)As + (abase ^ (kc << 5)));
-        const f32x4 b = *(const f32x4*)(brow + (((kc * 2 + h_t) ^ bkey) << 2));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
-      }
-    }
-    __syncthreads();  // every wave is done with the last tap's slab and with As: Bs becomes scratch, As takes the next tile
-    // (the landing first: it waits for its rows only; behind the flush's stores — in branches — it would wait for those too)
-    if (k + wpx < tcnt) {
-      const int tile2 = tbase + k + wpx;
-      const int grp2 = (P.G > 1 && tile2 >= P.tpg) ? 1 : 0;
-      gather_land(As, rr, nrows, frec + grp2 * 256, gp_buffer(fuse_all.dy_out + grp2 * P.src_gstride, dy_bytes), -P.min_off, TM);
-    }
-    {  // flush through this wave's own 2 KB of the idle slab, 16 tile rows x 32 columns at a time: every global store is 16 bytes per
-       // lane (lane = (row eg = lane >> 3, 4 channels at eslot = lane & 7); see conv64_fwd_kernel::flush16)
-      int tid_f = tid;  // (a fresh opaque copy: what the flush derives from the thread index does not live — in scratch — across the taps)
-      asm volatile("" : "+v"(tid_f));
-      const int lane_f = tid_f & 63, wave_f = tid_f >> 6;
-      const int wrow_f = wave_f & 3, wcol_f = wave_f >> 2, h_f = lane_f >> 5, l31_f = lane_f & 31;
-      float* S = Bs + wave_f * 512;
-      const int eg = lane_f >> 3, eslot = lane_f & 7;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int rq = 0; rq < 8; ++rq) {
-          const int rowl = (rq & 3) + 8 * (rq >> 2) + 4 * h_f;
-          S[rowl * 32 + l31_f] = acc[8 * half + rq];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int rowl = eg + 8 * kk;
-          const int row = wrow_f * 32 + 16 * half + rowl;
-          const f32x4 v = *(const f32x4*)(S + rowl * 32 + eslot * 4);
-          const int n = ri[row];
-          const int y = ri[TM + row], x = ri[2 * TM + row];
-          const bool inside = n >= 0 && y < P.Hd && x < P.Wd;  // (branch-free store: see gp_buffer)
-          __builtin_amdgcn_raw_buffer_store_b128(v, dst, inside ? (unsigned)((n * P.Hd + y) * P.Wd + x) * 256u + wcol_f * 128 + eslot * 16 : GP_DROP,
-                                                 0, 0);
-        }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // The stride-2 gather programs with a PLAIN operand — conv3's forward (27x27 -> 14x14, with the BatchNorm statistics of its output)
-// and the data gradient of the decoder's first ConvTranspose — software-pipelined like conv64_dgrad_pipe_kernel (round 5).
+// and the data gradient of the decoder's first ConvTranspose — software-pipelined like conv64_bwd_fused_kernel's data-gradient half (round 5).
 // In conv64_fwd_kernel<4, false> such a tile stages its four source classes in four synchronous HBM round trips between barriers,
 // and conv3 has only 900 tiles of them for 512 workgroup slots: 102 us for 47 us of matrix work.  Here, as in the fused kernel above:
 // persistent workgroups (2 per CU) walk their XCD's tiles, class c + 1 is requested behind the barrier that opens class c and lands
@@ -1204,7 +988,8 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_gather_pipe_kernel(const
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    int tid_t = tid;  // (one opaque copy of the thread index per tile: see conv64_dgrad_pipe_kernel)
+    int tid_t = tid;  // (one opaque copy of the thread index per tile: what the nine taps derive from it must not live in registers
+                      // across the tile loop, or the rows in flight are pushed into scratch)
     asm volatile("" : "+v"(tid_t));
     const int lane_t = tid_t & 63, wave_t = tid_t >> 6;
     const int wrow_t = wave_t & 3, wcol_t = wave_t >> 2;
@@ -1304,7 +1089,7 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_gather_pipe_kernel(const
 // ---------------------------------------------------------------------------------------------------------------
 // The WHOLE backward of a decoder block's ConvTranspose2d(64, 64, 3, stride 2) in one launch: data gradient, weight gradient and
 // bias gradient from ONE staging of the rebuilt d(loss)/dy.
-// conv64_dgrad_pipe_kernel reads (dA, y) = 3.2 GB at the 111x111 layer, rebuilds dy and — only so that the weight-gradient
+// A separate fused data-gradient launch reads (dA, y) = 3.2 GB at the 111x111 layer, rebuilds dy and — only so that the weight-gradient
 // kernel can read it back — stores it (1.6 GB written, 1.6 GB read again).  Both contractions consume the same operand:
 //     da(p)  = sum_t dy_{c_t}(p + off_t) . Wb[t]          (M = positions, N = ci, K = co)
 //     dW[t]  = sum_p a(p)^T . dy_{c_t}(p + off_t)         (M = ci, N = co, K = positions),    a = relu(bn(y_prev)),
@@ -1314,7 +1099,7 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_gather_pipe_kernel(const
 //  * 512 threads, ONE workgroup per CU (256 registers per lane, 150 KB of LDS): the class rows are double-buffered in LDS, so a
 //    class lands two taps after it was requested — where the in-order vmcnt completes its loads anyway — while the previous
 //    class is still being read; the a-tile of the next tile lands at the tile boundary.
-//  * data gradient: wave = 32 positions x 32 channels (as conv64_dgrad_pipe_kernel).  Weight gradient: the 36 blocks
+//  * data gradient: wave = 32 positions x 32 channels (as conv64_gather_pipe_kernel).  Weight gradient: the 36 blocks
 //    (9 taps x 2x2 quadrants of 32x32) are spread over the 8 waves per CLASS so that every wave has 32 weight-gradient MFMAs
 //    in every tap period: class of 4 taps — wave w owns tap (w >> 1), quadrants (w & 1, {0, 1}), a quarter of the positions per
 //    period; classes of 2 taps — tap (w >> 2), quadrant (w & 1, (w >> 1) & 1), half of the positions per period; the 1-tap
@@ -1323,7 +1108,7 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_gather_pipe_kernel(const
 //  * positions are visited as p = 16 i + jj + 8 h (h = the MFMA's two k-lanes): for fixed (jj, h) the rows 16 i apart share the
 //    XOR key of the swizzled dy rows, so a lane reaches its eight k-steps from ONE address with immediate offsets
 //    (ds_read2st64_b32), for the dy operand as for the (unswizzled) a-tile.
-// Results: dx bit-identical to conv64_dgrad_pipe_kernel; dW / db differ from the two-kernel path by summation order only
+// Results: dx bit-identical to conv64_fwd_kernel<4, true>'s; dW / db differ from the two-kernel path by summation order only
 // (per-workgroup partials, fixed-order fp64 second stage: deterministic).
 // ---------------------------------------------------------------------------------------------------------------
 struct FusedBwd {
@@ -1386,7 +1171,7 @@ __device__ __forceinline__ void ytile_land(float* __restrict__ Ys, YRows& r, con
   }
 }
 
-// as gather_land, without the dy_out store; bs4 += the tile's own rows (every dy element belongs to exactly one tile's range)
+// the landing of a class's rows: BatchNorm + ReLU backward rebuilt from (dA, y), zero outside the tensor; bs4 += the tile's own rows (every dy element belongs to exactly one tile's range)
 __device__ __forceinline__ void gather_land_sum(float* __restrict__ lds, GatherRows& r, int nrows, const float* __restrict__ lrec,
                                                 f32x4& bs4) {
   int t = threadIdx.x;
@@ -1550,7 +1335,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // (one opaque copy of the lane index per tile: see conv64_dgrad_pipe_kernel)
+    // (one opaque copy of the lane index per tile: see conv64_gather_pipe_kernel)
     int lane_t = lane;
     asm volatile("" : "+v"(lane_t));
     const int h_t = lane_t >> 5, l31_t = lane_t & 31;
@@ -1616,7 +1401,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
     }
     __syncthreads();  // every wave is done with the last tap's slab, with class 3 and with the a-tile
     ytile_land(Ys, yr, xrec + grp2 * 128);  // (past the last tile: zeros)
-    {  // flush of the data gradient (see conv64_dgrad_pipe_kernel)
+    {  // flush of the data gradient (see conv64_gather_pipe_kernel)
       float* S = Bs + wave * 512;
       const int eg = lane_t >> 3, eslot = lane_t & 7;
 #pragma unroll
@@ -2444,6 +2229,15 @@ static size_t convn_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) 
 static size_t wgrad_lds_bytes(const ConvProg& P, int tk) { return (size_t)(tk + P.span + tk) * 256; }
 static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried: the extra staging registers spill
 
+// conv64_gather_pipe_kernel takes a program when it is a stride-2 gather with the tap groups {4, 2, 2, 1}, at most two BatchNorm groups,
+// a staged class of at most 192 rows (PW <= 63) and 32-bit byte offsets.  Geometry only: never the number of tiles.
+static bool gather_pipe_ok(const ConvProg& P) {
+  bool grouped = P.s2 && P.ss == 2 && P.G <= 2 && !P.dbg;
+  for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
+  const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;
+  return grouped && fits32 && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && -P.min_off <= P.PHW;
+}
+
 static int launch_fwd(const float* src, const float* wpack, const float* bias, float* dst, float* stats,
                       const ConvProg& P, hipStream_t st, const OpFuse src_fuse = SRLZ_NO_FUSE, const PoolSum* psum = nullptr) {
   const int ntiles = P.G * P.tpg;
@@ -2479,30 +2273,14 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
   if (src_fuse.y) {
     SRLZ_REQUIRE((long long)P.N * P.Hs * P.Ws * 64 < (1LL << 32), SRLZ_ERR_BAD_DESC,
                  "conv64: a group's operand has %lld floats (the fused staging keeps 32-bit row offsets)", (long long)P.N * P.Hs * P.Ws * 64);
-    // the software-pipelined persistent kernel (SRLZ_DGRAD_PIPE=0: the synchronous conv64_fwd_kernel<4, true>)
-    static const int use_pipe = [] { const char* e = getenv("SRLZ_DGRAD_PIPE"); return e ? atoi(e) : 1; }();
-    bool grouped = P.s2 && P.ss == 2 && P.G <= 2;
-    for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
-    int pgrid = 2 * srlz_device_cus();
-    if (pgrid > ntiles) pgrid = ntiles;
-    pgrid &= ~7;
-    const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;  // buffer resources: 32-bit byte counts
-    if (use_pipe && grouped && fits32 && !P.dbg && P.min_off == 0 && TM + P.span <= GP_RP * GP_BATCH && pgrid >= 8 && GP_RP <= P.PHW) {
-      const size_t plds = (size_t)(TM + P.span) * 256 + 16384 + 6 * TM * 4 + 2 * 256 * 4 + GT_WORDS * 4;
-      SRLZ_MAX_LDS(conv64_dgrad_pipe_kernel, plds);
-      hipLaunchKernelGGL(conv64_dgrad_pipe_kernel, dim3(pgrid), dim3(GP_THREADS), plds, st, src, wpack, dst, P, ntiles, src_fuse);
-      SRLZ_LAUNCHED();
-      return 0;
-    }
+    // (a fused BatchNorm-backward operand that must also be STORED for a separate weight-gradient launch: the shapes
+    // conv64_bwd_fused_kernel does not take — fewer than 8 tiles, a low-resolution grid wider than 63)
     SRLZ_FWD_LAUNCH(4, true);
   } else {
     // plain stride-2 gather programs (conv3 forward, ConvT1 data gradient): the software-pipelined persistent kernel.  The choice
     // depends on the program's geometry only — never on the number of tiles — so one BatchNorm group alone and the batched pair of
     // a step take the same kernel (their statistics are compared bit for bit).
-    bool grouped = P.s2 && P.ss == 2 && P.G <= 2 && !src_fuse.bnp && !bias && !P.dbg;
-    for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
-    const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;
-    if (grouped && fits32 && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && -P.min_off <= P.PHW) {
+    if (!src_fuse.bnp && !bias && gather_pipe_ok(P)) {
       int pgrid = 2 * srlz_device_cus();
       if (pgrid > ntiles) pgrid = ntiles;
       pgrid &= ~7;
@@ -2918,6 +2696,13 @@ static bool fused_bwd_ok(const ConvProg& P) {
   for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
   const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;
   return grouped && fits32 && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && fused_bwd_grid(P) >= 8;
+}
+
+extern "C" int srlz_conv64_gather_pipe_supported(const srlz_conv64_desc* d, int backward_data) {
+  if (check_desc(d)) return 0;
+  ConvProg P;
+  if (program_for(&P, d, backward_data)) return 0;
+  return gather_pipe_ok(P) ? 1 : 0;
 }
 
 extern "C" int srlz_conv64_bwd_fused_supported(const srlz_conv64_desc* d) {

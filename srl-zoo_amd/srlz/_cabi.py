@@ -64,6 +64,7 @@ _PROTOS = {
     "srlz_conv64_bwd_data": (c_int, [P, P, P, _BO, _C64, P]),
     "srlz_conv64_bwd_weight_workspace": (c_size_t, [_C64]),
     "srlz_conv64_bwd_fused_supported": (c_int, [_C64]),
+    "srlz_conv64_gather_pipe_supported": (c_int, [_C64, c_int]),
     "srlz_conv64_bwd_fused_workspace": (c_size_t, [_C64]),
     "srlz_conv64_bwd_fused": (c_int, [P, P, P, _BO, P, P, P, P, P, c_size_t, _C64, P]),
     "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, _BO, P, c_size_t, _C64, P]),
@@ -168,7 +169,7 @@ _PROTOS = {
 
 # entry points whose int return value is data, not a status
 _NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
-               "srlz_convT_out_bwd_fused_tiles", "srlz_convT_out_fwd_loss_workgroups", "srlz_conv64_bwd_fused_supported",
+               "srlz_convT_out_bwd_fused_tiles", "srlz_convT_out_fwd_loss_workgroups", "srlz_conv64_bwd_fused_supported", "srlz_conv64_gather_pipe_supported",
                "srlz_convT_out_bwd_fused_supported",
                "srlz_conv64_bwd_data_tiles",
                "srlz_conv64_debug_program", "srlz_comm_world"}

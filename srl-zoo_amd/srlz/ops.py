@@ -301,7 +301,8 @@ class Conv64Fn(Function):
         C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())
         y = torch.empty((n, d.ho, d.wo, 64), dtype=torch.float32, device=x.device)
         stats = torch.empty((C.conv64_fwd_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
-        _launch("conv64_fwd_kernel", _conv64_key(d, "fwd"), _conv64_flop(d),
+        name = "conv64_gather_pipe_kernel" if (bias is None and C.conv64_gather_pipe_supported(d, 0)) else "conv64_fwd_kernel"
+        _launch(name, _conv64_key(d, "fwd"), _conv64_flop(d),
                 lambda: C.conv64_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), None, d, stream()))
         ctx.save_for_backward(x, packs)
         ctx.desc = d
@@ -343,7 +344,8 @@ class Conv64Fn(Function):
                                                             ptr(pargmax), pd, ptr(part), d, stream()))
                 link.partials = part
             else:
-                _launch("conv64_fwd_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                _launch("conv64_gather_pipe_kernel" if C.conv64_gather_pipe_supported(d, 1) else "conv64_fwd_kernel",
+                        _conv64_key(d, "dgrad"), _conv64_flop(d),
                         lambda: C.conv64_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), None, d, stream()))
         return dx, _give(ctx.params[0], dw), _give(ctx.params[1], db), None, None, None, None, None
 
@@ -607,9 +609,9 @@ def _operand_from(link, materialise=True):
     return op, dy_out, rec
 
 
-# A/B switch: data + weight + bias gradient of a decoder block's ConvTranspose as ONE launch (0: data-gradient launch that stores the
-# rebuilt d(loss)/dy + weight-gradient launch that reads it back)
-_FUSED_CONVT_BWD = _os.environ.get("SRLZ_FUSED_CONVT_BWD", "1") != "0"
+# Data + weight + bias gradient of a decoder block's ConvTranspose are ONE launch wherever the shape allows
+# (srlz_conv64_bwd_fused_supported: at least 8 tiles, a low-resolution grid of at most 63 columns, two BatchNorm groups at most);
+# other shapes take a data-gradient launch that stores the rebuilt d(loss)/dy and a weight-gradient launch that reads it back.
 
 
 class DecBlockFn(Function):
@@ -644,7 +646,7 @@ class DecBlockFn(Function):
         y_prev, bnp, packs = ctx.saved_tensors
         d = ctx.desc
         dy = _check(dy, "decoder block dy")
-        if ctx.out_link is not None and ctx.out_link.record is not None and _FUSED_CONVT_BWD and C.conv64_bwd_fused_supported(d):
+        if ctx.out_link is not None and ctx.out_link.record is not None and C.conv64_bwd_fused_supported(d):
             # `dy` is dA of the following BatchNorm+ReLU: ONE kernel rebuilds the true dy while staging it and contracts it both ways
             # (data gradient and weight / bias gradient) — it is never written to memory
             dy_bn, _, keep = _operand_from(ctx.out_link, materialise=False)
@@ -1007,6 +1009,12 @@ class SqDiffSumFn(Function):
         return da, db, None
 
 
+def weighted(loss, weight):
+    """weight * loss — what every loss function of the reference returns (losses/losses.py:102-256; the trainer itself reads the
+    terms from the LossManager) — as one HIP launch: 0 + weight * loss with a separately rounded product is exactly that."""
+    return TotalLossFn.apply((float(weight),), None, loss)
+
+
 def add_scalars(a, b):
     """a + b of two 0-dim loss tensors as one HIP launch (srlz_weighted_total with weights 1, 1: (0 + 1 * a) + 1 * b is exactly a + b)."""
     return TotalLossFn.apply((1.0, 1.0), None, a, b)
@@ -1312,7 +1320,9 @@ class CrossEntropyFn(Function):
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
-        return dlogits * g, None
+        out = torch.empty_like(dlogits)
+        C.scale_by_scalar(ptr(dlogits), ptr(_check(g, "loss grad")), 1.0, 1.0, ptr(out), dlogits.numel(), stream())
+        return out, None
 
 
 class PReLUFn(Function):

@@ -13,7 +13,7 @@ import isa_audit  # noqa: E402
 
 HOT = ("conv64_fwd_kernel<4, false>", "conv64_fwd_kernel<4, true>", "conv64_wgrad_ring_kernel", "conv64_wgrad_gather_kernel",
        "conv64_dgrad_poolsum_kernel<1>", "conv64_dgrad_poolsum_kernel<2>",
-       "conv64_wgrad_ring_s2_kernel", "conv64_dgrad_pipe_kernel",
+       "conv64_wgrad_ring_s2_kernel", "conv64_gather_pipe_kernel",
        "skinny_conv_kernel<7, 3, false, false, float>",
        "skinny_conv_kernel<4, 0, true, false, float>", "skinny_wgrad_kernel<7, 3, true, float>",
        "skinny_wgrad_kernel<7, 3, true, unsigned char>", "skinny_wgrad_kernel<4, 0, false, float>",

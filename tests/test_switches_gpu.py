@@ -44,13 +44,14 @@ np.save(sys.argv[3], flat)
 print("RESULT " + json.dumps({"losses": rows, "names": list(lm.names), "bufs": bufs, "steps": srl.optimizer.steps()}))
 """
 
-# Round 5 retired the A/B residue (ten variables; DESIGN.md 5.1): what is left selects a feature (hipGraph replay), a debugging aid
-# (synchronise after every call) and the two-launch form of a ConvTranspose block's backward (pipelined data gradient + ring weight
-# gradient) with its synchronous predecessor.  The fallback ROUTES the retired variables used to select are reached the way the
-# product reaches them — by shape or by what the step needs — in tests/test_pair_gpu.py, test_step_gpu.py, test_trajectory_gpu.py.
-SWITCHES = [("SRLZ_GRAPH", "1"), ("SRLZ_FUSED_CONVT_BWD", "0"), ("SRLZ_DGRAD_PIPE", "0"), ("SRLZ_SYNC", "1")]
+# Round 5 retired the A/B residue (twelve variables; DESIGN.md 5.1): what is left selects a feature (hipGraph replay) and a debugging
+# aid (synchronise after every call).  The fallback ROUTES the retired variables used to select are reached the way the product
+# reaches them — by shape or by what the step needs — in tests/test_pair_gpu.py, test_step_gpu.py, test_trajectory_gpu.py,
+# test_kernels_gpu.py.
+SWITCHES = [("SRLZ_GRAPH", "1"), ("SRLZ_SYNC", "1")]
 RETIRED = ["SRLZ_DEFER_BN_BWD", "SRLZ_FUSE_ENC_IN", "SRLZ_DIRECT_GRADS", "SRLZ_WGRAD_RING", "SRLZ_WGRAD_S2_TK32", "SRLZ_PAIR",
-           "SRLZ_FUSED_TOTAL", "SRLZ_FUSED_OUT_BWD", "SRLZ_FUSED_RECON", "SRLZ_POOL_BWD_IN_DGRAD"]
+           "SRLZ_FUSED_TOTAL", "SRLZ_FUSED_OUT_BWD", "SRLZ_FUSED_RECON", "SRLZ_POOL_BWD_IN_DGRAD", "SRLZ_FUSED_CONVT_BWD",
+           "SRLZ_DGRAD_PIPE"]
 
 
 def _run_all(losses, tmp_path):
