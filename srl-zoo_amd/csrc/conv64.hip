@@ -2230,8 +2230,14 @@ static size_t wgrad_lds_bytes(const ConvProg& P, int tk) { return (size_t)(tk + 
 static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried: the extra staging registers spill
 
 // conv64_gather_pipe_kernel takes a program when it is a stride-2 gather with the tap groups {4, 2, 2, 1}, at most two BatchNorm groups,
-// a staged class of at most 192 rows (PW <= 63) and 32-bit byte offsets.  Geometry only: never the number of tiles.
+// a staged class of at most 192 rows (PW <= 63), 32-bit byte offsets — and at least 256 tiles PER BatchNorm GROUP: the pipeline pays
+// when a workgroup walks several tiles (conv3 forward at bs = 256: 450 tiles per group, 102 -> 92 us); with about one tile per
+// workgroup the 4-wave synchronous kernel is faster (bs = 32: 33 us against 51).  Per group, not per launch: one group alone and the
+// batched pair of a step must take the same kernel (their statistics are compared bit for bit, and the two kernels sum a tile's
+// partial in different orders).
+constexpr int GATHER_PIPE_MIN_TILES_PER_GROUP = 256;
 static bool gather_pipe_ok(const ConvProg& P) {
+  if (P.tpg < GATHER_PIPE_MIN_TILES_PER_GROUP) return false;
   bool grouped = P.s2 && P.ss == 2 && P.G <= 2 && !P.dbg;
   for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
   const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;
@@ -2277,9 +2283,8 @@ static int launch_fwd(const float* src, const float* wpack, const float* bias, f
     // conv64_bwd_fused_kernel does not take — fewer than 8 tiles, a low-resolution grid wider than 63)
     SRLZ_FWD_LAUNCH(4, true);
   } else {
-    // plain stride-2 gather programs (conv3 forward, ConvT1 data gradient): the software-pipelined persistent kernel.  The choice
-    // depends on the program's geometry only — never on the number of tiles — so one BatchNorm group alone and the batched pair of
-    // a step take the same kernel (their statistics are compared bit for bit).
+    // plain stride-2 gather programs with many tiles (conv3 forward at training batch sizes): the software-pipelined persistent
+    // kernel (gather_pipe_ok: a per-group criterion, so that one BatchNorm group alone and the batched pair take the same kernel)
     if (!src_fuse.bnp && !bias && gather_pipe_ok(P)) {
       int pgrid = 2 * srlz_device_cus();
       if (pgrid > ntiles) pgrid = ntiles;

@@ -112,18 +112,22 @@ def test_conv64_deterministic(C):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("n,hi,s,p,t,groups", [(4, 27, 2, 1, 0, 1), (4, 27, 2, 1, 0, 2), (1, 27, 2, 1, 0, 1), (300, 27, 2, 1, 0, 2),
-                                                (6, 6, 2, 0, 1, 2), (2, 13, 2, 0, 1, 1), (3, 31, 2, 1, 0, 1)])
+@pytest.mark.parametrize("n,hi,s,p,t,groups", [(300, 27, 2, 1, 0, 2), (146, 27, 2, 1, 0, 1), (512, 27, 2, 1, 0, 2), (120, 31, 2, 1, 0, 1),
+                                                (170, 13, 2, 0, 1, 1), (360, 13, 2, 0, 1, 2)])
 def test_gather_pipe_kernel_is_the_synchronous_kernel(C, n, hi, s, p, t, groups):
     """conv64_gather_pipe_kernel (round 5: the plain stride-2 gather programs — conv3's forward, a ConvTranspose's data gradient —
     persistent and software-pipelined) against conv64_fwd_kernel<4, false>, which still takes the same program when a bias is
     given: same tiles, same accumulation order -> the outputs are bit-identical (a zero bias adds +0); the per-tile BatchNorm
-    partials have the same tile geometry and agree to summation order.  One image, two BatchNorm groups, more tiles than
-    workgroups (n = 300: 528 tiles on 512 persistent workgroups) and a ragged grid (31 -> 16) included.
-    Reference: models/models.py:59 (conv3x3 stride 2) / :66 (the first ConvTranspose2d)."""
+    partials have the same tile geometry and agree to summation order.  One and two BatchNorm groups, more tiles than workgroups
+    (528 / 900 tiles on 512 persistent workgroups), a ragged grid (31 -> 16) and a ConvTranspose's data gradient included.  The
+    kernel takes a program from 256 tiles PER GROUP on — a per-group criterion, so that a group alone and the batched pair of a
+    step run the same kernel; below that the synchronous kernel is faster (bs = 32: 33 us against 51).
+    Reference: models/models.py:59 (conv3x3 stride 2) / :66-78 (ConvTranspose2d(64, 64, 3, stride 2))."""
     g = torch.Generator().manual_seed(n * 7 + hi)
     ho = out_size(hi, s, p, t)
     d = C.Conv64Desc(n, hi, hi, ho, ho, 3, s, p, t, groups)
+    small = C.Conv64Desc(8 * groups, hi, hi, ho, ho, 3, s, p, t, groups)
+    assert C.conv64_gather_pipe_supported(small, 1 if t else 0) == 0  # few tiles per group: the synchronous kernel
     st = C.stream()
     w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV)
     packs = torch.empty(2, C.conv64_packed_floats(), device=DEV)
