@@ -660,11 +660,13 @@ class SRL4robotics(BaseLearner):
                                  world_size=self.world_size, val_indices=val_indices,
                                  raw_uint8="planar" if use_bytes and (not self.use_dae or resident is not None) else False,
                                  index_switch=resident is not None)
-        test_data_loader = DataLoader(test_minibatchlist, images_path, n_workers=N_WORKERS,
-                                      multi_view=self.multi_view, use_triplets=self.use_triplets, max_queue_len=1,
-                                      is_training=False, apply_occlusion=self.use_dae,
-                                      occlusion_percentage=self.occlusion_percentage,
-                                      raw_uint8="planar" if use_bytes and not self.use_dae else False)
+        def makeTestLoader(minibatches=test_minibatchlist):
+            # (forked when it is needed — at the end of learn(): with the dataset resident the states are predicted from the store)
+            return DataLoader(minibatches, images_path, n_workers=N_WORKERS, multi_view=self.multi_view, use_triplets=self.use_triplets,
+                              max_queue_len=1, is_training=False, apply_occlusion=self.use_dae,
+                              occlusion_percentage=self.occlusion_percentage,
+                              raw_uint8="planar" if use_bytes and not self.use_dae else False,
+                              infinite_loop=minibatches is test_minibatchlist)
 
         loss_history = defaultdict(list)
         loss_manager = LossManager(self.model, loss_history)
@@ -796,7 +798,22 @@ class SRL4robotics(BaseLearner):
 
         print("Predicting states for all the observations...")
         self.model.eval()
+        t_pred = time.time()
         with th.no_grad():
-            pred_states = self.predStatesWithDataLoader(test_data_loader)
+            # The reference decodes every frame once more here (its test loader, learner.py:524-529).  With the dataset resident —
+            # and a model that looks at the frames as they are (no occlusion, no negative view) — the frames are already home: the few
+            # the minibatches never asked for (ragged tails) are decoded now, everything else is read from the store.
+            if resident is not None and n_epochs > 0 and not self.use_dae and not self.use_triplets:
+                missing = np.nonzero(~resident.have)[0]
+                if len(missing):
+                    chunks = [missing[i:i + 64] for i in range(0, len(missing), 64)]
+                    for chunk, frames in zip(chunks, makeTestLoader(chunks)):
+                        resident.absorb_indices(chunk, frames)
+                pred_states = np.concatenate([self._predFn(self._toDevice(resident.store[int(mb[0]):int(mb[-1]) + 1]))
+                                              for mb in test_minibatchlist if len(mb)], axis=0)
+                self.predict_stats = {"from_store": True, "decoded_now": int(len(missing)), "seconds": time.time() - t_pred}
+            else:
+                pred_states = self.predStatesWithDataLoader(makeTestLoader())
+                self.predict_stats = {"from_store": False, "decoded_now": int(len(images_path)), "seconds": time.time() - t_pred}
         pairs_loss_weight = [k for k in zip(loss_manager.names, loss_manager.weights)]
         return loss_history, pred_states, pairs_loss_weight

@@ -217,6 +217,24 @@ class ResidentFrames(object):
         self.store[start:start + n].copy_(frames, non_blocking=True)
         self._mark(np.arange(start, start + n, dtype=np.int64))
 
+    def absorb_indices(self, idx, frames):
+        """Frames of the observations idx (any order; uint8 [n, C, W, H], host or device) — e.g. the few a run's minibatches never
+        asked for, decoded when the states of the whole dataset are predicted from the store."""
+        idx = np.asarray(idx, dtype=np.int64)
+        n = len(idx)
+        if n == 0:
+            return
+        if tuple(frames.shape) != (n,) + self.frame_shape or frames.dtype != th.uint8:
+            raise ValueError("absorb_indices: %s frames %s for %d indices of a %s store" % (frames.dtype, tuple(frames.shape), n,
+                                                                                            self.frame_shape))
+        if self.on_device:
+            from srlz.ops import stream, ptr
+            frames = frames.to(self.device).contiguous()
+            self.C.copy_frames_u8(ptr(frames), None, 0, ptr(self.store), ptr(self._index(idx)), 0, n, self.frame_bytes, stream())
+        else:
+            self.store[th.from_numpy(idx)] = frames.cpu()
+        self._mark(idx)
+
     def slice_filled(self):
         lo, hi = self.slice()
         return bool(self.have[lo:hi].all())

@@ -189,6 +189,8 @@ if __name__ == '__main__':
         np.savez('{}/loss_history.npz'.format(args.log_folder), **loss_history)
         with open('{}/epoch_stats.json'.format(args.log_folder), 'w') as f:  # (build-specific: per-epoch wall time and frames)
             json.dump(getattr(srl, "epoch_stats", []), f)
+        with open('{}/predict_stats.json'.format(args.log_folder), 'w') as f:  # (where the final states' frames came from, seconds)
+            json.dump(getattr(srl, "predict_stats", {}), f)
         correlationCall(exp_config, plot=False)
     if world_size > 1:
         # (every rank's own per-epoch record: wall seconds, minibatches served from the resident store, the slice exchange)

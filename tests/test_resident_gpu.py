@@ -139,6 +139,11 @@ def test_learn_with_resident_frames_is_learn_with_redecoding(workdir, losses):
             srl = SRL4robotics(10, model_type="custom_cnn", seed=4, learning_rate=1e-3, cuda=True, losses=losses, n_actions=6,
                                log_folder=log, occlusion_percentage=0.3)
             hist, states, _ = srl.learn(paths, actions, rewards, starts)
+            # the final states: from the store (the frames no minibatch asked for decoded then) unless the model looks at occluded
+            # frames (DAE) or the run re-decodes anyway
+            assert srl.predict_stats["from_store"] == (resident and losses != ["dae"]), srl.predict_stats
+            if srl.predict_stats["from_store"]:
+                assert srl.predict_stats["decoded_now"] < 16 and srl._resident.have.all()
             return {k: list(v) for k, v in hist.items()}, states, srl._resident
         finally:
             learner.RESIDENT_FRAMES = True
