@@ -4,7 +4,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 env "$@" python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timers 2>&1 | tail -1 | cut -c1-220 > gpurun_out/${tag}_bench.txt
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers > /dev/null 2>&1
+env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-vae-leg --allow-short > /dev/null 2>&1
 f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 python - "$f" > gpurun_out/${tag}_stats.txt <<'PY'
 import csv, sys

@@ -2,7 +2,7 @@
 # usage (on the GPU box): tools/prof_quick.sh [extra bench.py flags]   -> per-kernel table of one rocprofv3 --kernel-trace --stats run
 mkdir -p gpurun_out; export TMPDIR=/tmp
 rm -rf /tmp/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers "$@" > gpurun_out/pb.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-vae-leg --allow-short "$@" > gpurun_out/pb.json 2>/dev/null
 cp "$(find /tmp/prof -name '*kernel_stats.csv' | head -1)" gpurun_out/ks.csv
 python - <<'PY'
 import csv, json

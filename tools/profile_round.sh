@@ -15,16 +15,16 @@ mkdir -p gpurun_out
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_ae_bs256.json 2> gpurun_out/${tag}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --losses vae > gpurun_out/${tag}_bench_vae_bs256.json 2>> gpurun_out/${tag}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --losses autoencoder inverse forward > gpurun_out/${tag}_bench_aeif_bs256.json 2>> gpurun_out/${tag}_bench.err
-python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-timers --batch-size 32 > gpurun_out/${tag}_bench_ae_bs32.json 2>> gpurun_out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline \
+python bench.py --steps 150 --warmup 10 --no-cpu-baseline --no-kernel-timers --batch-size 32 > gpurun_out/${tag}_bench_ae_bs32.json 2>> gpurun_out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae-leg \
     > gpurun_out/${tag}_bench_ae_bs256_profiled.json 2> /dev/null
 cp "$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_bench_ae_bs256_kernel_stats.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$ctr -o p -- python bench.py --steps 3 --warmup 2 \
-      --no-cpu-baseline --no-kernel-timers > /dev/null 2>&1
+      --no-cpu-baseline --no-kernel-timers --no-vae-leg --allow-short > /dev/null 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pmc_${tag}_MFMA -o p -- \
-    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers > /dev/null 2>&1
+    python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-vae-leg --allow-short > /dev/null 2>&1
 python - "$tag" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
