@@ -647,8 +647,11 @@ extern "C" int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* po
                                      const srlz_pool_desc* d, srlz_stream_t stream) {
   if (int rc = check_pool(d)) return rc;
   SRLZ_REQUIRE(y && bnp && pooled, SRLZ_ERR_NULL, "bn_relu_pool_fwd: null pointer");
-  SRLZ_REQUIRE((long long)d->n * d->hp <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*hp too large for one launch");
   const int gx = (d->wp * 16 + 255) / 256;
+  // (a 1-D grid: the 65535 blocks of a grid.y capped a call at 1149 images until round 5; what bounds it now are the 31-bit row index
+  //  n * H + iy and the grid itself)
+  SRLZ_REQUIRE((long long)gx * d->n * d->hp <= 0x7fffffffLL && (long long)d->n * (d->h + 2) <= 0x7fffffffLL, SRLZ_ERR_BAD_DESC,
+               "pool: %d images of %d x %d are too many for one launch", d->n, d->h, d->w);
   hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(gx * d->n * d->hp), dim3(256), 0, as_stream(stream), y, bnp, pooled,
                      argmax, d->n, d->h, d->w, d->hp, d->wp, d->pool_pad, d->out_nchw, d->n / norm_groups(d->groups), gx);
   SRLZ_LAUNCHED();
@@ -699,7 +702,8 @@ extern "C" int srlz_bn_relu_pool_bwd(const float* y, const float* bnp, const uin
   float* sums = (float*)((double*)ws + (RED_BLOCKS + STAGE_ROWS) * 128);  // [groups][128]
   if (int rc = pool_bwd_sums(y, bnp, argmax, dpooled, pooled, sums, dgamma, dbeta, ws, d, st)) return rc;
   const int HB = (d->h + d->pool_pad + 1) / 2, WB = (d->w + d->pool_pad + 1) / 2;
-  SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
+  SRLZ_REQUIRE((long long)((WB * 16 + 255) / 256) * d->n * HB <= 0x7fffffffLL && (long long)d->n * (d->h + 2) <= 0x7fffffffLL,
+               SRLZ_ERR_BAD_DESC, "pool: %d images of %d x %d are too many for one launch", d->n, d->h, d->w);
   const int npg = d->n / norm_groups(d->groups);
   const float inv_count = 1.0f / (float)((double)npg * d->h * d->w);
   const int gx = (WB * 16 + 255) / 256;
@@ -715,7 +719,8 @@ extern "C" int srlz_bn_relu_pool_bwd_apply(const float* y, const float* bnp, con
   if (int rc = check_pool(d)) return rc;
   SRLZ_REQUIRE(y && bnp && argmax && dpooled && sums && dy, SRLZ_ERR_NULL, "bn_relu_pool_bwd_apply: null pointer");
   const int HB = (d->h + d->pool_pad + 1) / 2, WB = (d->w + d->pool_pad + 1) / 2;
-  SRLZ_REQUIRE((long long)d->n * HB <= 65535, SRLZ_ERR_BAD_DESC, "pool: n*h too large for one launch (%d x %d)", d->n, HB);
+  SRLZ_REQUIRE((long long)((WB * 16 + 255) / 256) * d->n * HB <= 0x7fffffffLL && (long long)d->n * (d->h + 2) <= 0x7fffffffLL,
+               SRLZ_ERR_BAD_DESC, "pool: %d images of %d x %d are too many for one launch", d->n, d->h, d->w);
   const int npg = d->n / norm_groups(d->groups);
   const float inv_count = 1.0f / (float)((double)npg * d->h * d->w);
   const int gx = (WB * 16 + 255) / 256;

@@ -284,7 +284,7 @@ class SRL4robotics(BaseLearner):
         # from a graph, so the cure for small minibatches is fewer kernels (which is what the batched pair delivers).
         # The two frames of a step run as ONE batched model call with two BatchNorm groups (SRLModules.forwardPair): half the
         # launches, twice the grid of every small layer, per-call BatchNorm semantics intact.
-        self._use_pair = True  # (False: two model calls per step — what minibatches above 574 samples fall back to; tests set it)
+        self._use_pair = True  # (False: two model calls per step — frames of different shape take that route; tests set it)
         self._use_graph = os.environ.get("SRLZ_GRAPH", "0") == "1"
         self._graphs = {}
         from srlz import ops as _ops
@@ -375,11 +375,10 @@ class SRL4robotics(BaseLearner):
         recon = (target, next_target, mean): the caller only needs the reconstruction / generation LOSS of the two decoded
         frames against these targets, not the frames: the loss is then taken inside the last ConvTranspose (ops.DecOutLossFn)
         and returned as third value (None when that was not possible: the caller computes the loss from the decoded frames).
-        Minibatches above 574 samples (one launch takes at most 65535 / 57 = 1149 images — the pooling kernels' grid.y, DESIGN.md
-        section 2) fall back to two separate model calls."""
+        (Until round 5 one launch took at most 1149 images — the pooling kernels' grid.y — and minibatches above 574 samples fell back
+        to two model calls; the grids are one-dimensional now and what bounds a call is memory: ~80 MB of activations per image.)"""
         from srlz import hotpath, ops
-        if self._use_pair and x.shape == next_x.shape and 2 * x.shape[0] <= 1149 \
-                and not self.use_triplets:
+        if self._use_pair and x.shape == next_x.shape and not self.use_triplets:
             target = ops.pair_of(recon[0], recon[1]) if recon is not None else None
             if target is not None:
                 with hotpath.recon_loss_into(target, recon[2]) as req:

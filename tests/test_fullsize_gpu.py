@@ -182,3 +182,38 @@ def test_full_size_loop_body(losses):
     assert vals2 == vals and total2 == total
     assert torch.equal(grad, grad2) and torch.isfinite(grad).all() and grad.abs().max().item() > 0
     assert torch.equal(srl.flat_params.flat, srl2.flat_params.flat)
+
+
+def test_one_batched_call_beyond_the_old_grid_limit():
+    """Until round 5 one model call took at most 1149 images (the pooling kernels' grid.y = 65535 / 57 rows) and minibatches above 574
+    samples fell back to two calls.  The grids are one-dimensional now: a 600-sample minibatch runs as ONE batched call of 1200 images
+    with two BatchNorm groups, and lands where the two separate calls land (reference models/learner.py:392-393)."""
+    import preprocessing.preprocess as pre
+    from models.learner import SRL4robotics
+    from losses.losses import LossManager
+    from srlz import ops
+    pre.N_CHANNELS = 3
+    B = 600
+    rs = np.random.RandomState(5)
+    frames = torch.from_numpy(rs.randint(0, 256, (2 * B, 3, 224, 224)).astype(np.uint8)).cuda()
+    actions = torch.from_numpy(rs.randint(0, 6, (B, 1)).astype(np.int64)).cuda()
+    out = []
+    for use_pair in (True, False):
+        srl = SRL4robotics(32, model_type="custom_cnn", seed=3, learning_rate=1e-3, cuda=True, losses=["autoencoder", "inverse"], n_actions=6,
+                           log_folder="/tmp")
+        srl._use_pair = use_pair
+        lm = LossManager(srl.model, None)
+        ops.timers_enable(True)
+        loss = srl.trainStep(*srl._toDevicePair(frames[:B], frames[B:]), actions, lm)
+        launches = ops.timers_report()
+        ops.timers_enable(False)
+        n_conv1 = sum(v["launches"] for k, v in launches.items() if k == "skinny_conv_kernel")
+        assert n_conv1 == (1 if use_pair else 2)  # one batched call of 1200 images / two calls of 600
+        out.append((float(loss.detach()), lm.lossValues(), srl.flat_params.flat.double().cpu(), [b.double().cpu() for b in srl.model.buffers()]))
+        del srl, lm
+        torch.cuda.empty_cache()
+    (l1, v1, p1, b1), (l0, v0, p0, b0) = out
+    assert np.isfinite(l1) and abs(l1 - l0) <= 1e-5 * abs(l0) and np.allclose(v1, v0, rtol=1e-5)
+    # forward outputs / running statistics bit-identical between the routes; parameters after Adam to summation order
+    assert all(torch.equal(a, b) for a, b in zip(b1, b0))
+    assert float((p1 - p0).abs().max()) <= 4e-3 * float(p0.abs().max())

@@ -208,7 +208,8 @@ def test_row_tables_address_the_rows_the_program_means(cabi, hi, s, p, t):
                 assert (ri >= 0 and (ri & need) == need) == inside, (backward, q, d)
                 if inside:
                     assert (ri >> 2) + (d >> 1) * P["Wd"] + (d & 1) == (n * P["Hd"] + ya + (d >> 1)) * P["Wd"] + xb + (d & 1)
-    # bit budget at the largest call the kernels accept (1149 images of the widest layer): 28-bit pixel indices, 32-bit float offsets
+    # bit budget at a large call (1149 images of the widest layer: the most one launch took until round 5; beyond their budget the
+    # launchers reject a call): 28-bit pixel indices, 32-bit float offsets
     P = get_program(cabi, 1149, hi, s, p, t, 0)
     assert P["N"] * P["Hs"] * P["Ws"] < 1 << 28 and P["N"] * P["Hs"] * P["Ws"] * 64 < 1 << 32
     assert P["N"] * P["Hd"] * P["Wd"] < 1 << 29
