@@ -2349,7 +2349,9 @@ static int wgrad_grid(const ConvProg& P) {
 __global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restrict__ src, const float* __restrict__ wpack,
                                                           float* __restrict__ dst, float* __restrict__ stats_partial,
                                                           const ConvProg P, int ntiles, int nci, int nco,
-                                                          const float* __restrict__ src_bnp) {
+                                                          const float* __restrict__ src_bnp, int only_tap) {
+  // only_tap >= 0: the program's tap index of the ONE tap whose weights are not zero — a 1x1 stride-2 convolution (ResNet's downsample
+  // branch) is the 3x3 stride-2 pad-1 program's centre tap; the other eight used to be multiplied through as zeros (4 % of the trunk)
   constexpr int NT = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* As = (float*)smem;
@@ -2387,10 +2389,48 @@ __global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restri
   f32x4 breg[BV];
   const float* wbase = wpack + (size_t)co * nci * NTAPS * 4096;
   {
-    const f32x4* wsrc = (const f32x4*)(wbase + (size_t)P.tw[0] * 4096);
+    const f32x4* wsrc = (const f32x4*)(wbase + (size_t)P.tw[only_tap >= 0 ? only_tap : 0] * 4096);
 #pragma unroll
     for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
   }
+  if (only_tap >= 0) {
+    // one tap per input-channel block: stage the tap's source class, one slab, 64 MFMAs per wave
+    const int tsrc = P.tsrc[only_tap];
+    for (int ci = 0; ci < nci; ++ci) {
+      const OpFuse fuse = OpFuse{src_bnp ? src_bnp + ci * 256 : nullptr, nullptr, nullptr, 0.f, 0, nullptr};
+      __syncthreads();
+      stage_rows<true, BATCH_FWD, NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span, fuse, 0, 0,
+                              cin, ci * 64);
+      {
+        f32x4* wdst = (f32x4*)Bs;
+#pragma unroll
+        for (int i = 0; i < BV; ++i) wdst[i * NT + tid] = breg[i];
+      }
+      __syncthreads();
+      if (ci + 1 < nci) {
+        const f32x4* wsrc = (const f32x4*)(wbase + ((size_t)(ci + 1) * NTAPS + P.tw[only_tap]) * 4096);
+#pragma unroll
+        for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
+      }
+      const int R = wave * 32 + l31 + P.toff[only_tap] - P.min_off;
+      const float* arow = As + R * 64;
+      const int akey = R & 15;
+      const float* brow = Bs + l31 * 64;
+      const int bkey = lane & 15;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const int slot = kc * 2 + h;
+        const f32x4 a = *(const f32x4*)(arow + ((slot ^ akey) << 2));
+        const f32x4 b0 = *(const f32x4*)(brow + ((slot ^ bkey) << 2));
+        const f32x4 b1 = *(const f32x4*)(brow + 2048 + ((slot ^ bkey) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0[r], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1[r], acc[1], 0, 0, 0);
+        }
+      }
+    }
+  } else
   for (int ci = 0; ci < nci; ++ci) {
     int cur_src = -1;
     const OpFuse fuse = OpFuse{src_bnp ? src_bnp + ci * 256 : nullptr, nullptr, nullptr, 0.f, 0, nullptr};
@@ -2539,8 +2579,14 @@ extern "C" int srlz_convn_fwd(const float* x, const float* wpack, float* y, floa
   const size_t lds = convn_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "convn: tile needs %zu bytes of LDS", lds);
   SRLZ_MAX_LDS(convN_fwd_kernel, lds);
+  int only_tap = -1;
+  if (d->ksize == 1) {  // the tap of the 3x3 program that carries the 1x1 kernel: weight slab 4 = (ky, kx) = (1, 1)
+    for (int t = 0; t < NTAPS; ++t)
+      if (P.tw[t] == 4) only_tap = t;
+    SRLZ_REQUIRE(only_tap >= 0, SRLZ_ERR_BAD_DESC, "convn: no centre tap in the program of a 1x1 convolution");
+  }
   hipLaunchKernelGGL(convN_fwd_kernel, dim3(ntiles, d->cout / 64), dim3(256), lds, as_stream(stream), x, wpack, y, stats_partial, P,
-                     ntiles, d->cin / 64, d->cout / 64, x_bnp);
+                     ntiles, d->cin / 64, d->cout / 64, x_bnp, only_tap);
   SRLZ_LAUNCHED();
   return 0;
 }

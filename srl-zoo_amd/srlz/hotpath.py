@@ -191,11 +191,32 @@ def _bn_record(bn, stats, tiles, count, training, device):
     return bnp
 
 
+def _packed64(conv, d):
+    """As _packed, for a 64 -> 64 3x3 convolution in the conv64 kernels' layout (the forward pack only is used)."""
+    key = (conv.weight.data_ptr(), conv.weight._version)
+    cached = getattr(conv, "_srlz_pack64", None)
+    if cached is None or cached[0] != key:
+        pk = torch.empty((2, ops.C.conv64_packed_floats()), dtype=torch.float32, device=conv.weight.device)
+        ops.C.conv64_pack_weights(ops.ptr(conv.weight), ops.ptr(pk[0]), ops.ptr(pk[1]), d, ops.stream())
+        cached = (key, pk)
+        conv._srlz_pack64 = cached
+    return cached[1]
+
+
 def _convn(x, conv, bn, training, x_bnp=None):
     """raw = conv(x or relu(bn_prev(x))) for an NHWC tensor + the BatchNorm record of `bn` over that output."""
     n, hi, wi, cin = x.shape
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     ho, wo = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
+    if cin == 64 and conv.out_channels == 64 and k == 3 and s == 1 and p == 1:
+        # layer1 of the trunk (four 64 -> 64 3x3 convolutions at 56 x 56): the auto-encoder's own conv2 kernel — row tables, 16-byte
+        # epilogue stores, fused relu(bn(.)) operand — instead of the general-channel-count kernel (0.73 against 0.56 of the matrix peak)
+        d = ops.conv64_desc(n, hi, wi, 1, 1, False, 1)
+        y = torch.empty((n, ho, wo, 64), dtype=torch.float32, device=x.device)
+        tiles = ops.C.conv64_fwd_tiles(d)
+        stats = torch.empty((1, tiles, 128), dtype=torch.float32, device=x.device) if training else None
+        ops.C.conv64_fwd(ops.ptr(x), ops.ptr(_packed64(conv, d)[0]), None, ops.ptr(y), ops.ptr(stats), ops.ptr(x_bnp), d, ops.stream())
+        return y, _bn_record(bn, stats, tiles, n * ho * wo, training, x.device)
     d = ops.ConvNDesc(n, hi, wi, ho, wo, cin, conv.out_channels, k, s, p)
     y = torch.empty((n, ho, wo, conv.out_channels), dtype=torch.float32, device=x.device)
     tiles = ops.C.convn_fwd_tiles(d)
