@@ -348,14 +348,16 @@ __device__ __forceinline__ void rowtab_build(unsigned* __restrict__ tab, int tpa
 }
 
 // Rows of source class `cls` -> LDS (swizzled), through the table.  lrec != NULL: relu(batchnorm(.)) on the way in (scale, shift in LDS).
+// cshift / coff: the tensor has 2^cshift channels per pixel and channels [coff, coff + 64) are staged (convN_fwd_kernel; the 64-channel
+// kernels pass the defaults, which fold to the constants they had)
 template <int BATCH>
 __device__ __forceinline__ void stage_rows_tab(float* __restrict__ lds, const float* __restrict__ src,
                                                const unsigned* __restrict__ tab, int tpa, int cls, int W, int nrows,
-                                               const float* __restrict__ lrec) {
+                                               const float* __restrict__ lrec, int cshift = 6, int coff = 0) {
   const int t = threadIdx.x;
   const int slot = t & 15, r = t >> 4;
   const unsigned delta = (unsigned)((cls >> 1) * W + (cls & 1));
-  const float* __restrict__ base = src + slot * 4;
+  const float* __restrict__ base = src + coff + slot * 4;
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   if (lrec) { sc4 = *(const f32x4*)(lrec + slot * 4); sh4 = *(const f32x4*)(lrec + 64 + slot * 4); }
   for (int j0 = 0; j0 < tpa; j0 += BATCH) {
@@ -370,7 +372,7 @@ __device__ __forceinline__ void stage_rows_tab(float* __restrict__ lds, const fl
         const int j = jj + i;
         // branch-free (see stage_rows): m = all ones where the row's pixel of this class exists; any other row reads pixel 0
         const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)e[i], (unsigned)cls, 1u);
-        const unsigned off = (((e[i] >> 4) + delta) << 6) & m;  // floats (a group's tensor has < 2^32: checked by the host)
+        const unsigned off = (((e[i] >> 4) + delta) << cshift) & m;  // floats (a group's tensor has < 2^32: checked by the host)
         v[j] = *(const f32x4*)(base + off);
         okmask |= m & (1u << j);
       }
@@ -2225,7 +2227,10 @@ static int program_for(ConvProg* P, const srlz_conv64_desc* d, int backward_data
 static size_t fwd_lds_bytes(const ConvProg& P) {  // source rows, slab, row table, rowinfo, fused-operand coefficients
   return (size_t)(TM + P.span) * 256 + 16384 + (size_t)64 * rowtab_passes(TM + P.span) + TM * 4 + 256 * 4;
 }
-static size_t convn_lds_bytes(const ConvProg& P) { return (size_t)(TM + P.span) * 256 + 16384 + 3 * TM * 4 + 256 * 4; }
+// source rows, slab, row table, rowinfo, (scale, shift) of up to 8 input-channel blocks
+static size_t convn_lds_bytes(const ConvProg& P) {
+  return (size_t)(TM + P.span) * 256 + 16384 + (size_t)64 * rowtab_passes(TM + P.span) + TM * 4 + 8 * 128 * 4;
+}
 static size_t wgrad_lds_bytes(const ConvProg& P, int tk) { return (size_t)(tk + P.span + tk) * 256; }
 static int wgrad_tk(const ConvProg& P) { (void)P; return 64; }  // 128 was tried: the extra staging registers spill
 
@@ -2349,14 +2354,22 @@ static int wgrad_grid(const ConvProg& P) {
 __global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restrict__ src, const float* __restrict__ wpack,
                                                           float* __restrict__ dst, float* __restrict__ stats_partial,
                                                           const ConvProg P, int ntiles, int nci, int nco,
-                                                          const float* __restrict__ src_bnp, int only_tap) {
+                                                          const float* __restrict__ src_bnp, int only_tap, int cshift) {
+  // Round 5: rebuilt on the 64-channel family's machinery (conv64_fwd_body) — the tile's row table in LDS (one decomposition per row
+  // and tile instead of one per row, thread, class AND input-channel block), the BatchNorm coefficients of every input-channel block
+  // in LDS once per workgroup, operand fragments double-buffered in registers, the epilogue through a wave-private LDS transpose with
+  // 16-byte stores.  Same tiles and the same accumulation order as the round-2 kernel: outputs bit-identical to it.
   // only_tap >= 0: the program's tap index of the ONE tap whose weights are not zero — a 1x1 stride-2 convolution (ResNet's downsample
-  // branch) is the 3x3 stride-2 pad-1 program's centre tap; the other eight used to be multiplied through as zeros (4 % of the trunk)
+  // branch) is the 3x3 stride-2 pad-1 program's centre tap; the other eight used to be multiplied through as zeros (4 % of the trunk).
+  // cshift = log2(input channels).
   constexpr int NT = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* As = (float*)smem;
   float* Bs = As + (TM + P.span) * 64;
-  int* rowinfo = (int*)(Bs + 4096);
+  const int tpa = rowtab_passes(TM + P.span);
+  unsigned* rowtab = (unsigned*)(Bs + 4096);
+  int* rowinfo = (int*)(rowtab + 16 * tpa);      // [TM]: output pixel index, or -1
+  float* frec = (float*)(rowinfo + TM);          // [nci][128]: scale, shift of every input-channel block (fused relu(bn(.)) operand)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -2364,20 +2377,23 @@ __global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restri
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int co = blockIdx.y;
   const int q0 = tile * TM;
-  const int cin = nci * 64, cout = nco * 64;
+  const int cout = nco * 64;
 
   if (tid < TM) {
     const int q = q0 + tid;
-    int n = -1, ya = 0, xb = 0;
+    int ri = -1;
     if (q < P.total_q) {
-      n = fastdiv(q, P.mPHW, P.sPHW);
+      const int n = fastdiv(q, P.mPHW, P.sPHW);
       const int rem = q - n * P.PHW;
       const int a = fastdiv(rem, P.mPW, P.sPW);
-      ya = a * P.ds;
-      xb = (rem - a * P.PW) * P.ds;
+      const int ya = a * P.ds, xb = (rem - a * P.PW) * P.ds;
+      if (ya < P.Hd && xb < P.Wd) ri = (n * P.Hd + ya) * P.Wd + xb;
     }
-    rowinfo[tid] = n; rowinfo[TM + tid] = ya; rowinfo[2 * TM + tid] = xb;
+    rowinfo[tid] = ri;
   }
+  rowtab_build(rowtab, tpa, P, q0 + P.min_off, TM + P.span);
+  if (src_bnp)
+    for (int i = tid; i < nci * 128; i += NT) frec[i] = src_bnp[(i >> 7) * 256 + 128 + (i & 127)];
 
   f32x16 acc[2];
 #pragma unroll
@@ -2386,121 +2402,110 @@ __global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   constexpr int BV = 1024 / NT;
+  const int bslot = wave * (BV * 64) + lane;  // wave w moves (and may later scribble on) its own 4 KB of the slab
   f32x4 breg[BV];
   const float* wbase = wpack + (size_t)co * nci * NTAPS * 4096;
+  const int t_first = only_tap >= 0 ? only_tap : 0, t_count = only_tap >= 0 ? 1 : NTAPS;
   {
-    const f32x4* wsrc = (const f32x4*)(wbase + (size_t)P.tw[only_tap >= 0 ? only_tap : 0] * 4096);
+    const f32x4* wsrc = (const f32x4*)(wbase + (size_t)P.tw[t_first] * 4096);
 #pragma unroll
-    for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
+    for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
   }
-  if (only_tap >= 0) {
-    // one tap per input-channel block: stage the tap's source class, one slab, 64 MFMAs per wave
-    const int tsrc = P.tsrc[only_tap];
-    for (int ci = 0; ci < nci; ++ci) {
-      const OpFuse fuse = OpFuse{src_bnp ? src_bnp + ci * 256 : nullptr, nullptr, nullptr, 0.f, 0, nullptr};
-      __syncthreads();
-      stage_rows<true, BATCH_FWD, NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span, fuse, 0, 0,
-                              cin, ci * 64);
-      {
-        f32x4* wdst = (f32x4*)Bs;
-#pragma unroll
-        for (int i = 0; i < BV; ++i) wdst[i * NT + tid] = breg[i];
-      }
-      __syncthreads();
-      if (ci + 1 < nci) {
-        const f32x4* wsrc = (const f32x4*)(wbase + ((size_t)(ci + 1) * NTAPS + P.tw[only_tap]) * 4096);
-#pragma unroll
-        for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
-      }
-      const int R = wave * 32 + l31 + P.toff[only_tap] - P.min_off;
-      const float* arow = As + R * 64;
-      const int akey = R & 15;
-      const float* brow = Bs + l31 * 64;
-      const int bkey = lane & 15;
-#pragma unroll
-      for (int kc = 0; kc < 8; ++kc) {
-        const int slot = kc * 2 + h;
-        const f32x4 a = *(const f32x4*)(arow + ((slot ^ akey) << 2));
-        const f32x4 b0 = *(const f32x4*)(brow + ((slot ^ bkey) << 2));
-        const f32x4 b1 = *(const f32x4*)(brow + 2048 + ((slot ^ bkey) << 2));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0[r], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1[r], acc[1], 0, 0, 0);
-        }
-      }
+  const int nsteps = nci * t_count;
+  int ci = 0, tk = 0;       // the step's input-channel block and its tap (tk-th of the block's t_count)
+  int cur_src = -1;
+  for (int step = 0; step < nsteps; ++step) {
+    const int ti = t_first + tk;
+    const int tsrc = P.tsrc[ti], toff = P.toff[ti];
+    // the next step's (block, tap): its weight slab is requested behind this step's second barrier
+    int tk2 = tk + 1, ci2 = ci;
+    if (tk2 == t_count) { tk2 = 0; ci2 = ci + 1; }
+    __syncthreads();  // all waves are done with the previous step's Bs (and with As if it is about to be replaced)
+    if (tk == 0 || tsrc != cur_src) {
+      stage_rows_tab<BATCH_FWD>(As, src, rowtab, tpa, tsrc, P.Ws, TM + P.span, src_bnp ? frec + ci * 128 : nullptr, cshift, ci * 64);
+      cur_src = tsrc;
     }
-  } else
-  for (int ci = 0; ci < nci; ++ci) {
-    int cur_src = -1;
-    const OpFuse fuse = OpFuse{src_bnp ? src_bnp + ci * 256 : nullptr, nullptr, nullptr, 0.f, 0, nullptr};
+    {
+      f32x4* wdst = (f32x4*)Bs;
 #pragma unroll
-    for (int ti = 0; ti < NTAPS; ++ti) {
-      const int tsrc = P.tsrc[ti];
-      __syncthreads();
-      if (tsrc != cur_src) {
-        stage_rows<true, BATCH_FWD, NT>(As, src, P.Hs, P.Ws, P.ss, tsrc, P.PW, P.PH, P.total_q, q0 + P.min_off, TM + P.span, fuse, 0, 0,
-                                cin, ci * 64);
-        cur_src = tsrc;
-      }
-      {
-        f32x4* wdst = (f32x4*)Bs;
-#pragma unroll
-        for (int i = 0; i < BV; ++i) wdst[i * NT + tid] = breg[i];
-      }
-      __syncthreads();
-      if (ti + 1 < NTAPS || ci + 1 < nci) {
-        const int nti = (ti + 1 < NTAPS) ? ti + 1 : 0, nci_ = (ti + 1 < NTAPS) ? ci : ci + 1;
-        const f32x4* wsrc = (const f32x4*)(wbase + ((size_t)nci_ * NTAPS + P.tw[nti]) * 4096);
-#pragma unroll
-        for (int i = 0; i < BV; ++i) breg[i] = wsrc[i * NT + tid];
-      }
-      const int R = wave * 32 + l31 + P.toff[ti] - P.min_off;
-      const float* arow = As + R * 64;
-      const int akey = R & 15;
-      const float* brow = Bs + l31 * 64;
-      const int bkey = lane & 15;
-#pragma unroll
-      for (int kc = 0; kc < 8; ++kc) {
-        const int slot = kc * 2 + h;
-        const f32x4 a = *(const f32x4*)(arow + ((slot ^ akey) << 2));
-        const f32x4 b0 = *(const f32x4*)(brow + ((slot ^ bkey) << 2));
-        const f32x4 b1 = *(const f32x4*)(brow + 2048 + ((slot ^ bkey) << 2));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0[r], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1[r], acc[1], 0, 0, 0);
-        }
-      }
+      for (int i = 0; i < BV; ++i) wdst[bslot + i * 64] = breg[i];
     }
+    __syncthreads();
+    {  // (past the last step: block 0, first tap again — never a run-time condition around loads, see conv64_fwd_body)
+      const int cn = ci2 < nci ? ci2 : 0;
+      const f32x4* wsrc = (const f32x4*)(wbase + ((size_t)cn * NTAPS + P.tw[t_first + tk2]) * 4096);
+#pragma unroll
+      for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot + i * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the slab requests go out HERE, ahead of the step's MFMAs
+    const int R = wave * 32 + l31 + toff - P.min_off;
+    int abase = (R * 64 + ((h ^ (R & 15)) << 2)) * 4;  // bytes; slot (2kc + h) ^ (R & 15) is this XOR (kc << 5)
+    asm volatile("" : "+v"(abase));
+    const float* brow = Bs + l31 * 64;
+    const int bkey = lane & 15;
+    f32x4 a = *(const f32x4*)((const char*)As + abase);
+    f32x4 b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *(const f32x4*)(brow + j * 2048 + ((h ^ bkey) << 2));
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+      f32x4 an = a, bn[2] = {b[0], b[1]};
+      if (kc < 7) {
+        const int slot = (kc + 1) * 2 + h;
+        an = *(const f32x4*)((const char*)As + (abase ^ ((kc + 1) << 5)));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bn[j] = *(const f32x4*)(brow + j * 2048 + ((slot ^ bkey) << 2));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this chunk's MFMAs
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[j][r], acc[j], 0, 0, 0);
+      a = an; b[0] = bn[0]; b[1] = bn[1];
+    }
+    tk = tk2; ci = ci2;
   }
-  float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+  __syncthreads();  // every wave is done with the last slab: Bs becomes scratch
+  // epilogue: 16 tile rows at a time through this wave's 4 KB of the idle slab, so that every global store is 16 bytes per lane
+  // (lane = (row group eg = lane >> 4, channels 4 eslot ..)); the BatchNorm partials in the same layout (see conv64_fwd_body::flush16)
+  f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+  {
+    float* S = Bs + wave * 1024;
+    const int eg = lane >> 4, eslot = lane & 15;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int n = rowinfo[row];
-    const int y = rowinfo[TM + row], x = rowinfo[2 * TM + row];
-    if (n >= 0 && y < P.Hd && x < P.Wd) {
-      float* o = dst + ((size_t)(n * P.Hd + y) * P.Wd + x) * cout + co * 64 + l31;
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float v = acc[j][r];
-        o[32 * j] = v;
-        sum[j] += v; sq[j] += v * v;
+      for (int rr = 0; rr < 8; ++rr) {
+        const int rowl = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+        const int swz = (rowl & 4) << 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) S[rowl * 64 + ((32 * j + l31) ^ swz)] = acc[j][8 * half + rr];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rowl = eg + 4 * k;
+        const int row = wave * 32 + 16 * half + rowl;
+        const f32x4 v = *(const f32x4*)(S + rowl * 64 + ((eslot ^ ((rowl & 4) << 1)) << 2));
+        const int ri = rowinfo[row];
+        if (ri >= 0) {
+          *(f32x4*)(dst + (size_t)ri * cout + co * 64 + eslot * 4) = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s4[e] += v[e]; q4[e] += v[e] * v[e]; }
+        }
       }
     }
   }
   if (stats_partial) {
     __syncthreads();
-    float* red = Bs;
+    float* red = Bs;  // [4 waves][128]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      sum[j] += __shfl_xor(sum[j], 32, 64);
-      sq[j] += __shfl_xor(sq[j], 32, 64);
-      if (h == 0) {
-        red[wave * 128 + j * 32 + l31] = sum[j];
-        red[wave * 128 + 64 + j * 32 + l31] = sq[j];
-      }
+    for (int e = 0; e < 4; ++e) {
+      s4[e] += __shfl_xor(s4[e], 16, 64); s4[e] += __shfl_xor(s4[e], 32, 64);
+      q4[e] += __shfl_xor(q4[e], 16, 64); q4[e] += __shfl_xor(q4[e], 32, 64);
+    }
+    if (lane < 16) {
+      *(f32x4*)(red + wave * 128 + lane * 4) = s4;
+      *(f32x4*)(red + wave * 128 + 64 + lane * 4) = q4;
     }
     __syncthreads();
     // chunk-major: the partial records of one 64-channel block are contiguous (what srlz_bn_finalize_chunks reduces)
@@ -2579,6 +2584,12 @@ extern "C" int srlz_convn_fwd(const float* x, const float* wpack, float* y, floa
   const size_t lds = convn_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "convn: tile needs %zu bytes of LDS", lds);
   SRLZ_MAX_LDS(convN_fwd_kernel, lds);
+  int cshift = 6;
+  while ((1 << cshift) < d->cin) ++cshift;
+  SRLZ_REQUIRE((1 << cshift) == d->cin && d->cin <= 512, SRLZ_ERR_BAD_DESC, "convn: %d input channels (a power of two from 64 to 512)", d->cin);
+  // (the row table keeps pixel indices in 28 bits, the staging 32-bit float offsets)
+  SRLZ_REQUIRE((long long)d->n * d->hi * d->wi * d->cin < (1LL << 32) && (long long)d->n * d->hi * d->wi < (1LL << 28), SRLZ_ERR_BAD_DESC,
+               "convn: %d images of %d x %d x %d are beyond the tile tables' 32-bit offsets", d->n, d->hi, d->wi, d->cin);
   int only_tap = -1;
   if (d->ksize == 1) {  // the tap of the 3x3 program that carries the 1x1 kernel: weight slab 4 = (ky, kx) = (1, 1)
     for (int t = 0; t < NTAPS; ++t)
@@ -2586,7 +2597,7 @@ extern "C" int srlz_convn_fwd(const float* x, const float* wpack, float* y, floa
     SRLZ_REQUIRE(only_tap >= 0, SRLZ_ERR_BAD_DESC, "convn: no centre tap in the program of a 1x1 convolution");
   }
   hipLaunchKernelGGL(convN_fwd_kernel, dim3(ntiles, d->cout / 64), dim3(256), lds, as_stream(stream), x, wpack, y, stats_partial, P,
-                     ntiles, d->cin / 64, d->cout / 64, x_bnp, only_tap);
+                     ntiles, d->cin / 64, d->cout / 64, x_bnp, only_tap, cshift);
   SRLZ_LAUNCHED();
   return 0;
 }
