@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/profile_round.sh <tag>     e.g. r02a
+# usage (on the GPU box): tools/profile_round.sh <tag> [pmc]     e.g. r02a
 # Produces under gpurun_out/<tag>_*:
 #   _bench_ae_bs256.json            the un-profiled bench line (BASELINE.json configs[1])
 #   _bench_{vae,aeif}_bs256.json    configs[2] and configs[3]'s per-GPU workload, same command line otherwise
@@ -12,6 +12,7 @@
 tag=${1:-rXX}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+if [ "$2" != "pmc" ]; then  # (second argument "pmc": only the PMC passes below — a source change that does not warrant the whole set)
 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_ae_bs256.json 2> gpurun_out/${tag}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --losses vae > gpurun_out/${tag}_bench_vae_bs256.json 2>> gpurun_out/${tag}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --losses autoencoder inverse forward > gpurun_out/${tag}_bench_aeif_bs256.json 2>> gpurun_out/${tag}_bench.err
@@ -19,6 +20,7 @@ python bench.py --steps 150 --warmup 10 --no-cpu-baseline --no-kernel-timers --b
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae-leg \
     > gpurun_out/${tag}_bench_ae_bs256_profiled.json 2> /dev/null
 cp "$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_bench_ae_bs256_kernel_stats.csv
+fi
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$ctr -o p -- python bench.py --steps 3 --warmup 2 \
       --no-cpu-baseline --no-kernel-timers --no-vae-leg --allow-short > /dev/null 2>&1
@@ -90,4 +92,5 @@ for name, a in acc.items():
                            "lds_bank_conflict_cycles_per_launch": round(a["SQ_LDS_BANK_CONFLICT"] / a["launches"])}
 json.dump(mf, open("gpurun_out/%s_pmc_mfma.json" % tag, "w"), indent=1, sort_keys=True)
 PY
-tail -1 gpurun_out/${tag}_bench_ae_bs256.json | cut -c1-300
+[ "$2" != "pmc" ] && tail -1 gpurun_out/${tag}_bench_ae_bs256.json | cut -c1-300
+ls gpurun_out/${tag}_pmc_*.json
