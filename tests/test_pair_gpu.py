@@ -167,7 +167,7 @@ def test_pair_over_adjacent_halves_is_zero_copy():
 
 @pytest.mark.parametrize("losses", [["autoencoder", "inverse", "forward"], ["vae"]], ids=["aeif", "vae"])
 def test_train_step_pair_follows_two_call_path(losses):
-    """SRL4robotics.trainStep with the batched pair (default) against SRLZ_PAIR=0 over a few steps incl. a validation one."""
+    """SRL4robotics.trainStep with the batched pair (default) against the two-call route (`_use_pair = False`) over a few steps incl. a validation one."""
     import models.learner as learner
     import preprocessing.preprocess as pre
     from losses.losses import LossManager
@@ -210,7 +210,7 @@ def test_train_step_pair_follows_two_call_path(losses):
                          ids=["aeif", "vae", "vae_c6", "dae", "split_ae"])
 def test_recon_loss_in_the_decoder_epilogue_follows_the_unfused_step(losses, C, split):
     """SRL4robotics.trainStep with the reconstruction / generation loss taken inside the last ConvTranspose (default) against
-    SRLZ_FUSED_RECON=0 (decoded frames written, loss and its gradient as separate passes): the same loss values (fp64 partial
+    the un-fused route (`hotpath._FUSE_RECON = False`: decoded frames written, loss and its gradient as separate passes): the same loss values (fp64 partial
     sums in another fixed order: equal to fp32 rounding), and — the gradient handed to the decoder being bit-identical — the
     same parameters after a few steps including a validation one."""
     import models.learner as learner

@@ -280,7 +280,7 @@ def test_train_step_rides_along_the_oracle(name):
 
 
 def test_staging_overflow_is_exercised():
-    """l1 + l2 + two separately encoded frames (SRLZ_PAIR=0 path) = four gradient contributions per regularised weight: the
+    """l1 + l2 + two separately encoded frames (the two-call route, `_use_pair = False`) = four gradient contributions per regularised weight: the
     fourth finds no staging bucket (FlatParams.grad_buffer -> None) and must travel through autograd's own accumulation.
     The resulting step is checked against the oracle like any other."""
     from losses.losses import LossManager

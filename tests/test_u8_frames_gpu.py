@@ -181,7 +181,7 @@ def test_training_step_on_bytes_is_the_float_step_bit_for_bit(losses, B, channel
 
 def test_steps_that_need_floats_get_floats(monkeypatch):
     """A step with a reader of the observations that has no byte form (here: the reconstruction loss taken from the decoded frames,
-    SRLZ_FUSED_RECON=0) is handed the float tensor by _toDevicePair — same numbers again."""
+    `hotpath._FUSE_RECON = False`) is handed the float tensor by _toDevicePair — same numbers again."""
     from srlz import hotpath
     B = 4
     frames = _frames(2 * B, 3, 224, 224, 9)
