@@ -540,7 +540,7 @@ int srlz_conv64_debug_program(const srlz_conv64_desc* d, int backward_data, int*
 int srlz_debug_mfma_peak(float* out, int blocks, int iters, srlz_stream_t stream);
 /* The same MFMA stream with valu_per_mfma (0, 1, 2, 4, 8, 16) independent instructions of `kind` (0 v_fma_f32, 1 v_add_u32,
  * 2 v_pk_fma_f32, 3 v_mov_b32) behind every MFMA — in the same wave, or (split) in the SIMD's second wave: what an
- * instruction next to fp32 MFMAs costs on this chip.  out: blocks * 512 floats. */
+ * instruction next to fp32 MFMAs costs on this chip (profiles/NOTES.md 5.3).  out: blocks * 512 floats. */
 int srlz_debug_mfma_valu(float* out, int blocks, int iters, int valu_per_mfma, int kind, int split, srlz_stream_t stream);
 /* Debug: out[4*b..] = {XCC id, HW_ID register, start clock, end clock} of workgroup b of a launch whose workgroups each
  * hold lds_bytes of LDS and spin for `spin` ticks (how the dispatcher places / replaces co-resident workgroups). */

@@ -681,7 +681,7 @@ class SRL4robotics(BaseLearner):
 
         val_set = set(int(i) for i in val_indices)
         # build-specific record (train.py writes it to <log_folder>/epoch_stats.json): wall seconds, frames and index-only minibatches
-        # of every epoch — what shows epoch 1 decode-bound and the later epochs GPU-bound (DESIGN.md 5.4)
+        # of every epoch — what shows epoch 1 decode-bound and the later epochs GPU-bound (DESIGN.md 5)
         self.epoch_stats = []
         for epoch in range(n_epochs):
             epoch_loss, epoch_batches, val_loss, val_batches = 0.0, 0, 0.0, 0

@@ -1,4 +1,4 @@
-"""Static guard for the compiler-level pathologies of DESIGN.md 5.2, on the ISA hipcc generates for gfx950 (no GPU needed):
+"""Static guard for the compiler-level pathologies of profiles/NOTES.md 5.2, on the ISA hipcc generates for gfx950 (no GPU needed):
 no kernel may serialise its global stores behind full memory waits, and the hot kernels must not spill (a spill reload is a
 vector-memory load: waiting for it drains every store issued before it)."""
 import os

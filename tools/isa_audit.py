@@ -1,6 +1,6 @@
 """Static audit of the gfx950 ISA hipcc generates for every kernel of the library: python tools/isa_audit.py [file.hip ...]
 
-Looks for the patterns that silently cost this code base time:
+Looks for the patterns that silently cost this code base time (profiles/NOTES.md section 5.2):
   * store -> "s_waitcnt vmcnt(0)" -> store chains: every global store waits for the previous one (one HBM round trip each).
     Cause: loads consumed inside branches; after the join the compiler no longer knows which loads landed and protects the
     next use with a full wait, which — vmcnt being in-order — also covers the store just issued.

@@ -2,7 +2,7 @@
 # usage (GPU box): tools/pmc_instmix.sh <tag> -- <command ...>
 # Two rocprofv3 PMC passes (+ kernel trace) over <command>: the dynamic instruction mix of every kernel per MFMA and the split of its
 # wave cycles into issuing / waiting for an issue slot / parked (s_waitcnt, barrier).  -> gpurun_out/instmix_<tag>.txt
-# (behind fp32 MFMAs no instruction is free — this is where a kernel's non-MFMA SIMD time comes from.)
+# (profiles/NOTES.md 5.3: behind fp32 MFMAs no instruction is free — this is where a kernel's non-MFMA SIMD time comes from.)
 tag=$1; shift 2
 export TMPDIR=/tmp
 mkdir -p gpurun_out
