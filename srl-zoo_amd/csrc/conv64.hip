@@ -2747,17 +2747,19 @@ extern "C" int srlz_conv64_bwd_weight(const float* x, const float* dy, float* dw
 
 // ---- the fused backward of a decoder block's ConvTranspose (conv64_bwd_fused_kernel) ----
 static int fused_bwd_grid(const ConvProg& P) {
-  int g = srlz_device_cus();  // ONE workgroup per CU (150 KB of LDS, 256 registers per lane)
+  int g = srlz_device_cus() & ~7;  // ONE workgroup per CU (150 KB of LDS, 256 registers per lane); a multiple of 8 for the XCD walk
   const int ntiles = P.G * P.tpg;
-  if (g > ntiles) g = ntiles;
-  return g & ~7;
+  // fewer tiles than CUs: rounded UP to the multiple of 8 (a workgroup without a tile leaves a zero partial) — rounded down, 98 tiles
+  // (ConvT1's backward at bs = 32) ran on 96 workgroups, two of which took a second tile: 99 us for 50 us of work
+  if (g > ntiles) g = (ntiles + 7) & ~7;
+  return g;
 }
 
 static bool fused_bwd_ok(const ConvProg& P) {
   bool grouped = P.s2 && P.ss == 2 && P.G <= 2 && P.min_off == 0 && !P.dbg;
   for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
   const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;
-  return grouped && fits32 && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && fused_bwd_grid(P) >= 8;
+  return grouped && fits32 && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && P.G * P.tpg >= 8;
 }
 
 extern "C" int srlz_conv64_gather_pipe_supported(const srlz_conv64_desc* d, int backward_data) {

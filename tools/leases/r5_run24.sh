@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5, GPU call 24: the default bench line against the committed r05k PMC passes + the whole GPU suite + smoke
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+timeout 300 python bench.py > gpurun_out/r05k_bench_ae_bs256.json 2> gpurun_out/r5_24.err; echo "bench rc $?"
+python - <<'PY'
+import json
+d = json.loads([l for l in open("gpurun_out/r05k_bench_ae_bs256.json") if l.startswith("{")][-1])
+print(d["value"], d["ms_per_step"], d["vae"]["ms_per_step"], d["north_star"]["aggregate_frac"], d["roofline"]["frac"], d["roofline"]["stale"], d["roofline"]["traffic"], d["cpu_baseline"]["value"])
+PY
+timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/r5_24_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r5_24_pytest.log
+grep -E "passed|failed|FAILED|Error|rc " gpurun_out/r5_24_pytest.log | tail -n 8
+timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -n 2
