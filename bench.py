@@ -361,6 +361,14 @@ def main():
         return worst, own, torch.stack(totals).tolist()
 
     dt, own_dt, last_losses = timed(step, args.warmup, args.steps)
+    if dt < 0.2 and not args.allow_short:
+        # (dt is the maximum over the ranks, the same number everywhere: every rank takes this exit, here, before the other legs — a
+        # rank 0 leaving alone would strand the others in their next collective until the RCCL timeout)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        msg = "bench.py: the timed region was %.3f s (< 0.2 s: %d steps of %.3f ms) — too short to be a measurement; " \
+              "raise --steps (or pass --allow-short for a functional check)" % (dt, args.steps, 1e3 * dt / args.steps)
+        raise SystemExit(msg if rank == 0 else 1)
     rank_ms = None
     if world > 1:  # every rank's own clock around the same K steps: skew between the ranks shows here
         rank_ms = [None] * world
@@ -448,9 +456,6 @@ def main():
             where = "the loader's uint8 frames [B,C,W,H] resident in HBM"
         else:
             where = "normalised fp32 observations resident in HBM"
-        if dt < 0.2 and not args.allow_short:
-            raise SystemExit("bench.py: the timed region was %.3f s (< 0.2 s: %d steps of %.3f ms) — too short to be a measurement; "
-                             "raise --steps (or pass --allow-short for a functional check)" % (dt, args.steps, 1e3 * dt / args.steps))
         out = {
             "metric": "images/sec (224x224x3) AE+VAE train step", "value": round(images / dt, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),

@@ -24,6 +24,7 @@ class LossManager:
                            ".bias" not in name and param.requires_grad]
         self.loss_history = loss_history
         self.names, self.weights, self.losses = [], [], []
+        self.collect_only = False  # (True inside SRL4robotics.trainStep: the loss functions' return values are not formed)
 
     def addToLosses(self, name, weight, loss_value):
         self.names.append(name)
@@ -56,25 +57,34 @@ class LossManager:
         self.names, self.weights, self.losses = [], [], []
 
 
+def _returned(loss, weight, loss_manager):
+    """What a loss function returns: weight * loss, as in the reference (losses/losses.py:102-256) — one HIP launch.  The trainer reads
+    the terms from the LossManager and ignores the return value; it sets `loss_manager.collect_only` for the duration of its step so
+    that the launch (and its autograd node) is not made for nobody."""
+    if getattr(loss_manager, "collect_only", False):
+        return None
+    return ops.weighted(loss, weight)
+
+
 def l1Loss(params, weight, loss_manager):
     """L1 regularisation: sum over the parameter list of sum(|p|) (reference losses.py:132-142)."""
     l1_loss = ops.ParamNormFn.apply(0, *params)
     loss_manager.addToLosses('l1_loss', weight, l1_loss)
-    return ops.weighted(l1_loss, weight)
+    return _returned(l1_loss, weight, loss_manager)
 
 
 def l2Loss(params, weight, loss_manager):
     """L2 regularisation: mean over the parameter list of ||p||_2 (reference losses.py:145-155)."""
     l2_loss = ops.ParamNormFn.apply(1, *params)
     loss_manager.addToLosses('l2_loss', weight, l2_loss)
-    return ops.weighted(l2_loss, weight)
+    return _returned(l2_loss, weight, loss_manager)
 
 
 def rewardModelLoss(rewards_pred, rewards_st, weight, loss_manager):
     """cross-entropy between reward logits and the (categorical) reward (reference losses.py:158-170)."""
     reward_loss = ops.CrossEntropyFn.apply(rewards_pred, rewards_st.view(-1))
     loss_manager.addToLosses('reward_loss', weight, reward_loss)
-    return ops.weighted(reward_loss, weight)
+    return _returned(reward_loss, weight, loss_manager)
 
 
 def reconstructionLoss(input_image, target_image):
@@ -86,14 +96,14 @@ def forwardModelLoss(next_states_pred, next_states, weight, loss_manager):
     """mean squared error between predicted and encoded next states (reference losses.py:102-114)."""
     forward_loss = reconstructionLoss(next_states_pred, next_states)
     loss_manager.addToLosses('forward_loss', weight, forward_loss)
-    return ops.weighted(forward_loss, weight)
+    return _returned(forward_loss, weight, loss_manager)
 
 
 def inverseModelLoss(actions_pred, actions_st, weight, loss_manager):
     """cross-entropy between action logits and the taken actions (reference losses.py:117-129)."""
     inverse_loss = ops.CrossEntropyFn.apply(actions_pred, actions_st.view(-1))
     loss_manager.addToLosses('inverse_loss', weight, inverse_loss)
-    return ops.weighted(inverse_loss, weight)
+    return _returned(inverse_loss, weight, loss_manager)
 
 
 def _pairSqDiff(a, next_a, b, next_b, mean):
@@ -112,7 +122,7 @@ def autoEncoderLoss(obs, decoded_obs, next_obs, decoded_next_obs, weight, loss_m
     if ae_loss is None:
         ae_loss = ops.add_scalars(reconstructionLoss(obs, decoded_obs), reconstructionLoss(next_obs, decoded_next_obs))
     loss_manager.addToLosses('reconstruction_loss', weight, ae_loss)
-    return ops.weighted(ae_loss, weight)
+    return _returned(ae_loss, weight, loss_manager)
 
 
 def generationLoss(decoded, next_decoded, obs, next_obs, weight, loss_manager):
@@ -121,7 +131,7 @@ def generationLoss(decoded, next_decoded, obs, next_obs, weight, loss_manager):
     if generation_loss is None:
         generation_loss = ops.add_scalars(ops.SqDiffSumFn.apply(decoded, obs), ops.SqDiffSumFn.apply(next_decoded, next_obs))
     loss_manager.addToLosses('generation_loss', weight, generation_loss)
-    return ops.weighted(generation_loss, weight)
+    return _returned(generation_loss, weight, loss_manager)
 
 
 def perceptualSimilarityLoss(encoded_real, encoded_prediction, next_encoded_real, next_encoded_prediction,
@@ -131,18 +141,18 @@ def perceptualSimilarityLoss(encoded_real, encoded_prediction, next_encoded_real
     pretrained_dae_encoding_loss = ops.add_scalars(ops.SqDiffSumFn.apply(encoded_real, encoded_prediction),
                                                    ops.SqDiffSumFn.apply(next_encoded_real, next_encoded_prediction))
     loss_manager.addToLosses("denoising perceptual similarity", weight, pretrained_dae_encoding_loss)
-    return ops.weighted(pretrained_dae_encoding_loss, weight)
+    return _returned(pretrained_dae_encoding_loss, weight, loss_manager)
 
 
 def kullbackLeiblerLoss(mu, next_mu, logvar, next_logvar, loss_manager, beta=1):
     """KL(q(z|x) || N(0, I)) summed over elements and batch, both frames (reference losses.py:239-256)."""
     kl_divergence = ops.add_scalars(ops.KLSumFn.apply(mu, logvar), ops.KLSumFn.apply(next_mu, next_logvar))
     loss_manager.addToLosses('kl_loss', beta, kl_divergence)
-    return ops.weighted(kl_divergence, beta)
+    return _returned(kl_divergence, beta, loss_manager)
 
 
 def tripletLoss(states, p_states, n_states, weight, loss_manager, alpha=0.2):
     """Time-contrastive triplet loss: mean relu(|s - p|^2 - |s - n|^2 + alpha) (reference losses.py:360-376)."""
     tcn_triplet_loss = ops.TripletLossFn.apply(states, p_states, n_states, alpha)
     loss_manager.addToLosses('triplet_loss', weight, tcn_triplet_loss)
-    return ops.weighted(tcn_triplet_loss, weight)
+    return _returned(tcn_triplet_loss, weight, loss_manager)

@@ -516,6 +516,9 @@ class SRL4robotics(BaseLearner):
         n_heads = int(self.use_forward_loss) + int(self.use_inverse_loss) + int(self.use_reward_loss)
         states_fan, next_states_fan = ops.Fan(states, n_heads + int(self.use_triplets)), ops.Fan(next_states, n_heads)
         # same order as the reference's loop body (learner.py:420-449): regularisers, forward, inverse, reward, AE, VAE
+        # (the terms are read from the LossManager below; the loss functions' own `weight * loss` return values would be one launch
+        # per term for nobody)
+        loss_manager.collect_only = True
         if w['l1_reg'] > 0:
             l1Loss(loss_manager.reg_params, w['l1_reg'], loss_manager)
         if w['l2_reg'] > 0:
@@ -550,6 +553,7 @@ class SRL4robotics(BaseLearner):
         if self.use_triplets:
             tripletLoss(states_fan.take(), positive_states, negative_states, weight=w['triplet'], loss_manager=loss_manager, alpha=0.2)
 
+        loss_manager.collect_only = False
         # LossManager.computeTotalLoss() as one launch, which also drops the step's scalars [total, l_0, l_1, ...] into the tail
         # of the gradient bucket: with several GPUs every rank reads the SAME (mean) losses back, so the NaN exit and the
         # best-model decision are taken by all ranks together
@@ -642,7 +646,9 @@ class SRL4robotics(BaseLearner):
             import preprocessing.preprocess as _pre
             frame_shape = (6 if self.use_triplets else _pre.getNChannels(), _pre.IMAGE_WIDTH, _pre.IMAGE_HEIGHT)
             # (the DAE's device-side occlusion reads the store in HBM: no store at all when it would not fit there)
-            if not self.use_dae or ResidentFrames.fits_device(len(images_path), frame_shape, self.device):
+            # (... decided by ALL ranks together: free HBM differs between ranks, and a store on some ranks only would pair their
+            # slice exchange at the epoch boundary with the others' gradient all-reduce)
+            if optim.all_ranks(not self.use_dae or ResidentFrames.fits_device(len(images_path), frame_shape, self.device)):
                 needed = np.concatenate([np.concatenate((mb, mb + 1)) for mb in minibatchlist])
                 resident = ResidentFrames(len(images_path), frame_shape, self.device, needed, rank=self.rank,
                                           world_size=self.world_size)
@@ -806,8 +812,10 @@ class SRL4robotics(BaseLearner):
                 missing = np.nonzero(~resident.have)[0]
                 if len(missing):
                     chunks = [missing[i:i + 64] for i in range(0, len(missing), 64)]
-                    for chunk, frames in zip(chunks, makeTestLoader(chunks)):
+                    tail_loader = makeTestLoader(chunks)
+                    for chunk, frames in zip(chunks, tail_loader):
                         resident.absorb_indices(chunk, frames)
+                    tail_loader.shutdown()
                 pred_states = np.concatenate([self._predFn(self._toDevice(resident.store[int(mb[0]):int(mb[-1]) + 1]))
                                               for mb in test_minibatchlist if len(mb)], axis=0)
                 self.predict_stats = {"from_store": True, "decoded_now": int(len(missing)), "seconds": time.time() - t_pred}

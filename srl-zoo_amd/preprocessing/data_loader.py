@@ -193,6 +193,7 @@ class DataLoader(object):
             raise ValueError("raw_uint8 frames cannot carry the (normalised-space) occlusion of the DAE loader")
         self.raw_uint8 = raw_uint8
         # (created BEFORE the fork: the producer sees the same flag)
+        self._order_rng = None  # (several ranks: the producer's private copy of the forked RNG state, see _epochOrder)
         self.index_mode = Event() if (index_switch and is_training) else None
         self.epoch_gate = Event() if self.index_mode is not None else None
         self._index_of = None  # image stem -> frame index (built on first use by the triplet index path)
@@ -230,7 +231,13 @@ class DataLoader(object):
     def _epochOrder(self):
         if not self.shuffle:
             return np.arange(self.n_minibatches, dtype=np.int64)
-        order = np.random.permutation(self.n_minibatches).astype(np.int64)
+        # One rank: the reference's stream — np.random.permutation from the process's global state, interleaved with whatever else the
+        # producer draws from it (occlusion rectangles).  Several ranks: every rank must draw the SAME permutation every epoch, but the
+        # occlusion draws of a rank depend on its shard (np.random.randint rejects and redraws: a data-dependent number of variates),
+        # so the order comes from a private copy of the state the producers were forked with — identical on all ranks, and touched by
+        # nothing but these permutations.
+        rng = np.random if self._order_rng is None else self._order_rng
+        order = rng.permutation(self.n_minibatches).astype(np.int64)
         return shardOrder(order, self.rank, self.world_size, self.val_indices)
 
     def _run(self):
@@ -243,6 +250,9 @@ class DataLoader(object):
         # "Current thread: Garbage-collecting"; it showed as a training run waiting for ever or, since the watchdog, as exit code -11).
         gc.freeze()
         th.set_num_threads(1)
+        if self.world_size > 1 and self.shuffle:
+            self._order_rng = np.random.RandomState()
+            self._order_rng.set_state(np.random.get_state())
         # ... and the decoding threads must not run ATen kernels at all: the OpenMP thread count is a per-thread setting, a pool thread
         # starts with the default (all cores), and a tensor copy above ATen's grain size opens a parallel region in this forked child,
         # whose inherited OpenMP runtime has no threads — it hangs or crashes (seen on GPU boxes with the DAE loaders).  The workers
@@ -466,6 +476,23 @@ class DataLoader(object):
         return self._book(val)
 
     next = __next__
+
+    def shutdown(self):
+        """End the producer process for good: terminate, JOIN (no zombie, its shared-memory handles released) and close the queue with
+        its feeder thread and pipe.  For loaders that live shorter than the run (the slice's fill pass, the decode of the frames no
+        minibatch asked for); the training loader dies with the trainer (daemon process)."""
+        process, self.process = self.process, None
+        if process is not None:
+            try:
+                process.terminate()
+                process.join(5)
+            except Exception:
+                pass
+        try:
+            self.queue.close()
+            self.queue.cancel_join_thread()
+        except Exception:
+            pass
 
     def __del__(self):
         try:

@@ -109,11 +109,8 @@ class FillPass(object):
 
     def close(self):
         loader, self.loader = self.loader, None
-        if loader is not None and loader.process is not None:
-            try:
-                loader.process.terminate()
-            except Exception:
-                pass
+        if loader is not None:
+            loader.shutdown()
 
 
 class ResidentFrames(object):
@@ -305,9 +302,10 @@ class ResidentFrames(object):
             self._stage_i ^= 1
             if self._stage_ev[k] is not None:
                 self._stage_ev[k].synchronize()  # the copy that last read this staging buffer (two steps ago) is done
-            if self._stage[k] is None or self._stage[k].shape[0] < 2 * n:
-                self._stage[k] = th.empty((2 * n,) + self.frame_shape, dtype=th.uint8, pin_memory=th.cuda.is_available())
-            stage = self._stage[k][:2 * n]
+            # (the staging buffers are flat byte tensors in pair() and triplet_pair() alike: a store may serve both)
+            if self._stage[k] is None or self._stage[k].numel() < both.numel():
+                self._stage[k] = th.empty(both.numel(), dtype=th.uint8, pin_memory=th.cuda.is_available())
+            stage = self._stage[k][:both.numel()].view(both.shape)
             th.index_select(self.store, 0, hi, out=stage[:n])
             th.index_select(self.store, 0, hi + 1, out=stage[n:])
             both.copy_(stage, non_blocking=True)

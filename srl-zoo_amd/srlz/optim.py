@@ -318,6 +318,19 @@ def average_running_stats(state_dict):
     return state_dict
 
 
+def all_ranks(flag):
+    """True only when `flag` is true on EVERY rank (one small all-reduce, MIN; every rank must call it at the same point of the
+    program).  For decisions that create or skip later collectives — e.g. whether a rank-local memory budget allows the resident
+    dataset: a store on some ranks and none on others would pair one rank's slice exchange with another's gradient all-reduce."""
+    _, size = world()
+    if size == 1:
+        return bool(flag)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    ok = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return int(ok.item()) == 1
+
+
 def share_from_rank0(obj):
     """`obj` as rank 0 computed it, on every rank (log-folder names carry a wall-clock timestamp)."""
     _, size = world()
