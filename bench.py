@@ -51,14 +51,8 @@ def synthetic_batch(B, C, seed, device):
 
 def host_cores():
     """CPUs this process may actually use: min(affinity, cgroup cpu.max quota) — the GPU box's container is capped."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (IOError, OSError, ValueError):
-        pass
-    return n
+    from srlz.optim import usable_cores
+    return usable_cores()
 
 
 def cpu_baseline(losses, full=False):
@@ -260,6 +254,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend=_optim.dist_backend())  # "nccl" = RCCL over xGMI
+        # (collective) the communicator's own view of the job: under RCCL one distinct GPU per rank, or every rank stops with a message
+        placement = _optim.rank_devices()
         # communicator set-up (seconds) must never land in the timed region, whatever --warmup says
         warm = torch.zeros(1 << 20, device=device)
         _optim._sum_across_ranks(warm)
@@ -444,6 +440,9 @@ def main():
             torch.distributed.broadcast_object_list(box, src=0)
             k = box[0]
         s_dt, _, _ = timed(s_step, 0, k)
+        while s_dt < 0.2 and k < (1 << 20):  # (the probe ran slower than the steps do: s_dt is the maximum over the ranks, so every
+            k *= 2                           # rank takes the same decision)
+            s_dt, _, _ = timed(s_step, 0, k)
         strong = {"scaling": "strong", "global_batch": B, "per_gpu_batch": b, "steps": k, "ms_per_step": round(1e3 * s_dt / k, 3),
                   "images_per_s": round(2 * B * k / s_dt, 1), "timed_region_s": round(s_dt, 4)}
 
@@ -470,7 +469,9 @@ def main():
                                    "(%d frames fwd+bwd per step per GPU), Adam lr 0.005, %s"
                                    % (channels, " ".join(args.losses), args.state_dim, B, 2 * B, where),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                       # (from the process group and its gathered device table, not from the environment)
+                       "rccl_ranks": placement["ranks"] if world > 1 else 1,
+                       "devices": placement["devices"] if world > 1 else 1,
                        "final_loss": round(last_losses[-1], 6)},
         }
         if vae is not None:

@@ -640,6 +640,14 @@ class SRL4robotics(BaseLearner):
         # which keeps the two views of every time step; the loader process keeps drawing it with the reference's random.randint.
         use_bytes = bool(RAW_UINT8_INPUT)
         resident = fill = None
+        # Host cores (several ranks share one machine): decoding threads x loader processes of this rank x local ranks <= usable
+        # cores, and the loader processes pinned to the cores next to this rank's GPU (the reference's N_WORKERS = 4 assumes it owns
+        # the host: data_loader.py:129-193 is one process of one trainer)
+        will_fill = self.world_size > 1 and RESIDENT_FRAMES and use_bytes and n_epochs_planned(self.losses) > 1
+        n_workers = optim.loader_workers(N_WORKERS, passes=2 if will_fill else 1) if self.world_size > 1 else N_WORKERS
+        affinity = optim.numa_cpus_of_device(self.device.index) if (self.world_size > 1 and self.device.type == "cuda") else None
+        self.loader_placement = {"n_workers": n_workers, "requested": N_WORKERS, "cpu_affinity": affinity,
+                                 "usable_cores": optim.usable_cores()}
         if RESIDENT_FRAMES and use_bytes and n_epochs_planned(self.losses) > 1 \
                 and (not self.use_triplets or DataLoader.negativesIndexable(images_path)):
             from preprocessing.resident import ResidentFrames
@@ -657,17 +665,18 @@ class SRL4robotics(BaseLearner):
                 # by absorbing it — every rank decodes its own fixed slice of the dataset beside the first epoch (a second loader
                 # process, in order, bytes only) and the slices are exchanged at the epoch boundary (ResidentFrames.exchange)
                 from preprocessing.resident import FillPass
-                fill = FillPass(resident, images_path, n_workers=N_WORKERS, multi_view=self.multi_view)
+                fill = FillPass(resident, images_path, n_workers=n_workers, multi_view=self.multi_view, cpu_affinity=affinity)
         self._resident = resident
-        data_loader = DataLoader(minibatchlist, images_path, n_workers=N_WORKERS, multi_view=self.multi_view,
+        data_loader = DataLoader(minibatchlist, images_path, n_workers=n_workers, multi_view=self.multi_view,
                                  use_triplets=self.use_triplets, is_training=True, apply_occlusion=self.use_dae,
                                  occlusion_percentage=self.occlusion_percentage, rank=self.rank,
-                                 world_size=self.world_size, val_indices=val_indices,
+                                 world_size=self.world_size, val_indices=val_indices, cpu_affinity=affinity,
                                  raw_uint8="planar" if use_bytes and (not self.use_dae or resident is not None) else False,
                                  index_switch=resident is not None)
         def makeTestLoader(minibatches=test_minibatchlist):
             # (forked when it is needed — at the end of learn(): with the dataset resident the states are predicted from the store)
-            return DataLoader(minibatches, images_path, n_workers=N_WORKERS, multi_view=self.multi_view, use_triplets=self.use_triplets,
+            return DataLoader(minibatches, images_path, n_workers=n_workers, multi_view=self.multi_view, use_triplets=self.use_triplets,
+                              cpu_affinity=affinity,
                               max_queue_len=1, is_training=False, apply_occlusion=self.use_dae,
                               occlusion_percentage=self.occlusion_percentage,
                               raw_uint8="planar" if use_bytes and not self.use_dae else False,

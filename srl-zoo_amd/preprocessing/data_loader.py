@@ -135,7 +135,8 @@ def shardOrder(order, rank, world_size, val_indices=None):
 class DataLoader(object):
     def __init__(self, minibatchlist, images_path, n_workers=1, multi_view=False, use_triplets=False,
                  infinite_loop=True, max_queue_len=4, is_training=False, apply_occlusion=False,
-                 occlusion_percentage=0.5, rank=0, world_size=1, val_indices=None, raw_uint8=False, index_switch=False):
+                 occlusion_percentage=0.5, rank=0, world_size=1, val_indices=None, raw_uint8=False, index_switch=False,
+                 cpu_affinity=None):
         """
         :param minibatchlist: ([np.array]) observation indices grouped per minibatch
         :param images_path: (np.array) image paths (without the 'data/' prefix)
@@ -170,6 +171,8 @@ class DataLoader(object):
                           that boundary on every rank at once (preprocessing/resident.py::ResidentFrames.exchange).
         :param val_indices: minibatch ids used for validation; with world_size > 1 training and validation
                             minibatches are sharded separately (train first) so all ranks stay in lock-step
+        :param cpu_affinity: (list of int or None) CPUs the producer process and its decoding threads pin themselves to — the cores of
+                            the NUMA node the rank's GPU hangs off (srlz.optim.numa_cpus_of_device); None leaves the mask alone
         """
         super(DataLoader, self).__init__()
         if use_triplets and not multi_view:
@@ -188,6 +191,7 @@ class DataLoader(object):
         self.apply_occlusion = apply_occlusion
         self.occlusion_percentage = occlusion_percentage
         self.rank, self.world_size = rank, world_size
+        self.cpu_affinity = None if not cpu_affinity else sorted(int(c) for c in cpu_affinity)
         self.val_indices = None if val_indices is None else set(int(i) for i in val_indices)
         if raw_uint8 and raw_uint8 != "planar" and apply_occlusion:
             raise ValueError("raw_uint8 frames cannot carry the (normalised-space) occlusion of the DAE loader")
@@ -250,6 +254,11 @@ class DataLoader(object):
         # "Current thread: Garbage-collecting"; it showed as a training run waiting for ever or, since the watchdog, as exit code -11).
         gc.freeze()
         th.set_num_threads(1)
+        if self.cpu_affinity and hasattr(os, "sched_setaffinity"):
+            try:  # (threads created from here on — the decoding pool — inherit the mask)
+                os.sched_setaffinity(0, self.cpu_affinity)
+            except OSError:
+                pass  # a mask the container does not allow: stay where we are
         if self.world_size > 1 and self.shuffle:
             self._order_rng = np.random.RandomState()
             self._order_rng.set_state(np.random.get_state())

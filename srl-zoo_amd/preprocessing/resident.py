@@ -67,13 +67,13 @@ class FillPass(object):
         fill.finish(train_loader)    # COLLECTIVE: rest of the slice, exchange, then shipIndices() / keepPixels() on every rank alike
     """
 
-    def __init__(self, resident, images_path, n_workers=4, multi_view=False, chunk=64):
+    def __init__(self, resident, images_path, n_workers=4, multi_view=False, chunk=64, cpu_affinity=None):
         from .data_loader import DataLoader
         self.resident = resident
         self.ranges = resident.fillMinibatches(chunk)
         self._next_range = 0
         self.loader = DataLoader(self.ranges, images_path, n_workers=n_workers, multi_view=multi_view, is_training=False,
-                                 infinite_loop=False, max_queue_len=4, raw_uint8="planar")
+                                 infinite_loop=False, max_queue_len=4, raw_uint8="planar", cpu_affinity=cpu_affinity)
         self.done = False
         self.stats = {}
 

@@ -195,6 +195,8 @@ def init_native_comm():
         C.comm_unique_id(buf)
     payload = share_from_rank0(buf.raw)
     C.comm_init(ctypes.create_string_buffer(payload, nbytes), rank, size)
+    if C.comm_world() != size:  # (the communicator's own count)
+        raise RuntimeError("srlz_comm_init: the RCCL communicator has %d ranks, the process group %d" % (C.comm_world(), size))
     _native_ready = True
 
 
@@ -224,6 +226,91 @@ def local_device_index():
         raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible: RCCL needs one GPU per rank (SRLZ_DIST_BACKEND=gloo "
                            "lets ranks share a GPU for functional tests)" % (local_rank, n))
     return local_rank % n
+
+
+def device_identity(index=None):
+    """(host name, PCI address "dddd:bb:dd.0") of the rank's GPU — what tells two ranks on one device apart from two ranks on two."""
+    import socket
+    if not torch.cuda.is_available():
+        return socket.gethostname(), "cpu"  # (the CPU tests of the multi-rank control flow)
+    index = torch.cuda.current_device() if index is None else index
+    p = torch.cuda.get_device_properties(index)
+    return socket.gethostname(), "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+
+
+def rank_devices():
+    """COLLECTIVE, right after init_process_group: every rank's (host, PCI address), gathered over the process group — the
+    communicator's own view of the job, not the environment's.  Under backend "nccl" (RCCL: the product configuration) two ranks on one
+    device, or a communicator whose size differs from WORLD_SIZE, stop EVERY rank here with a message instead of a hang inside the
+    first collective (RCCL refuses the second rank of a device only after the others are already waiting for it).  The gloo debug
+    topology shares devices on purpose.  Returns {"ranks": W, "devices": distinct devices, "hosts": distinct hosts, "table": [...]}."""
+    import os
+    rank, size = world()
+    if size == 1:
+        host, pci = device_identity()
+        return {"ranks": 1, "devices": 1, "hosts": 1, "table": [[host, pci]]}
+    table = [None] * size
+    dist.all_gather_object(table, list(device_identity()))
+    distinct = len(set(tuple(t) for t in table))
+    info = {"ranks": size, "devices": distinct, "hosts": len(set(t[0] for t in table)), "table": table}
+    env_world = int(os.environ.get("WORLD_SIZE", size))
+    if dist.get_backend() == "nccl" and (distinct != size or env_world != size):
+        shared = sorted(set(tuple(t) for t in table if table.count(t) > 1))
+        raise RuntimeError("rank %d: %d ranks (WORLD_SIZE=%d) on %d distinct GPU(s); RCCL needs one GPU per rank.  Shared: %s.  "
+                           "Check LOCAL_RANK / HIP_VISIBLE_DEVICES of the launcher (SRLZ_DIST_BACKEND=gloo lets ranks share a GPU "
+                           "for functional tests)" % (rank, size, env_world, distinct, shared))
+    return info
+
+
+# ---- host cores: the loaders of all local ranks share one machine -----------------------------------------------------------
+def usable_cores():
+    """CPUs this process may use: min(affinity mask, cgroup cpu.max quota)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (IOError, OSError, ValueError):
+        pass
+    return n
+
+
+def loader_workers(requested, passes=1, local_ranks=None, cores=None):
+    """Decoding threads per loader process such that  threads x passes x local ranks <= usable cores  (passes = 2 while a rank's fill
+    pass decodes its dataset slice beside the first epoch).  The reference's N_WORKERS = 4 is a single-process setting; eight ranks x
+    two loader processes x 4 threads on a 32-core host would oversubscribe the cores the step's own launch thread needs."""
+    import os
+    if local_ranks is None:
+        local_ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    cores = usable_cores() if cores is None else cores
+    per_rank = max(1, (cores - local_ranks) // max(1, local_ranks))  # (one core per rank stays with the training process)
+    return int(max(1, min(int(requested), per_rank // max(1, passes))))
+
+
+def numa_cpus_of_device(index=None, sysfs="/sys"):
+    """CPUs of the NUMA node the rank's GPU hangs off, intersected with the CPUs this process may use (None: unknown, one node, or an
+    empty intersection — leave the affinity alone).  Read from <sysfs>/bus/pci/devices/<address>/numa_node and
+    <sysfs>/devices/system/node/node<k>/cpulist.  The loader processes pin themselves to it (DataLoader(cpu_affinity=...)): decoded
+    frames are written into shared memory next to the GPU's PCIe root and are not bounced between sockets."""
+    import os
+    try:
+        pci = device_identity(index)[1] if not isinstance(index, str) else index
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", pci, "numa_node")).read().strip())
+        if node < 0:
+            return None
+        text = open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read().strip()
+    except (IOError, OSError, ValueError, RuntimeError, AssertionError):
+        return None
+    cpus = set()
+    for part in text.split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else cpus
+    cpus &= set(allowed)
+    return sorted(cpus) if cpus and len(cpus) < len(allowed) else None
 
 
 # bench.py --gpus N: HIP-event pairs around every exchange of the instrumented steps (on the launch stream: torch.distributed's

@@ -97,6 +97,10 @@ def initDistributed():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     th.cuda.set_device(optim.local_device_index())
     th.distributed.init_process_group(backend=optim.dist_backend())  # "nccl" = RCCL over xGMI
+    placement = optim.rank_devices()  # (collective; under RCCL: one distinct GPU per rank, or every rank stops here with a message)
+    if th.distributed.get_rank() == 0:
+        print("{} ranks on {} GPU(s) of {} host(s), backend {}".format(placement["ranks"], placement["devices"], placement["hosts"],
+                                                                     th.distributed.get_backend()))
     if optim.native_comm_requested():  # SRLZ_COMM=rccl: the bucket travels through srlz_comm_allreduce_f32 (include/srlz.h)
         optim.init_native_comm()
     return th.distributed.get_rank(), world_size

@@ -58,6 +58,7 @@ if digest_dir:
                       log_folder=self.log_folder, world=self.world_size, adam_steps=self.optimizer.steps(),
                       states_shape=list(states.shape), states_finite=bool(np.isfinite(states).all()),
                       epoch_stats=list(getattr(self, "epoch_stats", [])),
+                      loader_placement=getattr(self, "loader_placement", None),
                       resident_complete=bool(self._resident is not None and self._resident.complete()
                                              and self._resident.have.all()),
                       backend=torch.distributed.get_backend() if self.world_size > 1 else None)

@@ -163,3 +163,94 @@ def test_bench_self_launches_its_ranks():
     assert st["global_batch"] == 8 and st["per_gpu_batch"] == 4 and st["timed_region_s"] >= 0.2 and st["images_per_s"] > 0
     # the headline is both legs of the metric: the VAE step measured in the same process
     assert out["vae"]["ms_per_step"] > 0 and np.isfinite(out["vae"]["final_loss"]) and out["timed_region_s"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# World 8 (round 6): the rank count of BASELINE.json configs[3] / [4] and of the driver's scaling run, on however many GPUs the box
+# has — eight ranks on one MI355X in the gloo debug topology when it has one (every kernel still runs on the GPU; the bucket bounces
+# through the host).  What a first run on an 8-GPU node exercises besides RCCL itself: eight training loaders + eight fill passes on
+# one host (decoding threads budgeted against the usable cores, srlz.optim.loader_workers), the slice exchange among eight owners,
+# lock-step step counts, one log folder, the fields of bench.py's multi-rank line.  With >= 8 GPUs the same tests run over RCCL.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dataset8(tmp_path_factory):
+    root = tmp_path_factory.mktemp("ddp_learn8")
+    make_dataset(str(root), name="tiny_ddp8", n_episodes=4, ep_len=42)
+    return root
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.timeout(1200)
+def test_eight_rank_train_cli(dataset8):
+    digest = dataset8 / "digest"
+    digest.mkdir()
+    args = ["--no-display-plots", "--data-folder", "tiny_ddp8", "--epochs", "2", "--seed", "0", "--val-size", "0.25", "--state-dim", "10",
+            "--model-type", "custom_cnn", "-bs", "4", "-lr", "0.001", "--losses", "autoencoder", "inverse"]
+    results, backend = _run_ranks(8, args, str(dataset8), {"SRLZ_TEST_DIGEST_DIR": str(digest)}, timeout=1000)
+    for rc, text in results:
+        assert rc == 0, text[-4000:]
+    ranks = [json.load(open(str(digest / ("rank%d.json" % r)))) for r in range(8)]
+    assert [d["world"] for d in ranks] == [8] * 8 and all(d["backend"] == backend for d in ranks)
+    assert len(glob.glob(str(dataset8 / "logs" / "tiny_ddp8" / "*"))) == 1
+    # identical histories, parameters and step counts on all eight ranks
+    for d in ranks[1:]:
+        assert d["loss_history"] == ranks[0]["loss_history"]
+        assert d["param_sum"] == ranks[0]["param_sum"] and d["param_abs_sum"] == ranks[0]["param_abs_sum"]
+        assert d["adam_steps"] == ranks[0]["adam_steps"] > 0
+    assert all(np.isfinite(v).all() for v in ranks[0]["loss_history"].values())
+    usable = ranks[0]["loader_placement"]["usable_cores"]
+    for d in ranks:
+        e1, e2 = d["epoch_stats"]
+        # eight loaders + eight fill passes survived; the slices of eight owners were exchanged; epoch 2 is index-only everywhere
+        assert d["resident_complete"] and e1["index_minibatches"] == 0 and e2["index_minibatches"] == e2["minibatches"] == e1["minibatches"]
+        assert e1["exchange"]["bytes"] == 168 * 3 * 224 * 224
+        assert d["states_shape"] == [168, 10] and d["states_finite"]
+        # decoding threads x 2 loader processes x 8 local ranks (+ the 8 training threads) fit the host, or are down to one thread
+        w = d["loader_placement"]["n_workers"]
+        assert 1 <= w <= 4 and (w == 1 or w * 2 * 8 + 8 <= usable), d["loader_placement"]
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks():
+    """`python bench.py --gpus 8 --batch-size 8 --allow-short`: eight self-launched ranks, ONE JSON line with the multi-rank fields the
+    driver's scaling run will be read through."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["SRLZ_DIST_BACKEND"] = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                           "--batch-size", "8", "--timer-steps", "2", "--allow-short", "--no-vae-leg"], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=800)
+    assert proc.returncode == 0, proc.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [l for l in proc.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["rccl_ranks"] == 8 and out["config"]["global_batch"] == 64
+    assert out["config"]["devices"] == (8 if env["SRLZ_DIST_BACKEND"] == "nccl" else torch.cuda.device_count())
+    assert out["value"] > 0 and out["scaling"] == "weak" and np.isfinite(out["config"]["final_loss"])
+    assert len(out["ranks"]["ms_per_step_per_rank"]) == 8
+    ar = out["allreduce"]
+    assert ar["calls_timed"] == 2 and ar["avg_us"] > 0 and ar["backend"] == env["SRLZ_DIST_BACKEND"]
+    assert ar["busbw_GBps"] == pytest.approx(ar["algbw_GBps"] * 2 * 7 / 8, rel=1e-2)
+    st = out["strong"]
+    assert st["scaling"] == "strong" and st["global_batch"] == 8 and st["per_gpu_batch"] == 1 and st["images_per_s"] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the library's own RCCL communicator needs one GPU per rank: runs the day the box has two")
+@pytest.mark.timeout(900)
+def test_bench_native_rccl_communicator():
+    """SRLZ_COMM=rccl: the bucket through srlz_comm_allreduce_f32 (include/srlz.h) instead of torch.distributed, on as many ranks as the
+    box has GPUs (at most 8).  Skipped on a 1-GPU lease — RCCL refuses two ranks on one device — and kept for the first node with more."""
+    n = min(8, torch.cuda.device_count())
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(SRLZ_DIST_BACKEND="nccl", SRLZ_COMM="rccl")
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+                           "--batch-size", "8", "--timer-steps", "2", "--allow-short", "--no-vae-leg"], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=800)
+    assert proc.returncode == 0, proc.stderr.decode("utf-8", "replace")[-3000:]
+    out = json.loads([l for l in proc.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == n and out["config"]["rccl_ranks"] == n and out["config"]["devices"] == n
+    assert out["allreduce"]["backend"] == "nccl" and np.isfinite(out["config"]["final_loss"])
