@@ -152,6 +152,28 @@ def committed_pmc_traffic(kernel):
     return rec["hbm_bytes_per_launch"], src, doc.get("csrc_sha16") != csrc_sha16()
 
 
+def committed_kernel_trace(kernel):
+    """(average launch duration in us of `kernel`, source file, stale) from the rocprofv3 --kernel-trace --stats summary of this same
+    command that tools/profile_round.sh recorded next to the newest PMC passes (profiles/<tag>_bench_ae_bs256_kernel_stats.csv):
+    the file whose average the live HIP-event time of the roofline object must agree with.  stale as in committed_pmc_traffic
+    (the CSV carries no fingerprint of its own: its tag's PMC file does)."""
+    import csv
+    doc, src = _newest_profile("_pmc_traffic.json")
+    if not src:
+        return None, None, None
+    path = os.path.join(REPO, src.replace("_pmc_traffic.json", "_bench_ae_bs256_kernel_stats.csv"))
+    if not os.path.exists(path):
+        return None, None, None
+    try:
+        for row in csv.DictReader(open(path)):
+            name = row["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+            if name.startswith(kernel + "(") or name.startswith(kernel + "<"):
+                return round(float(row["AverageNs"]) / 1e3, 2), "profiles/" + os.path.basename(path), doc.get("csrc_sha16") != csrc_sha16()
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, "profiles/" + os.path.basename(path), doc.get("csrc_sha16") != csrc_sha16()
+
+
 def committed_pmc_mfma(kernel):
     """(matrix-pipe busy fraction, measured clock, source file, stale) of `kernel` from the newest profiles/*_pmc_mfma.json."""
     doc, src = _newest_profile("_pmc_mfma.json")
@@ -531,15 +553,17 @@ def main():
             sym = SYMBOL.get(dom, dom)
             traffic, traffic_src, traffic_stale = committed_pmc_traffic(sym)
             busy, clock, busy_src, busy_stale = committed_pmc_mfma(sym)
+            trace_us, trace_src, trace_stale = committed_kernel_trace(sym)
             out["roofline"] = {"kernel": "%s (%s)" % (sym, NOTE.get(dom, "")),
                                "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": round(alg_bytes),
                                "mfma_busy_frac": busy, "clock_ghz": clock, "mfma_pmc_source": busy_src,
-                               "stale": bool(traffic_stale or busy_stale), "csrc_sha16": csrc_sha16(),
-                               "stale_note": "traffic / mfma_busy_frac / clock_ghz come from committed rocprofv3 PMC passes; stale = "
-                                             "those passes were recorded at other kernel sources than this build's",
+                               "kernel_trace_source": trace_src, "kernel_trace_avg_us": trace_us,
+                               "stale": bool(traffic_stale or busy_stale or trace_stale), "csrc_sha16": csrc_sha16(),
+                               "stale_note": "traffic / mfma_busy_frac / clock_ghz / kernel_trace_avg_us come from committed rocprofv3 passes of "
+                                             "this command (tools/profile_round.sh); stale = recorded at other kernel sources than this build's",
                                "timing": "%d instrumented steps (after 2 discarded ones) behind the timed region (HIP events on the launch stream)" % timer_steps,
                                "launches": k["launches"], "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                "algorithmic_gflop_per_launch": round(k["flop"] / k["launches"] / 1e9, 3),

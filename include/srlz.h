@@ -45,7 +45,7 @@ enum srlz_status {
  * 101 (round 4): srlz_convT_out_bwd_fused carries three gain arguments (added in round 3 without a bump); its partial records and
  *                workspace follow the strip geometry of csrc/convt_out.hip; srlz_convT_out_fwd_loss_workgroups counts those strips'
  *                workgroups. */
-#define SRLZ_ABI_VERSION 102
+#define SRLZ_ABI_VERSION 103
 int srlz_version(void);
 const char* srlz_last_error(void);
 /* Number of CUs of the current device (used by callers to size persistent grids / workspaces). */
@@ -152,6 +152,10 @@ typedef struct {
   int n, hi, wi, ho, wo; /* NHWC activations: x [n,hi,wi,cin] -> y [n,ho,wo,cout] */
   int cin, cout;         /* multiples of 64 */
   int ksize, stride, pad; /* (3, 1|2, 1) or (1, 2, 0) */
+  int groups;            /* BatchNorm groups batched along n (0 / 1 = one), as in srlz_conv64_desc: the launch is the union of
+                            `groups` independent trunk calls — the anchor / positive / negative views of obs and next_obs of one
+                            time-contrastive step, models/learner.py:383-391.  stats_partial is then
+                            [cout/64][groups][tiles / groups][128], x_bnp [groups][cin/64][256] */
 } srlz_convn_desc;
 size_t srlz_convn_packed_floats(const srlz_convn_desc* d);
 /* w_ref [cout,cin,k,k] (torch layout) -> the kernel's packed copy (srlz_convn_packed_floats floats) */
@@ -279,16 +283,22 @@ int srlz_bn_finalize(const float* stats_partial, int n_partials, int groups, lon
 /* A C-channel BatchNorm (C = 64 * chunks) of the frozen ResNet-18 trunk as `chunks` independent 64-channel layers:
  * stats_partial is srlz_convn_fwd's [chunks][tiles][128]; gamma / beta / running_* hold C floats; bnp receives `chunks`
  * records of 256 floats (training-mode forward of nn.BatchNorm2d: batch statistics + one momentum update; the trunk's
- * parameters are frozen but the reference leaves it in train() mode, models/learner.py:365 — so its statistics do move). */
-int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, int chunks, long long count, const float* gamma,
+ * parameters are frozen but the reference leaves it in train() mode, models/learner.py:365 — so its statistics do move).
+ * groups > 1 (ABI 103): `groups` independent BatchNorm calls batched along n — stats_partial is
+ * [chunks][groups][tiles / groups][128] (`tiles` counts all groups), count is PER GROUP, bnp receives [groups][chunks][256]
+ * (a group's records contiguous), the running statistics take the groups' momentum updates in order and the counter += groups:
+ * bit for bit what `groups` separate calls leave.  ws >= srlz_bn_finalize_chunks_workspace(chunks, groups) bytes. */
+size_t srlz_bn_finalize_chunks_workspace(int chunks, int groups);
+int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, int chunks, int groups, long long count, const float* gamma,
                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                            long long* num_batches_tracked /* += 1; may be NULL */, float* bnp, void* ws, size_t ws_bytes,
+                            long long* num_batches_tracked /* += groups; may be NULL */, float* bnp, void* ws, size_t ws_bytes,
                             srlz_stream_t stream);
 int srlz_bn_eval_params_chunks(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                float eps, int chunks, float* bnp, srlz_stream_t stream);
-/* out = relu(bn(a) + (b_bnp ? bn(b) : b)) over pixels x 64*chunks — BasicBlock's `out = relu(bn2(out) + identity)` */
+/* out = relu(bn(a) + (b_bnp ? bn(b) : b)) over pixels x 64*chunks — BasicBlock's `out = relu(bn2(out) + identity)`;
+ * groups > 1: records [groups][chunks][256], group g = pixels [g, g+1) * pixels / groups */
 int srlz_bn_add_relu(const float* a, const float* a_bnp, const float* b, const float* b_bnp, float* out, long long pixels,
-                     int chunks, srlz_stream_t stream);
+                     int chunks, int groups, srlz_stream_t stream);
 /* out[n,c] = mean over hw of x[n,hw,c] — resnet18.avgpool */
 int srlz_avgpool_nhwc(const float* x, float* out, int n, int hw, int c, srlz_stream_t stream);
 /* Eval-mode bnp from running statistics. */

@@ -52,11 +52,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
   if (tick && blockIdx.x == 0 && threadIdx.x == 0) tick[0] += groups;
   // blockIdx.x > 0 only in CHANNEL-BLOCK mode (srlz_bn_finalize_chunks: a C-channel BatchNorm handled as C/64 independent
   // 64-channel layers, one block each): everything per-channel moves on by 64, the staged partials by one block's rows
+  // (with `groups` > 1 in channel-block mode — the views of a triplet step batched along n — a block's staged partials are
+  // [group][n_partials][128] and the records come out group-major, bnp[(g * blocks + block) * 256 ..]: every group's records are one
+  // contiguous [blocks][256] run, which is what a single-group consumer expects)
   gamma += blockIdx.x * 64; beta += blockIdx.x * 64;
   if (running_mean) running_mean += blockIdx.x * 64;
   if (running_var) running_var += blockIdx.x * 64;
   bnp += blockIdx.x * 256;
-  partial += (size_t)blockIdx.x * n_partials * 128;
+  partial += (size_t)blockIdx.x * groups * n_partials * 128;
+  const int rec_stride = 256 * (int)gridDim.x;
   // one block of 1024 threads: thread (c = tid & 63, part = tid >> 6) sums a strided sixteenth of the partial records
   // (the chain of dependent loads, not bandwidth, is what this kernel waits for)
   constexpr int NP = 16;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
       const float invstd = (float)(1.0 / sqrt(var + (double)eps));
       const float ga = gamma[c], be = beta[c];
       const float scale = ga * invstd;
-      float* rec = bnp + g * 256;
+      float* rec = bnp + g * rec_stride;
       rec[c] = (float)mean; rec[64 + c] = invstd; rec[128 + c] = scale; rec[192 + c] = be - (float)mean * scale;
       const double unbiased = (count > 1.0) ? var * count / (count - 1.0) : var;
       if (batch_stat) { batch_stat[g * 128 + c] = (float)mean; batch_stat[g * 128 + 64 + c] = (float)unbiased; }
@@ -555,20 +559,31 @@ extern "C" int srlz_bn_finalize(const float* stats_partial, int n_partials, int 
   return 0;
 }
 
-extern "C" int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, int chunks, long long count, const float* gamma,
-                                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                                       long long* num_batches_tracked, float* bnp, void* ws, size_t ws_bytes,
+extern "C" size_t srlz_bn_finalize_chunks_workspace(int chunks, int groups) {
+  const size_t pairs = (size_t)(chunks > 1 ? chunks : 1) * norm_groups(groups);
+  const size_t need = pairs * STAGE_ROWS * 128 * sizeof(double);
+  const size_t base = srlz_bn_bwd_workspace(0);
+  return need > base ? need : base;
+}
+
+extern "C" int srlz_bn_finalize_chunks(const float* stats_partial, int tiles, int chunks, int groups, long long count,
+                                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                       float* running_var, long long* num_batches_tracked, float* bnp, void* ws, size_t ws_bytes,
                                        srlz_stream_t stream) {
   SRLZ_REQUIRE(stats_partial && gamma && beta && bnp && ws, SRLZ_ERR_NULL, "bn_finalize_chunks: null pointer");
-  SRLZ_REQUIRE(tiles > 0 && count > 0 && chunks >= 1 && chunks <= MAX_GROUPS, SRLZ_ERR_BAD_DESC,
-               "bn_finalize_chunks: %d tiles, %d channel blocks", tiles, chunks);
-  SRLZ_REQUIRE(ws_bytes >= srlz_bn_bwd_workspace(0), SRLZ_ERR_WORKSPACE, "bn_finalize_chunks: workspace too small");
+  const int G = norm_groups(groups);
+  SRLZ_REQUIRE(tiles > 0 && count > 0 && chunks >= 1 && chunks <= MAX_GROUPS && G <= MAX_GROUPS && tiles % G == 0, SRLZ_ERR_BAD_DESC,
+               "bn_finalize_chunks: %d tiles, %d channel blocks, %d groups", tiles, chunks, G);
+  SRLZ_REQUIRE(ws_bytes >= srlz_bn_finalize_chunks_workspace(chunks, G), SRLZ_ERR_WORKSPACE, "bn_finalize_chunks: workspace too small");
   double* staged = (double*)ws;
-  const int g = stage_blocks(tiles);
-  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, chunks), dim3(256), 0, as_stream(stream), stats_partial, tiles, staged);
+  // stats_partial is [chunk][group][tiles / G][128] (what srlz_convn_fwd writes: chunk-major, a group's tiles contiguous); every
+  // (chunk, group) pair is staged with exactly the geometry a single-group call uses, so G batched calls = G separate calls bit for bit
+  const int per = tiles / G;
+  const int g = stage_blocks(per);
+  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(g, chunks * G), dim3(256), 0, as_stream(stream), stats_partial, per, staged);
   SRLZ_LAUNCHED();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(chunks), dim3(1024), 0, as_stream(stream), (const double*)staged, g, (double)count,
-                     gamma, beta, eps, momentum, 1, running_mean, running_var, bnp, (float*)nullptr, 1, num_batches_tracked);
+                     gamma, beta, eps, momentum, 1, running_mean, running_var, bnp, (float*)nullptr, G, num_batches_tracked);
   SRLZ_LAUNCHED();
   return 0;
 }
@@ -596,12 +611,14 @@ extern "C" int srlz_bn_eval_params_chunks(const float* gamma, const float* beta,
 // (torchvision resnet.py: out = self.bn2(out); out += identity; out = self.relu(out)); records per block of 64 channels
 __global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restrict__ a, const float* __restrict__ a_bnp,
                                                          const float* __restrict__ b, const float* __restrict__ b_bnp,
-                                                         float* __restrict__ out, long long pixels, int chunks) {
+                                                         float* __restrict__ out, long long pixels, int chunks,
+                                                         long long per_group) {
+  // per_group = float4 elements of one BatchNorm group (records are [group][chunk][256]; one group: per_group = the whole tensor)
   const int q4 = chunks * 16;  // float4 per pixel
   const long long total = pixels * q4;
   for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
     const int cq = (int)(id % q4);
-    const int chunk = cq >> 4, c4 = cq & 15;
+    const int chunk = (int)(id / per_group) * chunks + (cq >> 4), c4 = cq & 15;
     const f32x4 sa = *(const f32x4*)(a_bnp + chunk * 256 + 128 + c4 * 4), ha = *(const f32x4*)(a_bnp + chunk * 256 + 192 + c4 * 4);
     const f32x4 va = *(const f32x4*)(a + id * 4);
     f32x4 vb = *(const f32x4*)(b + id * 4);
@@ -618,11 +635,12 @@ __global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restric
 }
 
 extern "C" int srlz_bn_add_relu(const float* a, const float* a_bnp, const float* b, const float* b_bnp, float* out,
-                                long long pixels, int chunks, srlz_stream_t stream) {
+                                long long pixels, int chunks, int groups, srlz_stream_t stream) {
   SRLZ_REQUIRE(a && a_bnp && b && out, SRLZ_ERR_NULL, "bn_add_relu: null pointer");
-  SRLZ_REQUIRE(pixels > 0 && chunks >= 1, SRLZ_ERR_BAD_DESC, "bn_add_relu: empty tensor");
+  const int G = norm_groups(groups);
+  SRLZ_REQUIRE(pixels > 0 && chunks >= 1 && pixels % G == 0, SRLZ_ERR_BAD_DESC, "bn_add_relu: %lld pixels, %d groups", pixels, G);
   hipLaunchKernelGGL(bn_add_relu_kernel, dim3(grid_for(pixels * chunks * 16, 256)), dim3(256), 0, as_stream(stream), a, a_bnp, b,
-                     b_bnp, out, pixels, chunks);
+                     b_bnp, out, pixels, chunks, pixels / G * chunks * 16);
   SRLZ_LAUNCHED();
   return 0;
 }

@@ -2376,8 +2376,15 @@ __global__ __launch_bounds__(256, 2) void convN_fwd_kernel(const float* __restri
   const int h = lane >> 5, l31 = lane & 31;
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int co = blockIdx.y;
-  const int q0 = tile * TM;
   const int cout = nco * 64;
+  // BatchNorm groups (round 6: the six views of a time-contrastive step batched along n — models/learner.py:383-391 calls the trunk
+  // once per view): tiles [g * tpg, (g + 1) * tpg) cover group g's own virtual grid, exactly as in conv64_fwd_body — a tile's
+  // statistics partial belongs to one group, its fused operand uses that group's records ([group][input-channel block][256])
+  const int grp = (P.G > 1) ? tile / P.tpg : 0;
+  const int q0 = (tile - grp * P.tpg) * TM;
+  src += (size_t)grp * P.src_gstride * nci;
+  dst += (size_t)grp * P.dst_gstride * nco;
+  if (src_bnp) src_bnp += (size_t)grp * nci * 256;
 
   if (tid < TM) {
     const int q = q0 + tid;
@@ -2533,6 +2540,8 @@ static int check_convn(const srlz_convn_desc* d) {
   SRLZ_REQUIRE(d != nullptr, SRLZ_ERR_NULL, "convn: null descriptor");
   SRLZ_REQUIRE(d->n > 0 && d->cin > 0 && d->cout > 0 && d->cin % 64 == 0 && d->cout % 64 == 0, SRLZ_ERR_BAD_DESC,
                "convn: channels must be multiples of 64 (cin=%d cout=%d)", d->cin, d->cout);
+  SRLZ_REQUIRE(d->groups >= 0 && (d->groups <= 1 || d->n % d->groups == 0), SRLZ_ERR_BAD_DESC,
+               "convn: n = %d is not a multiple of groups = %d", d->n, d->groups);
   const bool k3 = d->ksize == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2);
   const bool k1 = d->ksize == 1 && d->pad == 0 && d->stride == 2;
   SRLZ_REQUIRE(k3 || k1, SRLZ_ERR_BAD_DESC, "convn: 3x3 pad 1 stride 1/2 or 1x1 stride 2 only (k=%d s=%d p=%d)", d->ksize, d->stride,
@@ -2545,7 +2554,7 @@ static int check_convn(const srlz_convn_desc* d) {
 
 static int convn_program(ConvProg* P, const srlz_convn_desc* d) {
   // (a 1x1 stride-2 pad-0 convolution samples exactly the centre-tap pixels of the 3x3 stride-2 pad-1 program)
-  const int rc = build_program(P, 1, d->stride, 1, d->n, d->hi, d->wi, d->ho, d->wo, 1);
+  const int rc = build_program(P, 1, d->stride, 1, d->n, d->hi, d->wi, d->ho, d->wo, d->groups > 1 ? d->groups : 1);
   SRLZ_REQUIRE(rc == 0, SRLZ_ERR_BAD_DESC, "convn: cannot build a grid program for this descriptor");
   return 0;
 }
@@ -2571,7 +2580,7 @@ extern "C" int srlz_convn_fwd_tiles(const srlz_convn_desc* d) {
   if (check_convn(d)) return -1;
   ConvProg P;
   if (convn_program(&P, d)) return -1;
-  return P.tpg;
+  return P.G * P.tpg;
 }
 
 extern "C" int srlz_convn_fwd(const float* x, const float* wpack, float* y, float* stats_partial, const float* x_bnp,
@@ -2580,7 +2589,7 @@ extern "C" int srlz_convn_fwd(const float* x, const float* wpack, float* y, floa
   SRLZ_REQUIRE(x && wpack && y, SRLZ_ERR_NULL, "convn_fwd: null pointer");
   ConvProg P;
   if (int rc = convn_program(&P, d)) return rc;
-  const int ntiles = P.tpg;
+  const int ntiles = P.G * P.tpg;
   const size_t lds = convn_lds_bytes(P);
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "convn: tile needs %zu bytes of LDS", lds);
   SRLZ_MAX_LDS(convN_fwd_kernel, lds);
@@ -2588,8 +2597,9 @@ extern "C" int srlz_convn_fwd(const float* x, const float* wpack, float* y, floa
   while ((1 << cshift) < d->cin) ++cshift;
   SRLZ_REQUIRE((1 << cshift) == d->cin && d->cin <= 512, SRLZ_ERR_BAD_DESC, "convn: %d input channels (a power of two from 64 to 512)", d->cin);
   // (the row table keeps pixel indices in 28 bits, the staging 32-bit float offsets)
-  SRLZ_REQUIRE((long long)d->n * d->hi * d->wi * d->cin < (1LL << 32) && (long long)d->n * d->hi * d->wi < (1LL << 28), SRLZ_ERR_BAD_DESC,
-               "convn: %d images of %d x %d x %d are beyond the tile tables' 32-bit offsets", d->n, d->hi, d->wi, d->cin);
+  // (per BatchNorm group: P.N images)
+  SRLZ_REQUIRE((long long)P.N * d->hi * d->wi * d->cin < (1LL << 32) && (long long)P.N * d->hi * d->wi < (1LL << 28), SRLZ_ERR_BAD_DESC,
+               "convn: a group of %d images of %d x %d x %d is beyond the tile tables' 32-bit offsets", P.N, d->hi, d->wi, d->cin);
   int only_tap = -1;
   if (d->ksize == 1) {  // the tap of the 3x3 program that carries the 1x1 kernel: weight slab 4 = (ky, kx) = (1, 1)
     for (int t = 0; t < NTAPS; ++t)

@@ -482,12 +482,17 @@ class SRL4robotics(BaseLearner):
         decoded_obs = decoded_next_obs = None
         recon_loss = None  # the reconstruction / generation loss when it was taken inside the last ConvTranspose
         if self.use_triplets:
-            # anchor / positive / negative views stacked along channels (reference learner.py:383-391); the frozen trunk runs
-            # once per view (six passes per step, each with its own BatchNorm batch statistics, as in the reference)
-            states, positive_states, negative_states = self.model.forwardTriplets(
-                obs[:, :3].contiguous(), obs[:, 3:6].contiguous(), obs[:, 6:].contiguous())
-            next_states, _next_positive, _next_negative = self.model.forwardTriplets(
-                next_obs[:, :3].contiguous(), next_obs[:, 3:6].contiguous(), next_obs[:, 6:].contiguous())
+            # anchor / positive / negative views stacked along channels (reference learner.py:383-391: six trunk calls per step, each
+            # with its own BatchNorm batch statistics) — here ONE batched pass of the frozen trunk with six BatchNorm groups in the
+            # reference's call order (round 6; `_use_pair = False`: the six separate passes, kept for the tests)
+            if self._use_pair:
+                states, positive_states, negative_states, next_states = self.model.forwardTripletPair(obs, next_obs)
+            else:
+                states, positive_states, negative_states = self.model.model(obs[:, :3].contiguous()), \
+                    self.model.model(obs[:, 3:6].contiguous()), self.model.model(obs[:, 6:].contiguous())
+                next_states = self.model.model(next_obs[:, :3].contiguous())
+                self.model.model(next_obs[:, 3:6].contiguous())
+                self.model.model(next_obs[:, 6:].contiguous())
         elif self.use_autoencoder:
             (states, decoded_obs), (next_states, decoded_next_obs), recon_loss = self._forwardPair(obs, next_obs, (obs, next_obs, True))
         elif self.use_dae:

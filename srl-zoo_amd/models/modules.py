@@ -76,7 +76,22 @@ class SRLModules(BaseForwardModel, BaseInverseModel, BaseRewardModel):
 
     def forwardTriplets(self, anchor, positive, negative):
         """(model(anchor), model(positive), model(negative)) — reference modules.py:92-100."""
+        if hasattr(self.model, "forwardViews"):  # one batched pass of the frozen trunk, one BatchNorm group per view
+            return tuple(self.model.forwardViews([anchor, positive, negative]))
         return self.model(anchor), self.model(positive), self.model(negative)
+
+    def forwardTripletPair(self, obs, next_obs):
+        """The six trunk calls of one time-contrastive step (reference models/learner.py:383-391: forwardTriplets on the three views
+        of obs, then of next_obs) as ONE batched pass with six BatchNorm groups in that call order.
+        obs / next_obs: [B, 9, W, H] = anchor ; positive ; negative views stacked along channels.
+        Returns (states, positive_states, negative_states, next_states) — the reference discards the other two of next_obs."""
+        views = [obs[:, :3], obs[:, 3:6], obs[:, 6:], next_obs[:, :3], next_obs[:, 3:6], next_obs[:, 6:]]
+        if hasattr(self.model, "forwardViews") and obs.shape == next_obs.shape:
+            out = self.model.forwardViews(views, want=[True, True, True, True, False, False])
+            return out[0], out[1], out[2], out[3]
+        states, positive, negative = self.forwardTriplets(*[v.contiguous() for v in views[:3]])
+        next_states, _, _ = self.forwardTriplets(*[v.contiguous() for v in views[3:]])
+        return states, positive, negative, next_states
 
 
 class SRLModulesSplit(BaseForwardModel, BaseInverseModel, BaseRewardModel):

@@ -99,13 +99,29 @@ class EmbeddingNet(BaseModelSRL):
         self.conv_layers.fc = nn.Linear(n_units, embedding_size)
         self.fc = nn.Sequential(nn.PReLU(), nn.Linear(embedding_size, state_dim))
 
-    def forward(self, x):
-        hotpath.require_gpu(x, "EmbeddingNet")
-        feat = hotpath.resnet18_forward(self.conv_layers, x, self.conv_layers.training)  # [B, 512], no gradient
+    def _head(self, feat):
         x = hotpath.linear(self.conv_layers.fc, feat)
         x = x.view(x.size(0), -1)
         x = ops.PReLUFn.apply(x, self.fc[0].weight)
         return hotpath.linear(self.fc[1], x)
+
+    def forward(self, x):
+        hotpath.require_gpu(x, "EmbeddingNet")
+        feat = hotpath.resnet18_forward(self.conv_layers, x, self.conv_layers.training)  # [B, 512], no gradient
+        return self._head(feat)
+
+    def forwardViews(self, views, want=None):
+        """[self(v) for v in views] with ONE pass of the frozen trunk over all the views batched along n, one BatchNorm group per
+        view (hotpath.resnet18_forward(groups=len(views))): features, running statistics and num_batches_tracked are those of the
+        separate calls in list order (the reference makes them one after the other, models/learner.py:383-391 via
+        modules.py:92-100).  want[i] = False: the trunk still sees view i (its BatchNorm statistics move, as in the reference) but
+        the head is not run for it and None is returned in its place."""
+        hotpath.require_gpu(views[0], "EmbeddingNet")
+        b = views[0].shape[0]
+        assert all(v.shape == views[0].shape for v in views), "the views of one batched trunk pass have one shape"
+        x = th.cat([ops.frames_as_float(v) for v in views], 0)
+        feat = hotpath.resnet18_forward(self.conv_layers, x, self.conv_layers.training, groups=len(views))
+        return [self._head(feat[i * b:(i + 1) * b]) if (want is None or want[i]) else None for i in range(len(views))]
 
     def getStates(self, observations):
         """For inference the forward pass is done on the positive observation (first view)."""

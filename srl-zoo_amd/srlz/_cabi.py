@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrlz_hip.so")
 
 
-ABI_VERSION = 102  # include/srlz.h SRLZ_ABI_VERSION these prototypes were written for
+ABI_VERSION = 103  # include/srlz.h SRLZ_ABI_VERSION these prototypes were written for
 
 
 class SrlzError(RuntimeError):
@@ -36,7 +36,10 @@ class PoolDesc(Structure):
 
 class ConvNDesc(Structure):
     _fields_ = [("n", c_int), ("hi", c_int), ("wi", c_int), ("ho", c_int), ("wo", c_int), ("cin", c_int), ("cout", c_int),
-                ("ksize", c_int), ("stride", c_int), ("pad", c_int)]
+                ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("groups", c_int)]
+
+    def __init__(self, n, hi, wi, ho, wo, cin, cout, ksize, stride, pad, groups=1):
+        super(ConvNDesc, self).__init__(n, hi, wi, ho, wo, cin, cout, ksize, stride, pad, groups)
 
 
 class BnBwdOperand(Structure):
@@ -76,9 +79,10 @@ _PROTOS = {
     "srlz_convn_pack_weights": (c_int, [P, P, _CN, P]),
     "srlz_convn_fwd_tiles": (c_int, [_CN]),
     "srlz_convn_fwd": (c_int, [P, P, P, P, P, _CN, P]),
-    "srlz_bn_finalize_chunks": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "srlz_bn_finalize_chunks_workspace": (c_size_t, [c_int, c_int]),
+    "srlz_bn_finalize_chunks": (c_int, [P, c_int, c_int, c_int, c_longlong, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params_chunks": (c_int, [P, P, P, P, c_float, c_int, P, P]),
-    "srlz_bn_add_relu": (c_int, [P, P, P, P, P, c_longlong, c_int, P]),
+    "srlz_bn_add_relu": (c_int, [P, P, P, P, P, c_longlong, c_int, c_int, P]),
     "srlz_avgpool_nhwc": (c_int, [P, P, c_int, c_int, c_int, P]),
     "srlz_prelu_fwd": (c_int, [P, P, P, c_longlong, P]),
     "srlz_prelu_bwd": (c_int, [P, P, P, P, P, c_longlong, P]),

@@ -174,20 +174,24 @@ def _packed(conv, d):
     return cached[1]
 
 
-def _bn_record(bn, stats, tiles, count, training, device):
-    """One 256-float record per block of 64 channels of a C-channel BatchNorm2d (train: batch statistics + momentum update
-    of the running statistics + num_batches_tracked; eval: running statistics)."""
+def _bn_record(bn, stats, tiles, count, training, device, groups=1):
+    """One 256-float record per BatchNorm group and block of 64 channels of a C-channel BatchNorm2d, [groups][C / 64][256] (train:
+    per-group batch statistics, the running statistics take the groups' momentum updates in order, num_batches_tracked += groups;
+    eval: running statistics, the same record for every group).  tiles counts all groups, count is per group."""
     chunks = bn.num_features // 64
-    bnp = torch.empty(256 * chunks, dtype=torch.float32, device=device)
     if training:
-        nbytes = ops.C.bn_bwd_workspace(0)
+        bnp = torch.empty(256 * chunks * groups, dtype=torch.float32, device=device)
+        nbytes = ops.C.bn_finalize_chunks_workspace(chunks, groups)
         ws = ops._ws(nbytes, device)
-        ops.C.bn_finalize_chunks(ops.ptr(stats), tiles, chunks, count, ops.ptr(bn.weight), ops.ptr(bn.bias), ops.BN_EPS,
+        ops.C.bn_finalize_chunks(ops.ptr(stats), tiles, chunks, groups, count, ops.ptr(bn.weight), ops.ptr(bn.bias), ops.BN_EPS,
                                  ops.BN_MOMENTUM, ops.ptr(bn.running_mean), ops.ptr(bn.running_var),
                                  ops.ptr(bn.num_batches_tracked), ops.ptr(bnp), ops.ptr(ws), nbytes, ops.stream())
     else:
+        bnp = torch.empty(256 * chunks, dtype=torch.float32, device=device)
         ops.C.bn_eval_params_chunks(ops.ptr(bn.weight), ops.ptr(bn.bias), ops.ptr(bn.running_mean), ops.ptr(bn.running_var),
                                     ops.BN_EPS, chunks, ops.ptr(bnp), ops.stream())
+        if groups > 1:
+            bnp = bnp.repeat(groups)
     return bnp
 
 
@@ -203,59 +207,66 @@ def _packed64(conv, d):
     return cached[1]
 
 
-def _convn(x, conv, bn, training, x_bnp=None):
-    """raw = conv(x or relu(bn_prev(x))) for an NHWC tensor + the BatchNorm record of `bn` over that output."""
+def _convn(x, conv, bn, training, x_bnp=None, groups=1):
+    """raw = conv(x or relu(bn_prev(x))) for an NHWC tensor + the BatchNorm record(s) of `bn` over that output; `groups` independent
+    calls batched along n (x_bnp and the returned records are [groups][channel blocks][256])."""
     n, hi, wi, cin = x.shape
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     ho, wo = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
     if cin == 64 and conv.out_channels == 64 and k == 3 and s == 1 and p == 1:
         # layer1 of the trunk (four 64 -> 64 3x3 convolutions at 56 x 56): the auto-encoder's own conv2 kernel — row tables, 16-byte
         # epilogue stores, fused relu(bn(.)) operand — instead of the general-channel-count kernel (0.73 against 0.56 of the matrix peak)
-        d = ops.conv64_desc(n, hi, wi, 1, 1, False, 1)
+        d = ops.conv64_desc(n, hi, wi, 1, 1, False, groups)
         y = torch.empty((n, ho, wo, 64), dtype=torch.float32, device=x.device)
         tiles = ops.C.conv64_fwd_tiles(d)
         stats = torch.empty((1, tiles, 128), dtype=torch.float32, device=x.device) if training else None
         ops.C.conv64_fwd(ops.ptr(x), ops.ptr(_packed64(conv, d)[0]), None, ops.ptr(y), ops.ptr(stats), ops.ptr(x_bnp), d, ops.stream())
-        return y, _bn_record(bn, stats, tiles, n * ho * wo, training, x.device)
-    d = ops.ConvNDesc(n, hi, wi, ho, wo, cin, conv.out_channels, k, s, p)
+        return y, _bn_record(bn, stats, tiles, n // groups * ho * wo, training, x.device, groups)
+    d = ops.ConvNDesc(n, hi, wi, ho, wo, cin, conv.out_channels, k, s, p, groups)
     y = torch.empty((n, ho, wo, conv.out_channels), dtype=torch.float32, device=x.device)
     tiles = ops.C.convn_fwd_tiles(d)
     stats = torch.empty((conv.out_channels // 64, tiles, 128), dtype=torch.float32, device=x.device) if training else None
     ops.C.convn_fwd(ops.ptr(x), ops.ptr(_packed(conv, d)), ops.ptr(y), ops.ptr(stats), ops.ptr(x_bnp), d, ops.stream())
-    return y, _bn_record(bn, stats, tiles, n * ho * wo, training, x.device)
+    return y, _bn_record(bn, stats, tiles, n // groups * ho * wo, training, x.device, groups)
 
 
-def resnet18_forward(trunk, x, training):
+def resnet18_forward(trunk, x, training, groups=1):
     """torchvision resnet18 up to (and including) avgpool: x [B,3,224,224] (reference layout) -> [B,512] features.
     Forward only (the trunk is frozen, reference models/triplet.py:17-19): runs under no_grad, the result carries no
-    gradient.  `training` selects BatchNorm's mode exactly as nn.Module.train()/eval() would."""
+    gradient.  `training` selects BatchNorm's mode exactly as nn.Module.train()/eval() would.
+    groups > 1 (round 6): x holds `groups` trunk calls of B / groups images each, batched along n — the anchor / positive / negative
+    views of obs and of next_obs of one time-contrastive step (reference models/learner.py:383-391 + modules.py:92-100: six
+    `self.model(view)` calls).  Every BatchNorm works per group (its own batch statistics, the running statistics moved once per group,
+    in call order, num_batches_tracked += groups): features, running statistics and counters are those of `groups` separate calls,
+    with one launch per layer instead of six and six times the tiles per launch."""
     x = ops.frames_as_float(x)
     require_gpu(x, "resnet18 trunk")
     with torch.no_grad():
         x = ops._check(x, "resnet18 input")
         n, c, h, w = x.shape
         assert c == 3, "the ResNet-18 trunk takes one 3-channel view at a time"
+        assert groups >= 1 and n % groups == 0, (n, groups)
         # stem: Conv2d(3,64,7,2,3) -> BatchNorm2d -> ReLU -> MaxPool2d(3,2,1): the kernels of the auto-encoder's first block
-        d = ops._skinny_desc(n, c, h, w, 0)
+        d = ops._skinny_desc(n, c, h, w, 0, groups)
         y = torch.empty((n, d.hf, d.wf, 64), dtype=torch.float32, device=x.device)
         tiles = ops.C.skinny_tiles(d)
         stats = torch.empty((1, tiles, 128), dtype=torch.float32, device=x.device) if training else None
         ops.C.conv1_fwd(ops.ptr(x), ops.ptr(trunk.conv1.weight), ops.ptr(y), ops.ptr(stats), d, ops.stream())
-        bnp = _bn_record(trunk.bn1, stats, tiles, n * d.hf * d.wf, training, x.device)
+        bnp = _bn_record(trunk.bn1, stats, tiles, n // groups * d.hf * d.wf, training, x.device, groups)
         hp, wp = (d.hf + 2 - 3) // 2 + 1, (d.wf + 2 - 3) // 2 + 1
         act = torch.empty((n, hp, wp, 64), dtype=torch.float32, device=x.device)
-        ops.C.bn_relu_pool_fwd(ops.ptr(y), ops.ptr(bnp), ops.ptr(act), None, ops.PoolDesc(n, d.hf, d.wf, hp, wp, 1, 0, 1), ops.stream())
+        ops.C.bn_relu_pool_fwd(ops.ptr(y), ops.ptr(bnp), ops.ptr(act), None, ops.PoolDesc(n, d.hf, d.wf, hp, wp, 1, 0, groups), ops.stream())
         for layer in (trunk.layer1, trunk.layer2, trunk.layer3, trunk.layer4):
             for block in layer:
-                c1, rec1 = _convn(act, block.conv1, block.bn1, training)
-                c2, rec2 = _convn(c1, block.conv2, block.bn2, training, x_bnp=rec1)
+                c1, rec1 = _convn(act, block.conv1, block.bn1, training, groups=groups)
+                c2, rec2 = _convn(c1, block.conv2, block.bn2, training, x_bnp=rec1, groups=groups)
                 out = torch.empty_like(c2)
                 pixels, chunks = c2.numel() // c2.shape[3], c2.shape[3] // 64
                 if block.downsample is not None:
-                    cd, recd = _convn(act, block.downsample[0], block.downsample[1], training)
-                    ops.C.bn_add_relu(ops.ptr(c2), ops.ptr(rec2), ops.ptr(cd), ops.ptr(recd), ops.ptr(out), pixels, chunks, ops.stream())
+                    cd, recd = _convn(act, block.downsample[0], block.downsample[1], training, groups=groups)
+                    ops.C.bn_add_relu(ops.ptr(c2), ops.ptr(rec2), ops.ptr(cd), ops.ptr(recd), ops.ptr(out), pixels, chunks, groups, ops.stream())
                 else:
-                    ops.C.bn_add_relu(ops.ptr(c2), ops.ptr(rec2), ops.ptr(act), None, ops.ptr(out), pixels, chunks, ops.stream())
+                    ops.C.bn_add_relu(ops.ptr(c2), ops.ptr(rec2), ops.ptr(act), None, ops.ptr(out), pixels, chunks, groups, ops.stream())
                 act = out
         n, ho, wo, ch = act.shape
         feat = torch.empty((n, ch), dtype=torch.float32, device=x.device)

@@ -235,7 +235,10 @@ def device_identity(index=None):
         return socket.gethostname(), "cpu"  # (the CPU tests of the multi-rank control flow)
     index = torch.cuda.current_device() if index is None else index
     p = torch.cuda.get_device_properties(index)
-    return socket.gethostname(), "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    pci = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    # (partitioned GPUs can share a PCI address: the device's UUID, when the runtime reports one, tells the partitions apart)
+    uuid = str(getattr(p, "uuid", "") or "")
+    return socket.gethostname(), pci + ("/" + uuid if uuid.strip("0-") else "")
 
 
 def rank_devices():
@@ -250,7 +253,11 @@ def rank_devices():
         host, pci = device_identity()
         return {"ranks": 1, "devices": 1, "hosts": 1, "table": [[host, pci]]}
     table = [None] * size
-    dist.all_gather_object(table, list(device_identity()))
+    try:
+        mine = list(device_identity())
+    except Exception as e:  # an identity the runtime cannot report is never mistaken for a shared device
+        mine = ["rank%d" % rank, "unknown (%s)" % type(e).__name__]
+    dist.all_gather_object(table, mine)
     distinct = len(set(tuple(t) for t in table))
     info = {"ranks": size, "devices": distinct, "hosts": len(set(t[0] for t in table)), "table": table}
     env_world = int(os.environ.get("WORLD_SIZE", size))
@@ -295,7 +302,7 @@ def numa_cpus_of_device(index=None, sysfs="/sys"):
     frames are written into shared memory next to the GPU's PCIe root and are not bounced between sockets."""
     import os
     try:
-        pci = device_identity(index)[1] if not isinstance(index, str) else index
+        pci = device_identity(index)[1].split("/")[0] if not isinstance(index, str) else index
         node = int(open(os.path.join(sysfs, "bus/pci/devices", pci, "numa_node")).read().strip())
         if node < 0:
             return None

@@ -165,6 +165,66 @@ def test_triplet_train_steps_ride_along_the_oracle():
         assert float((fp.flat.double() - expect).abs().max()) <= 3e-7
 
 
+@pytest.mark.parametrize("B", [2, 5])
+def test_six_views_in_one_trunk_pass_are_six_trunk_calls(B):
+    """Round 6: the six trunk calls of a time-contrastive step (reference models/learner.py:383-391 via modules.py:92-100) run as ONE
+    batched pass with six BatchNorm groups (hotpath.resnet18_forward(groups=6): `groups` in srlz_convn_fwd / srlz_bn_finalize_chunks /
+    srlz_bn_add_relu and in the auto-encoder's conv1 / pooling / conv2 kernels).  Same tiles, same accumulation order, per-group
+    statistics staged with the single-call geometry: features, every running statistic after its six momentum updates in call order
+    and num_batches_tracked are BIT-IDENTICAL to six separate calls — and the whole training step (losses, gradient bucket,
+    parameters after Adam) is the same step."""
+    import models.learner as learner
+    import preprocessing.preprocess as pre
+    from losses.losses import LossManager
+    from srlz import hotpath
+    pre.N_CHANNELS = 9
+    model = _build().to("cuda")
+    model.train()
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    obs, nxt = _views(B, 23)
+    views = [v.contiguous().cuda() for v in (obs[:, :3], obs[:, 3:6], obs[:, 6:], nxt[:, :3], nxt[:, 3:6], nxt[:, 6:])]
+    trunk = model.model.conv_layers
+    sep = torch.cat([hotpath.resnet18_forward(trunk, v, True) for v in views])
+    after_sep = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(init)
+    one = hotpath.resnet18_forward(trunk, torch.cat(views), True, groups=6)
+    torch.cuda.synchronize()
+    assert torch.equal(one, sep)
+    after_one = model.state_dict()
+    moved = 0
+    for k in init:
+        assert torch.equal(after_one[k], after_sep[k]), k
+        if "running_mean" in k and "conv_layers" in k:
+            moved += int(not torch.equal(after_one[k], init[k]))
+        if "num_batches_tracked" in k and "conv_layers" in k:
+            assert int(after_one[k]) == int(init[k]) + 6, k
+    assert moved == 20  # every BatchNorm of the trunk (stem + 16 in the blocks + 3 downsample branches)
+    # eval mode: one record for all groups
+    model.load_state_dict(init)
+    model.eval()
+    with torch.no_grad():
+        e_one = hotpath.resnet18_forward(trunk, torch.cat(views), False, groups=6)
+        e_sep = torch.cat([hotpath.resnet18_forward(trunk, v, False) for v in views])
+    assert torch.equal(e_one, e_sep)
+
+    # ---- the training step: batched (default) against the six separate calls (_use_pair = False)
+    learner.BATCH_SIZE = B
+    act = torch.from_numpy(np.random.RandomState(B).randint(0, 6, (B,)).astype(np.int64)).view(-1, 1).cuda()
+    out = []
+    for use_pair in (True, False):
+        srl = learner.SRL4robotics(16, model_type="custom_cnn", seed=4, learning_rate=1e-3, cuda=True, multi_view=True,
+                                   losses=["triplet", "inverse"], n_actions=6, log_folder="/tmp")
+        srl._use_pair = use_pair
+        lm = LossManager(srl.model, None)
+        loss = srl.trainStep(obs.cuda(), nxt.cuda(), act, lm)
+        torch.cuda.synchronize()
+        out.append((float(loss.detach()), lm.lossValues(), srl.flat_params.grad.clone(), srl.flat_params.flat.clone(),
+                    {k: v.detach().clone() for k, v in srl.model.state_dict().items()}))
+    (l1, v1, g1, p1, sd1), (l0, v0, g0, p0, sd0) = out
+    assert l1 == l0 and v1 == v0 and torch.equal(g1, g0) and torch.equal(p1, p0)
+    assert all(torch.equal(sd1[k], sd0[k]) for k in sd0)
+
+
 def test_train_cli_multi_view_triplet(tmp_path):
     """`python train.py --multi-view --losses triplet ...` end to end: 9-channel loader, EmbeddingNet, checkpoint with
     torchvision's key names, learned states from the first view."""

@@ -8,6 +8,10 @@
 #   _pmc_traffic.json               HBM bytes per launch and kernel (PMC FETCH_SIZE / WRITE_SIZE, separate passes)
 #   _pmc_mfma.json                  per kernel: matrix-pipe busy fraction, measured clock, LDS bank-conflict cycles
 #                                   (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, SQ_LDS_BANK_CONFLICT in one pass + kernel trace)
+#   _instmix.txt                    per MFMA kernel: VALU / SALU / LDS / VMEM instructions per MFMA, wave-cycle split (tools/pmc_instmix.sh)
+#   _bench_{vae_c6_bs128,triplet_bs128,ae_bs256_u8,ae_bs256_hostinput}.json   the other configurations / input modes
+#   _bench_gloo8.json (or _rccl8.json on an 8-GPU box)   eight ranks
+# ONE invocation = ONE lease = ONE csrc_sha16 in every file (bench.py's roofline.kernel_trace_source names the CSV of the same tag).
 # Copy the files you want judged into profiles/.
 tag=${1:-rXX}
 export TMPDIR=/tmp
@@ -92,5 +96,33 @@ for name, a in acc.items():
                            "lds_bank_conflict_cycles_per_launch": round(a["SQ_LDS_BANK_CONFLICT"] / a["launches"])}
 json.dump(mf, open("gpurun_out/%s_pmc_mfma.json" % tag, "w"), indent=1, sort_keys=True)
 PY
-[ "$2" != "pmc" ] && tail -1 gpurun_out/${tag}_bench_ae_bs256.json | cut -c1-300
-ls gpurun_out/${tag}_pmc_*.json
+# instruction mix per MFMA kernel and the split of its wave cycles (two more PMC passes) -> <tag>_instmix.txt
+bash tools/pmc_instmix.sh $tag -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-vae-leg --allow-short > /dev/null 2>&1
+[ -f gpurun_out/instmix_${tag}.txt ] && mv gpurun_out/instmix_${tag}.txt gpurun_out/${tag}_instmix.txt
+if [ "$2" != "pmc" ]; then
+# the other configurations of BASELINE.json and the input modes, same sources, same box
+python bench.py --no-cpu-baseline --no-kernel-timers --losses vae --channels 6 --batch-size 128 --steps 40 > gpurun_out/${tag}_bench_vae_c6_bs128.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --no-cpu-baseline --no-kernel-timers --losses triplet --batch-size 128 --steps 10 > gpurun_out/${tag}_bench_triplet_bs128.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --no-cpu-baseline --no-kernel-timers --u8-resident --steps 30 > gpurun_out/${tag}_bench_ae_bs256_u8.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --no-cpu-baseline --no-kernel-timers --host-input --steps 30 > gpurun_out/${tag}_bench_ae_bs256_hostinput.json 2>> gpurun_out/${tag}_bench.err
+# eight ranks: RCCL when the box has eight GPUs, else the gloo debug topology on the GPUs there are (a functional line, not a scaling number)
+ngpu=$(python -c "import torch; print(torch.cuda.device_count())")
+if [ "$ngpu" -ge 8 ]; then
+  python bench.py --gpus 8 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_rccl8.json 2>> gpurun_out/${tag}_bench.err
+else
+  SRLZ_DIST_BACKEND=gloo python bench.py --gpus 8 --batch-size 32 --steps 10 --warmup 3 --no-vae-leg > gpurun_out/${tag}_bench_gloo8.json 2>> gpurun_out/${tag}_bench.err
+fi
+python - "$tag" <<'PY'
+import json, glob, sys
+tag = sys.argv[1]
+for f in sorted(glob.glob("gpurun_out/%s_bench_*.json" % tag)):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+        r = d.get("roofline", {})
+        print(f.split("/")[-1], d["value"], d["ms_per_step"], "vae", d.get("vae", {}).get("ms_per_step"), "north*", d.get("north_star", {}).get("aggregate_frac"),
+              "roofline", r.get("frac"), r.get("avg_launch_us"), "sha", r.get("csrc_sha16"), "step", d.get("step_roofline", {}).get("frac_of_fp32_mfma_peak"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+fi
+ls gpurun_out/${tag}_pmc_*.json gpurun_out/${tag}_instmix.txt
