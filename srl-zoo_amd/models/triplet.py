@@ -7,7 +7,8 @@ is not installed here, and the pre-trained weights cannot be downloaded: `ResNet
 torchvision ResNet-18 module tree (same sub-module names -> same state_dict keys, same construction order and
 initialisers: kaiming_normal_(fan_out, relu) convolutions, BatchNorm weight 1 / bias 0), so a torchvision `resnet18` state_dict
 loads as is (`SRLZ_RESNET18_WEIGHTS=/path/to/resnet18.pth`, else the random initialisation stays).  PARITY IS UNPINNED for
-the trunk: there is no reference run to compare with, only the CPU oracle's restatement (oracle/torch_twin.py).
+the trunk against the reference: there is no reference run to compare with, only the CPU oracle's restatement (oracle/torch_twin.py),
+which tests/test_oracle_resnet_independent.py holds to Hugging Face transformers' independent ResNet-18 on the same weights.
 
 The containers hold parameters only; the forward runs the HIP kernels (srlz/hotpath.py::resnet18_forward): forward-only —
 nothing is back-propagated through a frozen trunk — with BatchNorm in whatever mode the module is in (the reference leaves
