@@ -132,6 +132,18 @@ static int build_program(ConvProg* P, int gather, int stride, int pad, int N, in
   for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) cnt[kcls[ky] * stride + kcls[kx]]++;
   for (int i = 0; i < nclass; ++i) for (int j = i + 1; j < nclass; ++j)
     if (cnt[order[j]] > cnt[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+  if (nclass == 4 && cnt[order[1]] == cnt[order[2]]) {
+    // Of the two 2-tap classes the one whose taps reach LESS far ahead comes first (round 6).  conv64_bwd_fused_kernel keeps the
+    // classes of a tile in two alternating LDS buffers (classes 0 / 2 in one, 1 / 3 in the other): with the {0, +1} class second
+    // and the 1-tap class fourth the second buffer needs TM + 1 rows instead of TM + PW, which is what makes room for a second
+    // weight slab (one barrier per tap instead of two).  Every kernel reads the order from the program: results differ from the
+    // other order by the summation order of the taps only.
+    int reach[4] = {0, 0, 0, 0};
+    for (int c = 0; c < 4; ++c)
+      for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
+        if (kcls[ky] * stride + kcls[kx] == c) { const int o = kd[ky] * P->PW + kd[kx]; if (o > reach[c]) reach[c] = o; }
+    if (reach[order[2]] < reach[order[1]]) { int t = order[1]; order[1] = order[2]; order[2] = t; }
+  }
   int nt = 0;
   P->min_off = 0; int max_off = 0;
   for (int g = 0; g < nclass; ++g) {
@@ -813,6 +825,10 @@ __device__ __forceinline__ void gtab_build(unsigned* __restrict__ tab, const Con
   }
 }
 
+// NJ: how many of the thread's six rows (32 j + (t >> 4)) this class needs — a class whose taps reach at most `off` positions ahead
+// reads rows [0, TM + off) of its buffer, so the 2-tap class with offsets {0, 1} needs 129 rows (NJ = 5) and the 1-tap class 128
+// (NJ = 4): the rows beyond were requested, rebuilt and landed for nobody (3 of a tile's 24 row slots per thread; round 6).
+template <int NJ = GP_BATCH>
 __device__ __forceinline__ void gather_request(GatherRows& r, const float* __restrict__ src, const float* __restrict__ y,
                                                const unsigned* __restrict__ tab, int cls, int W) {
   int t = threadIdx.x;
@@ -821,12 +837,13 @@ __device__ __forceinline__ void gather_request(GatherRows& r, const float* __res
   const unsigned delta = (unsigned)((cls >> 1) * W + (cls & 1));
   const unsigned* __restrict__ tp = tab + (t >> 4) * GT_P;
   const uint4 e03 = *(const uint4*)tp;
-  const uint2 e45 = *(const uint2*)(tp + 4);
+  uint2 e45 = {0u, 0u};
+  if constexpr (NJ > 4) e45 = *(const uint2*)(tp + 4);
   const unsigned e[GP_BATCH] = {e03.x, e03.y, e03.z, e03.w, e45.x, e45.y};
-  static_assert(GP_BATCH == 6, "the table read above takes six rows");
+  static_assert(GP_BATCH == 6 && NJ >= GP_CORE && NJ <= GP_BATCH, "the table read above takes six rows");
   unsigned okmask = 0;
 #pragma unroll
-  for (int j = 0; j < GP_BATCH; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     // branch-free: m = all ones where the row's pixel of this class exists; any other row reads pixel 0 and is zeroed when it lands
     const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)e[j], (unsigned)cls, 1u);
     const unsigned off = ((((e[j] >> 4) + delta) << 6) & m) + slot * 4;
@@ -1119,6 +1136,11 @@ struct FusedBwd {
   float* wpartial;       // [workgroups][9 * 4096 + 64]
 };
 
+// rows per thread the second / fourth class of a tile need (gather_request<NJ>): their taps reach at most 1 / 0 positions ahead
+// (fused_bwd_ok checks it: build_program puts the 2-tap class {0, +1} of a stride-2 ConvTranspose's data gradient second, the 1-tap class {0} last)
+constexpr int FB_NJ1 = 5, FB_NJ3 = 4;
+constexpr int FB_REACH1 = FB_NJ1 * GP_RP - TM, FB_REACH3 = FB_NJ3 * GP_RP - TM;  // 32 and 0 positions
+
 struct YRows { f32x4 v[4]; unsigned ok; };  // the tile's 128 rows of y_prev: rows (t >> 4) + 32 j
 
 // ... and of the tile's own 128 positions in the low-resolution tensor (y_prev): entry = pixel index << 1 | 1, 0 = outside;
@@ -1174,6 +1196,7 @@ __device__ __forceinline__ void ytile_land(float* __restrict__ Ys, YRows& r, con
 }
 
 // the landing of a class's rows: BatchNorm + ReLU backward rebuilt from (dA, y), zero outside the tensor; bs4 += the tile's own rows (every dy element belongs to exactly one tile's range)
+template <int NJ = GP_BATCH>
 __device__ __forceinline__ void gather_land_sum(float* __restrict__ lds, GatherRows& r, int nrows, const float* __restrict__ lrec,
                                                 f32x4& bs4) {
   int t = threadIdx.x;
@@ -1182,7 +1205,7 @@ __device__ __forceinline__ void gather_land_sum(float* __restrict__ lds, GatherR
   const f32x4 sc4 = *(const f32x4*)(lrec + slot * 4), sh4 = *(const f32x4*)(lrec + 64 + slot * 4);
   const f32x4 c0 = *(const f32x4*)(lrec + 128 + slot * 4), c1 = *(const f32x4*)(lrec + 192 + slot * 4);
 #pragma unroll
-  for (int j = 0; j < GP_BATCH; ++j) {
+  for (int j = 0; j < NJ; ++j) {  // (rows 32 NJ .. of the buffer keep an earlier class's values: this class's taps never read them)
     const int R = (t >> 4) + GP_RP * j;
     const bool ok = (r.ok >> j) & 1u;
     f32x4 v = r.v[j];
@@ -1238,11 +1261,13 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
                                                                         const OpFuse fuse_all, const FusedBwd fb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nrows = TM + P.span;
-  float* As0 = (float*)smem;                // class rows, double-buffered: classes 0 / 2 here,
-  float* As1 = As0 + nrows * 64;            // classes 1 / 3 here
-  float* Ys = As1 + nrows * 64;             // [TM][64]: relu(bn(y_prev)) of the tile's positions
-  float* Bs = Ys + TM * 64;                 // 64 x 64 weight slab of the current tap
-  int* rowinfo = (int*)(Bs + 4096);         // [2 (tile parity)][3][TM]
+  constexpr int nrows1 = TM + FB_REACH1;    // what the short-reach classes (second, fourth) can touch of their buffer
+  float* As0 = (float*)smem;                // class rows, double-buffered: classes 0 / 2 here (TM + span rows),
+  float* As1 = As0 + nrows * 64;            // classes 1 / 3 here (TM + 32 rows)
+  float* Ys = As1 + nrows1 * 64;            // [TM][64]: relu(bn(y_prev)) of the tile's positions
+  float* Bs0 = Ys + TM * 64;                // 2 x (64 x 64): the weight slabs of the current tap and of the next one (round 6: the slab of
+                                            // tap t + 1 is written WHILE tap t runs, so a tap needs one barrier, not two)
+  int* rowinfo = (int*)(Bs0 + 2 * 4096);    // [2 (tile parity)][3][TM]
   float* frec = (float*)(rowinfo + 6 * TM); // [G <= 2][4][64]: scale, shift, c0, c1 of this layer's BatchNorm backward
   float* xrec = frec + 512;                 // [G <= 2][2][64]: scale, shift of the previous layer's BatchNorm
   unsigned* gtab = (unsigned*)(xrec + 256); // row tables of the tile whose rows are being requested: source side (gtab_build)
@@ -1308,6 +1333,19 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
     gather_land_sum(As0, rr, nrows, frec + grp * 256, bs4);
     ytile_land(Ys, yr, xrec + grp * 128);
   }
+  // The slab of the first tile's tap 0 goes to slab buffer 0 now (published by that tap's barrier) and tap 1's is requested: from here
+  // on tap t writes the slab of tap t + 1 into the buffer tap t - 1 read, so a tap needs ONE barrier — the one that says "everybody is
+  // done with tap t - 1" — instead of two (until round 6: slab write and landings sat between two barriers, with every matrix pipe idle)
+  // Tap t reads slab buffer t & 1 (compile-time); a tile has nine taps, so its last tap and the next tile's first both read buffer 0:
+  // tap 8 writes no slab, the next tile's first slab is written behind the tile's closing barrier instead.
+  {
+    f32x4* wdst = (f32x4*)Bs0;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) wdst[wave * (BV * 64) + lane + i * 64] = breg[i];
+    const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[1] * 4096);
+#pragma unroll
+    for (int i = 0; i < BV; ++i) breg[i] = wsrc[wave * (BV * 64) + lane + i * 64];
+  }
   for (; k < tcnt; k += wpx, parity ^= 1) {
     const int tile = tbase + k;
     const int grp = (P.G > 1 && tile >= P.tpg) ? 1 : 0;
@@ -1342,7 +1380,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
     asm volatile("" : "+v"(lane_t));
     const int h_t = lane_t >> 5, l31_t = lane_t & 31;
     const int arow0 = wrow * 32 + l31_t;
-    const float* brow = Bs + (wcol * 32 + l31_t) * 64;
+    const int brow_off = (wcol * 32 + l31_t) * 64;
     const int bkey = lane_t & 15;
     const int bslot_t = wave * (BV * 64) + lane_t;
 
@@ -1350,31 +1388,37 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
     for (int ti = 0; ti < NTAPS; ++ti) {
       // class of this tap and the LDS buffer that holds it (compile-time after unrolling)
       const float* Ac = (ti < 4 || ti == 6 || ti == 7) ? As0 : As1;
-      __syncthreads();  // all waves are done with the previous tap's Bs — and with the class buffer that is about to be refilled
-      {
-        f32x4* wdst = (f32x4*)Bs;
+      const float* Bcur = Bs0 + (ti & 1) * 4096;
+      float* Bnext = Bs0 + ((ti + 1) & 1) * 4096;
+      // ONE barrier per tap: every wave has finished tap ti - 1, so the slab buffer that tap read (Bnext) and the class buffer that is
+      // about to be refilled are free, and this tap's slab (written during tap ti - 1) and the rows landed meanwhile are visible.
+      // Everything up to the MFMAs below runs per wave, un-synchronised: a wave that is done landing starts its matrix work while its
+      // neighbours are still landing.
+      __syncthreads();
+      if (ti < NTAPS - 1) {
+        f32x4* wdst = (f32x4*)Bnext;  // the slab of tap ti + 1
 #pragma unroll
         for (int i = 0; i < BV; ++i) wdst[bslot_t + i * 64] = breg[i];
-      }
-      {
-        const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[(ti + 1) % NTAPS] * 4096);
+        // ... and the request for the one after it (behind tap 7: tap 0 of the next tile — same weights — which is written behind the
+        // tile's closing barrier)
+        const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[(ti + 2) % NTAPS] * 4096);
 #pragma unroll
         for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot_t + i * 64];
       }
       // rows requested two taps ago land now (the in-order vmcnt has completed them with the slab just written): class 1 -> As1
-      // while taps 2, 3 still read class 0 in As0; class 2 -> As0 once class 0 is done; class 3 -> As1; the next tile's class 0 -> As0
-      if (ti == 2) gather_land_sum(As1, rr, nrows, lrec, bs4);
+      // while taps 2, 3 still read class 0 in As0; class 2 -> As0 once class 0 is done; class 3 -> As1; the next tile's class 0 -> As0.
+      // (Two barriers — those of taps ti + 1 and ti + 2 — lie between a landing and the first tap that reads it.)
+      if (ti == 2) gather_land_sum<FB_NJ1>(As1, rr, nrows1, lrec, bs4);
       if (ti == 4) gather_land_sum(As0, rr, nrows, lrec, bs4);
-      if (ti == 6) gather_land_sum(As1, rr, nrows, lrec, bs4);
+      if (ti == 6) gather_land_sum<FB_NJ3>(As1, rr, nrows1, lrec, bs4);
       if (ti == 8) gather_land_sum(As0, rr, nrows, frec + grp2 * 256, bs4);  // (past the last tile: every row masked off -> zeros; no
                                                                              // run-time branch around a landing, or its join costs a full vmcnt(0))
-      // the NEXT tile's row tables, between the last request of this tile (behind tap 4's second barrier) and the first of the next
-      // (tap 6); past the end: no rows -> every entry 0 -> every row reads pixel 0 and is dropped.  (Tap 5 has no landing.)
+      // the NEXT tile's row tables, between the last request of this tile (tap 4) and the first of the next (tap 6) — the barriers of
+      // taps 5 and 6 fence both sides; past the end: no rows -> every entry 0 -> every row reads pixel 0 and is dropped
       if (ti == 5) { gtab_build(gtab, P, q02, more ? nrows : 0); ytab_build(ytab, P, q02, more); }
-      __syncthreads();
-      if (ti == 0) gather_request(rr, src, ysrc, gtab, cls1, P.Ws);
+      if (ti == 0) gather_request<FB_NJ1>(rr, src, ysrc, gtab, cls1, P.Ws);
       if (ti == 2) gather_request(rr, src, ysrc, gtab, cls2, P.Ws);
-      if (ti == 4) gather_request(rr, src, ysrc, gtab, cls3, P.Ws);
+      if (ti == 4) gather_request<FB_NJ3>(rr, src, ysrc, gtab, cls3, P.Ws);
       if (ti == 6) gather_request(rr, src_all + grp2 * P.src_gstride, fuse_all.y + grp2 * P.src_gstride, gtab, cls0, P.Ws);
       if (ti == 8) ytile_request(yr, fb.x + grp2 * P.dst_gstride, ytab);
       __builtin_amdgcn_sched_barrier(0);
@@ -1385,7 +1429,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
           const f32x4 a = *(const f32x4*)((const char*)Ac + (abase ^ (kc << 5)));
-          const f32x4 b = *(const f32x4*)(brow + (((kc * 2 + h_t) ^ bkey) << 2));
+          const f32x4 b = *(const f32x4*)(Bcur + brow_off + (((kc * 2 + h_t) ^ bkey) << 2));
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
         }
@@ -1401,10 +1445,18 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
       else if (ti < 8) wgrad_steps<1, 4>(aw2, Ys, As0, off_c2, wmi, wnj, 4 * (ti - 6), h_p, l31_p);
       else wgrad_steps<1, 4>(aw3, Ys, As1, off_c3, wmi, wnj, 4 * wk, h_p, l31_p);
     }
-    __syncthreads();  // every wave is done with the last tap's slab, with class 3 and with the a-tile
+    __syncthreads();  // every wave is done with the last tap's slab (buffer 0), with class 3 and with the a-tile
+    {  // the next tile's first slab -> buffer 0, its second requested (cf. the prologue)
+      f32x4* wdst = (f32x4*)Bs0;
+#pragma unroll
+      for (int i = 0; i < BV; ++i) wdst[bslot_t + i * 64] = breg[i];
+      const f32x4* wsrc = (const f32x4*)(wpack + (size_t)P.tw[1] * 4096);
+#pragma unroll
+      for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot_t + i * 64];
+    }
     ytile_land(Ys, yr, xrec + grp2 * 128);  // (past the last tile: zeros)
-    {  // flush of the data gradient (see conv64_gather_pipe_kernel)
-      float* S = Bs + wave * 512;
+    {  // flush of the data gradient (see conv64_gather_pipe_kernel) through slab buffer 1 (tap 7 was its last reader)
+      float* S = Bs0 + 4096 + wave * 512;
       const int eg = lane_t >> 3, eslot = lane_t & 7;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -2769,7 +2821,11 @@ static bool fused_bwd_ok(const ConvProg& P) {
   bool grouped = P.s2 && P.ss == 2 && P.G <= 2 && P.min_off == 0 && !P.dbg;
   for (int t = 0; t < NTAPS; ++t) grouped = grouped && P.tsrc[t] == P.tsrc[t < 4 ? 0 : t < 6 ? 4 : t < 8 ? 6 : 8] && P.tdst[t] == 0;
   const bool fits32 = P.src_gstride * 4 < (1LL << 32) - 65536 && P.dst_gstride * 4 < (1LL << 32) - 65536;
-  return grouped && fits32 && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && P.G * P.tpg >= 8;
+  // the second and fourth class are requested and landed for the rows their taps can reach only (FB_NJ1 / FB_NJ3); they share the
+  // short LDS buffer As1 (TM + FB_REACH1 rows)
+  const bool reach = P.toff[4] >= 0 && P.toff[5] >= 0 && P.toff[4] < FB_REACH1 && P.toff[5] < FB_REACH1 && P.toff[8] >= 0 &&
+                     P.toff[8] <= FB_REACH3;
+  return grouped && fits32 && reach && TM + P.span <= GP_RP * GP_BATCH && GP_RP <= P.PHW && P.G * P.tpg >= 8;
 }
 
 extern "C" int srlz_conv64_gather_pipe_supported(const srlz_conv64_desc* d, int backward_data) {
@@ -2809,7 +2865,9 @@ extern "C" int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const f
   SRLZ_REQUIRE(ws_bytes >= (size_t)grid * (NTAPS * 4096 + 64) * sizeof(float), SRLZ_ERR_WORKSPACE,
                "conv64_bwd_fused: workspace too small (%zu bytes)", ws_bytes);
   hipStream_t st = as_stream(stream);
-  const size_t lds = (size_t)(TM + P.span) * 256 * 2 + (size_t)TM * 256 + 16384 + 6 * TM * 4 + 512 * 4 + 256 * 4 + (GT_WORDS + YT_WORDS) * 4;
+  // class rows (TM + span; TM + 32 for the short-reach classes), the a-tile, two weight slabs, rowinfo, records, row tables
+  const size_t lds = (size_t)(TM + P.span) * 256 + (size_t)(TM + FB_REACH1) * 256 + (size_t)TM * 256 + 2 * 16384 + 6 * TM * 4 + 512 * 4 +
+                     256 * 4 + (GT_WORDS + YT_WORDS) * 4;
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64_bwd_fused: tile needs %zu bytes of LDS", lds);
   FusedBwd fb;
   fb.x = x; fb.x_bnp = x_bnp; fb.wpartial = (float*)ws;
