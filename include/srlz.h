@@ -307,6 +307,17 @@ int srlz_bn_eval_params(const float* gamma, const float* beta, const float* runn
 /* running = (1-m)*running + m*batch_stat, once (replay of a previous call's statistics). */
 int srlz_bn_replay(const float* batch_stat, float momentum, float* running_mean, float* running_var,
                    srlz_stream_t stream);
+/* The same for up to SRLZ_BN_REPLAY_MAX different layers in ONE launch, each with its nn.BatchNorm2d.num_batches_tracked (+= 1; may be
+ * NULL): the learner's getStates(obs) after forward(obs) in train mode (models/learner.py:402 with models.py:131-139) re-runs the three
+ * encoder BatchNorms of a frame on the same batch.  `items` is a HOST array. */
+#define SRLZ_BN_REPLAY_MAX 8
+typedef struct {
+  const float* batch_stat;  /* [128]: batch mean, unbiased batch variance (srlz_bn_finalize's batch_stat record of the group) */
+  float* running_mean;
+  float* running_var;
+  long long* num_batches_tracked;
+} srlz_bn_replay_item;
+int srlz_bn_replay_many(const srlz_bn_replay_item* items, int n, float momentum, srlz_stream_t stream);
 
 typedef struct srlz_pool_desc_s {
   int n, h, w;      /* input  [N,h,w,64] */

@@ -679,6 +679,30 @@ extern "C" int srlz_bn_replay(const float* batch_stat, float momentum, float* ru
   return 0;
 }
 
+// several layers' replays in ONE launch (the VAE getStates quirk replays the three encoder BatchNorms of a frame: one launch instead of
+// three + three counter increments); items travel by value in the kernel arguments
+struct ReplayTable { srlz_bn_replay_item it[SRLZ_BN_REPLAY_MAX]; };
+__global__ void bn_replay_many_kernel(const ReplayTable t, float momentum) {
+  const srlz_bn_replay_item it = t.it[blockIdx.x];
+  const int c = threadIdx.x;
+  it.running_mean[c] = (1.f - momentum) * it.running_mean[c] + momentum * it.batch_stat[c];
+  it.running_var[c] = (1.f - momentum) * it.running_var[c] + momentum * it.batch_stat[64 + c];
+  if (c == 0 && it.num_batches_tracked) it.num_batches_tracked[0] += 1;
+}
+
+extern "C" int srlz_bn_replay_many(const srlz_bn_replay_item* items, int n, float momentum, srlz_stream_t stream) {
+  SRLZ_REQUIRE(items && n >= 1 && n <= SRLZ_BN_REPLAY_MAX, SRLZ_ERR_BAD_DESC, "bn_replay_many: %d items (1 .. %d)", n, SRLZ_BN_REPLAY_MAX);
+  ReplayTable t;
+  for (int i = 0; i < n; ++i) {
+    SRLZ_REQUIRE(items[i].batch_stat && items[i].running_mean && items[i].running_var, SRLZ_ERR_NULL, "bn_replay_many: null pointer");
+    t.it[i] = items[i];
+  }
+  for (int i = n; i < SRLZ_BN_REPLAY_MAX; ++i) t.it[i] = items[0];
+  hipLaunchKernelGGL(bn_replay_many_kernel, dim3(n), dim3(64), 0, as_stream(stream), t, momentum);
+  SRLZ_LAUNCHED();
+  return 0;
+}
+
 extern "C" int srlz_bn_relu_pool_fwd(const float* y, const float* bnp, float* pooled, uint8_t* argmax,
                                      const srlz_pool_desc* d, srlz_stream_t stream) {
   if (int rc = check_pool(d)) return rc;

@@ -42,6 +42,11 @@ class ConvNDesc(Structure):
         super(ConvNDesc, self).__init__(n, hi, wi, ho, wo, cin, cout, ksize, stride, pad, groups)
 
 
+class BnReplayItem(Structure):
+    """srlz_bn_replay_item"""
+    _fields_ = [("batch_stat", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p)]
+
+
 class BnBwdOperand(Structure):
     """srlz_bn_bwd_operand: raw device pointers + count; build with bn_bwd_operand() so the tensors stay referenced."""
     _fields_ = [("y", c_void_p), ("bnp", c_void_p), ("sums", c_void_p), ("count", c_longlong), ("training", c_int),
@@ -121,6 +126,7 @@ _PROTOS = {
     "srlz_bn_finalize": (c_int, [P, c_int, c_int, c_longlong, P, P, c_float, c_float, c_int, P, P, P, P, P, P, c_size_t, P]),
     "srlz_bn_eval_params": (c_int, [P, P, P, P, c_float, P, P]),
     "srlz_bn_replay": (c_int, [P, c_float, P, P, P]),
+    "srlz_bn_replay_many": (c_int, [POINTER(BnReplayItem), c_int, c_float, P]),
     "srlz_bn_relu_pool_fwd": (c_int, [P, P, P, P, _PD, P]),
     "srlz_bn_bwd_workspace": (c_size_t, [c_longlong]),
     "srlz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, c_size_t, _PD, P]),

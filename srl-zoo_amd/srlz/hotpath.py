@@ -108,11 +108,10 @@ def replay_encoder_bn(seq, stats, group=0):
     """Second train-mode pass over the same batch (VAE getStates quirk, models/learner.py:402): running statistics
     receive the same batch statistics once more and num_batches_tracked advances; outputs are unchanged.
     `group`: which BatchNorm group's statistics (the batch was one half of a batched pair)."""
-    for bn, st in zip((seq[1], seq[5], seq[9]), stats):
-        def update(bn=bn, st=st[128 * group:128 * (group + 1)]):
-            ops.bn_replay(st, bn.running_mean, bn.running_var)
-            bn.num_batches_tracked.add_(1)
-        ops._ordered_bn_update(bn.running_mean, update)
+    bns = (seq[1], seq[5], seq[9])
+    items = [(st[128 * group:128 * (group + 1)], bn.running_mean, bn.running_var, bn.num_batches_tracked) for bn, st in zip(bns, stats)]
+    # (one launch for the three layers, counters included — until round 6: three launches + three torch increments per frame)
+    ops._ordered_bn_update([bn.running_mean for bn in bns], lambda: ops.bn_replay_many(items))
 
 
 def decoder_forward(seq, z, training):

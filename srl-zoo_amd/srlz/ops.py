@@ -360,15 +360,19 @@ _bn_last_update = {}
 
 
 def _ordered_bn_update(running_mean, fn):
-    key = running_mean.data_ptr()
-    cur = torch.cuda.current_stream(running_mean.device)
-    prev = _bn_last_update.get(key)
-    if prev is not None and prev[0] != cur.cuda_stream:
-        cur.wait_event(prev[1])
+    """Run `fn` (a launch that updates the running statistics of one layer — or of several: a list) behind the previous update of the
+    same buffers, whichever stream that was enqueued on."""
+    rms = running_mean if isinstance(running_mean, (list, tuple)) else [running_mean]
+    cur = torch.cuda.current_stream(rms[0].device)
+    for rm in rms:
+        prev = _bn_last_update.get(rm.data_ptr())
+        if prev is not None and prev[0] != cur.cuda_stream:
+            cur.wait_event(prev[1])
     fn()
     ev = torch.cuda.Event()
     ev.record(cur)
-    _bn_last_update[key] = (cur.cuda_stream, ev)
+    for rm in rms:
+        _bn_last_update[rm.data_ptr()] = (cur.cuda_stream, ev)
 
 
 def _bn_params(stats, count, gamma, beta, running_mean, running_var, training, device, tick=None):
@@ -1420,3 +1424,13 @@ def adam_step_dev(p, g, m, v, lr, step_dev, bc_dev, grad_scale=1.0, betas=(0.9, 
 
 def bn_replay(batch_stat, running_mean, running_var):
     C.bn_replay(ptr(batch_stat), BN_MOMENTUM, ptr(running_mean), ptr(running_var), stream())
+
+
+def bn_replay_many(items):
+    """[(batch_stat [128], running_mean, running_var, num_batches_tracked)] of up to 8 layers: one more momentum update each with the
+    given batch statistics and the counters += 1, in ONE launch."""
+    table = (C.BnReplayItem * len(items))()
+    for i, (st, rm, rv, tick) in enumerate(items):
+        table[i].batch_stat, table[i].running_mean, table[i].running_var = st.data_ptr(), rm.data_ptr(), rv.data_ptr()
+        table[i].num_batches_tracked = tick.data_ptr() if tick is not None else None
+    C.bn_replay_many(table, len(items), BN_MOMENTUM, stream())

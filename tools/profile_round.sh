@@ -18,8 +18,8 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 if [ "$2" != "pmc" ]; then  # (second argument "pmc": only the PMC passes below — a source change that does not warrant the whole set)
 python bench.py --steps 100 --warmup 10 > gpurun_out/${tag}_bench_ae_bs256.json 2> gpurun_out/${tag}_bench.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --losses vae > gpurun_out/${tag}_bench_vae_bs256.json 2>> gpurun_out/${tag}_bench.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --losses autoencoder inverse forward > gpurun_out/${tag}_bench_aeif_bs256.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --steps 60 --warmup 10 --no-cpu-baseline --losses vae > gpurun_out/${tag}_bench_vae_bs256.json 2>> gpurun_out/${tag}_bench.err
+python bench.py --steps 60 --warmup 10 --no-cpu-baseline --losses autoencoder inverse forward > gpurun_out/${tag}_bench_aeif_bs256.json 2>> gpurun_out/${tag}_bench.err
 python bench.py --steps 150 --warmup 10 --no-cpu-baseline --no-kernel-timers --batch-size 32 > gpurun_out/${tag}_bench_ae_bs32.json 2>> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-vae-leg \
     > gpurun_out/${tag}_bench_ae_bs256_profiled.json 2> /dev/null
