@@ -45,7 +45,7 @@ enum srlz_status {
  * 101 (round 4): srlz_convT_out_bwd_fused carries three gain arguments (added in round 3 without a bump); its partial records and
  *                workspace follow the strip geometry of csrc/convt_out.hip; srlz_convT_out_fwd_loss_workgroups counts those strips'
  *                workgroups. */
-#define SRLZ_ABI_VERSION 103
+#define SRLZ_ABI_VERSION 104
 int srlz_version(void);
 const char* srlz_last_error(void);
 /* Number of CUs of the current device (used by callers to size persistent grids / workspaces). */
@@ -131,9 +131,17 @@ int srlz_conv64_bwd_fused_supported(const srlz_conv64_desc* d);
  * will list the launch under. */
 int srlz_conv64_gather_pipe_supported(const srlz_conv64_desc* d, int backward_data);
 size_t srlz_conv64_bwd_fused_workspace(const srlz_conv64_desc* d);
+/* x_bn_bwd_partial (may be NULL; round 6): dx of this call is dA of the BatchNorm + ReLU that produced the layer's input from x —
+ * the previous decoder block's (models/models.py:67-77) — and the tile that writes it holds relu(bn(x)) of the same positions, so the
+ * launch also leaves that layer's two BatchNorm-backward sums,  sum dA*[bn(x)>0]  and  sum dA*[bn(x)>0]*xhat,  as
+ * srlz_conv64_bwd_fused_bn_rows(d) partial records of 128 floats ([groups][rows / groups][128]) for srlz_bn_bwd_finalize_partials:
+ * srlz_bn_relu_bwd_sums' separate pass over (x, dx) disappears.  (Channels whose BatchNorm scale is (almost) 0 are summed from x
+ * itself by a companion launch inside this call — normally a ~4 us no-op.) */
+int srlz_conv64_bwd_fused_bn_rows(const srlz_conv64_desc* d);
 int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const float* dy, const srlz_bn_bwd_operand* dy_bn,
-                          const float* wpack_bwd, float* dx, float* dw_ref, float* dbias /* may be NULL */, void* ws, size_t ws_bytes,
-                          const srlz_conv64_desc* d, srlz_stream_t stream);
+                          const float* wpack_bwd, float* dx, float* dw_ref, float* dbias /* may be NULL */,
+                          float* x_bn_bwd_partial /* may be NULL */, void* ws, size_t ws_bytes, const srlz_conv64_desc* d,
+                          srlz_stream_t stream);
 /* workspace (bytes) for bwd_weight */
 size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d);
 /* dw_ref (reference layout) = d(loss)/d(w); dbias[64] = sum of dy over n,h,w (may be NULL).

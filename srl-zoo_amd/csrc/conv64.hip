@@ -1130,10 +1130,35 @@ __global__ __launch_bounds__(GP_THREADS, 4) void conv64_gather_pipe_kernel(const
 // Results: dx bit-identical to conv64_fwd_kernel<4, true>'s; dW / db differ from the two-kernel path by summation order only
 // (per-workgroup partials, fixed-order fp64 second stage: deterministic).
 // ---------------------------------------------------------------------------------------------------------------
+// which channels of a BatchNorm record cannot give xhat back from the activation (shared by the fused kernel and its companion)
+__host__ __device__ __forceinline__ bool bnpart_zero_scale(float scale, float shift) {
+  return fabsf(scale) <= 1e-3f * fabsf(shift) || scale == 0.f;
+}
+
+// Folding one lane bit of TWO per-lane values with one add (gfx950): fold32(a, b) = { a[l] + a[l + 32] in lanes l < 32, b[l - 32] + b[l]
+// in lanes l >= 32 };  fold16(a, b) = { a's rows (16 lanes) 0 + 1 in row 0, b's rows 0 + 1 in row 1, a's 2 + 3 in row 2, b's 2 + 3 in row 3 }.
+__device__ __forceinline__ float fold32(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 struct FusedBwd {
   const float* x;        // raw y_prev [N, Hd, Wd, 64] (the ConvTranspose's input before BatchNorm + ReLU)
   const float* x_bnp;    // its BatchNorm record(s): a = relu(bn(x))
   float* wpartial;       // [workgroups][9 * 4096 + 64]
+  // Round 6: the data gradient this kernel writes is dA of the PREVIOUS layer's BatchNorm + ReLU (x is that layer's raw output), and the
+  // tile that writes it holds relu(bn(x)) of the same 128 positions in LDS (the weight gradient's operand) — so the flush also leaves
+  // the two BatchNorm-backward sums of that layer,  sum dz  and  sum dz * xhat  (dz = dA where relu(bn(x)) > 0; there the activation
+  // IS gamma * xhat + beta, so xhat follows from it), as partial records for srlz_bn_bwd_finalize_partials: the separate pass of
+  // srlz_bn_relu_bwd_sums over (x, dA) — 0.8 GB at the 55 x 55 layer — disappears.  bnpart: [groups][bn_rows][128] floats, rows
+  // 4 * tile + (wave & 3) of a group from this kernel (channels whose BatchNorm scale is (almost) 0 contribute 0 here: xhat cannot be
+  // recovered from the activation — the rows behind them come from conv64_bnpart_zero_scale_kernel); NULL = off.
+  float* bnpart;
+  int bn_rows;           // records per BatchNorm group
 };
 
 // rows per thread the second / fourth class of a tile need (gather_request<NJ>): their taps reach at most 1 / 0 positions ahead
@@ -1141,10 +1166,15 @@ struct FusedBwd {
 constexpr int FB_NJ1 = 5, FB_NJ3 = 4;
 constexpr int FB_REACH1 = FB_NJ1 * GP_RP - TM, FB_REACH3 = FB_NJ3 * GP_RP - TM;  // 32 and 0 positions
 
-struct YRows { f32x4 v[4]; unsigned ok; };  // the tile's 128 rows of y_prev: rows (t >> 4) + 32 j
+struct YRows { f32x4 v[4]; unsigned ok; };  // a thread's share of the tile's 128 rows of y_prev (ytile_row)
 
-// ... and of the tile's own 128 positions in the low-resolution tensor (y_prev): entry = pixel index << 1 | 1, 0 = outside;
-// row R at (R & 31) * 4 + (R >> 5).  Built by threads [256, 384).
+// The a-tile is WAVE-PRIVATE between its landing and the flush that reads it back (round 6): wave (wrow = wave & 3, wcol = wave >> 2)
+// requests, lands and — in the flush, for the BatchNorm-backward sums of the layer that produced y_prev — re-reads rows
+// 32 wrow + 8 j + (lane >> 3), j = 0..3, channels 32 wcol + 4 (lane & 7) ..: exactly the block of the data gradient it flushes.  So a
+// wave may read its block back BEHIND the tile's closing barrier and land the next tile's block over it without another barrier
+// (every other reader of the a-tile — the weight-gradient steps of all waves — sits between the tap barriers).
+// ... and the table of the tile's own 128 positions in the low-resolution tensor (y_prev): entry = pixel index << 1 | 1, 0 = outside;
+// row R at ((R >> 5) * 8 + (R & 7)) * 4 + ((R >> 3) & 3): one 16-byte read per thread.  Built by threads [256, 384).
 constexpr int YT_WORDS = GP_RP * 4;
 __device__ __forceinline__ void ytab_build(unsigned* __restrict__ tab, const ConvProg& P, int q0, bool live) {
   int R = (int)threadIdx.x - 256;
@@ -1156,20 +1186,21 @@ __device__ __forceinline__ void ytab_build(unsigned* __restrict__ tab, const Con
     const int a = fastdiv(rem, P.mPW, P.sPW);
     const int b = rem - a * P.PW;
     const bool ok = live && n < P.N && a < P.Hd && b < P.Wd;
-    tab[(R & (GP_RP - 1)) * 4 + (R >> 5)] = ok ? ((unsigned)((n * P.Hd + a) * P.Wd + b) << 1) | 1u : 0u;
+    tab[((R >> 5) * 8 + (R & 7)) * 4 + ((R >> 3) & 3)] = ok ? ((unsigned)((n * P.Hd + a) * P.Wd + b) << 1) | 1u : 0u;
   }
 }
 
 __device__ __forceinline__ void ytile_request(YRows& r, const float* __restrict__ x, const unsigned* __restrict__ tab) {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));
-  const int slot = t & 15;
-  const uint4 q = *(const uint4*)(tab + (t >> 4) * 4);
+  const int lane = t & 63, wave = t >> 6;
+  const int col = (wave >> 2) * 32 + (lane & 7) * 4;
+  const uint4 q = *(const uint4*)(tab + ((wave & 3) * 8 + (lane >> 3)) * 4);
   const unsigned e[4] = {q.x, q.y, q.z, q.w};
   unsigned okmask = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    r.v[j] = *(const f32x4*)(x + ((e[j] >> 1) << 6) + slot * 4);  // (a row outside reads pixel 0; zeroed when it lands)
+    r.v[j] = *(const f32x4*)(x + ((e[j] >> 1) << 6) + col);  // (a row outside reads pixel 0; zeroed when it lands)
     okmask |= (e[j] & 1u) << j;
   }
   r.ok = okmask;
@@ -1179,8 +1210,10 @@ __device__ __forceinline__ void ytile_request(YRows& r, const float* __restrict_
 __device__ __forceinline__ void ytile_land(float* __restrict__ Ys, YRows& r, const float* __restrict__ xrec) {
   int t = threadIdx.x;
   asm volatile("" : "+v"(t));
-  const int slot = t & 15;
-  const f32x4 sc4 = *(const f32x4*)(xrec + slot * 4), sh4 = *(const f32x4*)(xrec + 64 + slot * 4);
+  const int lane = t & 63, wave = t >> 6;
+  const int col = (wave >> 2) * 32 + (lane & 7) * 4;
+  const int row0 = (wave & 3) * 32 + (lane >> 3);
+  const f32x4 sc4 = *(const f32x4*)(xrec + col), sh4 = *(const f32x4*)(xrec + 64 + col);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const bool ok = (r.ok >> j) & 1u;
@@ -1191,7 +1224,7 @@ __device__ __forceinline__ void ytile_land(float* __restrict__ Ys, YRows& r, con
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(z4[e], 0.f, hi);
     }
-    *(f32x4*)(Ys + ((t >> 4) + GP_RP * j) * 64 + slot * 4) = v;
+    *(f32x4*)(Ys + (row0 + 8 * j) * 64 + col) = v;
   }
 }
 
@@ -1272,6 +1305,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
   float* xrec = frec + 512;                 // [G <= 2][2][64]: scale, shift of the previous layer's BatchNorm
   unsigned* gtab = (unsigned*)(xrec + 256); // row tables of the tile whose rows are being requested: source side (gtab_build)
   unsigned* ytab = gtab + GT_WORDS;         // ... and its own 128 positions in y_prev (ytab_build)
+  float* prec = (float*)(ytab + YT_WORDS);  // [G <= 2][3][64]: pA, pB, threshold — xhat = a * pA + pB where a = relu(bn(x)) > threshold
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1301,6 +1335,17 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
     fr[c] = sc; fr[64 + c] = sh; fr[128 + c] = c0; fr[192 + c] = c1;
     xrec[g * 128 + c] = fb.x_bnp[g * 256 + 128 + c];
     xrec[g * 128 + 64 + c] = fb.x_bnp[g * 256 + 192 + c];
+    {  // a = scale * x + shift = gamma * xhat + beta  =>  xhat = a * (invstd / scale) - (shift / scale + mean) * invstd; a channel whose
+       // |scale| is tiny against |shift| (exactly 0 included) would lose xhat in the cancellation: it contributes nothing here
+       // (threshold +inf) and is summed by conv64_bnpart_zero_scale_kernel from x itself (cf. the pooled-block epilogue, PSUM)
+      const float xmean = fb.x_bnp[g * 256 + c], xinv = fb.x_bnp[g * 256 + 64 + c];
+      const float xsc = fb.x_bnp[g * 256 + 128 + c], xsh = fb.x_bnp[g * 256 + 192 + c];
+      const bool zero = bnpart_zero_scale(xsc, xsh);
+      const float isc = zero ? 0.f : 1.f / xsc;
+      prec[g * 192 + c] = xinv * isc;
+      prec[g * 192 + 64 + c] = -(xsh * isc + xmean) * xinv;
+      prec[g * 192 + 128 + c] = zero ? __builtin_inff() : 0.f;
+    }
   }
 
   constexpr int BV = 1024 / GP_THREADS;
@@ -1311,6 +1356,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
     for (int i = 0; i < BV; ++i) breg[i] = wsrc[wave * (BV * 64) + lane + i * 64];
   }
   const unsigned dst_bytes = (unsigned)P.dst_gstride * 4u;
+  const __amdgpu_buffer_rsrc_t bnbuf = gp_buffer(fb.bnpart, fb.bnpart ? (unsigned)(P.G * fb.bn_rows) * 512u : 0u);
 
   f32x16 aw0[2], aw1[1], aw2[1], aw3[1];  // weight-gradient accumulators of the four classes
 #pragma unroll
@@ -1454,10 +1500,16 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
 #pragma unroll
       for (int i = 0; i < BV; ++i) breg[i] = wsrc[bslot_t + i * 64];
     }
-    ytile_land(Ys, yr, xrec + grp2 * 128);  // (past the last tile: zeros)
-    {  // flush of the data gradient (see conv64_gather_pipe_kernel) through slab buffer 1 (tap 7 was its last reader)
+    {  // flush of the data gradient (see conv64_gather_pipe_kernel) through this wave's own 2 KB of slab buffer 1 (tap 7 was its last
+       // reader).  Round 6: the lane that stores four channels of a position also reads relu(bn(x)) of the same four out of the a-tile —
+       // this wave's own block of it (ytile_request), so no barrier is needed before the next tile's block lands over it below — for the
+       // BatchNorm-backward sums of the layer that produced x (FusedBwd::bnpart): s = sum of dA where a > 0, q = sum of dA * a (a is 0
+       // where the ReLU is closed and outside the tensor, so q needs no mask); sum dz * xhat = pA q + pB s per lane.
       float* S = Bs0 + 4096 + wave * 512;
       const int eg = lane_t >> 3, eslot = lane_t & 7;
+      const int cbase = wcol * 32 + eslot * 4;  // this lane's four channels
+      const f32x4 pT = *(const f32x4*)(prec + grp * 192 + 128 + cbase);
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -1470,14 +1522,43 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
           const int rowl = eg + 8 * kk;
           const int row = wrow * 32 + 16 * half + rowl;
           const f32x4 v = *(const f32x4*)(S + rowl * 32 + eslot * 4);
+          const f32x4 av = *(const f32x4*)(Ys + row * 64 + cbase);  // relu(bn(x)) of the position; 0 outside the tensor
           const int n = ri[row];
           const int y = ri[TM + row], x = ri[2 * TM + row];
           const bool inside = n >= 0 && y < P.Hd && x < P.Wd;
           __builtin_amdgcn_raw_buffer_store_b128(v, dst, inside ? (unsigned)((n * P.Hd + y) * P.Wd + x) * 256u + wcol * 128 + eslot * 16 : GP_DROP,
                                                  0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s4[e] += av[e] > pT[e] ? v[e] : 0.f;
+            q4[e] = __builtin_fmaf(v[e], av[e], q4[e]);
+          }
         }
       }
+      {
+        const f32x4 pA = *(const f32x4*)(prec + grp * 192 + cbase), pB = *(const f32x4*)(prec + grp * 192 + 64 + cbase);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q4[e] = __builtin_fmaf(pA[e], q4[e], pB[e] * s4[e]);
+      }
+      // this wave's 32 rows = the eight row groups (lane bits 3-5) of the eight sums, as a transposing butterfly (gfx950's
+      // v_permlane32_swap / v_permlane16_swap: one add folds a lane bit of TWO values): 14 vector instructions instead of 24 ds_bpermute + 24
+      // adds, fixed order.  Afterwards lane L holds channel 4 eslot + {0, 2, 1, 3}[L >> 4] of s (in s4[0]) and of q (in q4[0]); the lanes
+      // with bit 3 clear leave the wave's half of record 4 * tile + wrow (branch-free: the other lanes — and every lane when bnpart is
+      // NULL, a zero-sized buffer — store out of range)
+      {
+        const float u0 = fold32(s4[0], s4[1]), u1 = fold32(s4[2], s4[3]), u2 = fold32(q4[0], q4[1]), u3 = fold32(q4[2], q4[3]);
+        float w0 = fold16(u0, u1), w1 = fold16(u2, u3);
+        w0 += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(w0), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+        w1 += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(w1), 0x128, 0xf, 0xf, false));
+        const int erow = lane_t >> 4;
+        const unsigned rec = (unsigned)(grp * fb.bn_rows + 4 * (tile - grp * P.tpg) + wrow) * 512u +
+                             (unsigned)(cbase + ((erow & 1) << 1) + (erow >> 1)) * 4u;
+        const bool mine = (lane_t & 8) == 0;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(w0), bnbuf, mine ? rec : GP_DROP, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(w1), bnbuf, mine ? rec + 256u : GP_DROP, 0, 0);
+      }
     }
+    ytile_land(Ys, yr, xrec + grp2 * 128);  // (past the last tile: zeros)
   }
 
   // ---- the workgroup's weight-gradient partial [9 (reference tap index)][64 ci][64 co] and bias partial [64]
@@ -1516,6 +1597,50 @@ __global__ __launch_bounds__(GP_THREADS, 2) void conv64_bwd_fused_kernel(const f
       for (int r = 0; r < GP_RP; ++r) t += red[r * 64 + tid];
       out[NTAPS * 4096 + tid] = t;
     }
+  }
+}
+
+// Companion of conv64_bwd_fused_kernel's BatchNorm-backward records (FusedBwd::bnpart): the channels whose BatchNorm scale is (almost)
+// 0 — xhat cannot be recovered from relu(bn(x)) there — summed from x itself, as srlz_bn_relu_bwd_sums does for every channel, into
+// the BNZ_BLOCKS records behind the fused kernel's.  A group without such a channel (the normal case) costs one ~4 us launch that
+// writes zero records; with one, this is a pass over (x, dA): rare, and slow on purpose.
+constexpr int BNZ_BLOCKS = 64;
+__global__ __launch_bounds__(256) void conv64_bnpart_zero_scale_kernel(const float* __restrict__ x, const float* __restrict__ x_bnp,
+                                                                      const float* __restrict__ da, float* __restrict__ bnpart,
+                                                                      long long pixels, int bn_rows, int first_row) {
+  const int g = blockIdx.y;  // BatchNorm group; pixels = positions of ONE group
+  x_bnp += g * 256;
+  x += (size_t)g * pixels * 64;
+  da += (size_t)g * pixels * 64;
+  const int c4 = threadIdx.x & 15;
+  const f32x4 mean = *(const f32x4*)(x_bnp + c4 * 4), invstd = *(const f32x4*)(x_bnp + 64 + c4 * 4);
+  const f32x4 sc = *(const f32x4*)(x_bnp + 128 + c4 * 4), sh = *(const f32x4*)(x_bnp + 192 + c4 * 4);
+  unsigned zmask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) zmask |= (bnpart_zero_scale(sc[j], sh[j]) ? 1u : 0u) << j;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (__syncthreads_or(zmask != 0)) {
+    for (long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < pixels; pix += (long long)gridDim.x * 16) {
+      const f32x4 v = *(const f32x4*)(x + pix * 64 + c4 * 4);
+      const f32x4 d = *(const f32x4*)(da + pix * 64 + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (((zmask >> j) & 1u) && v[j] * sc[j] + sh[j] > 0.f) {
+          s1[j] += (double)d[j];
+          s2[j] += (double)(d[j] * ((v[j] - mean[j]) * invstd[j]));
+        }
+    }
+  }
+  __shared__ double sm[16][128];
+  const int prow = threadIdx.x >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sm[prow][c4 * 4 + j] = s1[j]; sm[prow][64 + c4 * 4 + j] = s2[j]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sm[r][threadIdx.x];
+    bnpart[((size_t)g * bn_rows + first_row + blockIdx.x) * 128 + threadIdx.x] = (float)t;
   }
 }
 
@@ -2842,6 +2967,13 @@ extern "C" int srlz_conv64_bwd_fused_supported(const srlz_conv64_desc* d) {
   return fused_bwd_ok(P) ? 1 : 0;
 }
 
+extern "C" int srlz_conv64_bwd_fused_bn_rows(const srlz_conv64_desc* d) {
+  if (check_desc(d)) return -1;
+  ConvProg P;
+  if (program_for(&P, d, 1)) return -1;
+  return P.G * (4 * P.tpg + BNZ_BLOCKS);
+}
+
 extern "C" size_t srlz_conv64_bwd_fused_workspace(const srlz_conv64_desc* d) {
   if (check_desc(d)) return 0;
   ConvProg P;
@@ -2850,8 +2982,8 @@ extern "C" size_t srlz_conv64_bwd_fused_workspace(const srlz_conv64_desc* d) {
 }
 
 extern "C" int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const float* dy, const srlz_bn_bwd_operand* dy_bn,
-                                     const float* wpack_bwd, float* dx, float* dw_ref, float* dbias, void* ws, size_t ws_bytes,
-                                     const srlz_conv64_desc* d, srlz_stream_t stream) {
+                                     const float* wpack_bwd, float* dx, float* dw_ref, float* dbias, float* x_bn_bwd_partial,
+                                     void* ws, size_t ws_bytes, const srlz_conv64_desc* d, srlz_stream_t stream) {
   if (int rc = check_desc(d)) return rc;
   SRLZ_REQUIRE(d->transposed && d->stride == 2, SRLZ_ERR_BAD_DESC, "conv64_bwd_fused: ConvTranspose2d(64, 64, 3, stride 2) only");
   SRLZ_REQUIRE(x && x_bnp && dy && dy_bn && wpack_bwd && dx && dw_ref && ws, SRLZ_ERR_NULL, "conv64_bwd_fused: null pointer");
@@ -2867,10 +2999,11 @@ extern "C" int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const f
   hipStream_t st = as_stream(stream);
   // class rows (TM + span; TM + 32 for the short-reach classes), the a-tile, two weight slabs, rowinfo, records, row tables
   const size_t lds = (size_t)(TM + P.span) * 256 + (size_t)(TM + FB_REACH1) * 256 + (size_t)TM * 256 + 2 * 16384 + 6 * TM * 4 + 512 * 4 +
-                     256 * 4 + (GT_WORDS + YT_WORDS) * 4;
+                     256 * 4 + (GT_WORDS + YT_WORDS) * 4 + 2 * 192 * 4;
   SRLZ_REQUIRE(lds <= 160 * 1024, SRLZ_ERR_BAD_DESC, "conv64_bwd_fused: tile needs %zu bytes of LDS", lds);
   FusedBwd fb;
   fb.x = x; fb.x_bnp = x_bnp; fb.wpartial = (float*)ws;
+  fb.bnpart = x_bn_bwd_partial; fb.bn_rows = 4 * P.tpg + BNZ_BLOCKS;
   SRLZ_MAX_LDS(conv64_bwd_fused_kernel, lds);
   hipLaunchKernelGGL(conv64_bwd_fused_kernel, dim3(grid), dim3(GP_THREADS), lds, st, dy, wpack_bwd, dx, P, P.G * P.tpg, gf, fb);
   SRLZ_LAUNCHED();
@@ -2878,6 +3011,11 @@ extern "C" int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const f
   hipLaunchKernelGGL(conv64_wgrad_reduce, dim3((NTAPS * 4096 + 64 + 255) / 256), dim3(1024), 0, st, (const float*)ws, grid, dw_ref, dbias,
                      1, NTAPS * 4096 + 64);
   SRLZ_LAUNCHED();
+  if (x_bn_bwd_partial) {  // the records of the channels the fused kernel cannot sum from the activation (normally: zeros)
+    hipLaunchKernelGGL(conv64_bnpart_zero_scale_kernel, dim3(BNZ_BLOCKS, P.G), dim3(256), 0, st, x, x_bnp, (const float*)dx,
+                       x_bn_bwd_partial, (long long)P.N * P.Hd * P.Wd, fb.bn_rows, 4 * P.tpg);
+    SRLZ_LAUNCHED();
+  }
   return 0;
 }
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrlz_hip.so")
 
 
-ABI_VERSION = 103  # include/srlz.h SRLZ_ABI_VERSION these prototypes were written for
+ABI_VERSION = 104  # include/srlz.h SRLZ_ABI_VERSION these prototypes were written for
 
 
 class SrlzError(RuntimeError):
@@ -74,7 +74,8 @@ _PROTOS = {
     "srlz_conv64_bwd_fused_supported": (c_int, [_C64]),
     "srlz_conv64_gather_pipe_supported": (c_int, [_C64, c_int]),
     "srlz_conv64_bwd_fused_workspace": (c_size_t, [_C64]),
-    "srlz_conv64_bwd_fused": (c_int, [P, P, P, _BO, P, P, P, P, P, c_size_t, _C64, P]),
+    "srlz_conv64_bwd_fused": (c_int, [P, P, P, _BO, P, P, P, P, P, P, c_size_t, _C64, P]),
+    "srlz_conv64_bwd_fused_bn_rows": (c_int, [_C64]),
     "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, _BO, P, c_size_t, _C64, P]),
     "srlz_conv64_debug_program": (c_int, [_C64, c_int, POINTER(c_int), c_int]),
     "srlz_debug_placement": (c_int, [P, c_int, c_int, c_int, P]),
@@ -181,7 +182,7 @@ _PROTOS = {
 _NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
                "srlz_convT_out_bwd_fused_tiles", "srlz_convT_out_fwd_loss_workgroups", "srlz_conv64_bwd_fused_supported", "srlz_conv64_gather_pipe_supported",
                "srlz_convT_out_bwd_fused_supported",
-               "srlz_conv64_bwd_data_tiles",
+               "srlz_conv64_bwd_data_tiles", "srlz_conv64_bwd_fused_bn_rows",
                "srlz_conv64_debug_program", "srlz_comm_world"}
 
 EXPORTED = sorted(_PROTOS.keys())

@@ -659,10 +659,12 @@ class DecBlockFn(Function):
             db = _gbuf(ctx.params[3], 64, dy.device)
             nbytes = C.conv64_bwd_fused_workspace(d)
             ws = _ws(nbytes, dy.device, slot=1)
+            # with the producer's BatchNorm backward deferred (in_link), its two sums come out of this launch's flush as partial records
+            part = torch.empty((C.conv64_bwd_fused_bn_rows(d), 128), dtype=torch.float32, device=dy.device) if ctx.in_link is not None else None
             _launch("conv64_bwd_fused_kernel", _conv64_key(d, "dgrad+wgrad"), 2.0 * _conv64_flop(d),
-                    lambda: C.conv64_bwd_fused(ptr(y_prev), ptr(bnp), ptr(dy), dy_bn, ptr(packs[1]), ptr(da), ptr(dw), ptr(db), ptr(ws),
-                                               nbytes, d, stream()))
-            dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, gb=ctx.params[:2])
+                    lambda: C.conv64_bwd_fused(ptr(y_prev), ptr(bnp), ptr(dy), dy_bn, ptr(packs[1]), ptr(da), ptr(dw), ptr(db), ptr(part),
+                                               ptr(ws), nbytes, d, stream()))
+            dy_prev, dgamma, dbeta = _bn_backward_for_producer(ctx.in_link, y_prev, bnp, da, ctx.training, partial=part, gb=ctx.params[:2])
             gp, bp, wp, cp = ctx.params
             return dy_prev, None, _give(gp, dgamma), _give(bp, dbeta), None, None, None, _give(wp, dw), _give(cp, db), None, None, None
         # dy_bn not None: `dy` is dA of the following BatchNorm+ReLU; the data-gradient kernel rebuilds the true dy in its

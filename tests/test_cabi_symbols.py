@@ -29,7 +29,7 @@ def test_binding_covers_header(cabi):
 
 
 def test_version_and_error_text(cabi):
-    assert cabi.version() == cabi.ABI_VERSION == 103
+    assert cabi.version() == cabi.ABI_VERSION == 104
     d = cabi.Conv64Desc(1, 8, 8, 9, 9, 3, 1, 1, 0)  # inconsistent output size -> host-side rejection
     assert cabi._lib.srlz_conv64_fwd_tiles(ctypes.byref(d)) == -1
     assert "inconsistent" in cabi.error_text()

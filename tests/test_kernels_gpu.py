@@ -987,8 +987,9 @@ def test_total_loss_is_pythons_left_to_right_fp32_sum(C):
 
 
 
-@pytest.mark.parametrize("n,hi,groups,training", [(2, 27, 1, 1), (8, 27, 2, 1), (6, 55, 2, 1), (32, 13, 2, 1), (4, 27, 2, 0)])
-def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
+@pytest.mark.parametrize("n,hi,groups,training,zero_gamma", [(2, 27, 1, 1, False), (8, 27, 2, 1, True), (6, 55, 2, 1, False),
+                                                           (32, 13, 2, 1, False), (4, 27, 2, 0, True)])
+def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training, zero_gamma):
     """srlz_conv64_bwd_fused — data, weight and bias gradient of ConvTranspose2d(64,64,3,2) whose output went through
     BatchNorm2d + ReLU and whose input was relu(batchnorm(x)), from ONE staging of the rebuilt d(loss)/dy — against
     (i) fp64 autograd through relu(bn(x)) -> conv_transpose2d -> batch_norm -> relu per BatchNorm group, EVERY element of dx
@@ -1007,6 +1008,10 @@ def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
     x = torch.randn(n, 64, hi, hi, generator=g) * 1.2 + 0.1            # raw output of the previous layer
     w, b = torch.randn(64, 64, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g) * 0.1
     gx, bx = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    if zero_gamma:  # input-side BatchNorm channels without a usable scale: exactly 0 (with a positive and a negative shift) and tiny
+        gx[3], bx[3] = 0.0, 0.3
+        gx[17], bx[17] = 0.0, -0.2
+        gx[40], bx[40] = 1e-5, 0.25
     gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
     rm, rv = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
     da = torch.randn(n, 64, ho, ho, generator=g)
@@ -1023,7 +1028,8 @@ def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
         recs64.append((sc, sh))
         z = xs * sc + sh
         near = z.abs() < 1e-3
-        xs = torch.where(near, (torch.where(z >= 0, 2e-3, -2e-3) - sh) / sc, xs)
+        movable = (sc.abs() > 1e-2).expand_as(z)  # (a channel without a scale cannot be moved off the threshold — nor does it sit on it)
+        xs = torch.where(near & movable, (torch.where(z >= 0, 2e-3, -2e-3) - sh) / torch.where(sc.abs() > 1e-2, sc, torch.ones(())), xs)
         x[gi * per:(gi + 1) * per] = xs.float()
         assert float(((x[gi * per:(gi + 1) * per].double() * sc + sh).abs()).min()) > 5e-4
     # ---- device: forward through the C ABI to get y, its statistics and the backward sums
@@ -1087,13 +1093,29 @@ def test_conv64_bwd_fused_whole_block_backward(C, n, hi, groups, training):
     dw1, db1 = torch.full((64, 64, 3, 3), float("nan"), device=DEV), torch.full((64,), float("nan"), device=DEV)
     nb1 = C.conv64_bwd_fused_workspace(d)
     ws1 = torch.full((nb1 // 4,), float("nan"), device=DEV)
-    C.conv64_bwd_fused(C.ptr(xd), C.ptr(xbnp), C.ptr(dad), op1, C.ptr(packs[1]), C.ptr(dx1), C.ptr(dw1), C.ptr(db1), C.ptr(ws1), nb1, d, st)
-    # determinism: a second launch, bit for bit
+    rows = C.conv64_bwd_fused_bn_rows(d)
+    part1 = torch.full((rows, 128), float("nan"), device=DEV)
+    C.conv64_bwd_fused(C.ptr(xd), C.ptr(xbnp), C.ptr(dad), op1, C.ptr(packs[1]), C.ptr(dx1), C.ptr(dw1), C.ptr(db1), C.ptr(part1), C.ptr(ws1), nb1,
+                       d, st)
+    # determinism: a second launch, bit for bit (this one without the BatchNorm-backward records: the other outputs do not depend on them)
     dx2, dw2, db2 = torch.empty_like(dx1), torch.empty_like(dw1), torch.empty_like(db1)
-    C.conv64_bwd_fused(C.ptr(xd), C.ptr(xbnp), C.ptr(dad), op1, C.ptr(packs[1]), C.ptr(dx2), C.ptr(dw2), C.ptr(db2), C.ptr(ws1), nb1, d, st)
+    C.conv64_bwd_fused(C.ptr(xd), C.ptr(xbnp), C.ptr(dad), op1, C.ptr(packs[1]), C.ptr(dx2), C.ptr(dw2), C.ptr(db2), None, C.ptr(ws1), nb1, d, st)
     torch.cuda.synchronize()
     assert torch.isfinite(dx1).all() and torch.equal(dx1, dx0)
     assert torch.equal(dx2, dx1) and torch.equal(dw2, dw1) and torch.equal(db2, db1)
+    # ---- round 6: the BatchNorm-backward sums of the layer that produced x, out of the same launch's flush (+ its companion for the
+    # channels without a usable scale), against srlz_bn_relu_bwd_sums' separate pass over (x, dx) — sums per group, dgamma / dbeta
+    assert torch.isfinite(part1).all()
+    sums_a, dg_a, db_a = torch.empty(128 * groups, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    C.bn_bwd_finalize_partials(C.ptr(part1), rows, groups, C.ptr(sums_a), C.ptr(dg_a), C.ptr(db_a), C.ptr(bws), nbn, st)
+    sums_b, dg_b, db_b = torch.empty(128 * groups, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    C.bn_relu_bwd_sums(C.ptr(xd), C.ptr(xbnp), C.ptr(dx1), C.ptr(sums_b), C.ptr(dg_b), C.ptr(db_b), C.ptr(bws), nbn, n * hi * hi, groups, st)
+    torch.cuda.synchronize()
+    for got, want in ((sums_a, sums_b), (dg_a, dg_b), (db_a, db_b)):
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 2e-5 * scale, float((got - want).abs().max()) / scale
+    if zero_gamma:  # those channels DID go through the companion (the activation is the constant max(shift, 0) there)
+        assert float(sums_b.view(groups, 128)[:, 3].abs().min()) > 0 and float(sums_b.view(groups, 128)[:, 17].abs().max()) == 0.0
     # fp64 oracle with the decisions out of the way (docstring): EVERY element, every size
     dev_dx = (nchw(dx1).double().cpu() - dx_ref).abs() / float(dx_ref.abs().max())
     assert float(dev_dx.max()) < 1e-4, float(dev_dx.max())

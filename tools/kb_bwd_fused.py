@@ -28,10 +28,11 @@ for label, hi in (("convT4 55->111", 55), ("convT3 27->55", 27), ("convT2 13->27
     sums = torch.zeros(256, device="cuda")
     dw, db = torch.empty(64, 64, 3, 3, device="cuda"), torch.empty(64, device="cuda")
     nb = C.conv64_bwd_fused_workspace(d)
+    part = torch.empty(C.conv64_bwd_fused_bn_rows(d), 128, device="cuda") if os.environ.get("KB_BNPART", "1") != "0" else None
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     op = C.BnBwdOperand(y.data_ptr(), rec.data_ptr(), sums.data_ptr(), N // 2 * ho * ho, 1, None)
     report("%s block backward, ONE launch" % label,
-           *timeit(lambda: C.conv64_bwd_fused(C.ptr(x), C.ptr(rec), C.ptr(da), op, C.ptr(packs[1]), C.ptr(dx), C.ptr(dw), C.ptr(db), C.ptr(ws), nb, d, st)),
+           *timeit(lambda: C.conv64_bwd_fused(C.ptr(x), C.ptr(rec), C.ptr(da), op, C.ptr(packs[1]), C.ptr(dx), C.ptr(dw), C.ptr(db), C.ptr(part), C.ptr(ws), nb, d, st)),
            flop=2 * flop)
     if os.environ.get("KB_TWO", "1") != "0":
         nb2 = C.conv64_bwd_weight_workspace(d)
