@@ -142,6 +142,27 @@ int srlz_conv64_bwd_fused(const float* x, const float* x_bnp, const float* dy, c
                           const float* wpack_bwd, float* dx, float* dw_ref, float* dbias /* may be NULL */,
                           float* x_bn_bwd_partial /* may be NULL */, void* ws, size_t ws_bytes, const srlz_conv64_desc* d,
                           srlz_stream_t stream);
+/* ---- conv3x3 stride 1 pad 1 (conv2 of the encoder, models/models.py:54) as Winograd F(2x2, 3x3) on the fp32 matrix cores (round 6;
+ * csrc/wino.hip): 16 multiplications per (ci, co) and 2x2 output patch instead of 36 — what cuDNN, the reference's backend, runs for
+ * this layer.  Products and accumulation stay fp32; outputs differ from the direct fp32 chain by a few 1e-7 of the output scale and do
+ * not depend on how images are batched or grouped.  srlz_conv64_wino_supported: non-transposed, stride 1, pad 1, even sizes.
+ * upack_* = srlz_conv64_wino_packed_floats() floats each (G g G^T in the kernel's layout; fwd for srlz_conv64_wino_fwd, bwd for
+ * srlz_conv64_wino_bwd_data*; either may be NULL).  stats_partial: srlz_conv64_wino_tiles(d) records of 128 floats, group after group. */
+int srlz_conv64_wino_supported(const srlz_conv64_desc* d);
+size_t srlz_conv64_wino_packed_floats(void);
+int srlz_conv64_wino_pack_weights(const float* w_ref, float* upack_fwd, float* upack_bwd, srlz_stream_t stream);
+int srlz_conv64_wino_tiles(const srlz_conv64_desc* d);
+int srlz_conv64_wino_fwd(const float* x, const float* upack_fwd, const float* bias /* may be NULL */, float* y,
+                         float* stats_partial /* may be NULL */, const srlz_conv64_desc* d, srlz_stream_t stream);
+/* dx = d(loss)/dx from dy, same kernel with upack_bwd.  The _pool_sums form is srlz_conv64_bwd_data_pool_sums' (above): dx is the gradient
+ * of the pooled map `pd` describes and the launch also leaves the pooled block's two BatchNorm-backward sums as
+ * srlz_conv64_wino_bwd_data_rows(d) records of 128 floats (group after group; a group's last 64 records come from a companion launch
+ * for channels whose BatchNorm scale is (almost) 0 — normally zeros) for srlz_bn_bwd_finalize_partials. */
+int srlz_conv64_wino_bwd_data(const float* dy, const float* upack_bwd, float* dx, const srlz_conv64_desc* d, srlz_stream_t stream);
+int srlz_conv64_wino_bwd_data_rows(const srlz_conv64_desc* d);
+int srlz_conv64_wino_bwd_data_pool_sums(const float* dy, const float* upack_bwd, float* dx, const float* pooled, const float* pool_bnp,
+                                        const float* pool_y, const uint8_t* pool_argmax, const struct srlz_pool_desc_s* pd,
+                                        float* bn_bwd_partial, const srlz_conv64_desc* d, srlz_stream_t stream);
 /* workspace (bytes) for bwd_weight */
 size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d);
 /* dw_ref (reference layout) = d(loss)/d(w); dbias[64] = sum of dy over n,h,w (may be NULL).

@@ -76,6 +76,14 @@ _PROTOS = {
     "srlz_conv64_bwd_fused_workspace": (c_size_t, [_C64]),
     "srlz_conv64_bwd_fused": (c_int, [P, P, P, _BO, P, P, P, P, P, P, c_size_t, _C64, P]),
     "srlz_conv64_bwd_fused_bn_rows": (c_int, [_C64]),
+    "srlz_conv64_wino_supported": (c_int, [_C64]),
+    "srlz_conv64_wino_packed_floats": (c_size_t, []),
+    "srlz_conv64_wino_pack_weights": (c_int, [P, P, P, P]),
+    "srlz_conv64_wino_tiles": (c_int, [_C64]),
+    "srlz_conv64_wino_fwd": (c_int, [P, P, P, P, P, _C64, P]),
+    "srlz_conv64_wino_bwd_data": (c_int, [P, P, P, _C64, P]),
+    "srlz_conv64_wino_bwd_data_rows": (c_int, [_C64]),
+    "srlz_conv64_wino_bwd_data_pool_sums": (c_int, [P, P, P, P, P, P, P, _PD, P, _C64, P]),
     "srlz_conv64_bwd_weight": (c_int, [P, P, P, P, P, _BO, P, c_size_t, _C64, P]),
     "srlz_conv64_debug_program": (c_int, [_C64, c_int, POINTER(c_int), c_int]),
     "srlz_debug_placement": (c_int, [P, c_int, c_int, c_int, P]),
@@ -182,7 +190,8 @@ _PROTOS = {
 _NOT_STATUS = {"srlz_version", "srlz_device_cus", "srlz_conv64_fwd_tiles", "srlz_skinny_tiles", "srlz_convn_fwd_tiles",
                "srlz_convT_out_bwd_fused_tiles", "srlz_convT_out_fwd_loss_workgroups", "srlz_conv64_bwd_fused_supported", "srlz_conv64_gather_pipe_supported",
                "srlz_convT_out_bwd_fused_supported",
-               "srlz_conv64_bwd_data_tiles", "srlz_conv64_bwd_fused_bn_rows",
+               "srlz_conv64_bwd_data_tiles", "srlz_conv64_bwd_fused_bn_rows", "srlz_conv64_wino_supported", "srlz_conv64_wino_packed_floats",
+               "srlz_conv64_wino_tiles", "srlz_conv64_wino_bwd_data_rows",
                "srlz_conv64_debug_program", "srlz_comm_world"}
 
 EXPORTED = sorted(_PROTOS.keys())

@@ -296,14 +296,23 @@ class Conv64Fn(Function):
         n, hi, wi, ch = x.shape
         assert ch == 64 and tuple(w.shape) == (64, 64, 3, 3)
         d = conv64_desc(n, hi, wi, stride, pad, transposed, cur_groups(want_stats))
-        npk = C.conv64_packed_floats()
-        packs = torch.empty((2, npk), dtype=torch.float32, device=x.device)
-        C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())
         y = torch.empty((n, d.ho, d.wo, 64), dtype=torch.float32, device=x.device)
-        stats = torch.empty((C.conv64_fwd_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
-        name = "conv64_gather_pipe_kernel" if (bias is None and C.conv64_gather_pipe_supported(d, 0)) else "conv64_fwd_kernel"
-        _launch(name, _conv64_key(d, "fwd"), _conv64_flop(d),
-                lambda: C.conv64_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), None, d, stream()))
+        ctx.wino = bool(C.conv64_wino_supported(d))
+        if ctx.wino:
+            # conv3x3 stride 1 pad 1 on an even map (conv2, models/models.py:54): Winograd F(2x2, 3x3) — 16 multiplications per 2x2 output
+            # patch and (ci, co) instead of 36 (csrc/wino.hip), forward and data gradient; the weight gradient stays the direct contraction.
+            packs = torch.empty((2, C.conv64_wino_packed_floats()), dtype=torch.float32, device=x.device)  # (G g G^T, both directions)
+            C.conv64_wino_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), stream())
+            stats = torch.empty((C.conv64_wino_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
+            _launch("conv64_wino_kernel", _conv64_key(d, "fwd"), _conv64_flop(d),
+                    lambda: C.conv64_wino_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), d, stream()))
+        else:
+            packs = torch.empty((2, C.conv64_packed_floats()), dtype=torch.float32, device=x.device)
+            C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())
+            stats = torch.empty((C.conv64_fwd_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
+            name = "conv64_gather_pipe_kernel" if (bias is None and C.conv64_gather_pipe_supported(d, 0)) else "conv64_fwd_kernel"
+            _launch(name, _conv64_key(d, "fwd"), _conv64_flop(d),
+                    lambda: C.conv64_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), None, d, stream()))
         ctx.save_for_backward(x, packs)
         ctx.desc = d
         ctx.has_bias = bias is not None
@@ -338,11 +347,20 @@ class Conv64Fn(Function):
             if rec is not None and rec[0].data_ptr() == x.data_ptr():
                 # dx = d(pooled): the pooled block's BatchNorm-backward sums come out of this launch's epilogue
                 pooled, pbnp, py, pargmax, pd = rec
-                part = torch.empty((C.conv64_bwd_data_tiles(d), 128), dtype=torch.float32, device=x.device)
-                _launch("conv64_dgrad_poolsum_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
-                        lambda: C.conv64_bwd_data_pool_sums(ptr(dy), ptr(packs[1]), ptr(dx), ptr(pooled), ptr(pbnp), ptr(py),
-                                                            ptr(pargmax), pd, ptr(part), d, stream()))
+                if ctx.wino:
+                    part = torch.empty((C.conv64_wino_bwd_data_rows(d), 128), dtype=torch.float32, device=x.device)
+                    _launch("conv64_wino_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                            lambda: C.conv64_wino_bwd_data_pool_sums(ptr(dy), ptr(packs[1]), ptr(dx), ptr(pooled), ptr(pbnp), ptr(py),
+                                                                     ptr(pargmax), pd, ptr(part), d, stream()))
+                else:
+                    part = torch.empty((C.conv64_bwd_data_tiles(d), 128), dtype=torch.float32, device=x.device)
+                    _launch("conv64_dgrad_poolsum_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                            lambda: C.conv64_bwd_data_pool_sums(ptr(dy), ptr(packs[1]), ptr(dx), ptr(pooled), ptr(pbnp), ptr(py),
+                                                                ptr(pargmax), pd, ptr(part), d, stream()))
                 link.partials = part
+            elif ctx.wino:
+                _launch("conv64_wino_kernel", _conv64_key(d, "dgrad"), _conv64_flop(d),
+                        lambda: C.conv64_wino_bwd_data(ptr(dy), ptr(packs[1]), ptr(dx), d, stream()))
             else:
                 _launch("conv64_gather_pipe_kernel" if C.conv64_gather_pipe_supported(d, 1) else "conv64_fwd_kernel",
                         _conv64_key(d, "dgrad"), _conv64_flop(d),
