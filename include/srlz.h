@@ -163,6 +163,12 @@ int srlz_conv64_wino_bwd_data_rows(const srlz_conv64_desc* d);
 int srlz_conv64_wino_bwd_data_pool_sums(const float* dy, const float* upack_bwd, float* dx, const float* pooled, const float* pool_bnp,
                                         const float* pool_y, const uint8_t* pool_argmax, const struct srlz_pool_desc_s* pd,
                                         float* bn_bwd_partial, const srlz_conv64_desc* d, srlz_stream_t stream);
+/* dw_ref (reference layout [co][ci][3][3]) = d(loss)/d(w) of the same layer by the transposed Winograd algorithm: per transform-domain
+ * component one [co] x [ci] contraction over all 2x2 patches of (A dY A^T) and (B^T x B), G^T . G in the (fixed-order, fp64) second
+ * stage.  Layers without a bias (conv3x3 of the reference has none); ws: srlz_conv64_wino_bwd_weight_workspace(d) bytes. */
+size_t srlz_conv64_wino_bwd_weight_workspace(const srlz_conv64_desc* d);
+int srlz_conv64_wino_bwd_weight(const float* x, const float* dy, float* dw_ref, void* ws, size_t ws_bytes, const srlz_conv64_desc* d,
+                                srlz_stream_t stream);
 /* workspace (bytes) for bwd_weight */
 size_t srlz_conv64_bwd_weight_workspace(const srlz_conv64_desc* d);
 /* dw_ref (reference layout) = d(loss)/d(w); dbias[64] = sum of dy over n,h,w (may be NULL).

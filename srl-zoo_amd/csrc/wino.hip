@@ -210,9 +210,7 @@ __device__ __forceinline__ void wn_mfma_phase(f32x4 (&acc)[16][2], f32x4 (&aq)[W
         acc[comp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[i], acc[comp][1], 0, 0, 0);
       }
     }
-#ifndef WN_X_NOA
     aq[step % WN_AQ] = wn_uload(ub, uvoff, step + WN_AQ, uo);
-#endif
   }
   // the order of the phase, spelled out for the scheduler (which otherwise sinks every operand read to the MFMA that consumes it):
   // the reads of component c + 1, the eight MFMAs of component c, the weight request of component c + WN_AQ
@@ -369,10 +367,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv64_wino_kernel(const float*
     f32x4 acc[16][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-#ifndef WN_X_NOBAR
       __syncthreads();  // chunk p has landed in V[p & 1] (all waves), and everybody is done multiplying chunk p - 1 out of V[(p + 1) & 1]
-#endif
-#ifndef WN_X_NOLAND
       wn_land(rw, Vw + ((p + 1) & 1) * WN_VCHUNK);  // chunk p + 1 (p == 3: the next tile's chunk 0)
       if (p < 2) {
         wn_request(rw, wp, xb, P.W, p + 2);
@@ -380,7 +375,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv64_wino_kernel(const float*
         if (p == 2) wn_patch(wp, P, tile2 - grp2 * P.tpg, t_pt, t_cp, ptab + (parity ^ 1) * WN_TP + t_pt);
         wn_request(rw, wp, xb2, P.W, p - 2);
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       if (p == 0) wn_mfma_phase<0>(acc, aq, Bp, ub, uvoff, uo);
       if (p == 1) wn_mfma_phase<1>(acc, aq, Bp + WN_VCHUNK, ub, uvoff, uo);
@@ -389,11 +383,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv64_wino_kernel(const float*
     }
     // ---- epilogue: Y = A^T M A per patch, bias, stores, BatchNorm partial sums.  A lane holds, of the patches 32 pb + 16 s + l15,
     // the channels 16 cb + 4 g + {0..3}
-#ifdef WN_X_NOEPI
-    const __amdgpu_buffer_rsrc_t yb = wn_buffer(y_all + grp * P.gstride, acc[0][0][0] == 12345.f ? ybytes : 0u);
-#else
     const __amdgpu_buffer_rsrc_t yb = wn_buffer(y_all + grp * P.gstride, ybytes);
-#endif
     f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (bias) bias4 = *(const f32x4*)(bias + 16 * cb + 4 * g);
@@ -481,6 +471,293 @@ int wino_program(WinoProg* P, const srlz_conv64_desc* d) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The weight gradient of the same layer, by the transposed algorithm:
+//     dW = G^T [ sum over patches  (A dY A^T) .* (B^T d B) ] G
+// — per transform-domain component (xi, nu) ONE [co 64] x [ci 64] contraction over all patches, 16 / 36 of the direct weight gradient's
+// multiply-adds; V = B^T d B is the forward's patch transform, Z = A dY A^T (A 4 x 2: entries 0, +-1) turns the patch's 2 x 2 output
+// gradients into 16 values with 12 additions.  G^T . G (4 x 4 -> 3 x 3) runs once, in the second stage of the split-K reduction.
+//
+// Workgroup (256 threads, two per CU): HALF of the components — nu in {2 S, 2 S + 1}, S = workgroup parity — over a contiguous run of
+// 8-patch stages; both operands of a stage ([8 comps][8 patches][64 channels], 16 KB each) live in LDS, double-buffered, one barrier per
+// stage, the raw pixels of stage s + 2 in flight during the matrix work of stage s (the forward kernel's pipeline).  A thread transforms
+// one patch x one channel PAIR of both operands (12 + 4 loads of 8 bytes: the half needs three of the patch's four columns).
+// Wave (ch = wave & 1, cq = wave >> 1): output channels 32 ch .., components 4 cq .. of the half, all 64 input channels:
+// 4 comps x 2 blocks of 32 x 32 = 128 accumulator registers, v_mfma_f32_32x32x2_f32 (k = 2 patches per instruction), operands as
+// ds_read_b64 (two k-steps per read) from [comp][j][h][channel][e] with patch-in-stage = 4 j + 2 h + e... any bijection serves as long as
+// Z and V share it; this one makes both the reads (32 lanes = 256 contiguous bytes) and the transform's writes conflict-free.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WG_SP = 8;                    // patches per stage
+constexpr int WG_OP = 8 * WG_SP * 64;       // floats of one operand of a stage (8 comps): 16 KB
+constexpr int WG_COMP = WG_SP * 64;         // floats of one component of an operand: [j 2][h 2][channel 64][e 2]
+
+struct WinoWgradRaw { f32x2 d[12]; f32x2 g[4]; };
+
+struct WinoWgradProg {
+  int N, H, W, PA, PB, ppi;
+  int total;      // patches of all images
+  int stages;     // ceil(total / 8)
+  int spw;        // stages per workgroup pair
+  unsigned mPPI, mPB;
+  int sPPI, sPB;
+};
+
+struct WinoWgradPatch { unsigned vtop, vmid, vbot, vdy; bool lef, rig; };
+
+__device__ __forceinline__ void wg_patch(WinoWgradPatch& wp, const WinoWgradProg& P, int patch, int chan_pair) {
+  const bool ok = patch < P.total;
+  const int n = wn_div(patch, P.mPPI, P.sPPI);
+  const int rem = patch - n * P.ppi;
+  const int a = wn_div(rem, P.mPB, P.sPB);
+  const int b = rem - a * P.PB;
+  const int pix = (n * P.H + 2 * a) * P.W + 2 * b;
+  const unsigned vbase = (unsigned)pix * 256u + (unsigned)chan_pair * 8u;
+  wp.vmid = ok ? vbase : WN_DROP;
+  wp.vtop = (ok && a > 0) ? vbase : WN_DROP;
+  wp.vbot = (ok && a < P.PA - 1) ? vbase : WN_DROP;
+  wp.vdy = wp.vmid;
+  wp.lef = b > 0; wp.rig = b < P.PB - 1;
+}
+
+// S = 0: columns 0..2 of the 4 x 4 input patch, S = 1: columns 1..3; and the 2 x 2 output gradients
+template <int S>
+__device__ __forceinline__ void wg_request(WinoWgradRaw& rw, const WinoWgradPatch& wp, __amdgpu_buffer_rsrc_t xb, __amdgpu_buffer_rsrc_t gb, int W) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned vr = r == 0 ? wp.vtop : r == 3 ? wp.vbot : wp.vmid;
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const int c = cc + S;
+      const unsigned off = c == 0 ? (wp.lef ? vr : WN_DROP) : c == 3 ? (wp.rig ? vr : WN_DROP) : vr;
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xb, off + (unsigned)(c * 256), r * W * 256, 0);
+      rw.d[r * 3 + cc] = f32x2{__uint_as_float(v[0]), __uint_as_float(v[1])};
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(gb, wp.vdy + (unsigned)(j * 256), i * W * 256, 0);
+      rw.g[i * 2 + j] = f32x2{__uint_as_float(v[0]), __uint_as_float(v[1])};
+    }
+}
+
+// the thread's patch x channel pair of both operands -> LDS: V[xi][nu] = (B^T d B)[xi][nu], Z[xi][nu] = (A dY A^T)[xi][nu], nu in the half
+template <int S>
+__device__ __forceinline__ void wg_land(const WinoWgradRaw& rw, float* __restrict__ Zw, float* __restrict__ Vw) {
+  {
+    f32x2 e[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x2 d0 = rw.d[r * 3], d1 = rw.d[r * 3 + 1], d2 = rw.d[r * 3 + 2];
+      if (S == 0) { e[r][0] = d0 - d2; e[r][1] = d1 + d2; }   // columns 0, 1, 2: nu = 0, 1
+      else        { e[r][0] = d1 - d0; e[r][1] = d0 - d2; }   // columns 1, 2, 3: nu = 2, 3
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x2 v0 = e[0][j] - e[2][j], v1 = e[1][j] + e[2][j], v2 = e[2][j] - e[1][j], v3 = e[1][j] - e[3][j];
+      const f32x2 v[4] = {v0, v1, v2, v3};
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {  // the pair's two channels are two rows of the operand: 8 bytes apart
+        Vw[(xi * 2 + j) * WG_COMP] = v[xi][0];
+        Vw[(xi * 2 + j) * WG_COMP + 2] = v[xi][1];
+      }
+    }
+  }
+  {
+    f32x2 t[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (S == 0) { t[i][0] = rw.g[i * 2]; t[i][1] = rw.g[i * 2] + rw.g[i * 2 + 1]; }
+      else        { t[i][0] = rw.g[i * 2] - rw.g[i * 2 + 1]; t[i][1] = -rw.g[i * 2 + 1]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x2 z0 = t[0][j], z1 = t[0][j] + t[1][j], z2 = t[0][j] - t[1][j], z3 = -t[1][j];
+      const f32x2 z[4] = {z0, z1, z2, z3};
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        Zw[(xi * 2 + j) * WG_COMP] = z[xi][0];
+        Zw[(xi * 2 + j) * WG_COMP + 2] = z[xi][1];
+      }
+    }
+  }
+}
+
+// one stage: 4 comps x 2 patch quads x 2 k-steps x 2 input-channel blocks = 32 MFMAs per wave; the operands of component c + 1 are read
+// under the MFMAs of component c (spelled out for the scheduler, which otherwise sinks every read to the MFMA that consumes it)
+__device__ __forceinline__ void wg_mfma_stage(f32x16 (&acc)[4][2], const float* __restrict__ Zp, const float* __restrict__ Vp) {
+  f32x2 an[2], bn[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    an[j] = *(const f32x2*)(Zp + j * 256);
+    bn[j][0] = *(const f32x2*)(Vp + j * 256);
+    bn[j][1] = *(const f32x2*)(Vp + j * 256 + 64);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f32x2 a[2], b[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { a[j] = an[j]; b[j][0] = bn[j][0]; b[j][1] = bn[j][1]; }
+    if (c < 3) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        an[j] = *(const f32x2*)(Zp + (c + 1) * WG_COMP + j * 256);
+        bn[j][0] = *(const f32x2*)(Vp + (c + 1) * WG_COMP + j * 256);
+        bn[j][1] = *(const f32x2*)(Vp + (c + 1) * WG_COMP + j * 256 + 64);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][e], b[j][0][e], acc[c][0], 0, 0, 0);
+        acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][e], b[j][1][e], acc[c][1], 0, 0, 0);
+      }
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int S>
+__device__ __forceinline__ void wg_body(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ wpart,
+                                        const WinoWgradProg& P, float* __restrict__ smem, int slice) {
+  const int tid = threadIdx.x;
+  int lane = tid & 63;
+  asm volatile("" : "+v"(lane));
+  const int wave = tid >> 6;
+  // transform role: patch q of the stage (LDS coordinates e = q & 1, h = (q >> 1) & 1, j = q >> 2), channel pair 8 wave + (lane & 7)
+  const int q = lane >> 3, cpair = wave * 8 + (lane & 7);
+  const int tw = (((q >> 2) * 2 + ((q >> 1) & 1)) * 64 + 2 * cpair) * 2 + (q & 1);
+  // matrix role
+  const int ch = wave & 1, cq = wave >> 1, l31 = lane & 31, h = lane >> 5;
+  const int tz = cq * 4 * WG_COMP + (h * 64 + 32 * ch + l31) * 2, tv = cq * 4 * WG_COMP + (h * 64 + l31) * 2;
+
+  const long long tfl = (long long)P.N * P.H * P.W * 64;
+  const __amdgpu_buffer_rsrc_t xb = wn_buffer(x - (P.W + 1) * 64, (unsigned)(tfl * 4) + (unsigned)(P.W + 1) * 256u);
+  const __amdgpu_buffer_rsrc_t gb = wn_buffer(dy, (unsigned)(tfl * 4));
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][b][r] = 0.f;
+
+  const int s0 = slice * P.spw;
+  int s1 = s0 + P.spw;
+  if (s1 > P.stages) s1 = P.stages;
+  WinoWgradRaw rw;
+  WinoWgradPatch wp;
+  if (s0 < s1) {
+    // stage s0 -> buffer 0; stage s0 + 1 requested
+    wg_patch(wp, P, s0 * WG_SP + q, cpair);
+    wg_request<S>(rw, wp, xb, gb, P.W);
+    wg_land<S>(rw, smem + tw, smem + WG_OP + tw);
+    wg_patch(wp, P, (s0 + 1) * WG_SP + q, cpair);   // (past the run: stages nobody multiplies; past the tensor: zeros)
+    wg_request<S>(rw, wp, xb, gb, P.W);
+    for (int s = s0; s < s1; ++s) {
+      const int par = (s - s0) & 1;
+      float* cur = smem + par * 2 * WG_OP;
+      float* nxt = smem + (par ^ 1) * 2 * WG_OP;
+      __syncthreads();  // stage s has landed in `cur` (all waves), and everybody is done multiplying stage s - 1 out of `nxt`
+      wg_land<S>(rw, nxt + tw, nxt + WG_OP + tw);
+      wg_patch(wp, P, (s + 2) * WG_SP + q, cpair);
+      wg_request<S>(rw, wp, xb, gb, P.W);
+      __builtin_amdgcn_sched_barrier(0);
+      wg_mfma_stage(acc, cur + tz, cur + WG_OP + tv);
+    }
+  }
+  // the workgroup's partial: [comp 8 (xi * 2 + nu & 1)][co 64][ci 64]
+  float* out = wpart + (size_t)blockIdx.x * (8 * 4096);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * ch + (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[((cq * 4 + c) * 64 + co) * 64 + 32 * b + l31] = acc[c][b][r];
+      }
+}
+
+__global__ __launch_bounds__(256, 2) void conv64_wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ wpart, const WinoWgradProg P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* smem = (float*)smem_raw;  // [2 (stage parity)][Z | V][WG_OP]
+  // workgroup b: XCD b & 7; within the XCD, consecutive workgroups are the two halves of one slice (they read the same pixels)
+  const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int slice = xcd * (wpx >> 1) + (wi >> 1);
+  if (wi & 1) wg_body<1>(x, dy, wpart, P, smem, slice);
+  else wg_body<0>(x, dy, wpart, P, smem, slice);
+}
+
+// second stage, part one: the partials of `per` workgroups summed in fp64, fixed order -> mid[chunk][comp 16][co][ci] (double)
+__global__ __launch_bounds__(256) void conv64_wino_wgrad_reduce_a(const float* __restrict__ wpart, double* __restrict__ mid, int nwg, int per) {
+  const int id = blockIdx.x * 256 + threadIdx.x;  // (comp 16, co, ci)
+  const int chunk = blockIdx.y;
+  const int comp = id >> 12, rest = id & 4095;
+  const int xi = comp >> 2, nu = comp & 3;
+  const int half = nu >> 1, local = xi * 2 + (nu & 1);
+  // workgroup b holds half (b >> 3) & 1
+  double t = 0.0;
+  const int npair = nwg >> 1;
+  for (int k = chunk * per; k < (chunk + 1) * per && k < npair; ++k) {
+    const int b = ((k >> 3) * 2 + half) * 8 + (k & 7);  // the k-th workgroup of this half: pairs are (wi = 2 m, 2 m + 1) on XCD b & 7
+    t += (double)wpart[(size_t)b * (8 * 4096) + local * 4096 + rest];
+  }
+  mid[((size_t)chunk * 16 + comp) * 4096 + rest] = t;
+}
+
+// ... part two: the chunks summed (one thread per component and (co, ci): 16 x 4096 threads), then dW = G^T M G per (co, ci) through LDS
+// -> the reference layout [co][ci][3][3]
+__global__ __launch_bounds__(256) void conv64_wino_wgrad_reduce_b(const double* __restrict__ mid, int chunks, float* __restrict__ dw_ref) {
+  __shared__ double m[16][17];
+  const int comp = threadIdx.x >> 4, pr = threadIdx.x & 15;
+  const int id = blockIdx.x * 16 + pr;  // (co, ci)
+  double t = 0.0;
+  for (int k = 0; k < chunks; ++k) t += mid[((size_t)k * 16 + comp) * 4096 + id];
+  m[pr][comp] = t;
+  __syncthreads();
+  if (threadIdx.x < 144) {  // (pair, ky, kx);  G^T (3 x 4) = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]
+    const int p2 = threadIdx.x / 9, tap = threadIdx.x - p2 * 9, ky = tap / 3, kx = tap - ky * 3;
+    double r[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const double m0 = m[p2][nu], m1 = m[p2][4 + nu], m2 = m[p2][8 + nu], m3 = m[p2][12 + nu];
+      r[nu] = ky == 0 ? m0 + 0.5 * (m1 + m2) : ky == 1 ? 0.5 * (m1 - m2) : 0.5 * (m1 + m2) + m3;
+    }
+    const double v = kx == 0 ? r[0] + 0.5 * (r[1] + r[2]) : kx == 1 ? 0.5 * (r[1] - r[2]) : 0.5 * (r[1] + r[2]) + r[3];
+    dw_ref[(blockIdx.x * 16 + p2) * 9 + tap] = (float)v;
+  }
+}
+
+constexpr int WG_CHUNKS = 8;
+
+int wino_wgrad_program(WinoWgradProg* P, const srlz_conv64_desc* d, int* grid) {
+  WinoProg F;
+  if (wino_program(&F, d)) return 1;
+  const long long total = (long long)d->n * F.ppi;
+  if ((long long)d->n * d->hi * d->wi * 256 + (long long)(d->wi + 1) * 256 >= 0x7FFF0000LL || total + 64 >= (1LL << 31)) return 1;
+  P->N = d->n; P->H = d->hi; P->W = d->wi; P->PA = F.PA; P->PB = F.PB; P->ppi = F.ppi;
+  P->total = (int)total;
+  P->stages = (int)((total + WG_SP - 1) / WG_SP);
+  P->mPPI = F.mPPI; P->sPPI = F.sPPI; P->mPB = F.mPB; P->sPB = F.sPB;
+  int g = 2 * srlz_device_cus();          // two workgroups per CU: pairs = the two component halves of one slice
+  g = (g + 15) & ~15;
+  while (g > 16 && (g >> 1) * 4 > P->stages) g -= 16;  // (small launches: at least four stages per slice)
+  const int slices = g >> 1;
+  P->spw = (P->stages + slices - 1) / slices;
+  *grid = g;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int srlz_conv64_wino_supported(const srlz_conv64_desc* d) {
@@ -565,4 +842,35 @@ extern "C" int srlz_conv64_wino_bwd_data_pool_sums(const float* dy, const float*
                pd->wp, d->n, d->hi, d->wi);
   const WinoPoolSum ps = {pooled, pool_bnp, pool_y, pool_argmax, (long long)(pd->n / P.G) * pd->h * pd->w * 64, pd->h, pd->w, pd->pool_pad};
   return wino_launch(dy, upack_bwd, nullptr, dx, bn_bwd_partial, P, &ps, stream);
+}
+
+extern "C" size_t srlz_conv64_wino_bwd_weight_workspace(const srlz_conv64_desc* d) {
+  WinoWgradProg P;
+  int grid;
+  if (wino_wgrad_program(&P, d, &grid)) return 0;
+  return (size_t)grid * 8 * 4096 * sizeof(float) + (size_t)WG_CHUNKS * 16 * 4096 * sizeof(double);
+}
+
+extern "C" int srlz_conv64_wino_bwd_weight(const float* x, const float* dy, float* dw_ref, void* ws, size_t ws_bytes,
+                                           const srlz_conv64_desc* d, srlz_stream_t stream) {
+  SRLZ_REQUIRE(x && dy && dw_ref && ws, SRLZ_ERR_NULL, "conv64_wino_bwd_weight: null pointer");
+  WinoWgradProg P;
+  int grid;
+  SRLZ_REQUIRE(wino_wgrad_program(&P, d, &grid) == 0, SRLZ_ERR_BAD_DESC,
+               "conv64_wino_bwd_weight: 3x3 stride 1 pad 1 on even sizes only (ask srlz_conv64_wino_supported)");
+  const size_t part_bytes = (size_t)grid * 8 * 4096 * sizeof(float);
+  SRLZ_REQUIRE(ws_bytes >= part_bytes + (size_t)WG_CHUNKS * 16 * 4096 * sizeof(double), SRLZ_ERR_WORKSPACE,
+               "conv64_wino_bwd_weight: workspace too small (%zu bytes)", ws_bytes);
+  hipStream_t st = as_stream(stream);
+  const size_t lds = (size_t)4 * WG_OP * 4;
+  SRLZ_MAX_LDS(conv64_wino_wgrad_kernel, lds);
+  hipLaunchKernelGGL(conv64_wino_wgrad_kernel, dim3(grid), dim3(256), lds, st, x, dy, (float*)ws, P);
+  SRLZ_LAUNCHED();
+  double* mid = (double*)((char*)ws + part_bytes);
+  const int npair = grid >> 1, per = (npair + WG_CHUNKS - 1) / WG_CHUNKS;
+  hipLaunchKernelGGL(conv64_wino_wgrad_reduce_a, dim3(65536 / 256, WG_CHUNKS), dim3(256), 0, st, (const float*)ws, mid, grid, per);
+  SRLZ_LAUNCHED();
+  hipLaunchKernelGGL(conv64_wino_wgrad_reduce_b, dim3(256), dim3(256), 0, st, (const double*)mid, WG_CHUNKS, dw_ref);
+  SRLZ_LAUNCHED();
+  return 0;
 }

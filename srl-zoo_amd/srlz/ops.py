@@ -334,11 +334,17 @@ class Conv64Fn(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):  # (a frozen layer needs neither)
             dw = _gbuf(ctx.params[0])
             db = _gbuf(ctx.params[1]) if ctx.has_bias else None
-            nbytes = C.conv64_bwd_weight_workspace(d)
-            ws = _ws(nbytes, x.device, slot=1)
-            _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
-                    lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, None, ptr(ws), nbytes, d,
-                                                stream()))
+            if ctx.wino and not ctx.has_bias:
+                nbytes = C.conv64_wino_bwd_weight_workspace(d)
+                ws = _ws(nbytes, x.device, slot=1)
+                _launch("conv64_wino_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                        lambda: C.conv64_wino_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, d, stream()))
+            else:
+                nbytes = C.conv64_bwd_weight_workspace(d)
+                ws = _ws(nbytes, x.device, slot=1)
+                _launch("conv64_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
+                        lambda: C.conv64_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(db), None, None, ptr(ws), nbytes, d,
+                                                    stream()))
         dx = None
         if ctx.needs_dx:
             dx = torch.empty_like(x)

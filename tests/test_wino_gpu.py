@@ -208,3 +208,38 @@ def test_conv64_wino_data_gradient_with_the_pooled_blocks_sums(C, n, h, groups, 
     for got, want in zip(outs[0], outs[1]):
         scale = float(want.abs().max())
         assert float((got - want).abs().max()) <= 2e-5 * scale, float((got - want).abs().max()) / scale
+
+
+@pytest.mark.parametrize("n,h", [(1, 4), (2, 8), (3, 56), (5, 10), (7, 14), (64, 56), (512, 56)])
+def test_conv64_wino_weight_gradient(C, n, h):
+    """srlz_conv64_wino_bwd_weight: dW = G^T [sum over patches (A dY A^T) .* (B^T x B)] G against fp64 autograd (every element; the
+    sums run over n * h * h positions — up to 1.6 M at the step's size, held to north_star's 1e-4 there) and the direct weight gradient;
+    deterministic (two launches, bit for bit)."""
+    g = torch.Generator().manual_seed(11 * h + n)
+    x = torch.randn(n, 64, h, h, generator=g)
+    x[:, :, 0, :] += 1.0
+    x[:, :, :, -1] -= 1.0
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    dy = torch.randn(n, 64, h, h, generator=g)
+    wr = w.double().requires_grad_(True)
+    F.conv2d(x.double(), wr, None, stride=1, padding=1).backward(dy.double())
+    d = C.Conv64Desc(n, h, h, h, h, 3, 1, 1, 0, 2 if n % 2 == 0 else 1)
+    st = C.stream()
+    xd, dyd = nhwc(x).to(DEV), nhwc(dy).to(DEV)
+    nb = C.conv64_wino_bwd_weight_workspace(d)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, 64, 3, 3), float("nan"), device=DEV)
+    C.conv64_wino_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw), C.ptr(ws), nb, d, st)
+    dw2 = torch.empty_like(dw)
+    ws.fill_(255)
+    C.conv64_wino_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dw2), C.ptr(ws), nb, d, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all() and torch.equal(dw, dw2)
+    nb2 = C.conv64_bwd_weight_workspace(d)
+    ws2 = torch.empty(nb2, dtype=torch.uint8, device=DEV)
+    dwd = torch.empty_like(dw)
+    C.conv64_bwd_weight(C.ptr(xd), C.ptr(dyd), C.ptr(dwd), None, None, None, C.ptr(ws2), nb2, d, st)
+    torch.cuda.synchronize()
+    err, err_direct = rel_err(dw, wr.grad), rel_err(dwd, wr.grad)
+    print("wino wgrad n=%d h=%d: max error / scale %.2e (direct weight gradient %.2e)" % (n, h, err, err_direct))
+    assert err < (2e-5 if n < 512 else 1e-4), err
