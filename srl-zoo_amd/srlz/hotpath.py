@@ -206,6 +206,18 @@ def _packed64(conv, d):
     return cached[1]
 
 
+def _packed_wino(conv):
+    """As _packed, for a 64 -> 64 3x3 stride-1 convolution in the Winograd kernel's layout (G g G^T, forward direction)."""
+    key = (conv.weight.data_ptr(), conv.weight._version)
+    cached = getattr(conv, "_srlz_pack_wino", None)
+    if cached is None or cached[0] != key:
+        pk = torch.empty(ops.C.conv64_wino_packed_floats(), dtype=torch.float32, device=conv.weight.device)
+        ops.C.conv64_wino_pack_weights(ops.ptr(conv.weight), ops.ptr(pk), None, ops.stream())
+        cached = (key, pk)
+        conv._srlz_pack_wino = cached
+    return cached[1]
+
+
 def _convn(x, conv, bn, training, x_bnp=None, groups=1):
     """raw = conv(x or relu(bn_prev(x))) for an NHWC tensor + the BatchNorm record(s) of `bn` over that output; `groups` independent
     calls batched along n (x_bnp and the returned records are [groups][channel blocks][256])."""
@@ -217,6 +229,12 @@ def _convn(x, conv, bn, training, x_bnp=None, groups=1):
         # epilogue stores, fused relu(bn(.)) operand — instead of the general-channel-count kernel (0.73 against 0.56 of the matrix peak)
         d = ops.conv64_desc(n, hi, wi, 1, 1, False, groups)
         y = torch.empty((n, ho, wo, 64), dtype=torch.float32, device=x.device)
+        if x_bnp is None and ops.C.conv64_wino_supported(d):
+            # ... and where the input is a materialised activation (the first convolution of a block): Winograd F(2x2, 3x3), csrc/wino.hip
+            tiles = ops.C.conv64_wino_tiles(d)
+            stats = torch.empty((1, tiles, 128), dtype=torch.float32, device=x.device) if training else None
+            ops.C.conv64_wino_fwd(ops.ptr(x), ops.ptr(_packed_wino(conv)), None, ops.ptr(y), ops.ptr(stats), d, ops.stream())
+            return y, _bn_record(bn, stats, tiles, n // groups * ho * wo, training, x.device, groups)
         tiles = ops.C.conv64_fwd_tiles(d)
         stats = torch.empty((1, tiles, 128), dtype=torch.float32, device=x.device) if training else None
         ops.C.conv64_fwd(ops.ptr(x), ops.ptr(_packed64(conv, d)[0]), None, ops.ptr(y), ops.ptr(stats), ops.ptr(x_bnp), d, ops.stream())
