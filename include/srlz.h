@@ -153,7 +153,9 @@ size_t srlz_conv64_wino_packed_floats(void);
 int srlz_conv64_wino_pack_weights(const float* w_ref, float* upack_fwd, float* upack_bwd, srlz_stream_t stream);
 int srlz_conv64_wino_tiles(const srlz_conv64_desc* d);
 int srlz_conv64_wino_fwd(const float* x, const float* upack_fwd, const float* bias /* may be NULL */, float* y,
-                         float* stats_partial /* may be NULL */, const srlz_conv64_desc* d, srlz_stream_t stream);
+                         float* stats_partial /* may be NULL */, const float* x_bnp /* may be NULL: as srlz_conv64_fwd's — x is the raw
+                         output of the previous convolution, the layer's input relu(batchnorm(x)) with these records */,
+                         const srlz_conv64_desc* d, srlz_stream_t stream);
 /* dx = d(loss)/dx from dy, same kernel with upack_bwd.  The _pool_sums form is srlz_conv64_bwd_data_pool_sums' (above): dx is the gradient
  * of the pooled map `pd` describes and the launch also leaves the pooled block's two BatchNorm-backward sums as
  * srlz_conv64_wino_bwd_data_rows(d) records of 128 floats (group after group; a group's last 64 records come from a companion launch

@@ -102,8 +102,8 @@ __global__ void conv64_wino_pack_kernel(const float* __restrict__ w_ref, float* 
   }
 }
 
-// the raw 4 x 4 patch of two channels a thread transforms
-struct WinoRaw { f32x2 d[16]; };
+// the raw 4 x 4 patch of two channels a thread transforms (FUSE: + scale / shift of the input-side BatchNorm for those two channels)
+struct WinoRaw { f32x2 d[16]; f32x2 sc, sh; };
 
 struct WinoPatch {  // a thread's patch for the transform role: byte offsets of input pixel (2a, 2b) (+ the thread's channel pair) in the
   unsigned vtop, vmid, vbot;  // group's tensor as seen by rows 2a - 1 / 2a, 2a + 1 / 2a + 2 (WN_DROP where the row or the patch does not exist)
@@ -127,7 +127,13 @@ __device__ __forceinline__ void wn_patch(WinoPatch& wp, const WinoProg& P, int t
 }
 
 // request chunk `p` of the patch: 16 loads of 8 bytes; outside the image an out-of-range offset reads 0
-__device__ __forceinline__ void wn_request(WinoRaw& rw, const WinoPatch& wp, __amdgpu_buffer_rsrc_t xb, int W, int p) {
+template <bool FUSE = false>
+__device__ __forceinline__ void wn_request(WinoRaw& rw, const WinoPatch& wp, __amdgpu_buffer_rsrc_t xb, int W, int p,
+                                           const float* __restrict__ bnrec = nullptr, int t_cp = 0) {
+  if constexpr (FUSE) {  // (travels with the pixels: the landing needs no idea of which group or chunk it is landing)
+    rw.sc = *(const f32x2*)(bnrec + 128 + 16 * p + 2 * t_cp);
+    rw.sh = *(const f32x2*)(bnrec + 192 + 16 * p + 2 * t_cp);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const unsigned vr = r == 0 ? wp.vtop : r == 3 ? wp.vbot : wp.vmid;
@@ -144,7 +150,24 @@ __device__ __forceinline__ void wn_request(WinoRaw& rw, const WinoPatch& wp, __a
 
 // V = B^T d B for the thread's two channels -> LDS (two columns of the transform domain at a time: 16 temporaries, not 32 — the landing
 // is where the kernel's register demand peaks)
-__device__ __forceinline__ void wn_land(const WinoRaw& rw, float* __restrict__ Vw) {
+// FUSE: the tensor holds the RAW output of the previous convolution and the layer's input is relu(batchnorm(raw)) (cf. srlz_conv64_fwd's
+// x_bnp): applied here, per loaded value — and the zero padding re-imposed behind it (an out-of-range load read 0, not relu(shift)).
+template <bool FUSE = false>
+__device__ __forceinline__ void wn_land(WinoRaw& rw, const WinoPatch& wp, float* __restrict__ Vw) {
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool rok = (r == 0 ? wp.vtop : r == 3 ? wp.vbot : wp.vmid) != WN_DROP;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = rok && (c == 0 ? wp.lef : c == 3 ? wp.rig : true);
+        f32x2 a = __builtin_elementwise_fma(rw.d[r * 4 + c], rw.sc, rw.sh);
+        a[0] = ok ? __builtin_fmaxf(a[0], 0.f) : 0.f;
+        a[1] = ok ? __builtin_fmaxf(a[1], 0.f) : 0.f;
+        rw.d[r * 4 + c] = a;
+      }
+    }
+  }
 #pragma unroll
   for (int hv = 0; hv < 2; ++hv) {
     f32x2 e[4][2];
@@ -297,11 +320,11 @@ __global__ __launch_bounds__(256) void conv64_wino_poolsum_zero_scale_kernel(con
   }
 }
 
-template <bool PSUM>
+template <bool PSUM, bool FUSE>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv64_wino_kernel(const float* __restrict__ x_all, const float* __restrict__ upack,
                                                                     const float* __restrict__ bias, float* __restrict__ y_all,
                                                                     float* __restrict__ stats_partial, const WinoProg P, int ntiles,
-                                                                    const WinoPoolSum ps) {
+                                                                    const WinoPoolSum ps, const float* __restrict__ x_bnp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Vs = (float*)smem;                // [2 (chunk parity)][WN_VCHUNK]
   int* ptab = (int*)(Vs + 2 * WN_VCHUNK);  // [2 (tile parity)][32]: pixel index of output (2a, 2b) of a tile's patches, -1 = no such patch
@@ -346,9 +369,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv64_wino_kernel(const float*
     const int grp = tile / P.tpg;
     const __amdgpu_buffer_rsrc_t xb = wn_buffer(x_all + grp * P.gstride - (P.W + 1) * 64, xbytes);
     wn_patch(wp, P, tile - grp * P.tpg, t_pt, t_cp, ptab + t_pt);
-    wn_request(rw, wp, xb, P.W, 0);
-    wn_land(rw, Vw);
-    wn_request(rw, wp, xb, P.W, 1);
+    const float* bnrec = FUSE ? x_bnp + grp * 256 : nullptr;
+    wn_request<FUSE>(rw, wp, xb, P.W, 0, bnrec, t_cp);
+    wn_land<FUSE>(rw, wp, Vw);
+    wn_request<FUSE>(rw, wp, xb, P.W, 1, bnrec, t_cp);
 #pragma unroll
     for (int i = 0; i < WN_AQ; ++i) aq[i] = wn_uload(ub, uvoff, i, 0);
   }
@@ -368,12 +392,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv64_wino_kernel(const float*
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       __syncthreads();  // chunk p has landed in V[p & 1] (all waves), and everybody is done multiplying chunk p - 1 out of V[(p + 1) & 1]
-      wn_land(rw, Vw + ((p + 1) & 1) * WN_VCHUNK);  // chunk p + 1 (p == 3: the next tile's chunk 0)
+      wn_land<FUSE>(rw, wp, Vw + ((p + 1) & 1) * WN_VCHUNK);  // chunk p + 1 (p == 3: the next tile's chunk 0)
       if (p < 2) {
-        wn_request(rw, wp, xb, P.W, p + 2);
+        wn_request<FUSE>(rw, wp, xb, P.W, p + 2, FUSE ? x_bnp + grp * 256 : nullptr, t_cp);
       } else {
         if (p == 2) wn_patch(wp, P, tile2 - grp2 * P.tpg, t_pt, t_cp, ptab + (parity ^ 1) * WN_TP + t_pt);
-        wn_request(rw, wp, xb2, P.W, p - 2);
+        wn_request<FUSE>(rw, wp, xb2, P.W, p - 2, FUSE ? x_bnp + grp2 * 256 : nullptr, t_cp);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (p == 0) wn_mfma_phase<0>(acc, aq, Bp, ub, uvoff, uo);
@@ -436,6 +460,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv64_wino_kernel(const float*
                    ((z10[e] > pthr[e] ? y10[e] : 0.f) + (z11[e] > pthr[e] ? y11[e] : 0.f));
         }
         q4 += (y00 * z00 + y01 * z01) + (y10 * z10 + y11 * z11);
+      } else if constexpr (FUSE) {  // (a patch that does not exist has transformed relu(shift), not zeros)
+        const f32x4 ts = (y00 + y01) + (y10 + y11), tq = (y00 * y00 + y01 * y01) + (y10 * y10 + y11 * y11);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s4[e] += ok ? ts[e] : 0.f; q4[e] += ok ? tq[e] : 0.f; }
       } else {
         s4 += (y00 + y01) + (y10 + y11);
         q4 += (y00 * y00 + y01 * y01) + (y10 * y10 + y11 * y11);
@@ -781,23 +809,27 @@ extern "C" int srlz_conv64_wino_tiles(const srlz_conv64_desc* d) {
 }
 
 static int wino_launch(const float* x, const float* upack, const float* bias, float* y, float* partial, const WinoProg& P,
-                       const WinoPoolSum* ps, srlz_stream_t stream) {
+                       const WinoPoolSum* ps, const float* x_bnp, srlz_stream_t stream) {
   const int ntiles = P.G * P.tpg;
   int grid = 2 * srlz_device_cus();  // two workgroups per CU (64 KB of LDS, 256 registers each): one's barriers, landings and epilogue
   if (ntiles < grid) grid = ntiles;  // run under the other's matrix work
   grid = (grid + 7) & ~7;
   const size_t lds = (size_t)2 * WN_VCHUNK * 4 + 2 * WN_TP * 4;
+  const WinoPoolSum none = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  hipStream_t st = as_stream(stream);
   if (ps) {
-    SRLZ_MAX_LDS(conv64_wino_kernel<true>, lds);
-    hipLaunchKernelGGL(conv64_wino_kernel<true>, dim3(grid), dim3(WN_THREADS), lds, as_stream(stream), x, upack, bias, y, partial, P, ntiles, *ps);
+    SRLZ_MAX_LDS((conv64_wino_kernel<true, false>), lds);
+    hipLaunchKernelGGL((conv64_wino_kernel<true, false>), dim3(grid), dim3(WN_THREADS), lds, st, x, upack, bias, y, partial, P, ntiles, *ps, x_bnp);
+  } else if (x_bnp) {
+    SRLZ_MAX_LDS((conv64_wino_kernel<false, true>), lds);
+    hipLaunchKernelGGL((conv64_wino_kernel<false, true>), dim3(grid), dim3(WN_THREADS), lds, st, x, upack, bias, y, partial, P, ntiles, none, x_bnp);
   } else {
-    SRLZ_MAX_LDS(conv64_wino_kernel<false>, lds);
-    hipLaunchKernelGGL(conv64_wino_kernel<false>, dim3(grid), dim3(WN_THREADS), lds, as_stream(stream), x, upack, bias, y, partial, P, ntiles,
-                       WinoPoolSum{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0});
+    SRLZ_MAX_LDS((conv64_wino_kernel<false, false>), lds);
+    hipLaunchKernelGGL((conv64_wino_kernel<false, false>), dim3(grid), dim3(WN_THREADS), lds, st, x, upack, bias, y, partial, P, ntiles, none, x_bnp);
   }
   SRLZ_LAUNCHED();
   if (ps) {  // the records of the channels the main kernel cannot sum from the pooled value (normally: zeros)
-    hipLaunchKernelGGL(conv64_wino_poolsum_zero_scale_kernel, dim3(WN_ZBLOCKS, P.G), dim3(256), 0, as_stream(stream), (const float*)y, *ps, partial,
+    hipLaunchKernelGGL(conv64_wino_poolsum_zero_scale_kernel, dim3(WN_ZBLOCKS, P.G), dim3(256), 0, st, (const float*)y, *ps, partial,
                        P.N, P.H, P.W, P.gstride, P.tpg + WN_ZBLOCKS, P.tpg);
     SRLZ_LAUNCHED();
   }
@@ -811,12 +843,12 @@ extern "C" int srlz_conv64_wino_bwd_data_rows(const srlz_conv64_desc* d) {
 }
 
 extern "C" int srlz_conv64_wino_fwd(const float* x, const float* upack, const float* bias, float* y, float* stats_partial,
-                                    const srlz_conv64_desc* d, srlz_stream_t stream) {
+                                    const float* x_bnp, const srlz_conv64_desc* d, srlz_stream_t stream) {
   SRLZ_REQUIRE(x && upack && y, SRLZ_ERR_NULL, "conv64_wino_fwd: null pointer");
   WinoProg P;
   SRLZ_REQUIRE(wino_program(&P, d) == 0, SRLZ_ERR_BAD_DESC,
                "conv64_wino_fwd: 3x3 stride 1 pad 1 on even sizes only (ask srlz_conv64_wino_supported)");
-  return wino_launch(x, upack, bias, y, stats_partial, P, nullptr, stream);
+  return wino_launch(x, upack, bias, y, stats_partial, P, nullptr, x_bnp, stream);
 }
 
 extern "C" int srlz_conv64_wino_bwd_data(const float* dy, const float* upack_bwd, float* dx, const srlz_conv64_desc* d, srlz_stream_t stream) {
@@ -824,7 +856,7 @@ extern "C" int srlz_conv64_wino_bwd_data(const float* dy, const float* upack_bwd
   WinoProg P;
   SRLZ_REQUIRE(wino_program(&P, d) == 0, SRLZ_ERR_BAD_DESC,
                "conv64_wino_bwd_data: 3x3 stride 1 pad 1 on even sizes only (ask srlz_conv64_wino_supported)");
-  return wino_launch(dy, upack_bwd, nullptr, dx, nullptr, P, nullptr, stream);
+  return wino_launch(dy, upack_bwd, nullptr, dx, nullptr, P, nullptr, nullptr, stream);
 }
 
 extern "C" int srlz_conv64_wino_bwd_data_pool_sums(const float* dy, const float* upack_bwd, float* dx, const float* pooled,
@@ -841,7 +873,7 @@ extern "C" int srlz_conv64_wino_bwd_data_pool_sums(const float* dy, const float*
                SRLZ_ERR_BAD_DESC, "conv64_wino_bwd_data_pool_sums: the pooled map [%d,%d,%d] is not this layer's input [%d,%d,%d]", pd->n, pd->hp,
                pd->wp, d->n, d->hi, d->wi);
   const WinoPoolSum ps = {pooled, pool_bnp, pool_y, pool_argmax, (long long)(pd->n / P.G) * pd->h * pd->w * 64, pd->h, pd->w, pd->pool_pad};
-  return wino_launch(dy, upack_bwd, nullptr, dx, bn_bwd_partial, P, &ps, stream);
+  return wino_launch(dy, upack_bwd, nullptr, dx, bn_bwd_partial, P, &ps, nullptr, stream);
 }
 
 extern "C" size_t srlz_conv64_wino_bwd_weight_workspace(const srlz_conv64_desc* d) {

@@ -80,7 +80,7 @@ _PROTOS = {
     "srlz_conv64_wino_packed_floats": (c_size_t, []),
     "srlz_conv64_wino_pack_weights": (c_int, [P, P, P, P]),
     "srlz_conv64_wino_tiles": (c_int, [_C64]),
-    "srlz_conv64_wino_fwd": (c_int, [P, P, P, P, P, _C64, P]),
+    "srlz_conv64_wino_fwd": (c_int, [P, P, P, P, P, P, _C64, P]),
     "srlz_conv64_wino_bwd_data": (c_int, [P, P, P, _C64, P]),
     "srlz_conv64_wino_bwd_weight_workspace": (c_size_t, [_C64]),
     "srlz_conv64_wino_bwd_weight": (c_int, [P, P, P, P, c_size_t, _C64, P]),

@@ -229,11 +229,12 @@ def _convn(x, conv, bn, training, x_bnp=None, groups=1):
         # epilogue stores, fused relu(bn(.)) operand — instead of the general-channel-count kernel (0.73 against 0.56 of the matrix peak)
         d = ops.conv64_desc(n, hi, wi, 1, 1, False, groups)
         y = torch.empty((n, ho, wo, 64), dtype=torch.float32, device=x.device)
-        if x_bnp is None and ops.C.conv64_wino_supported(d):
-            # ... and where the input is a materialised activation (the first convolution of a block): Winograd F(2x2, 3x3), csrc/wino.hip
+        if ops.C.conv64_wino_supported(d):
+            # ... as Winograd F(2x2, 3x3) (csrc/wino.hip) on even maps: a materialised input (the first convolution of a block) as it is, the
+            # raw output of the block's first convolution through the fused relu(bn(.)) landing (x_bnp)
             tiles = ops.C.conv64_wino_tiles(d)
             stats = torch.empty((1, tiles, 128), dtype=torch.float32, device=x.device) if training else None
-            ops.C.conv64_wino_fwd(ops.ptr(x), ops.ptr(_packed_wino(conv)), None, ops.ptr(y), ops.ptr(stats), d, ops.stream())
+            ops.C.conv64_wino_fwd(ops.ptr(x), ops.ptr(_packed_wino(conv)), None, ops.ptr(y), ops.ptr(stats), ops.ptr(x_bnp), d, ops.stream())
             return y, _bn_record(bn, stats, tiles, n // groups * ho * wo, training, x.device, groups)
         tiles = ops.C.conv64_fwd_tiles(d)
         stats = torch.empty((1, tiles, 128), dtype=torch.float32, device=x.device) if training else None

@@ -305,7 +305,7 @@ class Conv64Fn(Function):
             C.conv64_wino_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), stream())
             stats = torch.empty((C.conv64_wino_tiles(d), 128), dtype=torch.float32, device=x.device) if want_stats else None
             _launch("conv64_wino_kernel", _conv64_key(d, "fwd"), _conv64_flop(d),
-                    lambda: C.conv64_wino_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), d, stream()))
+                    lambda: C.conv64_wino_fwd(ptr(x), ptr(packs[0]), ptr(bias), ptr(y), ptr(stats), None, d, stream()))
         else:
             packs = torch.empty((2, C.conv64_packed_floats()), dtype=torch.float32, device=x.device)
             C.conv64_pack_weights(ptr(w), ptr(packs[0]), ptr(packs[1]), d, stream())

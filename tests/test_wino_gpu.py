@@ -56,7 +56,7 @@ def test_conv64_wino_forward(C, n, h, groups, with_bias):
     rows = C.conv64_wino_tiles(d)
     y = torch.full((n, h, h, 64), float("nan"), device=DEV)
     stats = torch.full((rows, 128), float("nan"), device=DEV)
-    C.conv64_wino_fwd(C.ptr(xd), C.ptr(up[0]), C.ptr(bd), C.ptr(y), C.ptr(stats), d, st)
+    C.conv64_wino_fwd(C.ptr(xd), C.ptr(up[0]), C.ptr(bd), C.ptr(y), C.ptr(stats), None, d, st)
     torch.cuda.synchronize()
     assert torch.isfinite(y).all() and torch.isfinite(stats).all()
     err = rel_err(nchw(y), ref)
@@ -78,7 +78,7 @@ def test_conv64_wino_forward(C, n, h, groups, with_bias):
         assert (st64[gi, 64:] - (yg ** 2).sum(0)).abs().max().item() <= 1e-5 * (yg ** 2).sum(0).max().item()
     # without the statistics output; and a second launch, bit for bit
     y3 = torch.empty_like(y)
-    C.conv64_wino_fwd(C.ptr(xd), C.ptr(up[0]), C.ptr(bd), C.ptr(y3), None, d, st)
+    C.conv64_wino_fwd(C.ptr(xd), C.ptr(up[0]), C.ptr(bd), C.ptr(y3), None, None, d, st)
     torch.cuda.synchronize()
     assert torch.equal(y3, y)
 
@@ -97,7 +97,7 @@ def test_conv64_wino_does_not_depend_on_batching(C):
         d = C.Conv64Desc(xs.shape[0], 12, 12, 12, 12, 3, 1, 1, 0, groups)
         y = torch.empty_like(xs)
         stats = torch.empty(C.conv64_wino_tiles(d), 128, device=DEV)
-        C.conv64_wino_fwd(C.ptr(xs), C.ptr(up[0]), None, C.ptr(y), C.ptr(stats), d, st)
+        C.conv64_wino_fwd(C.ptr(xs), C.ptr(up[0]), None, C.ptr(y), C.ptr(stats), None, d, st)
         torch.cuda.synchronize()
         return y, stats
 
@@ -243,3 +243,43 @@ def test_conv64_wino_weight_gradient(C, n, h):
     err, err_direct = rel_err(dw, wr.grad), rel_err(dwd, wr.grad)
     print("wino wgrad n=%d h=%d: max error / scale %.2e (direct weight gradient %.2e)" % (n, h, err, err_direct))
     assert err < (2e-5 if n < 512 else 1e-4), err
+
+
+@pytest.mark.parametrize("n,h,groups", [(2, 8, 1), (3, 10, 1), (6, 56, 2), (12, 14, 6)])
+def test_conv64_wino_forward_with_the_fused_bn_relu_operand(C, n, h, groups):
+    """srlz_conv64_wino_fwd with x_bnp: the tensor is the RAW output of the previous convolution, the layer's input relu(batchnorm(raw))
+    per BatchNorm group — applied in the landing, the zero padding re-imposed behind it (the second convolution of a ResNet block,
+    models/triplet.py:16) — against fp64 torch and the direct kernel's fused operand; BatchNorm partial records included."""
+    g = torch.Generator().manual_seed(17 * h + n)
+    x = torch.randn(n, 64, h, h, generator=g) * 1.5
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    per = n // groups
+    scale, shift = torch.randn(groups, 64, generator=g), torch.randn(groups, 64, generator=g) * 0.5   # (negative scales included)
+    act = torch.cat([F.relu(x[gi * per:(gi + 1) * per].double() * scale[gi].double().view(1, 64, 1, 1) + shift[gi].double().view(1, 64, 1, 1))
+                     for gi in range(groups)])
+    ref = F.conv2d(act, w.double(), None, stride=1, padding=1)
+    bnp = torch.zeros(groups, 256)
+    bnp[:, 128:192], bnp[:, 192:256] = scale, shift
+    d = C.Conv64Desc(n, h, h, h, h, 3, 1, 1, 0, groups)
+    st = C.stream()
+    xd, wd, bd = nhwc(x).to(DEV), w.to(DEV), bnp.to(DEV)
+    up = torch.empty(2, C.conv64_wino_packed_floats(), device=DEV)
+    C.conv64_wino_pack_weights(C.ptr(wd), C.ptr(up[0]), None, st)
+    rows = C.conv64_wino_tiles(d)
+    y = torch.full((n, h, h, 64), float("nan"), device=DEV)
+    stats = torch.full((rows, 128), float("nan"), device=DEV)
+    C.conv64_wino_fwd(C.ptr(xd), C.ptr(up[0]), None, C.ptr(y), C.ptr(stats), C.ptr(bd), d, st)
+    packs = torch.empty(2, C.conv64_packed_floats(), device=DEV)
+    C.conv64_pack_weights(C.ptr(wd), C.ptr(packs[0]), C.ptr(packs[1]), d, st)
+    y2 = torch.empty_like(y)
+    C.conv64_fwd(C.ptr(xd), C.ptr(packs[0]), None, C.ptr(y2), None, C.ptr(bd), d, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and torch.isfinite(stats).all()
+    err = rel_err(nchw(y), ref)
+    print("wino fused n=%d h=%d: max error / output scale %.2e (direct fused kernel %.2e)" % (n, h, err, rel_err(nchw(y2), ref)))
+    assert err < 2e-5, err
+    st64 = stats.double().view(groups, rows // groups, 128).sum(1).cpu()
+    for gi in range(groups):
+        yg = y[gi * per:(gi + 1) * per].double().reshape(-1, 64).cpu()
+        assert (st64[gi, :64] - yg.sum(0)).abs().max().item() <= 1e-5 * yg.abs().sum(0).max().item()
+        assert (st64[gi, 64:] - (yg ** 2).sum(0)).abs().max().item() <= 1e-5 * (yg ** 2).sum(0).max().item()

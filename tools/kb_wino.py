@@ -37,7 +37,7 @@ def timeit(fn, reps=20):
     return sum(ts) / len(ts), ts[0]
 
 
-for label, fn in (("winograd F(2x2,3x3)", lambda: C.conv64_wino_fwd(C.ptr(x), C.ptr(up[0]), None, C.ptr(y), C.ptr(s1), d, st)),
+for label, fn in (("winograd F(2x2,3x3)", lambda: C.conv64_wino_fwd(C.ptr(x), C.ptr(up[0]), None, C.ptr(y), C.ptr(s1), None, d, st)),
                   ("direct implicit GEMM", lambda: C.conv64_fwd(C.ptr(x), C.ptr(packs[0]), None, C.ptr(y), C.ptr(s2), None, d, st))):
     avg, best = timeit(fn)
     print("conv2 forward N=%d %-22s %8.1f us  (best %8.1f)  %6.1f algorithmic TFLOP/s = %.3f of the fp32 matrix peak" %
