@@ -110,7 +110,7 @@ ngpu=$(python -c "import torch; print(torch.cuda.device_count())")
 if [ "$ngpu" -ge 8 ]; then
   python bench.py --gpus 8 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_rccl8.json 2>> gpurun_out/${tag}_bench.err
 else
-  SRLZ_DIST_BACKEND=gloo python bench.py --gpus 8 --batch-size 32 --steps 10 --warmup 3 --no-vae-leg > gpurun_out/${tag}_bench_gloo8.json 2>> gpurun_out/${tag}_bench.err
+  SRLZ_DIST_BACKEND=gloo python bench.py --gpus 8 --batch-size 32 --steps 20 --warmup 3 --no-vae-leg > gpurun_out/${tag}_bench_gloo8.json 2>> gpurun_out/${tag}_bench.err
 fi
 python - "$tag" <<'PY'
 import json, glob, sys
