@@ -131,14 +131,25 @@ def csrc_sha16():
 
 
 def _newest_profile(suffix):
+    """The committed profile file to quote: the one recorded at THESE kernel sources (csrc_sha16) when there is one — tags do not sort by
+    time (r06w was recorded after r06z) — else the last by name (the caller then reports stale = True)."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*" + suffix)))
     if not files:
         return None, None
-    try:
-        return json.load(open(files[-1])), "profiles/" + os.path.basename(files[-1])
-    except (OSError, ValueError):
+    sha = csrc_sha16()
+    docs = []
+    for f in reversed(files):
+        try:
+            doc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if doc.get("csrc_sha16") == sha:
+            return doc, "profiles/" + os.path.basename(f)
+        docs.append((doc, f))
+    if not docs:
         return None, None
+    return docs[0][0], "profiles/" + os.path.basename(docs[0][1])
 
 
 def committed_pmc_traffic(kernel):
