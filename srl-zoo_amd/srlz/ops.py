@@ -334,8 +334,8 @@ class Conv64Fn(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):  # (a frozen layer needs neither)
             dw = _gbuf(ctx.params[0])
             db = _gbuf(ctx.params[1]) if ctx.has_bias else None
-            if ctx.wino and not ctx.has_bias:
-                nbytes = C.conv64_wino_bwd_weight_workspace(d)
+            nbytes = C.conv64_wino_bwd_weight_workspace(d) if (ctx.wino and not ctx.has_bias) else 0
+            if nbytes > 0:  # (0: not a shape the transposed Winograd kernel takes — it indexes ALL groups' images with 32-bit offsets)
                 ws = _ws(nbytes, x.device, slot=1)
                 _launch("conv64_wino_wgrad_kernel", _conv64_key(d, "wgrad"), _conv64_flop(d),
                         lambda: C.conv64_wino_bwd_weight(ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, d, stream()))

@@ -33,3 +33,23 @@ def test_version_and_error_text(cabi):
     d = cabi.Conv64Desc(1, 8, 8, 9, 9, 3, 1, 1, 0)  # inconsistent output size -> host-side rejection
     assert cabi._lib.srlz_conv64_fwd_tiles(ctypes.byref(d)) == -1
     assert "inconsistent" in cabi.error_text()
+
+
+def test_winograd_route_is_offered_only_where_it_applies(cabi):
+    """Host-side shape logic of the Winograd entry points (no GPU needed): conv3x3 stride 1 pad 1 on even maps whose images split evenly
+    over the BatchNorm groups and whose per-group tensor stays below the 32-bit buffer offsets; everything else keeps the direct kernels
+    (srlz/ops.py asks these predicates per call).  Reference layer: conv3x3(64, 64) at 56 x 56, models/models.py:54."""
+    D = cabi.Conv64Desc
+    assert cabi.conv64_wino_supported(D(512, 56, 56, 56, 56, 3, 1, 1, 0, 2)) == 1
+    assert cabi.conv64_wino_tiles(D(512, 56, 56, 56, 56, 3, 1, 1, 0, 2)) == 2 * (256 * 28 * 28 // 32)
+    assert cabi.conv64_wino_bwd_data_rows(D(512, 56, 56, 56, 56, 3, 1, 1, 0, 2)) == 2 * (256 * 28 * 28 // 32 + 64)
+    assert cabi.conv64_wino_bwd_weight_workspace(D(512, 56, 56, 56, 56, 3, 1, 1, 0, 2)) > 0
+    for d in (D(2, 27, 27, 14, 14, 3, 2, 1, 0, 1),      # stride 2 (conv3)
+              D(2, 13, 13, 27, 27, 3, 2, 0, 1, 1),      # ConvTranspose
+              D(2, 9, 9, 9, 9, 3, 1, 1, 0, 1),          # odd map
+              D(3, 8, 8, 8, 8, 3, 1, 1, 0, 2),          # images do not split over the groups
+              D(3000, 56, 56, 56, 56, 3, 1, 1, 0, 1)):  # one group beyond 2 GB
+        assert cabi.conv64_wino_supported(d) == 0 and cabi.conv64_wino_tiles(d) == -1
+    # two groups of 1500 images fit the forward / data gradient (per-group offsets) but not the weight gradient (all images in one buffer)
+    big = D(3000, 56, 56, 56, 56, 3, 1, 1, 0, 2)
+    assert cabi.conv64_wino_supported(big) == 1 and cabi.conv64_wino_bwd_weight_workspace(big) == 0
