@@ -53,3 +53,21 @@ def test_winograd_route_is_offered_only_where_it_applies(cabi):
     # two groups of 1500 images fit the forward / data gradient (per-group offsets) but not the weight gradient (all images in one buffer)
     big = D(3000, 56, 56, 56, 56, 3, 1, 1, 0, 2)
     assert cabi.conv64_wino_supported(big) == 1 and cabi.conv64_wino_bwd_weight_workspace(big) == 0
+
+
+def test_bench_quotes_the_profile_recorded_at_its_own_sources(tmp_path, monkeypatch):
+    """bench.py's roofline object quotes committed rocprofv3 passes (profiles/<tag>_pmc_*.json): the tag recorded at the kernel sources
+    this tree builds from (csrc_sha16) wins over the last tag by name — tags do not sort by time."""
+    import json
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    sha = bench.csrc_sha16()  # (of the scratch tree: no sources -> the hash of nothing; what matters is that one file carries it)
+    (prof / "r01a_pmc_traffic.json").write_text(json.dumps({"csrc_sha16": sha, "kernels": {"k": {"hbm_bytes_per_launch": 1}}}))
+    (prof / "r01z_pmc_traffic.json").write_text(json.dumps({"csrc_sha16": "0" * 16, "kernels": {"k": {"hbm_bytes_per_launch": 2}}}))
+    assert bench.committed_pmc_traffic("k") == (1, "profiles/r01a_pmc_traffic.json", False)
+    (prof / "r01a_pmc_traffic.json").unlink()
+    assert bench.committed_pmc_traffic("k") == (2, "profiles/r01z_pmc_traffic.json", True)
