@@ -8,22 +8,26 @@
 // i.e. 16 independent [co 64] x [ci 64] x [patches] GEMMs (one per component (xi, nu) of the 4 x 4 transform domain) whose results are
 // folded 16 -> 4 per patch.  The transforms are additions only (B, A have entries 0, +-1): ~3 % of the multiply-adds they replace.
 //
-// Numerics: every product and every accumulation is fp32 as before; the transforms add ~2 roundings per operand, so an output differs from
-// the direct fp32 chain by a few 1e-7 relative to the layer's output scale (tests/test_kernels_gpu.py::test_conv64_wino_* hold it to the
-// fp64 oracle at 2e-6 and to the direct kernel); it is deterministic and position-independent (the arithmetic of a patch does not depend
-// on which tile or launch it falls into), so batching, BatchNorm groups and batch size leave every output bit unchanged.
+// Numerics: every product and every accumulation is fp32 as before; the transforms add two roundings per operand, the accumulation chains
+// are 2.25x shorter — against fp64 the outputs are CLOSER than the direct fp32 chain's (4.5e-7 against 1.2e-6 of the output scale at
+// N = 512; tests/test_wino_gpu.py holds every element to 2e-5 and prints both); deterministic and position-independent (the arithmetic of
+// a patch does not depend on which tile or launch it falls into), so batching, BatchNorm groups and batch size leave every bit unchanged.
 //
-// Structure (one workgroup of 512 threads per CU, persistent, XCD-contiguous tile runs):
-//   tile  = 64 consecutive patches of a BatchNorm group's patch grid (n, a, b) — 256 outputs x 64 channels;
-//   phase = 16 input channels (a quarter of K): V[16 comps][64 patches][16 ci] (64 KB of LDS) is built from the raw 4 x 4 x 2-channel
-//           patches every thread loaded DURING THE PREVIOUS PHASE's matrix work (zero padding = out-of-range buffer loads), the matching
-//           64 KB of transformed weights U[16][64 co][16 ci] arrive the same way, then every wave runs 16 comps x 8 v_mfma_f32_16x16x4_f32:
-//           wave (cb = wave >> 1, pb = wave & 1) owns output channels 16 cb .. and patches 32 pb .. (two 16 x 16 tiles per component),
-//           128 accumulator registers for the 16 components;
-//   epilogue: 16 -> 4 fold in registers (96 packed adds), bias, 16-byte NHWC stores (a lane holds 4 consecutive channels of one patch),
-//           BatchNorm partial sums (sum y, sum y^2) of the wave's 32 patches as one record per (tile, pb).
-// Operand layouts in LDS: [comp][g = k / 4][row][k % 4] — a ds_read_b128 of lane (row = lane & 15, g = lane >> 4) feeds four MFMAs and
-// the 16 lanes of a group read 256 contiguous bytes (conflict-free).
+// Forward / data gradient — conv64_wino_kernel<PSUM, FUSE> (256 threads, 64 KB of LDS: TWO workgroups per CU, persistent over
+// XCD-contiguous tile runs; the other workgroup's matrix work covers this one's barriers, landings and epilogue):
+//   tile  = 32 consecutive patches of a BatchNorm group's patch grid (n, a, b) — 128 outputs x 64 channels;
+//   chunk = 16 input channels (a quarter of K).  During the matrix work of chunk c every thread transforms the raw 4 x 4 x 2-channel patch
+//           it loaded during chunk c - 1 (zero padding = out-of-range buffer loads; FUSE: relu(batchnorm(raw)) applied as it lands) into
+//           V[16 comps][32 patches][16 ci] of the OTHER LDS buffer (32 KB each, ONE barrier per chunk) and requests chunk c + 2;
+//   matrix work: wave w owns output channels 16 w .. of all 32 patches (two 16 x 16 tiles per component: 128 accumulator registers for the
+//           16 components), v_mfma_f32_16x16x4_f32; the transformed weights U never touch LDS — 1 KB per wave and component straight
+//           from L2 into the MFMA's A operand, four components ahead; V as ds_read_b128 one component ahead (one read feeds four MFMAs);
+//   epilogue: 16 -> 4 fold in registers, bias, 16-byte NHWC stores (a lane holds 4 consecutive channels of one patch), BatchNorm partial
+//           sums (sum y, sum y^2) of the tile as one record; PSUM (conv2's data gradient = d pooled1): the pooled block's two
+//           BatchNorm-BACKWARD sums instead (WinoPoolSum).
+// Weight gradient — conv64_wino_wgrad_kernel: the transposed algorithm (below).
+// LDS layouts are conflict-free against the hardware's lane groups: ds_read_b128 is served as {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31},
+// ... (not 16 consecutive lanes), ds_write_b64 in runs of 16 lanes over 32 banks (MI355X_MICROARCH.md, LDS).
 #include "common.h"
 
 namespace {
